@@ -1,0 +1,824 @@
+/*
+ * gs_oracle.c -- CPU restatement of the reference Grad-Shafranov hot path (see gs_oracle.h).
+ * TEST INFRASTRUCTURE ONLY: used by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg as the checker; never by the product path.
+ *
+ * Every function cites the reference file:line it follows (paths relative to the
+ * reference checkout, src/scpn_fusion/...).  Operation order follows the NumPy expressions
+ * exactly; compile with -ffp-contract=off.
+ */
+#include "gs_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CAP 1.0e250 /* core/fusion_kernel_numerics.py:16 NUMERIC_SANITIZE_CAP */
+#define IDX(iz, ir) ((long)(iz) * nr + (ir))
+
+static double *dalloc(long n) { return (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double)); }
+
+/* numpy/_core/function_base.py linspace: y = arange(n)*step + start; y[-1] = stop */
+void orc_linspace(double start, double stop, int n, double *out) {
+    if (n <= 0) return;
+    if (n == 1) { out[0] = start; return; }
+    double div = (double)(n - 1);
+    double delta = stop - start;
+    double step = delta / div;
+    for (int i = 0; i < n; ++i) {
+        double y = (double)i;
+        if (step != 0.0) y = y * step;
+        else y = (y / div) * delta;
+        out[i] = y + start;
+    }
+    out[n - 1] = stop;
+}
+
+/* numpy/_core/src/umath/loops_utils.h.src  DOUBLE_pairwise_sum (PW_BLOCKSIZE 128) */
+static double pairwise(const double *a, long n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (long i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        long i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        long n2 = n / 2;
+        n2 -= n2 % 8;
+        return pairwise(a, n2) + pairwise(a + n2, n - n2);
+    }
+}
+/* np.add.reduce over a contiguous vector: the ufunc machinery hands the inner loop at most
+ * NPY_BUFSIZE (8192) elements at a time and accumulates the pairwise sums of the chunks
+ * sequentially (verified against numpy 2.2.6 in tests/test_oracle_golden.py). */
+double orc_np_sum(const double *a, long n) {
+    double s = 0.0;
+    for (long i = 0; i < n; i += 8192) s = s + pairwise(a + i, (n - i) < 8192 ? (n - i) : 8192);
+    return s;
+}
+
+static int omega_ok(double omega) { /* core/multigrid_solve.py:33-54 */
+    return isfinite(omega) && omega >= 1.0 && omega < 2.0;
+}
+
+/* interior coefficient tables a_E, a_W  -- core/multigrid_solve.py:184-189 */
+static void coeffs(const double *r_grid, int nz, int nr, double dr, double dr2, double *a_e,
+                   double *a_w) {
+    int ni = nr - 2;
+    for (int iz = 1; iz < nz - 1; ++iz)
+        for (int ir = 1; ir < nr - 1; ++ir) {
+            double r_safe = fmax(r_grid[IDX(iz, ir)], 1e-10);
+            double t = 1.0 / ((2.0 * r_safe) * dr);
+            a_e[(long)(iz - 1) * ni + (ir - 1)] = 1.0 / dr2 - t;
+            a_w[(long)(iz - 1) * ni + (ir - 1)] = 1.0 / dr2 + t;
+        }
+}
+
+/* one red-black sweep; clip!=0 adds the +-CAP clip of _sor_step (iterative_solver.py:158) */
+static void rb_sweep(double *psi, const double *source, const double *a_e, const double *a_w,
+                     double a_ns, double a_c, int nz, int nr, double omega, int clip) {
+    int ni = nr - 2;
+    for (int parity = 0; parity < 2; ++parity)
+        for (int iz = 1; iz < nz - 1; ++iz)
+            for (int ir = 1; ir < nr - 1; ++ir) {
+                /* mask = ((ii + jj) % 2) == parity with ii,jj the GLOBAL indices
+                 * (np.mgrid[1:nz-1, 1:nr-1]) -- core/multigrid_solve.py:191-195 */
+                if (((iz + ir) & 1) != parity) continue;
+                long c = (long)(iz - 1) * ni + (ir - 1);
+                double gs = (a_e[c] * psi[IDX(iz, ir + 1)] + a_w[c] * psi[IDX(iz, ir - 1)] +
+                             a_ns * psi[IDX(iz - 1, ir)] + a_ns * psi[IDX(iz + 1, ir)] -
+                             source[IDX(iz, ir)]) /
+                            a_c;
+                double old = psi[IDX(iz, ir)];
+                double v = (1.0 - omega) * old + omega * gs;
+                if (clip) v = fmin(fmax(v, -CAP), CAP);
+                psi[IDX(iz, ir)] = v;
+            }
+}
+
+int orc_mg_smooth(double *psi, const double *source, const double *r_grid, int nz, int nr,
+                  double dr, double dz, double omega, int n_sweeps) {
+    if (!omega_ok(omega)) return -1;
+    if (nz < 3 || nr < 3) return 0;
+    double dr2 = pow(dr, 2.0), dz2 = pow(dz, 2.0);
+    long ni = (long)(nz - 2) * (nr - 2);
+    double *a_e = dalloc(ni), *a_w = dalloc(ni);
+    coeffs(r_grid, nz, nr, dr, dr2, a_e, a_w);
+    double a_ns = 1.0 / dz2;
+    double a_c = 2.0 / dr2 + 2.0 / dz2;
+    for (int s = 0; s < n_sweeps; ++s) rb_sweep(psi, source, a_e, a_w, a_ns, a_c, nz, nr, omega, 0);
+    free(a_e);
+    free(a_w);
+    return 0;
+}
+
+void orc_mg_residual(const double *psi, const double *source, const double *r_grid, int nz,
+                     int nr, double dr, double dz, double *out) {
+    double dr2 = pow(dr, 2.0), dz2 = pow(dz, 2.0);
+    memset(out, 0, sizeof(double) * (size_t)nz * nr);
+    for (int iz = 1; iz < nz - 1; ++iz)
+        for (int ir = 1; ir < nr - 1; ++ir) {
+            double r_safe = fmax(r_grid[IDX(iz, ir)], 1e-10);
+            double c = psi[IDX(iz, ir)];
+            double e = psi[IDX(iz, ir + 1)], w = psi[IDX(iz, ir - 1)];
+            double n = psi[IDX(iz + 1, ir)], s = psi[IDX(iz - 1, ir)];
+            double d2r = (e - 2.0 * c + w) / dr2;
+            double d1r = (e - w) / (2.0 * dr);
+            double d2z = (n - 2.0 * c + s) / dz2;
+            double lpsi = d2r - d1r / r_safe + d2z;
+            out[IDX(iz, ir)] = lpsi - source[IDX(iz, ir)];
+        }
+}
+
+double orc_residual_linf(const double *psi, const double *source, const double *r_grid, int nz,
+                         int nr, double dr, double dz) {
+    if (nz < 3 || nr < 3) return 0.0;
+    double *r = dalloc((long)nz * nr);
+    orc_mg_residual(psi, source, r_grid, nz, nr, dr, dz, r);
+    double m = 0.0;
+    int any = 0;
+    /* np.max(np.abs(residual[1:-1,1:-1])): NaN propagates */
+    for (int iz = 1; iz < nz - 1; ++iz)
+        for (int ir = 1; ir < nr - 1; ++ir) {
+            double a = fabs(r[IDX(iz, ir)]);
+            if (!any) { m = a; any = 1; }
+            else if (isnan(a) || a > m) { if (!isnan(m)) m = a; }
+        }
+    free(r);
+    return m;
+}
+
+double orc_stable_rms(const double *v, long n) {
+    if (n == 0) return 0.0;
+    double *vals = dalloc(n);
+    double max_abs = 0.0;
+    for (long i = 0; i < n; ++i) { /* sanitize_numeric_array */
+        double x = v[i];
+        if (isnan(x)) x = 0.0;
+        else if (isinf(x)) x = x > 0 ? CAP : -CAP;
+        vals[i] = x;
+        if (fabs(x) > max_abs) max_abs = fabs(x);
+    }
+    if (max_abs > CAP) {
+        for (long i = 0; i < n; ++i) vals[i] = fmin(fmax(vals[i], -CAP), CAP);
+        max_abs = CAP;
+    }
+    if (max_abs <= 0.0) { free(vals); return 0.0; }
+    for (long i = 0; i < n; ++i) {
+        double s = vals[i] / max_abs;
+        vals[i] = s * s;
+    }
+    double mean = orc_np_sum(vals, n) / (double)n;
+    free(vals);
+    return max_abs * sqrt(mean);
+}
+
+double orc_gs_residual_rms(const double *psi, const double *source, const double *r_grid, int nz,
+                           int nr, double dr, double dz) {
+    if (nz < 3 || nr < 3) return 0.0;
+    double *r = dalloc((long)nz * nr);
+    orc_mg_residual(psi, source, r_grid, nz, nr, dr, dz, r);
+    long ni = (long)(nz - 2) * (nr - 2);
+    double *in = dalloc(ni);
+    for (int iz = 1; iz < nz - 1; ++iz)
+        memcpy(in + (long)(iz - 1) * (nr - 2), r + IDX(iz, 1), sizeof(double) * (size_t)(nr - 2));
+    double rms = orc_stable_rms(in, ni);
+    free(in);
+    free(r);
+    return rms;
+}
+
+void orc_restrict_full_weight(const double *fine, int nz_f, int nr_f, double *coarse) {
+    int nz_c = (nz_f + 1) / 2, nr_c = (nr_f + 1) / 2;
+    int nr = nr_f; /* for IDX on the fine grid */
+    memset(coarse, 0, sizeof(double) * (size_t)nz_c * nr_c);
+    for (int ic = 1; ic < nz_c - 1; ++ic)
+        for (int jc = 1; jc < nr_c - 1; ++jc) {
+            int i = 2 * ic, j = 2 * jc;
+            double v = (4.0 * fine[IDX(i, j)] +
+                        2.0 * (fine[IDX(i - 1, j)] + fine[IDX(i + 1, j)] + fine[IDX(i, j - 1)] +
+                               fine[IDX(i, j + 1)]) +
+                        (fine[IDX(i - 1, j - 1)] + fine[IDX(i - 1, j + 1)] +
+                         fine[IDX(i + 1, j - 1)] + fine[IDX(i + 1, j + 1)])) /
+                       16.0;
+            coarse[(long)ic * nr_c + jc] = v;
+        }
+    /* boundary injection, rows first then columns (core/multigrid_solve.py:94-97) */
+    for (int jc = 0; jc < nr_c; ++jc) coarse[jc] = fine[IDX(0, 2 * jc)];
+    for (int jc = 0; jc < nr_c; ++jc) coarse[(long)(nz_c - 1) * nr_c + jc] = fine[IDX(nz_f - 1, 2 * jc)];
+    for (int ic = 0; ic < nz_c; ++ic) coarse[(long)ic * nr_c] = fine[IDX(2 * ic, 0)];
+    for (int ic = 0; ic < nz_c; ++ic) coarse[(long)ic * nr_c + nr_c - 1] = fine[IDX(2 * ic, nr_f - 1)];
+}
+
+int orc_prolongate_bilinear(const double *coarse, int nz_c, int nr_c, int nz_f, int nr_f,
+                            double *fine) {
+    if (nz_c != (nz_f + 1) / 2 || nr_c != (nr_f + 1) / 2) return -1;
+    int nr = nr_f;
+#define C(i, j) coarse[(long)(i) * nr_c + (j)]
+    memset(fine, 0, sizeof(double) * (size_t)nz_f * nr_f);
+    int nz_used = nz_c, nr_used = nr_c; /* = min(n_c, (n_f+1)//2) */
+    int h_end = 2 * (nr_c - 1) < nr_f - 1 ? 2 * (nr_c - 1) : nr_f - 1;
+    int v_end = 2 * (nz_c - 1) < nz_f - 1 ? 2 * (nz_c - 1) : nz_f - 1;
+    for (int i = 0; i < nz_used; ++i)
+        for (int j = 0; j < nr_used; ++j) fine[IDX(2 * i, 2 * j)] = C(i, j);
+    for (int i = 0; i < nz_used; ++i)
+        for (int jf = 1; jf < h_end; jf += 2) {
+            int j = (jf - 1) / 2;
+            fine[IDX(2 * i, jf)] = 0.5 * (C(i, j) + C(i, j + 1));
+        }
+    for (int iff = 1; iff < v_end; iff += 2) {
+        int i = (iff - 1) / 2;
+        for (int j = 0; j < nr_used; ++j) fine[IDX(iff, 2 * j)] = 0.5 * (C(i, j) + C(i + 1, j));
+    }
+    for (int iff = 1; iff < v_end; iff += 2) {
+        int i = (iff - 1) / 2;
+        for (int jf = 1; jf < h_end; jf += 2) {
+            int j = (jf - 1) / 2;
+            fine[IDX(iff, jf)] = 0.25 * (C(i, j) + C(i + 1, j) + C(i, j + 1) + C(i + 1, j + 1));
+        }
+    }
+#undef C
+    return 0;
+}
+
+int orc_multigrid_vcycle(double *psi, const double *source, const double *r_grid, int nz, int nr,
+                         double dr, double dz, double omega, int pre_smooth, int post_smooth,
+                         int min_grid) {
+    if (!omega_ok(omega)) return -1;
+    if (min_grid >= nz || min_grid >= nr) /* base case, core/multigrid_solve.py:292-293 */
+        return orc_mg_smooth(psi, source, r_grid, nz, nr, dr, dz, omega, 50);
+    orc_mg_smooth(psi, source, r_grid, nz, nr, dr, dz, omega, pre_smooth);
+    long n = (long)nz * nr;
+    double *defect = dalloc(n);
+    orc_mg_residual(psi, source, r_grid, nz, nr, dr, dz, defect);
+    for (long i = 0; i < n; ++i) defect[i] = -defect[i];
+    int nz_c = (nz + 1) / 2, nr_c = (nr + 1) / 2;
+    long nc = (long)nz_c * nr_c;
+    double *d_c = dalloc(nc), *r_c = dalloc(nc), *e_c = dalloc(nc);
+    orc_restrict_full_weight(defect, nz, nr, d_c);
+    orc_restrict_full_weight(r_grid, nz, nr, r_c);
+    orc_multigrid_vcycle(e_c, d_c, r_c, nz_c, nr_c, dr * 2.0, dz * 2.0, omega, pre_smooth,
+                         post_smooth, min_grid);
+    double *corr = defect; /* reuse */
+    orc_prolongate_bilinear(e_c, nz_c, nr_c, nz, nr, corr);
+    for (long i = 0; i < n; ++i) psi[i] = psi[i] + corr[i];
+    orc_mg_smooth(psi, source, r_grid, nz, nr, dr, dz, omega, post_smooth);
+    free(defect);
+    free(d_c);
+    free(r_c);
+    free(e_c);
+    return 0;
+}
+
+static void meshgrid_r(const double *r_axis, int nz, int nr, double *rr) {
+    for (int iz = 0; iz < nz; ++iz) memcpy(rr + (long)iz * nr, r_axis, sizeof(double) * (size_t)nr);
+}
+
+static void apply_bc(double *psi, const double *bc, int nz, int nr) {
+    /* core/fusion_kernel_iterative_solver.py:316-329 */
+    for (int ir = 0; ir < nr; ++ir) {
+        psi[IDX(0, ir)] = bc[IDX(0, ir)];
+        psi[IDX(nz - 1, ir)] = bc[IDX(nz - 1, ir)];
+    }
+    for (int iz = 0; iz < nz; ++iz) {
+        psi[IDX(iz, 0)] = bc[IDX(iz, 0)];
+        psi[IDX(iz, nr - 1)] = bc[IDX(iz, nr - 1)];
+    }
+}
+
+int orc_multigrid_solve(const double *source, double *psi, double r_min, double r_max,
+                        double z_min, double z_max, int nr, int nz, double tol, int max_cycles,
+                        double omega, int pre_smooth, int post_smooth, int min_grid,
+                        double *residual_out, int *n_cycles_out, int *converged_out) {
+    if (!(isfinite(tol) && tol > 0.0)) return -1;
+    if (max_cycles < 1) return -1;
+    if (!omega_ok(omega)) return -1;
+    long n = (long)nz * nr;
+    double *r_axis = dalloc(nr), *z_axis = dalloc(nz), *rr = dalloc(n), *bc = dalloc(n);
+    orc_linspace(r_min, r_max, nr, r_axis);
+    orc_linspace(z_min, z_max, nz, z_axis);
+    meshgrid_r(r_axis, nz, nr, rr);
+    double dr = nr > 1 ? r_axis[1] - r_axis[0] : 1.0;
+    double dz = nz > 1 ? z_axis[1] - z_axis[0] : 1.0;
+    memcpy(bc, psi, sizeof(double) * (size_t)n);
+    int n_cycles = 0;
+    double residual = orc_residual_linf(psi, source, rr, nz, nr, dr, dz);
+    int converged = residual < tol;
+    while (!converged && n_cycles < max_cycles) {
+        orc_multigrid_vcycle(psi, source, rr, nz, nr, dr, dz, omega, pre_smooth, post_smooth,
+                             min_grid);
+        apply_bc(psi, bc, nz, nr);
+        n_cycles += 1;
+        residual = orc_residual_linf(psi, source, rr, nz, nr, dr, dz);
+        converged = residual < tol;
+    }
+    *residual_out = residual;
+    *n_cycles_out = n_cycles;
+    *converged_out = converged;
+    free(r_axis);
+    free(z_axis);
+    free(rr);
+    free(bc);
+    return 0;
+}
+
+static double sanitize1(double x) { /* core/fusion_kernel_numerics.py:19-25 */
+    if (isnan(x)) return 0.0;
+    if (isinf(x)) return x > 0 ? CAP : -CAP;
+    return fmin(fmax(x, -CAP), CAP);
+}
+
+void orc_jacobi_step(const double *psi_in, const double *source_in, const double *r_grid, int nz,
+                     int nr, double dr, double dz, double *out) {
+    long n = (long)nz * nr;
+    double *psi = dalloc(n), *src = dalloc(n);
+    for (long i = 0; i < n; ++i) { psi[i] = sanitize1(psi_in[i]); src[i] = sanitize1(source_in[i]); }
+    memcpy(out, psi, sizeof(double) * (size_t)n);
+    double dr2 = pow(dr, 2.0), dz2 = pow(dz, 2.0);
+    double a_ns = 1.0 / dz2, a_c = 2.0 / dr2 + 2.0 / dz2;
+    for (int iz = 1; iz < nz - 1; ++iz)
+        for (int ir = 1; ir < nr - 1; ++ir) {
+            double r_safe = fmax(r_grid[IDX(iz, ir)], 1e-10);
+            double t = 1.0 / ((2.0 * r_safe) * dr);
+            double a_e = 1.0 / dr2 - t, a_w = 1.0 / dr2 + t;
+            double v = (a_e * psi[IDX(iz, ir + 1)] + a_w * psi[IDX(iz, ir - 1)] +
+                        a_ns * psi[IDX(iz - 1, ir)] + a_ns * psi[IDX(iz + 1, ir)] -
+                        src[IDX(iz, ir)]) /
+                       a_c;
+            out[IDX(iz, ir)] = fmin(fmax(v, -CAP), CAP);
+        }
+    free(psi);
+    free(src);
+}
+
+int orc_sor_step(const double *psi_in, const double *source_in, const double *r_grid, int nz,
+                 int nr, double dr, double dz, double omega, double *out) {
+    if (!omega_ok(omega)) return -1;
+    long n = (long)nz * nr;
+    double *src = dalloc(n);
+    for (long i = 0; i < n; ++i) { out[i] = sanitize1(psi_in[i]); src[i] = sanitize1(source_in[i]); }
+    if (nz >= 3 && nr >= 3) {
+        double dr2 = pow(dr, 2.0), dz2 = pow(dz, 2.0);
+        long ni = (long)(nz - 2) * (nr - 2);
+        double *a_e = dalloc(ni), *a_w = dalloc(ni);
+        coeffs(r_grid, nz, nr, dr, dr2, a_e, a_w);
+        rb_sweep(out, src, a_e, a_w, 1.0 / dz2, 2.0 / dr2 + 2.0 / dz2, nz, nr, omega, 1);
+        free(a_e);
+        free(a_w);
+    }
+    free(src);
+    return 0;
+}
+
+/* K(m), E(m) by the arithmetic-geometric mean (A&S 17.6.3-17.6.4) */
+void orc_ellip_ke(double m, double *K, double *E) {
+    double a = 1.0, b = sqrt(1.0 - m);
+    double s = 0.5 * m, pw = 0.5;
+    for (int it = 0; it < 40; ++it) {
+        double c = 0.5 * (a - b);
+        double an = 0.5 * (a + b);
+        b = sqrt(a * b);
+        a = an;
+        pw *= 2.0;
+        s += pw * c * c;
+        if (fabs(c) <= 1e-17 * a) break;
+    }
+    double k = M_PI / (2.0 * a);
+    *K = k;
+    *E = k * (1.0 - s);
+}
+
+void orc_vacuum_field(const double *r_axis, const double *z_axis, int nz, int nr, int n_coils,
+                      const double *coil_r, const double *coil_z, const double *coil_i, double mu0,
+                      double *psi_vac) {
+    memset(psi_vac, 0, sizeof(double) * (size_t)nz * nr);
+    for (int c = 0; c < n_coils; ++c) {
+        double rc = coil_r[c], zc = coil_z[c], cur = coil_i[c];
+        double prefactor = (mu0 * cur) / (2.0 * M_PI);
+        for (int iz = 0; iz < nz; ++iz)
+            for (int ir = 0; ir < nr; ++ir) {
+                double R = r_axis[ir], dZ = z_axis[iz] - zc;
+                double rp = (R + rc) * (R + rc);
+                double k2 = ((4.0 * R) * rc) / (rp + dZ * dZ);
+                k2 = fmin(fmax(k2, 1e-12), 1.0 - 1e-12);
+                double K, E;
+                orc_ellip_ke(k2, &K, &E);
+                double sqrt_term = sqrt(R * rc);
+                double k = sqrt(k2);
+                double term = ((2.0 - k2) * K - 2.0 * E) / k;
+                psi_vac[IDX(iz, ir)] += (prefactor * sqrt_term) * term;
+            }
+    }
+}
+
+#define MU0_SI (4e-7 * M_PI)
+
+static double green_vec(double r_src, double z_src, double r_obs, double z_obs) {
+    /* core/fusion_kernel_free_boundary.py:58-80 */
+    double dr = r_obs - r_src, dz = z_obs - z_src;
+    int self_mask = (dr * dr + dz * dz) < 1e-24;
+    double denom = (r_obs + r_src) * (r_obs + r_src) + dz * dz;
+    double k2 = denom > 1e-30 ? ((4.0 * r_obs) * r_src) / fmax(denom, 1e-30) : 0.0;
+    k2 = fmin(fmax(k2, 1e-12), 1.0 - 1e-12);
+    double k = sqrt(k2), K, E;
+    orc_ellip_ke(k2, &K, &E);
+    double prefactor = (MU0_SI / (2.0 * M_PI)) * sqrt(r_obs * r_src);
+    double flux = (prefactor * ((2.0 - k2) * K - 2.0 * E)) / k;
+    return self_mask ? 0.0 : flux;
+}
+
+double orc_green_function(double r_src, double z_src, double r_obs, double z_obs) {
+    if (!isfinite(r_src) || !isfinite(z_src) || !isfinite(r_obs) || !isfinite(z_obs)) return NAN;
+    if (r_src <= 0.0 || r_obs <= 0.0) return NAN;
+    return green_vec(r_src, z_src, r_obs, z_obs);
+}
+
+void orc_external_flux(const double *r_axis, const double *z_axis, int nz, int nr, int n_coils,
+                       const double *coil_r, const double *coil_z, const double *coil_i,
+                       const double *coil_turns, double *psi_ext) {
+    memset(psi_ext, 0, sizeof(double) * (size_t)nz * nr);
+    for (int c = 0; c < n_coils; ++c) {
+        double i_eff = coil_i[c] * (coil_turns ? coil_turns[c] : 1.0);
+        for (int iz = 0; iz < nz; ++iz)
+            for (int ir = 0; ir < nr; ++ir)
+                psi_ext[IDX(iz, ir)] += i_eff * green_vec(coil_r[c], coil_z[c], r_axis[ir], z_axis[iz]);
+    }
+}
+
+void orc_find_axis(const double *psi, int nz, int nr, int *iz, int *ir, double *psi_axis) {
+    long n = (long)nz * nr, best = 0;
+    /* np.argmax: first occurrence; a NaN wins */
+    for (long i = 1; i < n; ++i) {
+        if (isnan(psi[best])) break;
+        if (isnan(psi[i]) || psi[i] > psi[best]) best = i;
+    }
+    *iz = (int)(best / nr);
+    *ir = (int)(best % nr);
+    double v = psi[best];
+    if (fabs(v) < 1e-6) v = 1e-6;
+    *psi_axis = v;
+}
+
+static double nan_to_num300(double x) {
+    if (isnan(x)) return 0.0;
+    if (isinf(x)) return x > 0 ? 1e300 : -1e300;
+    return x;
+}
+
+void orc_find_x_point(const double *psi, const double *z_axis, int nz, int nr, double dr, double dz,
+                      double z_min_cfg, long *idx_out, double *psi_x) {
+    long n = (long)nz * nr;
+    int any_finite = 0;
+    for (long i = 0; i < n; ++i) if (isfinite(psi[i])) { any_finite = 1; break; }
+    if (!any_finite) { *idx_out = -2; *psi_x = 0.0; return; }
+    double zthr = z_min_cfg * 0.5;
+    long best = -1;
+    double bestv = INFINITY;
+    for (int iz = 0; iz < nz; ++iz) {
+        if (!(zthr > z_axis[iz])) continue;
+        for (int ir = 0; ir < nr; ++ir) {
+#define P(a, b) nan_to_num300(psi[IDX(a, b)])
+            double gz, gr; /* np.gradient(psi, dZ, dR), edge_order=1 */
+            if (iz == 0) gz = (P(1, ir) - P(0, ir)) / dz;
+            else if (iz == nz - 1) gz = (P(nz - 1, ir) - P(nz - 2, ir)) / dz;
+            else gz = (P(iz + 1, ir) - P(iz - 1, ir)) / (2.0 * dz);
+            if (ir == 0) gr = (P(iz, 1) - P(iz, 0)) / dr;
+            else if (ir == nr - 1) gr = (P(iz, nr - 1) - P(iz, nr - 2)) / dr;
+            else gr = (P(iz, ir + 1) - P(iz, ir - 1)) / (2.0 * dr);
+#undef P
+            double b = hypot(gr, gz);
+            if (isfinite(b) && (best < 0 || b < bestv)) { best = IDX(iz, ir); bestv = b; }
+            else if (isnan(b) && best >= 0 && !isnan(bestv)) { /* np.argmin: first NaN wins */
+                best = IDX(iz, ir); bestv = b;
+            }
+        }
+    }
+    if (best >= 0) {
+        double v = psi[best];
+        if (!isfinite(v)) v = nan_to_num300(v);
+        *idx_out = best;
+        *psi_x = v;
+        return;
+    }
+    double m = INFINITY; /* fallback: min over finite psi, core/fusion_kernel.py:339-340 */
+    for (long i = 0; i < n; ++i) if (isfinite(psi[i]) && psi[i] < m) m = psi[i];
+    *idx_out = -1;
+    *psi_x = m;
+}
+
+static double mtanh1(double x, const double *p) { /* core/fusion_kernel.py:359-390 */
+    double y = (p[0] - x) / p[1];
+    y = fmin(fmax(y, -20.0), 20.0);
+    double pedestal = (0.5 * p[2]) * (1.0 + tanh(y));
+    double core = 0.0;
+    if (x < p[0]) {
+        double q = x / p[0];
+        core = fmax(0.0, 1.0 - q * q);
+    }
+    return pedestal + p[3] * core;
+}
+
+double orc_update_source(const double *psi, const double *r_axis, int nz, int nr, double dr,
+                         double dz, double psi_axis, double psi_bnd, double mu0, double i_target,
+                         int hmode, const double *ped_p, const double *ped_ff, double *j_phi) {
+    long n = (long)nz * nr;
+    double denom = psi_bnd - psi_axis;
+    if (fabs(denom) < 1e-9) denom = 1e-9;
+    const double beta_mix = 0.5;
+    for (int iz = 0; iz < nz; ++iz)
+        for (int ir = 0; ir < nr; ++ir) {
+            double R = r_axis[ir];
+            double pn = (psi[IDX(iz, ir)] - psi_axis) / denom;
+            int mask = (pn >= 0) && (pn < 1.0);
+            double p = 0.0, ff = 0.0;
+            if (mask) {
+                if (hmode) { p = mtanh1(pn, ped_p); ff = mtanh1(pn, ped_ff); }
+                else { p = 1.0 - pn; ff = p; }
+            }
+            double j_p = R * p;
+            double j_f = (1.0 / (mu0 * R)) * ff;
+            j_phi[IDX(iz, ir)] = beta_mix * j_p + (1 - beta_mix) * j_f;
+        }
+    double i_current = (orc_np_sum(j_phi, n) * dr) * dz;
+    if (fabs(i_current) > 1e-9) {
+        double s = i_target / i_current;
+        for (long i = 0; i < n; ++i) j_phi[i] = j_phi[i] * s;
+    } else {
+        memset(j_phi, 0, sizeof(double) * (size_t)n);
+    }
+    return i_current;
+}
+
+int orc_picard_solve(const orc_picard_params *p, double *psi, const double *boundary_flux,
+                     double *j_phi, orc_picard_result *res, double *trace, int max_iter_budget) {
+    int nz = p->nz, nr = p->nr;
+    long n = (long)nz * nr;
+    memset(res, 0, sizeof(*res));
+    res->x_idx = -1;
+    double *r_axis = dalloc(nr), *z_axis = dalloc(nz);
+    orc_linspace(p->r_min, p->r_max, nr, r_axis);
+    orc_linspace(p->z_min, p->z_max, nz, z_axis);
+    double dr = r_axis[1] - r_axis[0], dz = z_axis[1] - z_axis[0];
+    double *rr = dalloc(n);
+    meshgrid_r(r_axis, nz, nr, rr);
+    int rc = 0;
+
+    /* zero-current short-circuit, core/fusion_kernel_newton_solver.py:448-465 */
+    if (fabs(p->i_target) < 1e-12 && !p->preserve_initial_state) {
+        orc_vacuum_field(r_axis, z_axis, nz, nr, p->n_coils, p->coil_r, p->coil_z, p->coil_i, p->mu0, psi);
+        memset(j_phi, 0, sizeof(double) * (size_t)n);
+        res->converged = 1;
+        res->iterations = 0;
+        free(r_axis); free(z_axis); free(rr);
+        return 0;
+    }
+
+    /* _prepare_initial_flux, core/fusion_kernel_iterative_solver.py:412-451 */
+    double *bc = dalloc(n);
+    if (p->has_boundary_flux && boundary_flux) memcpy(bc, boundary_flux, sizeof(double) * (size_t)n);
+    else if (p->preserve_initial_state) memcpy(bc, psi, sizeof(double) * (size_t)n);
+    else orc_vacuum_field(r_axis, z_axis, nz, nr, p->n_coils, p->coil_r, p->coil_z, p->coil_i, p->mu0, bc);
+    if (p->preserve_initial_state) apply_bc(psi, bc, nz, nr);
+    else memcpy(psi, bc, sizeof(double) * (size_t)n);
+
+    double *psi_best = dalloc(n), *source = dalloc(n), *psi_new = dalloc(n), *tmp = dalloc(n);
+    memcpy(psi_best, psi, sizeof(double) * (size_t)n);
+    double diff_best = 1e9, gs_best = INFINITY, gs_last = INFINITY;
+    int converged = 0, final_iter = 0, ran = 0;
+
+    /* _seed_plasma, core/fusion_kernel_iterative_solver.py:384-410 */
+    if (fabs(p->i_target) < 1e-12) {
+        memset(j_phi, 0, sizeof(double) * (size_t)n);
+    } else {
+        double r_center = (p->r_min + p->r_max) / 2.0;
+        for (int iz = 0; iz < nz; ++iz)
+            for (int ir = 0; ir < nr; ++ir) {
+                double a = r_axis[ir] - r_center;
+                double dist_sq = a * a + z_axis[iz] * z_axis[iz];
+                j_phi[IDX(iz, ir)] = exp(-dist_sq / 2.0);
+            }
+        double i_seed = (orc_np_sum(j_phi, n) * dr) * dz;
+        if (i_seed > 0) {
+            double s = p->i_target / i_seed;
+            for (long i = 0; i < n; ++i) j_phi[i] *= s;
+        }
+        for (int iz = 0; iz < nz; ++iz)
+            for (int ir = 0; ir < nr; ++ir) source[IDX(iz, ir)] = ((-p->mu0) * r_axis[ir]) * j_phi[IDX(iz, ir)];
+        for (int s = 0; s < 50; ++s) {
+            orc_jacobi_step(psi, source, rr, nz, nr, dr, dz, tmp);
+            memcpy(psi, tmp, sizeof(double) * (size_t)n);
+        }
+    }
+
+    int max_iter = p->max_iter;
+    if (max_iter_budget >= 0 && max_iter_budget < max_iter) max_iter = max_iter_budget;
+    for (int k = 0; k < max_iter; ++k) {
+        final_iter = k;
+        ran = 1;
+        int aiz, air;
+        double psi_axis, psi_bnd;
+        long xidx;
+        orc_find_axis(psi, nz, nr, &aiz, &air, &psi_axis);
+        orc_find_x_point(psi, z_axis, nz, nr, dr, dz, p->z_min, &xidx, &psi_bnd);
+        if (fabs(psi_axis - psi_bnd) < 0.1) psi_bnd = psi_axis * 0.1;
+        double i_current = NAN;
+        if (!p->external_profile_mode)
+            i_current = orc_update_source(psi, r_axis, nz, nr, dr, dz, psi_axis, psi_bnd, p->mu0,
+                                          p->i_target, p->hmode, p->ped_p, p->ped_ff, j_phi);
+        for (int iz = 0; iz < nz; ++iz)
+            for (int ir = 0; ir < nr; ++ir) source[IDX(iz, ir)] = ((-p->mu0) * r_axis[ir]) * j_phi[IDX(iz, ir)];
+        /* _elliptic_solve, core/fusion_kernel_iterative_solver.py:361-380 */
+        if (p->method == 2) {
+            orc_jacobi_step(psi, source, rr, nz, nr, dr, dz, psi_new);
+        } else if (p->method == 0) {
+            memcpy(psi_new, psi, sizeof(double) * (size_t)n);
+            rc = orc_multigrid_vcycle(psi_new, source, rr, nz, nr, dr, dz, p->sor_omega, 3, 3, 5);
+        } else {
+            rc = orc_sor_step(psi, source, rr, nz, nr, dr, dz, p->sor_omega, psi_new);
+        }
+        if (rc) break;
+        apply_bc(psi_new, bc, nz, nr);
+        int bad = 0;
+        for (long i = 0; i < n; ++i) if (!isfinite(psi_new[i])) { bad = 1; break; }
+        res->psi_axis = psi_axis;
+        res->psi_bnd = psi_bnd;
+        res->x_idx = xidx;
+        if (bad) {
+            memcpy(psi, psi_best, sizeof(double) * (size_t)n);
+            res->diverged = 1;
+            break;
+        }
+        for (long i = 0; i < n; ++i) tmp[i] = fabs(psi_new[i] - psi[i]);
+        double diff = orc_np_sum(tmp, n) / (double)n;
+        for (long i = 0; i < n; ++i) psi[i] = (1.0 - p->alpha) * psi[i] + p->alpha * psi_new[i];
+        double gs = orc_gs_residual_rms(psi, source, rr, nz, nr, dr, dz);
+        gs_last = gs;
+        if (gs < gs_best) gs_best = gs;
+        if (diff < diff_best) {
+            diff_best = diff;
+            memcpy(psi_best, psi, sizeof(double) * (size_t)n);
+        }
+        if (trace) {
+            double *t = trace + 6L * k;
+            t[0] = psi_axis; t[1] = psi_bnd; t[2] = (double)xidx; t[3] = i_current; t[4] = diff; t[5] = gs;
+        }
+        int upd = diff < p->tol;
+        int gsc = (!p->require_gs_residual) || (gs < p->gs_tol);
+        if (upd && gsc) { converged = 1; break; }
+    }
+    res->converged = converged;
+    res->iterations = ran ? final_iter + 1 : 1;
+    res->residual = diff_best;
+    res->gs_residual = gs_last;
+    res->gs_residual_best = gs_best;
+    free(r_axis); free(z_axis); free(rr); free(bc);
+    free(psi_best); free(source); free(psi_new); free(tmp);
+    return rc;
+}
+
+int orc_free_boundary_solve(const orc_picard_params *p, double *psi, double *j_phi, int n_fb_coils,
+                            const double *fb_r, const double *fb_z, const double *fb_i,
+                            const double *fb_turns, int max_outer, double tol, double *final_diff,
+                            int *picard_iters, orc_picard_result *last) {
+    int nz = p->nz, nr = p->nr;
+    long n = (long)nz * nr;
+    double *r_axis = dalloc(nr), *z_axis = dalloc(nz), *psi_ext = dalloc(n), *psi_old = dalloc(n);
+    orc_linspace(p->r_min, p->r_max, nr, r_axis);
+    orc_linspace(p->z_min, p->z_max, nz, z_axis);
+    orc_external_flux(r_axis, z_axis, nz, nr, n_fb_coils, fb_r, fb_z, fb_i, fb_turns, psi_ext);
+    orc_picard_params q = *p;
+    q.preserve_initial_state = 1;
+    q.has_boundary_flux = 1;
+    double diff = INFINITY;
+    int outer = 0;
+    for (outer = 0; outer < max_outer; ++outer) {
+        apply_bc(psi, psi_ext, nz, nr);
+        memcpy(psi_old, psi, sizeof(double) * (size_t)n);
+        orc_picard_result r;
+        orc_picard_solve(&q, psi, psi_ext, j_phi, &r, NULL, -1);
+        if (picard_iters) picard_iters[outer] = r.iterations;
+        if (last) *last = r;
+        diff = 0.0;
+        for (long i = 0; i < n; ++i) {
+            double d = fabs(psi[i] - psi_old[i]);
+            if (isnan(d) || d > diff) diff = d;
+        }
+        if (diff < tol) { outer += 1; break; }
+    }
+    if (outer > max_outer) outer = max_outer;
+    *final_diff = diff;
+    free(r_axis); free(z_axis); free(psi_ext); free(psi_old);
+    return outer;
+}
+
+void orc_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int nr, int nz,
+                     double ip_target, double mu0, int n_picard, int n_jacobi, double alpha,
+                     double omega_j, double beta_mix, double *psi) {
+    long n = (long)nz * nr;
+    double *r_axis = dalloc(nr), *z_axis = dalloc(nz);
+    orc_linspace(r_min, r_max, nr, r_axis);
+    orc_linspace(z_min, z_max, nz, z_axis);
+    double dr = r_axis[1] - r_axis[0], dz = z_axis[1] - z_axis[0];
+    double r_center = 0.5 * (r_min + r_max);
+    for (int iz = 0; iz < nz; ++iz)
+        for (int ir = 0; ir < nr; ++ir) {
+            double a = r_axis[ir] - r_center;
+            psi[IDX(iz, ir)] = exp(-(a * a) / 0.5) * 0.01;
+        }
+    for (int ir = 0; ir < nr; ++ir) { psi[IDX(0, ir)] = 0.0; psi[IDX(nz - 1, ir)] = 0.0; }
+    for (int iz = 0; iz < nz; ++iz) { psi[IDX(iz, 0)] = 0.0; psi[IDX(iz, nr - 1)] = 0.0; }
+    double *source = dalloc(n), *pe = dalloc(n), *pn = dalloc(n), *jraw = dalloc(n);
+    double dr2 = dr * dr, dz2 = dz * dz;
+    double a_ns = 1.0 / dz2, a_c = 2.0 / dr2 + 2.0 / dz2;
+    for (int it = 0; it < n_picard; ++it) {
+        /* _compute_source_np, core/jax_gs_solver.py:89-123 */
+        double psi_axis = -INFINITY;
+        for (int iz = 1; iz < nz - 1; ++iz)
+            for (int ir = 1; ir < nr - 1; ++ir)
+                if (psi[IDX(iz, ir)] > psi_axis) psi_axis = psi[IDX(iz, ir)];
+        double denom = 0.0 - psi_axis;
+        if (fabs(denom) < 1e-9) denom = denom != 0 ? (denom > 0 ? 1e-9 : -1e-9) : 1e-9;
+        for (int iz = 0; iz < nz; ++iz)
+            for (int ir = 0; ir < nr; ++ir) {
+                double R = r_axis[ir];
+                double x = (psi[IDX(iz, ir)] - psi_axis) / denom;
+                x = fmin(fmax(x, 0.0), 1.0);
+                double prof = (x >= 0.0 && x < 1.0) ? 1.0 - x : 0.0;
+                double r_safe = fmax(R, 1e-10);
+                double j_p = R * prof;
+                double j_f = prof / (mu0 * r_safe);
+                jraw[IDX(iz, ir)] = beta_mix * j_p + (1.0 - beta_mix) * j_f;
+            }
+        double i_cur = (orc_np_sum(jraw, n) * dr) * dz;
+        double scale = ip_target / fmax(fabs(i_cur), 1e-9);
+        for (int iz = 0; iz < nz; ++iz)
+            for (int ir = 0; ir < nr; ++ir)
+                source[IDX(iz, ir)] = ((-mu0) * r_axis[ir]) * (jraw[IDX(iz, ir)] * scale);
+        memcpy(pe, psi, sizeof(double) * (size_t)n);
+        for (int jt = 0; jt < n_jacobi; ++jt) {
+            /* _jacobi_gs_step_np, core/jax_gs_solver.py:58-86 */
+            memcpy(pn, pe, sizeof(double) * (size_t)n);
+            for (int iz = 1; iz < nz - 1; ++iz)
+                for (int ir = 1; ir < nr - 1; ++ir) {
+                    double r_safe = fmax(r_axis[ir], 1e-10);
+                    double t = 1.0 / ((2.0 * r_safe) * dr);
+                    double a_e = 1.0 / dr2 - t, a_w = 1.0 / dr2 + t;
+                    double upd = (a_e * pe[IDX(iz, ir + 1)] + a_w * pe[IDX(iz, ir - 1)] +
+                                  a_ns * (pe[IDX(iz - 1, ir)] + pe[IDX(iz + 1, ir)]) -
+                                  source[IDX(iz, ir)]) /
+                                 a_c;
+                    pn[IDX(iz, ir)] = (1.0 - omega_j) * pe[IDX(iz, ir)] + omega_j * upd;
+                }
+            double *sw = pe; pe = pn; pn = sw;
+        }
+        for (long i = 0; i < n; ++i) psi[i] = (1.0 - alpha) * psi[i] + alpha * pe[i];
+    }
+    free(r_axis); free(z_axis); free(source); free(pe); free(pn); free(jraw);
+}
+
+double orc_fastsolver_sweeps(double *psi, const double *j, int nr, int nz, double r_min,
+                             double r_max, double z_min, double z_max, double boundary_value,
+                             double omega, int iterations, double tol, int *performed) {
+    /* hpc/solver.cpp:63-199: dr from the extent (not linspace), R = r_min + r*dr, mu = 1.0 */
+    double dr = (r_max - r_min) / (nr - 1), dz = (z_max - z_min) / (nz - 1);
+    double dr_sq = dr * dr, dz_sq = dz * dz;
+    double last = 0.0;
+    int done = 0;
+    for (int it = 0; it < iterations; ++it) {
+        for (int r = 0; r < nr; ++r) { psi[r] = boundary_value; psi[(long)(nz - 1) * nr + r] = boundary_value; }
+        for (int z = 0; z < nz; ++z) { psi[(long)z * nr] = boundary_value; psi[(long)z * nr + nr - 1] = boundary_value; }
+        double mx[2] = {0.0, 0.0};
+        for (int parity = 0; parity < 2; ++parity)
+            for (int z = 1; z < nz - 1; ++z)
+                for (int r = 1; r < nr - 1; ++r) {
+                    if (((z + r) % 2) != parity) continue;
+                    long idx = (long)z * nr + r;
+                    double R = r_min + r * dr;
+                    double source = -1.0 * R * j[idx];
+                    double c_rp = 1.0 / dr_sq - 1.0 / (2.0 * R * dr);
+                    double c_rm = 1.0 / dr_sq + 1.0 / (2.0 * R * dr);
+                    double c_z = 1.0 / dz_sq;
+                    double center = 2.0 / dr_sq + 2.0 / dz_sq;
+                    double p_gs = (source + c_z * (psi[idx + nr] + psi[idx - nr]) +
+                                   c_rp * psi[idx + 1] + c_rm * psi[idx - 1]) /
+                                  center;
+                    double old = psi[idx];
+                    double nw = (1.0 - omega) * old + omega * p_gs;
+                    psi[idx] = nw;
+                    double d = fabs(nw - old);
+                    if (d > mx[parity]) mx[parity] = d;
+                }
+        last = mx[0] > mx[1] ? mx[0] : mx[1];
+        done = it + 1;
+        if (tol >= 0.0 && last <= tol) break;
+    }
+    if (performed) *performed = done;
+    return last;
+}

@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes are plain
+input/expected-output arrays -- no reference source or bytecode is stored.  Re-run with
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Recorded alongside each file: numpy / scipy versions used.
+Reference functions exercised (file:line in the docstring of each block).
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+sys.dont_write_bytecode = True
+REF = Path("/root/reference")
+sys.path.insert(0, str(REF / "src"))
+sys.path.insert(0, str(REF))
+
+import numpy as np  # noqa: E402
+import scipy  # noqa: E402
+from scipy.special import ellipe, ellipk  # noqa: E402
+
+from scpn_fusion.core import multigrid_solve as mg  # noqa: E402
+from scpn_fusion.core.fusion_kernel import CoilSet, FusionKernel  # noqa: E402
+from scpn_fusion.core.fusion_kernel_free_boundary import (  # noqa: E402
+    compute_external_flux,
+    green_function,
+)
+from scpn_fusion.core.fusion_kernel_solver_runtime import compute_gs_residual_rms  # noqa: E402
+from scpn_fusion.core.jax_gs_solver import gs_solve_np  # noqa: E402
+from validation.benchmark_vs_freegs import TokamakCase, build_config  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+META = {"numpy": np.__version__, "scipy": scipy.__version__, "python": sys.version.split()[0]}
+
+
+def save(name, **arrs):
+    np.savez_compressed(OUT / name, _meta=json.dumps(META), **arrs)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrs.items()})
+
+
+def grid(nz, nr, r0=4.0, r1=8.0, z0=-4.0, z1=4.0):
+    r = np.linspace(r0, r1, nr)
+    z = np.linspace(z0, z1, nz)
+    rr, zz = np.meshgrid(r, z)
+    return r, z, rr, zz
+
+
+def bench_problem(nz, nr, seed=2026):
+    """benchmarks/bench_gpu_gs_solver.py:54-63 (generalised to nz != nr)."""
+    rng = np.random.default_rng(seed)
+    r, z, rr, zz = grid(nz, nr)
+    source = -np.exp(-((rr - 6.0) ** 2 + zz**2) / 0.5)
+    psi0 = rng.normal(0.0, 1e-3, size=(nz, nr))
+    psi0[0, :] = psi0[-1, :] = psi0[:, 0] = psi0[:, -1] = 0.0
+    return psi0, source, rr, r, z
+
+
+# ── (a) mg_smooth  core/multigrid_solve.py:148-208 ────────────────────────────
+def gen_smooth():
+    out = {}
+    cases = []
+    for (nz, nr) in [(17, 17), (33, 33), (20, 37), (16, 16)]:
+        psi0, source, rr, r, z = bench_problem(nz, nr)
+        dr = (8.0 - 4.0) / (nr - 1)
+        dz = (4.0 + 4.0) / (nz - 1)
+        out[f"psi0_{nz}x{nr}"] = psi0
+        out[f"src_{nz}x{nr}"] = source
+        for omega in (1.0, 1.3, 1.6):
+            for sweeps in (1, 2, 50):
+                res = mg.mg_smooth(psi0.copy(), source, rr, dr, dz, omega, sweeps)
+                key = f"out_{nz}x{nr}_w{omega}_s{sweeps}"
+                out[key] = res
+                cases.append([nz, nr, omega, sweeps])
+    out["cases"] = np.array(cases)
+    save("smooth.npz", **out)
+
+
+# ── (b) residual / restrict / prolong / vcycle  core/multigrid_solve.py:57-335 ─
+def gen_operators():
+    out = {}
+    shapes = [(17, 17), (33, 33), (65, 65), (16, 16), (128, 128), (65, 33), (20, 37), (6, 7), (5, 5), (9, 9)]
+    out["shapes"] = np.array(shapes)
+    rng = np.random.default_rng(7)
+    for (nz, nr) in shapes:
+        tag = f"{nz}x{nr}"
+        psi0, source, rr, r, z = bench_problem(nz, nr)
+        dr = float(r[1] - r[0])
+        dz = float(z[1] - z[0])
+        psi = psi0 + 0.01 * np.sin(rr) * np.cos(0.3 * zz_of(z, nr))
+        out[f"psi_{tag}"] = psi
+        out[f"src_{tag}"] = source
+        out[f"res_{tag}"] = mg.mg_residual(psi, source, rr, dr, dz)
+        out[f"linf_{tag}"] = np.array(mg.residual_linf(psi, source, rr, dr, dz))
+        f = rng.normal(size=(nz, nr))
+        out[f"fine_{tag}"] = f
+        c = mg.restrict_full_weight(f)
+        out[f"restrict_{tag}"] = c
+        out[f"restrict_r_{tag}"] = mg.restrict_full_weight(rr)
+        out[f"prolong_{tag}"] = mg.prolongate_bilinear(c, nz, nr)
+        if min(nz, nr) >= 5:
+            for omega in (1.0, 1.6):
+                out[f"vcycle_{tag}_w{omega}"] = mg.multigrid_vcycle(psi.copy(), source, rr, dr, dz, omega=omega)
+    save("operators.npz", **out)
+
+
+def zz_of(z, nr):
+    return np.repeat(z[:, None], nr, axis=1)
+
+
+# ── (c) multigrid_solve  core/multigrid_solve.py:352-463 ──────────────────────
+def gen_mgsolve():
+    out = {}
+    # tests/test_multigrid_solve.py:26-44 problem
+    for n in (33, 65):
+        r, z, rr, zz = grid(n, n, 1.2, 2.2, -0.5, 0.5)
+        source = -rr * np.exp(-((rr - 1.7) ** 2 + zz**2) / 0.05)
+        psi_bc = np.zeros((n, n))
+        psi, res, ncy, conv = mg.multigrid_solve(source, psi_bc, 1.2, 2.2, -0.5, 0.5, n, n, tol=1e-6)
+        out[f"gauss{n}_source"] = source
+        out[f"gauss{n}_psi"] = psi
+        out[f"gauss{n}_stats"] = np.array([res, ncy, float(conv)])
+    # Solov'ev gate  validation/validate_grad_shafranov_solovev.py:98-178,353-425
+    for n in (33, 65, 97):
+        r0, a = 1.7, 0.5
+        r_min, r_max, z_min, z_max = r0 - 1.5 * a, r0 + 1.5 * a, -1.5 * a, 1.5 * a
+        r, z, rr, zz = grid(n, n, r_min, r_max, z_min, z_max)
+        exact = rr**4 / 8.0 + 0.5 * zz**2
+        source = rr**2 + 1.0
+        psi_bc = np.zeros((n, n))
+        psi_bc[0, :], psi_bc[-1, :], psi_bc[:, 0], psi_bc[:, -1] = exact[0, :], exact[-1, :], exact[:, 0], exact[:, -1]
+        psi, res, ncy, conv = mg.multigrid_solve(source, psi_bc, r_min, r_max, z_min, z_max, n, n, tol=1e-9, max_cycles=200)
+        out[f"solovev{n}_extent"] = np.array([r_min, r_max, z_min, z_max])
+        out[f"solovev{n}_psi"] = psi
+        out[f"solovev{n}_stats"] = np.array([res, ncy, float(conv)])
+        if n == 65:
+            psi2, res2, ncy2, conv2 = mg.multigrid_solve(source, psi_bc, r_min, r_max, z_min, z_max, n, n, tol=1e-9,
+                                                        max_cycles=200, omega=1.6, pre_smooth=2, post_smooth=1)
+            out["solovev65_w16_psi"] = psi2
+            out["solovev65_w16_stats"] = np.array([res2, ncy2, float(conv2)])
+    save("mgsolve.npz", **out)
+
+
+# ── (d) gs_solve_np  core/jax_gs_solver.py:126-167; validation/polyglot/gs_picard_reference.toml ─
+def gen_polyglot():
+    kw = dict(R_min=1.0, R_max=3.0, Z_min=-1.2, Z_max=1.2, Ip_target=1.0e6, mu0=1.2566370614359173e-6,
+              n_picard=8, n_jacobi=16, alpha=0.1, omega_j=0.6666666666666666, beta_mix=0.5)
+    out = {}
+    for n in (17, 65):
+        out[f"psi{n}"] = gs_solve_np(NR=n, NZ=n, **kw)
+    out["params"] = np.array([kw[k] for k in ("R_min", "R_max", "Z_min", "Z_max", "Ip_target", "mu0", "n_picard",
+                                             "n_jacobi", "alpha", "omega_j", "beta_mix")])
+    save("polyglot.npz", **out)
+
+
+# ── configs ──────────────────────────────────────────────────────────────────
+def iter_cfg(n, method="multigrid", omega=1.0, tol=1e-8, max_iter=1000, alpha=0.12, hmode=False):
+    cfg = build_config(TokamakCase("ITER-like", 6.2, 2.0, 5.3, 15.0, 1.7, n, n))
+    cfg["solver"].update(solver_method=method, sor_omega=omega, convergence_threshold=tol, max_iterations=max_iter,
+                         relaxation_factor=alpha)
+    if hmode:
+        cfg["physics"]["profiles"] = {"mode": "h-mode", "p_prime": {"ped_top": 0.9}, "ff_prime": {"core_alpha": 0.25}}
+    return cfg
+
+
+def d3d_cfg(n, tol=1e-8, max_iter=1000):
+    cfg = json.loads((REF / "validation" / "diiid_config.json").read_text())
+    cfg.pop("_reference", None)
+    cfg["grid_resolution"] = [n, n]
+    cfg["solver"].update(solver_method="multigrid", sor_omega=1.0, convergence_threshold=tol, max_iterations=max_iter,
+                         relaxation_factor=0.12)
+    cfg["solver"].pop("fail_on_diverge", None)
+    return cfg
+
+
+def make_kernel(cfg):
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False, dir="/tmp") as f:
+        json.dump(cfg, f)
+        path = f.name
+    k = FusionKernel(path)
+    os.unlink(path)
+    assert not k.hpc.is_available()
+    return k
+
+
+def traced_solve(k, **kw):
+    """Run solve_equilibrium recording (psi_axis, psi_bnd) per iteration via the source-update hook."""
+    rec = []
+    orig = k.update_plasma_source_nonlinear
+
+    def hook(pa, pb):
+        rec.append((pa, pb))
+        return orig(pa, pb)
+
+    k.update_plasma_source_nonlinear = hook
+    res = k.solve_equilibrium(**kw)
+    k.update_plasma_source_nonlinear = orig
+    return res, np.array(rec)
+
+
+# ── (e) Picard  core/fusion_kernel_newton_solver.py:390-615 ───────────────────
+def gen_picard():
+    out = {}
+    cases = {
+        "iter33_mg_w10": iter_cfg(33),
+        "iter65_mg_w10": iter_cfg(65),
+        "iter33_mg_w16": iter_cfg(33, omega=1.6),
+        "iter33_sor": iter_cfg(33, method="sor", omega=1.6, tol=1e-4, max_iter=120),
+        "iter33_jacobi": iter_cfg(33, method="jacobi", tol=1e-4, max_iter=60),
+        "iter33_hmode": iter_cfg(33, hmode=True),
+        "d3d33_mg": d3d_cfg(33),
+        "iter32_even_mg": iter_cfg(32, tol=1e-6),
+    }
+    cfgs = {}
+    for name, cfg in cases.items():
+        k = make_kernel(cfg)
+        res, rec = traced_solve(k)
+        cfgs[name] = cfg
+        out[f"{name}_psi"] = res["psi"]
+        out[f"{name}_jphi"] = k.J_phi
+        out[f"{name}_axis_bnd"] = rec
+        out[f"{name}_diff"] = np.array(res["residual_history"])
+        out[f"{name}_gs"] = np.array(res["gs_residual_history"])
+        out[f"{name}_stats"] = np.array([float(res["converged"]), res["iterations"], res["residual"], res["gs_residual"],
+                                         res["gs_residual_best"]])
+        print(name, res["iterations"], res["converged"], res["residual"])
+    out["_configs"] = np.array(json.dumps(cfgs))
+    save("picard.npz", **out)
+
+
+# ── (j,k) unit pieces: axis / x-point / source / jacobi / sor ────────────────
+def gen_pieces():
+    out = {}
+    cfg = iter_cfg(33, max_iter=12, tol=1e-12)
+    k = make_kernel(cfg)
+    k.solve_equilibrium()
+    psi = k.Psi.copy()
+    out["psi"] = psi
+    iz, ir, pa = k._find_magnetic_axis()
+    (rx, zx), px = k.find_x_point(psi)
+    out["axis"] = np.array([iz, ir, pa])
+    out["xpoint"] = np.array([rx, zx, px])
+    j = k.update_plasma_source_nonlinear(pa, px).copy()
+    out["jphi_lmode"] = j
+    k.profile_mode = "h-mode"
+    k.ped_params_p.update({"ped_top": 0.9})
+    out["jphi_hmode"] = k.update_plasma_source_nonlinear(pa, px).copy()
+    src = -1.0 * k.RR * j
+    out["source"] = src
+    out["jacobi"] = k._jacobi_step(psi, src)
+    out["sor_w16"] = k._sor_step(psi, src, omega=1.6)
+    out["gs_rms"] = np.array(compute_gs_residual_rms(k, src))
+    out["dims"] = np.array([k.R[0], k.R[-1], k.Z[0], k.Z[-1], k.dR, k.dZ, cfg["dimensions"]["Z_min"]])
+    # x-point fallback (Z_min >= 0 -> empty mask) is a host-logic path, tested without a fixture
+    save("pieces.npz", **out)
+
+
+# ── (f) Green's functions  core/fusion_kernel.py:218-251; core/fusion_kernel_free_boundary.py:31-93 ─
+def gen_green():
+    out = {}
+    m = np.concatenate([np.array([1e-12, 1e-9, 1e-6, 1e-3, 0.01]), np.linspace(0.05, 0.95, 19),
+                        1.0 - np.array([1e-2, 1e-3, 1e-6, 1e-9, 1e-12])])
+    out["m"] = m
+    out["ellipk"] = ellipk(m)
+    out["ellipe"] = ellipe(m)
+    cfg = iter_cfg(33)
+    k = make_kernel(cfg)
+    out["vacuum33"] = k.calculate_vacuum_field()
+    coils = CoilSet(positions=[(c["r"], c["z"]) for c in cfg["coils"]],
+                    currents=np.array([c["current"] for c in cfg["coils"]], dtype=float), turns=[1, 2, 3, 1, 10])
+    out["ext33"] = compute_external_flux(k, coils)
+    out["coils"] = np.array([[c["r"], c["z"], c["current"]] for c in cfg["coils"]])
+    out["turns"] = np.array(coils.turns, dtype=float)
+    pts = np.array([[9.2, 4.08, 6.2, 0.0], [9.2, 4.08, 9.2, 4.08], [2.25, 0.0, 10.2, -6.8], [5.2, 4.488, 5.3, 4.4],
+                    [0.42, 0.0, 0.8, 1.8]])
+    out["green_pts"] = pts
+    out["green_vals"] = np.array([green_function(*p) for p in pts])
+    kd = make_kernel(d3d_cfg(33))
+    out["vacuum33_d3d"] = kd.calculate_vacuum_field()
+    save("green.npz", **out)
+
+
+# ── (h) free boundary  core/fusion_kernel_free_boundary.py:623-739 ────────────
+def gen_free_boundary():
+    out = {}
+    cfgs = {}
+    for name, cfg in {"iter33": iter_cfg(33), "d3d33": d3d_cfg(33), "iter65": iter_cfg(65)}.items():
+        k = make_kernel(cfg)
+        its = []
+        orig = k.solve_equilibrium
+
+        def wrapped(**kw):
+            r = orig(**kw)
+            its.append(r["iterations"])
+            return r
+
+        k.solve_equilibrium = wrapped
+        coils = CoilSet(positions=[(c["r"], c["z"]) for c in cfg["coils"]],
+                        currents=np.array([c["current"] for c in cfg["coils"]], dtype=float), turns=[1] * len(cfg["coils"]))
+        r = k.solve_free_boundary(coils, max_outer_iter=20, tol=1e-4, optimize_shape=False)
+        cfgs[name] = cfg
+        out[f"{name}_psi"] = k.Psi
+        out[f"{name}_stats"] = np.array([r["outer_iterations"], r["final_diff"]] + its, dtype=float)
+        print(name, r["outer_iterations"], r["final_diff"], its)
+    out["_configs"] = np.array(json.dumps(cfgs))
+    save("free_boundary.npz", **out)
+
+
+# ── (g) compiled hpc/solver.cpp through oracle/_ref  hpc/solver.cpp:200-335 ──
+def gen_fastsolver():
+    sys.path.insert(0, str(OUT.parents[1]))
+    from oracle.oracle import RefFastSolver
+
+    out = {}
+    nr, nz = 33, 29
+    rng = np.random.default_rng(11)
+    j = rng.normal(size=(nz, nr))
+    s = RefFastSolver(nr, nz, 1.0, 3.0, -1.5, 1.5)
+    out["j"] = j
+    out["extent"] = np.array([1.0, 3.0, -1.5, 1.5])
+    out["run50_a"] = s.run_step(j, 50)
+    out["run50_b"] = s.run_step(j, 50)  # warm state persists in the handle
+    s.set_boundary(0.25)
+    out["run7_bc"] = s.run_step(j, 7)
+    psi, n, fd = s.run_step_converged(j, 500, 1.5, 1e-9)
+    out["conv_psi"] = psi
+    out["conv_stats"] = np.array([n, fd])
+    s.close()
+    save("fastsolver.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["smooth", "operators", "mgsolve", "polyglot", "picard", "pieces", "green",
+                             "free_boundary", "fastsolver"]
+    for w in which:
+        globals()[f"gen_{w}"]()

@@ -1,0 +1,208 @@
+"""CPU: the oracle (oracle/gs_oracle.c) against the golden vectors generated from the reference.
+
+Bit-exact (array_equal) for the linear elliptic operators whose operation order is
+deterministic; tight tolerances where libm / reduction details enter.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests._problems import bench_problem, configs_from, grid, operator_problem
+
+
+def test_np_sum_is_numpy_pairwise():
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 8, 9, 127, 128, 129, 1000, 4225, 66049, 263169):
+        a = rng.normal(size=n) * 10.0 ** rng.integers(-3, 3, size=n)
+        assert orc.np_sum(a) == float(np.sum(a)), n
+    a2 = rng.normal(size=(65, 65))
+    assert orc.np_sum(a2) == float(np.sum(a2))
+    assert orc.np_sum(np.abs(a2)) / a2.size == float(np.mean(np.abs(a2)))
+
+
+def test_linspace_matches_numpy():
+    for (a, b, n) in [(4.0, 8.0, 513), (0.8, 2.6, 65), (-6.8, 6.8, 257), (2.2, 10.2, 129), (1.0, 3.0, 17)]:
+        assert np.array_equal(orc.linspace(a, b, n), np.linspace(a, b, n))
+
+
+def test_smooth_bit_exact(golden):
+    g = golden("smooth.npz")
+    for nz, nr, omega, sweeps in g["cases"]:
+        nz, nr, sweeps = int(nz), int(nr), int(sweeps)
+        psi0, source, rr, r, z = bench_problem(nz, nr)
+        assert np.array_equal(psi0, g[f"psi0_{nz}x{nr}"])
+        dr, dz = 4.0 / (nr - 1), 8.0 / (nz - 1)
+        out = orc.mg_smooth(psi0, source, rr, dr, dz, omega, sweeps)
+        assert np.array_equal(out, g[f"out_{nz}x{nr}_w{omega}_s{sweeps}"]), (nz, nr, omega, sweeps)
+
+
+def test_smooth_rejects_bad_omega():
+    psi0, source, rr, r, z = bench_problem(9, 9)
+    for w in (0.99, 2.0, float("nan"), float("inf")):
+        with pytest.raises(ValueError):
+            orc.mg_smooth(psi0, source, rr, 0.5, 1.0, w, 1)
+
+
+def test_operators_bit_exact(golden):
+    g = golden("operators.npz")
+    for nz, nr in g["shapes"]:
+        nz, nr = int(nz), int(nr)
+        tag = f"{nz}x{nr}"
+        psi, source, rr, dr, dz = operator_problem(nz, nr)
+        assert np.array_equal(psi, g[f"psi_{tag}"])
+        assert np.array_equal(orc.mg_residual(psi, source, rr, dr, dz), g[f"res_{tag}"]), tag
+        assert orc.residual_linf(psi, source, rr, dr, dz) == float(g[f"linf_{tag}"])
+        fine = g[f"fine_{tag}"]
+        c = orc.restrict_full_weight(fine)
+        assert np.array_equal(c, g[f"restrict_{tag}"]), tag
+        assert np.array_equal(orc.restrict_full_weight(rr), g[f"restrict_r_{tag}"]), tag
+        assert np.array_equal(orc.prolongate_bilinear(c, nz, nr), g[f"prolong_{tag}"]), tag
+        if min(nz, nr) >= 5:
+            for omega in (1.0, 1.6):
+                v = orc.multigrid_vcycle(psi, source, rr, dr, dz, omega=omega)
+                assert np.array_equal(v, g[f"vcycle_{tag}_w{omega}"]), (tag, omega)
+
+
+def test_multigrid_solve_bit_exact(golden):
+    g = golden("mgsolve.npz")
+    for n in (33, 65):
+        psi, res, ncy, conv = orc.multigrid_solve(g[f"gauss{n}_source"], np.zeros((n, n)), 1.2, 2.2, -0.5, 0.5, n, n, tol=1e-6)
+        assert np.array_equal(psi, g[f"gauss{n}_psi"])
+        assert [res, ncy, float(conv)] == list(g[f"gauss{n}_stats"])
+        assert ncy < 50 and conv  # tests/test_multigrid_solve.py:35-44 of the reference
+    for n in (33, 65, 97):
+        r_min, r_max, z_min, z_max = g[f"solovev{n}_extent"]
+        r, z, rr, zz = grid(n, n, r_min, r_max, z_min, z_max)
+        exact = rr**4 / 8.0 + 0.5 * zz**2
+        source = rr**2 + 1.0
+        bc = np.zeros((n, n))
+        bc[0, :], bc[-1, :], bc[:, 0], bc[:, -1] = exact[0, :], exact[-1, :], exact[:, 0], exact[:, -1]
+        psi, res, ncy, conv = orc.multigrid_solve(source, bc, r_min, r_max, z_min, z_max, n, n, tol=1e-9, max_cycles=200)
+        assert np.array_equal(psi, g[f"solovev{n}_psi"]), n
+        assert [res, ncy, float(conv)] == list(g[f"solovev{n}_stats"])
+        # Dirichlet ring preserved exactly
+        assert np.array_equal(psi[0], bc[0]) and np.array_equal(psi[:, -1], bc[:, -1])
+        if n == 65:
+            psi2, res2, ncy2, conv2 = orc.multigrid_solve(source, bc, r_min, r_max, z_min, z_max, n, n, tol=1e-9,
+                                                          max_cycles=200, omega=1.6, pre_smooth=2, post_smooth=1)
+            assert np.array_equal(psi2, g["solovev65_w16_psi"])
+            assert [res2, ncy2, float(conv2)] == list(g["solovev65_w16_stats"])
+        if n == 97:  # published gate: NRMSE 1.1939e-6, 9 cycles (validation/reports/grad_shafranov_solovev.json:23-31)
+            inner = (psi - exact)[1:-1, 1:-1]
+            nrmse = np.sqrt(np.mean(inner**2)) / (exact.max() - exact.min())
+            assert ncy == 9 and abs(nrmse - 1.1939e-6) < 1e-9
+
+
+def test_multigrid_solve_rejects_bad_args():
+    src = np.zeros((9, 9))
+    for kw in (dict(tol=0.0), dict(tol=float("nan")), dict(max_cycles=0)):
+        with pytest.raises(ValueError):
+            orc.multigrid_solve(src, src, 1.0, 2.0, -1.0, 1.0, 9, 9, **kw)
+    with pytest.raises(ValueError):
+        orc.multigrid_solve(src, src, 1.0, 2.0, -1.0, 1.0, 9, 8)
+
+
+def test_polyglot_lane(golden):
+    g = golden("polyglot.npz")
+    p = g["params"]
+    for n in (17, 65):
+        psi = orc.gs_solve_np(p[0], p[1], p[2], p[3], n, n, p[4], p[5], int(p[6]), int(p[7]), p[8], p[9], p[10])
+        np.testing.assert_allclose(psi, g[f"psi{n}"], rtol=2e-14, atol=0)
+    # published golden: validation/reports/polyglot_gs_solver_comparison.json:117
+    psi17 = orc.gs_solve_np(p[0], p[1], p[2], p[3], 17, 17, p[4], p[5], int(p[6]), int(p[7]), p[8], p[9], p[10])
+    assert abs(psi17.max() - 0.042651828900105285) < 1e-15
+
+
+def test_pieces(golden):
+    g = golden("pieces.npz")
+    psi = g["psi"]
+    r0, r1, z0, z1, dr, dz, zmin_cfg = g["dims"]
+    r, z = np.linspace(r0, r1, psi.shape[1]), np.linspace(z0, z1, psi.shape[0])
+    iz, ir, pa = orc.find_axis(psi)
+    assert [iz, ir, pa] == list(g["axis"])
+    idx, px = orc.find_x_point(psi, z, dr, dz, zmin_cfg)
+    xiz, xir = divmod(idx, psi.shape[1])
+    assert [r[xir], z[xiz], px] == list(g["xpoint"])
+    j, _ = orc.update_source(psi, r, dr, dz, pa, px, 1.0, 15.0)
+    assert np.array_equal(j, g["jphi_lmode"])
+    jh, _ = orc.update_source(psi, r, dr, dz, pa, px, 1.0, 15.0, hmode=True, ped_p=(0.9, 0.05, 1.0, 0.3))
+    np.testing.assert_allclose(jh, g["jphi_hmode"], rtol=1e-14, atol=0)
+    rr = np.repeat(r[None, :], psi.shape[0], axis=0)
+    assert np.array_equal(orc.jacobi_step(psi, g["source"], rr, dr, dz), g["jacobi"])
+    assert np.array_equal(orc.sor_step(psi, g["source"], rr, dr, dz, 1.6), g["sor_w16"])
+    assert orc.gs_residual_rms(psi, g["source"], rr, dr, dz) == pytest.approx(float(g["gs_rms"]), rel=1e-15)
+
+
+def test_xpoint_fallback_when_mask_empty():
+    psi = np.arange(25, dtype=float).reshape(5, 5)
+    idx, px = orc.find_x_point(psi, np.linspace(0.5, 1.5, 5), 0.1, 0.1, 0.5)
+    assert idx == -1 and px == 0.0
+
+
+def test_green(golden):
+    g = golden("green.npz")
+    for m, k, e in zip(g["m"], g["ellipk"], g["ellipe"]):
+        K, E = orc.ellip_ke(m)
+        assert abs(K - k) <= 4e-15 * abs(k) and abs(E - e) <= 4e-15 * abs(e), m
+    co = g["coils"]
+    r, z = np.linspace(2.2, 10.2, 33), np.linspace(-6.8, 6.8, 33)
+    vac = orc.vacuum_field(r, z, co[:, 0], co[:, 1], co[:, 2], 1.0)
+    np.testing.assert_allclose(vac, g["vacuum33"], rtol=1e-12, atol=1e-14)
+    ext = orc.external_flux(r, z, co[:, 0], co[:, 1], co[:, 2], g["turns"])
+    np.testing.assert_allclose(ext, g["ext33"], rtol=1e-12, atol=1e-20)
+    for p, v in zip(g["green_pts"], g["green_vals"]):
+        assert orc.green_function(*p) == pytest.approx(v, rel=1e-12, abs=1e-22)
+    assert orc.green_function(9.2, 4.08, 9.2, 4.08) == 0.0
+    assert np.isnan(orc.green_function(-1.0, 0.0, 1.0, 0.0))
+
+
+@pytest.mark.parametrize("name", ["iter33_mg_w10", "iter65_mg_w10", "iter33_mg_w16", "iter33_sor", "iter33_jacobi",
+                                  "iter33_hmode", "d3d33_mg", "iter32_even_mg"])
+def test_picard_trace(golden, name):
+    g = golden("picard.npz")
+    cfg = configs_from(g)[name]
+    out = orc.picard_solve(cfg, trace=True)
+    conv, its, resid, gs, gs_best = g[f"{name}_stats"]
+    assert out["iterations"] == int(its) and out["converged"] == bool(conv)
+    tr = out["trace"]
+    np.testing.assert_allclose(tr[:, 0:2], g[f"{name}_axis_bnd"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(tr[:, 4], g[f"{name}_diff"], rtol=1e-7, atol=1e-16)
+    np.testing.assert_allclose(tr[:, 5], g[f"{name}_gs"], rtol=1e-6, atol=1e-14)
+    scale = np.abs(g[f"{name}_psi"]).max()
+    assert np.abs(out["psi"] - g[f"{name}_psi"]).max() <= 1e-12 * scale
+    np.testing.assert_allclose(out["j_phi"], g[f"{name}_jphi"], rtol=1e-10, atol=1e-13 * np.abs(g[f"{name}_jphi"]).max())
+    assert out["residual"] == pytest.approx(resid, rel=1e-6)
+
+
+@pytest.mark.parametrize("name", ["iter33", "d3d33", "iter65"])
+def test_free_boundary(golden, name):
+    g = golden("free_boundary.npz")
+    cfg = configs_from(g)[name]
+    co = cfg["coils"]
+    out = orc.free_boundary_solve(cfg, [c["r"] for c in co], [c["z"] for c in co], [c["current"] for c in co],
+                                  [1.0] * len(co))
+    st = g[f"{name}_stats"]
+    assert out["outer_iterations"] == int(st[0])
+    assert out["picard_iterations"] == [int(v) for v in st[2:]]
+    scale = np.abs(g[f"{name}_psi"]).max()
+    assert np.abs(out["psi"] - g[f"{name}_psi"]).max() <= 1e-12 * scale
+
+
+def test_fastsolver_restatement_matches_compiled_reference(golden):
+    g = golden("fastsolver.npz")
+    j = g["j"]
+    nz, nr = j.shape
+    ext = g["extent"]
+    psi = np.zeros((nz, nr))
+    psi, _, _ = orc.fastsolver_sweeps(psi, j, nr, nz, *ext, 0.0, 1.8, 50)
+    assert np.array_equal(psi, g["run50_a"])
+    psi, _, _ = orc.fastsolver_sweeps(psi, j, nr, nz, *ext, 0.0, 1.8, 50)
+    assert np.array_equal(psi, g["run50_b"])
+    psi, _, _ = orc.fastsolver_sweeps(psi, j, nr, nz, *ext, 0.25, 1.8, 7)
+    assert np.array_equal(psi, g["run7_bc"])
+    psi, last, done = orc.fastsolver_sweeps(psi, j, nr, nz, *ext, 0.25, 1.5, 500, tol=1e-9)
+    assert np.array_equal(psi, g["conv_psi"]) and [done, last] == list(g["conv_stats"])
+    if orc.RefFastSolver.available():  # live cross-check against oracle/_ref (the real solver.cpp)
+        s = orc.RefFastSolver(nr, nz, *ext)
+        assert np.array_equal(s.run_step(j, 50), g["run50_a"])
+        s.close()
