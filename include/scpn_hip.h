@@ -1,0 +1,211 @@
+/*
+ * scpn_hip.h -- C ABI of libscpn_hip.so, the MI355X (gfx950) Grad-Shafranov hot path.
+ *
+ * Plain C: pointers and sizes only, no torch / no C++ types.  Every field is C-contiguous
+ * float64 of shape (nz, nr), index [iz*nr + ir] (Z slow, R fast) -- the reference layout
+ * (core/fusion_kernel.py:163-174).  "batch" functions take `batch` such fields back to back.
+ * All host pointers are borrowed for the duration of the call; every call is synchronous
+ * (returns after results are copied out).  A handle must not be shared between threads;
+ * distinct handles are independent.
+ *
+ * Three groups:
+ *   1. the six legacy symbols of the reference's libscpn_solver.so (hpc/solver.cpp:200-335,
+ *      bound by hpc/hpc_bridge.py:190-250) with identical semantics;
+ *   2. the elliptic operator library: device counterparts of the free functions of
+ *      core/multigrid_solve.py:57-463 (what _multi_compat.dispatch("multigrid_solve") /
+ *      ("gs_rb_sor_smooth") providers call, core/_multi_compat_providers.py:322-375,720-792);
+ *   3. the resident ensemble solver: Picard / free-boundary solve of `batch` independent
+ *      equilibria entirely on the device (core/fusion_kernel_newton_solver.py:390-615,
+ *      core/fusion_kernel_free_boundary.py:623-739).
+ *
+ * Return codes (groups 2, 3): 0 ok; <0 error, see SCPN_E_*.  scpn_last_error() gives text.
+ */
+#ifndef SCPN_HIP_H
+#define SCPN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCPN_OK 0
+#define SCPN_E_ARG (-1)     /* invalid argument (the reference raises ValueError) */
+#define SCPN_E_DEVICE (-2)  /* no usable HIP device / HIP runtime error */
+#define SCPN_E_DIVERGED (-3)
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Legacy libscpn_solver ABI  (replaces hpc/solver.cpp:205-333)
+ * ---------------------------------------------------------------------------------------- */
+/* solver.cpp:205-222: NULL when nr<2 || nz<2 || rmin>=rmax || zmin>=zmax (or no device) */
+void *create_solver(int nr, int nz, double rmin, double rmax, double zmin, double zmax);
+/* solver.cpp:227-234: constant Dirichlet value forced on all four edges every sweep */
+void set_boundary_dirichlet(void *solver, double boundary_value);
+/* solver.cpp:243-268: input is J_phi; source = -1.0*R*J; `iterations` (>=1) red-black SOR sweeps
+ * at omega=1.8 on the psi state kept inside the handle; silent no-op on NULL / size mismatch */
+void run_step(void *solver, const double *j_array, double *psi_array, int size, int iterations);
+/* solver.cpp:273-321: sweeps until max|dpsi| <= tolerance; omega clamped to [0.1,1.99];
+ * returns sweeps executed (0 on invalid input) */
+int run_step_converged(void *solver, const double *j_array, double *psi_array, int size,
+                       int max_iterations, double omega, double tolerance, double *final_delta_out);
+/* solver.cpp:325-333 */
+void destroy_solver(void *solver);
+void delete_solver(void *solver);
+
+/* ------------------------------------------------------------------------------------------
+ * Device probes (replace scpn_fusion_rs.py_gpu_available / py_gpu_info,
+ * scpn-fusion-rs/crates/fusion-python/src/bindings/gpu.rs:82-90)
+ * ---------------------------------------------------------------------------------------- */
+int scpn_device_count(void);                /* number of HIP devices, 0 if none / no runtime */
+int scpn_device_info(char *buf, int buflen); /* "name | gfx arch | CUs | HBM GiB"; SCPN_E_DEVICE if none */
+int scpn_set_device(int device);            /* select the device used by subsequently created handles */
+const char *scpn_last_error(void);
+const char *scpn_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Elliptic operator library (host buffers in, host buffers out; `batch` fields per call)
+ *    r_axis[nr] is the 1-D R coordinate of the columns (the reference passes the 2-D meshgrid
+ *    of it; only R(ir) enters the stencil).
+ * ---------------------------------------------------------------------------------------- */
+/* core/multigrid_solve.py:148-208 mg_smooth: n_sweeps red-black SOR sweeps, in place.
+ * SCPN_E_ARG unless 1 <= omega < 2 (multigrid_solve.py:33-54) */
+int scpn_mg_smooth(double *psi, const double *source, const double *r_axis, int nz, int nr,
+                   int batch, double dr, double dz, double omega, int n_sweeps);
+/* core/multigrid_solve.py:211-249 mg_residual: out = L*psi - source, zero ring */
+int scpn_mg_residual(const double *psi, const double *source, const double *r_axis, int nz, int nr,
+                     int batch, double dr, double dz, double *out);
+/* core/multigrid_solve.py:338-349 residual_linf -> linf[batch] */
+int scpn_residual_linf(const double *psi, const double *source, const double *r_axis, int nz,
+                       int nr, int batch, double dr, double dz, double *linf);
+/* core/fusion_kernel_solver_runtime.py:45-51 compute_gs_residual_rms -> rms[batch] */
+int scpn_gs_residual_rms(const double *psi, const double *source, const double *r_axis, int nz,
+                         int nr, int batch, double dr, double dz, double *rms);
+/* core/multigrid_solve.py:57-99 restrict_full_weight: coarse is ((nz_f+1)/2, (nr_f+1)/2) */
+int scpn_restrict_full_weight(const double *fine, int nz_f, int nr_f, int batch, double *coarse);
+/* core/multigrid_solve.py:102-145 prolongate_bilinear (nz_c == (nz_f+1)/2 and nr_c == (nr_f+1)/2) */
+int scpn_prolongate_bilinear(const double *coarse, int nz_c, int nr_c, int nz_f, int nr_f,
+                             int batch, double *fine);
+/* core/multigrid_solve.py:252-335 multigrid_vcycle: psi replaced by the improved estimate */
+int scpn_multigrid_vcycle(double *psi, const double *source, const double *r_axis, int nz, int nr,
+                          int batch, double dr, double dz, double omega, int pre_smooth,
+                          int post_smooth, int min_grid);
+/* core/multigrid_solve.py:352-463 multigrid_solve.  psi: in = psi_bc (Dirichlet ring + initial
+ * interior), out = solution.  r_axis/z_axis = numpy.linspace of the extent (host side).
+ * residual/n_cycles/converged: [batch].  SCPN_E_ARG on tol<=0 / non-finite, max_cycles<1, omega */
+int scpn_multigrid_solve(const double *source, double *psi, const double *r_axis,
+                         const double *z_axis, int nr, int nz, int batch, double tol, int max_cycles,
+                         double omega, int pre_smooth, int post_smooth, int min_grid,
+                         double *residual, int *n_cycles, int *converged);
+/* core/fusion_kernel_iterative_solver.py:54-95 _jacobi_step / :97-161 _sor_step (sanitize+clip) */
+int scpn_jacobi_step(const double *psi, const double *source, const double *r_axis, int nz, int nr,
+                     int batch, double dr, double dz, double *out);
+int scpn_sor_step(const double *psi, const double *source, const double *r_axis, int nz, int nr,
+                  int batch, double dr, double dz, double omega, double *out);
+/* Coil Green's-function flux on the grid, sum over coils of  scale*I_c*turns_c*G(coil; R,Z).
+ * mode 0: core/fusion_kernel.py:218-251 calculate_vacuum_field (mu0 = `mu0`, turns ignored)
+ * mode 1: core/fusion_kernel_free_boundary.py:58-93 compute_external_flux (SI mu0, x turns,
+ *         self-point -> 0).  coil arrays are [batch][n_coils]; out is [batch][nz][nr]. */
+int scpn_coil_flux(const double *r_axis, const double *z_axis, int nz, int nr, int batch,
+                   int n_coils, const double *coil_r, const double *coil_z, const double *coil_i,
+                   const double *coil_turns, double mu0, int mode, double *out);
+/* core/fusion_kernel_free_boundary.py:31-55,137-153 green_function at arbitrary points (SI mu0):
+ * out[c*n_pts + p] = G(coil c -> point p); NaN where the reference raises ValueError */
+int scpn_green_points(int n_coils, const double *coil_r, const double *coil_z, int n_pts,
+                      const double *pts_r, const double *pts_z, double *out);
+/* core/jax_gs_solver.py:126-167 gs_solve_np (polyglot Picard + damped-Jacobi lane), batch=1 */
+int scpn_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int nr, int nz,
+                     const double *r_axis, const double *z_axis, const double *psi_seed,
+                     double ip_target, double mu0, int n_picard, int n_jacobi, double alpha,
+                     double omega_j, double beta_mix, double *psi_out);
+
+/* ------------------------------------------------------------------------------------------
+ * 3. Resident ensemble solver
+ * ---------------------------------------------------------------------------------------- */
+typedef struct scpn_gs scpn_gs;
+
+typedef struct scpn_picard_params {
+    double z_min_cfg;    /* cfg["dimensions"]["Z_min"]  (X-point mask, core/fusion_kernel.py:279) */
+    double r_center;     /* (R_min + R_max)/2 of the config (seed, iterative_solver.py:400) */
+    double mu0;          /* physics.vacuum_permeability */
+    int method;          /* 0 multigrid (one V-cycle / iteration), 1 sor, 2 jacobi */
+    double sor_omega;    /* solver.sor_omega */
+    double alpha;        /* solver.relaxation_factor */
+    double tol;          /* solver.convergence_threshold */
+    int max_iter;        /* solver.max_iterations */
+    int require_gs_residual;
+    double gs_tol;
+    int hmode;           /* physics.profiles.mode == h-mode */
+    double ped_p[4];     /* ped_top, ped_width, ped_height, core_alpha */
+    double ped_ff[4];
+    int preserve_initial_state;
+    int has_boundary_flux; /* use the field set by scpn_gs_set_boundary_flux as Dirichlet map */
+    int external_profile_mode;
+    int check_every;     /* host polls the device convergence word every this many iterations (>=1) */
+    int fail_on_diverge;
+    int skip_seed;       /* 1: do not run _seed_plasma (not a reference behaviour; benchmarking aid) */
+} scpn_picard_params;
+
+typedef struct scpn_picard_result {
+    int converged;
+    int iterations;
+    int diverged;
+    int reserved;
+    double residual;         /* best mean|dpsi| */
+    double gs_residual;      /* last GS RMS */
+    double gs_residual_best;
+    double psi_axis, psi_bnd; /* last topology step */
+    double x_r, x_z;          /* last X-point position */
+    double i_current;         /* last unnormalised current integral */
+} scpn_picard_result;
+
+/* grid: r_axis[nr], z_axis[nz] (numpy.linspace of the config extent), dr = R[1]-R[0], dz likewise */
+int scpn_gs_create(scpn_gs **out, int nr, int nz, int batch, const double *r_axis,
+                   const double *z_axis, double dr, double dz);
+void scpn_gs_destroy(scpn_gs *h);
+/* member = -1 addresses all members (buffer then holds `batch` fields) */
+int scpn_gs_set_psi(scpn_gs *h, int member, const double *psi);
+int scpn_gs_get_psi(scpn_gs *h, int member, double *psi);
+int scpn_gs_get_jphi(scpn_gs *h, int member, double *jphi);
+int scpn_gs_set_jphi(scpn_gs *h, int member, const double *jphi);
+int scpn_gs_get_source(scpn_gs *h, int member, double *source);
+int scpn_gs_set_boundary_flux(scpn_gs *h, int member, const double *psi_bc);
+int scpn_gs_get_boundary_flux(scpn_gs *h, int member, double *psi_bc);
+/* per-member plasma current target (physics.plasma_current_target); member=-1: i_target[batch] */
+int scpn_gs_set_current_target(scpn_gs *h, int member, const double *i_target);
+/* cfg["coils"] of each member for calculate_vacuum_field: arrays [batch][n_coils] */
+int scpn_gs_set_vacuum_coils(scpn_gs *h, int n_coils, const double *coil_r, const double *coil_z,
+                             const double *coil_i);
+/* optional host-computed Gaussian seed J (shape (nz,nr), before normalisation); NULL = computed
+ * inside with libm exp (core/fusion_kernel_iterative_solver.py:400-402) */
+int scpn_gs_set_seed(scpn_gs *h, const double *seed_j);
+
+/* core/fusion_kernel_newton_solver.py:390-615 on all members; results[batch].
+ * histories (may be NULL): [batch][max_iter] residual_history / gs_residual_history,
+ * trace (may be NULL): [batch][max_iter][6] = psi_axis, psi_bnd, x_idx, I_current, diff, gs */
+int scpn_gs_picard_solve(scpn_gs *h, const scpn_picard_params *p, scpn_picard_result *results,
+                         double *residual_history, double *gs_history, double *trace);
+
+/* core/fusion_kernel_free_boundary.py:623-739 with optimize_shape=False: coil arrays [batch][n];
+ * outer_iterations[batch], final_diff[batch], picard_iters [batch][max_outer] (may be NULL) */
+int scpn_gs_free_boundary_solve(scpn_gs *h, const scpn_picard_params *p, int n_coils,
+                                const double *coil_r, const double *coil_z, const double *coil_i,
+                                const double *coil_turns, int max_outer, double tol,
+                                int *outer_iterations, double *final_diff, int *picard_iters,
+                                scpn_picard_result *results);
+
+/* resident smoother / V-cycle on the handle state (psi, source): the zero-copy path the
+ * smoother benchmark's roofline figure is taken on */
+int scpn_gs_set_source(scpn_gs *h, int member, const double *source);
+int scpn_gs_rb_sor(scpn_gs *h, double omega, int n_sweeps);
+int scpn_gs_vcycle(scpn_gs *h, double omega, int pre_smooth, int post_smooth, int min_grid);
+/* post-solve products core/fusion_kernel.py:450-456 compute_b_field */
+int scpn_gs_compute_b_field(scpn_gs *h, int member, double *b_r, double *b_z);
+
+/* timing hooks for bench.py: average device time (ms) of the named kernel family since the last
+ * reset, measured with hipEvents on the handle's stream when profiling is enabled */
+int scpn_gs_profile(scpn_gs *h, int enable);
+int scpn_gs_profile_read(scpn_gs *h, const char *name, double *total_ms, long *launches);
+int scpn_gs_sync(scpn_gs *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

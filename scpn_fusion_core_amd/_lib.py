@@ -1,0 +1,199 @@
+"""ctypes binding of libscpn_hip.so (include/scpn_hip.h).  No PyTorch, no fallback.
+
+The product path is HIP-only: if the shared library is missing or no MI355X is visible every
+operator raises :class:`HipUnavailableError` -- nothing is ever routed to a CPU implementation.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libscpn_hip.so"
+CSRC = PKG_DIR / "csrc"
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+SCPN_OK, SCPN_E_ARG, SCPN_E_DEVICE, SCPN_E_DIVERGED = 0, -1, -2, -3
+
+
+class HipUnavailableError(RuntimeError):
+    """libscpn_hip.so is not built / cannot be loaded / no HIP device is present."""
+
+
+_d, _i = C.c_double, C.c_int
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_vp = C.c_void_p
+
+
+class PicardParams(C.Structure):
+    _fields_ = [
+        ("z_min_cfg", _d), ("r_center", _d), ("mu0", _d),
+        ("method", _i), ("sor_omega", _d), ("alpha", _d), ("tol", _d), ("max_iter", _i),
+        ("require_gs_residual", _i), ("gs_tol", _d),
+        ("hmode", _i), ("ped_p", _d * 4), ("ped_ff", _d * 4),
+        ("preserve_initial_state", _i), ("has_boundary_flux", _i), ("external_profile_mode", _i),
+        ("check_every", _i), ("fail_on_diverge", _i), ("skip_seed", _i),
+    ]
+
+
+class PicardResult(C.Structure):
+    _fields_ = [
+        ("converged", _i), ("iterations", _i), ("diverged", _i), ("reserved", _i),
+        ("residual", _d), ("gs_residual", _d), ("gs_residual_best", _d),
+        ("psi_axis", _d), ("psi_bnd", _d), ("x_r", _d), ("x_z", _d), ("i_current", _d),
+    ]
+
+
+# symbol -> (restype, argtypes); the single source of truth also checked by tests/test_abi_symbols.py
+SIGNATURES = {
+    # legacy libscpn_solver ABI
+    "create_solver": (_vp, [_i, _i, _d, _d, _d, _d]),
+    "set_boundary_dirichlet": (None, [_vp, _d]),
+    "run_step": (None, [_vp, _dp, _dp, _i, _i]),
+    "run_step_converged": (_i, [_vp, _dp, _dp, _i, _i, _d, _d, C.POINTER(_d)]),
+    "destroy_solver": (None, [_vp]),
+    "delete_solver": (None, [_vp]),
+    # probes
+    "scpn_device_count": (_i, []),
+    "scpn_device_info": (_i, [C.c_char_p, _i]),
+    "scpn_set_device": (_i, [_i]),
+    "scpn_last_error": (C.c_char_p, []),
+    "scpn_version": (C.c_char_p, []),
+    # operator library
+    "scpn_mg_smooth": (_i, [_dp, _dp, _dp, _i, _i, _i, _d, _d, _d, _i]),
+    "scpn_mg_residual": (_i, [_dp, _dp, _dp, _i, _i, _i, _d, _d, _dp]),
+    "scpn_residual_linf": (_i, [_dp, _dp, _dp, _i, _i, _i, _d, _d, _dp]),
+    "scpn_gs_residual_rms": (_i, [_dp, _dp, _dp, _i, _i, _i, _d, _d, _dp]),
+    "scpn_restrict_full_weight": (_i, [_dp, _i, _i, _i, _dp]),
+    "scpn_prolongate_bilinear": (_i, [_dp, _i, _i, _i, _i, _i, _dp]),
+    "scpn_multigrid_vcycle": (_i, [_dp, _dp, _dp, _i, _i, _i, _d, _d, _d, _i, _i, _i]),
+    "scpn_multigrid_solve": (_i, [_dp, _dp, _dp, _dp, _i, _i, _i, _d, _i, _d, _i, _i, _i, _dp, _ip, _ip]),
+    "scpn_jacobi_step": (_i, [_dp, _dp, _dp, _i, _i, _i, _d, _d, _dp]),
+    "scpn_sor_step": (_i, [_dp, _dp, _dp, _i, _i, _i, _d, _d, _d, _dp]),
+    "scpn_coil_flux": (_i, [_dp, _dp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _i, _dp]),
+    "scpn_green_points": (_i, [_i, _dp, _dp, _i, _dp, _dp, _dp]),
+    "scpn_gs_solve_np": (_i, [_d, _d, _d, _d, _i, _i, _dp, _dp, _vp, _d, _d, _i, _i, _d, _d, _d, _dp]),
+    # resident ensemble solver
+    "scpn_gs_create": (_i, [C.POINTER(_vp), _i, _i, _i, _dp, _dp, _d, _d]),
+    "scpn_gs_destroy": (None, [_vp]),
+    "scpn_gs_set_psi": (_i, [_vp, _i, _dp]),
+    "scpn_gs_get_psi": (_i, [_vp, _i, _dp]),
+    "scpn_gs_get_jphi": (_i, [_vp, _i, _dp]),
+    "scpn_gs_set_jphi": (_i, [_vp, _i, _dp]),
+    "scpn_gs_get_source": (_i, [_vp, _i, _dp]),
+    "scpn_gs_set_source": (_i, [_vp, _i, _dp]),
+    "scpn_gs_set_boundary_flux": (_i, [_vp, _i, _dp]),
+    "scpn_gs_get_boundary_flux": (_i, [_vp, _i, _dp]),
+    "scpn_gs_set_current_target": (_i, [_vp, _i, _dp]),
+    "scpn_gs_set_vacuum_coils": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "scpn_gs_set_seed": (_i, [_vp, _vp]),
+    "scpn_gs_picard_solve": (_i, [_vp, C.POINTER(PicardParams), C.POINTER(PicardResult), _vp, _vp, _vp]),
+    "scpn_gs_free_boundary_solve": (_i, [_vp, C.POINTER(PicardParams), _i, _vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp,
+                                         C.POINTER(PicardResult)]),
+    "scpn_gs_rb_sor": (_i, [_vp, _d, _i]),
+    "scpn_gs_vcycle": (_i, [_vp, _d, _i, _i, _i]),
+    "scpn_gs_compute_b_field": (_i, [_vp, _i, _dp, _dp]),
+    "scpn_gs_profile": (_i, [_vp, _i]),
+    "scpn_gs_profile_read": (_i, [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(C.c_long)]),
+    "scpn_gs_sync": (_i, [_vp]),
+}
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/scpn_hip.hip for gfx950 into the in-tree libscpn_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [CSRC / "scpn_hip.hip", CSRC / "gs_kernels.hip.h", PKG_DIR.parent / "include" / "scpn_hip.h"]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(LIB_PATH), str(CSRC / "scpn_hip.hip")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode:
+        print(" ".join(cmd), res.stdout, res.stderr, sep="\n")
+    if res.returncode:
+        raise RuntimeError(f"hipcc failed building {LIB_PATH.name}:\n{res.stderr[-2000:]}")
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    """Load libscpn_hip.so (symbols only -- no device is touched)."""
+    global _LIB
+    if _LIB is None:
+        path = Path(os.environ.get("SCPN_HIP_LIB", LIB_PATH))
+        if not path.exists():
+            raise HipUnavailableError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        try:
+            L = C.CDLL(str(path))
+        except OSError as exc:  # pragma: no cover - depends on the host
+            raise HipUnavailableError(f"cannot load {path}: {exc}") from exc
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def device_count() -> int:
+    try:
+        return int(lib().scpn_device_count())
+    except HipUnavailableError:
+        return 0
+
+
+def gpu_available() -> bool:
+    """True when a HIP device is visible and ``SCPN_DISABLE_GPU`` is not set (core/_multi_compat.py:101-120)."""
+    if os.environ.get("SCPN_DISABLE_GPU", "").strip().lower() in ("1", "true", "yes", "on"):
+        return False
+    return device_count() > 0
+
+
+def require_gpu() -> C.CDLL:
+    L = lib()
+    if L.scpn_device_count() <= 0:
+        raise HipUnavailableError("no HIP device visible: the HIP path has no CPU fallback")
+    return L
+
+
+def device_info() -> str | None:
+    try:
+        L = lib()
+    except HipUnavailableError:
+        return None
+    buf = C.create_string_buffer(256)
+    if L.scpn_device_info(buf, 256) != SCPN_OK:
+        return None
+    return buf.value.decode()
+
+
+def last_error() -> str:
+    return (lib().scpn_last_error() or b"").decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map C return codes to the reference's exceptions (ValueError for argument errors)."""
+    if rc == SCPN_OK:
+        return
+    msg = last_error() or what
+    if rc == SCPN_E_ARG:
+        raise ValueError(msg)
+    if rc == SCPN_E_DIVERGED:
+        raise RuntimeError(msg)
+    raise HipUnavailableError(msg)
+
+
+def as_f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)

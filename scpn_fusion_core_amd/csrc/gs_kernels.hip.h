@@ -1,0 +1,1010 @@
+// gs_kernels.hip.h -- CDNA4 (gfx950) device kernels of the Grad-Shafranov hot path.
+//
+// Conventions
+//   * fp64 everywhere; compiled with -ffp-contract=off: every expression keeps the
+//     operation order of the reference NumPy code so that the linear elliptic operators are
+//     bit-identical to it (red-black SOR is order-independent inside one colour).
+//   * a field is (nz, nr) with row pitch `ld` doubles (ld >= nr, rows 64-B aligned) and
+//     `stride` doubles between ensemble members; blockIdx.z (or .y) is the member index.
+//   * per-level 1-D coefficient tables a_e[ir], a_w[ir], r_safe[ir] are built on the host with
+//     the reference's arithmetic (core/multigrid_solve.py:184-189) -- no R-grid traffic.
+//   * wave = 64 lanes; reductions are fixed-shape trees (run-to-run deterministic).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gs {
+
+constexpr double CAP = 1.0e250;  // core/fusion_kernel_numerics.py:16
+
+struct Lvl {
+    int nz, nr, ld;
+    long stride;
+    double a_ns, a_c, dr2, dz2, two_dr, dr, dz;
+    const double* a_e;
+    const double* a_w;
+    const double* r_safe;
+};
+
+// A batched field whose member b may live in one of several ping-pong slots.
+struct Fld {
+    double* base;
+    const int* slot;  // nullptr -> slot 0
+    long stride;
+    int nb;  // members per slot
+    __device__ __forceinline__ double* at(int b) const {
+        int k = slot ? slot[b] : 0;
+        return base + ((long)k * nb + b) * stride;
+    }
+};
+
+// per-member solver state kept on the device for the whole Picard solve
+struct Member {
+    double psi_axis, psi_bnd, denom;  // topology of the current iteration
+    double x_r, x_z;
+    long x_idx;
+    double i_current, jscale;
+    double i_target;
+    double diff, diff_best, gs, gs_best;
+    int active, converged, diverged, iterations;
+    int cur, best, nxt, prev;  // ping-pong slots of psi
+    int improved, pad;
+};
+
+__device__ __forceinline__ double sanitize1(double x) {  // fusion_kernel_numerics.py:19-25
+    if (x != x) return 0.0;
+    if (x > CAP) return CAP;
+    if (x < -CAP) return -CAP;
+    return x;
+}
+__device__ __forceinline__ double nan_to_num300(double x) {  // fusion_kernel.py:273
+    if (x != x) return 0.0;
+    if (x > 1.79e308) return 1e300;
+    if (x < -1.79e308) return -1e300;
+    return x;
+}
+__device__ __forceinline__ bool finite_d(double x) { return fabs(x) <= 1.7976931348623157e308; }
+
+// ---------------------------------------------------------------- block reductions (256 thr)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) r += sh[i];
+    }
+    __syncthreads();
+    return r;  // valid in thread 0
+}
+template <int NT>
+__device__ __forceinline__ double block_max(double v, double* sh) {
+    v = wave_max(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+        r = sh[0];
+#pragma unroll
+        for (int i = 1; i < NT / 64; ++i) r = fmax(r, sh[i]);
+    }
+    __syncthreads();
+    return r;
+}
+// (value, index) reductions with numpy's first-occurrence tie rule
+struct VI {
+    double v;
+    long i;
+};
+__device__ __forceinline__ VI vi_max(VI a, VI b) {
+    bool tb = (b.i >= 0) && (a.i < 0 || b.v > a.v || (b.v == a.v && b.i < a.i));
+    return tb ? b : a;
+}
+__device__ __forceinline__ VI vi_min(VI a, VI b) {
+    bool tb = (b.i >= 0) && (a.i < 0 || b.v < a.v || (b.v == a.v && b.i < a.i));
+    return tb ? b : a;
+}
+template <bool MAX>
+__device__ __forceinline__ VI wave_vi(VI x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        VI y;
+        y.v = __shfl_down(x.v, o, 64);
+        y.i = __shfl_down((long long)x.i, o, 64);
+        x = MAX ? vi_max(x, y) : vi_min(x, y);
+    }
+    return x;
+}
+template <bool MAX, int NT>
+__device__ __forceinline__ VI block_vi(VI x, VI* sh) {
+    x = wave_vi<MAX>(x);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = x;
+    __syncthreads();
+    VI r = x;
+    if (threadIdx.x == 0) {
+        r = sh[0];
+#pragma unroll
+        for (int i = 1; i < NT / 64; ++i) r = MAX ? vi_max(r, sh[i]) : vi_min(r, sh[i]);
+    }
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------- elementwise / copies
+// dst <- src over the logical (nz, nr) window; grid (ceil(nr/64), ceil(nz/4), B), block (64,4)
+__global__ void k_copy(Fld dst, Fld src, int nz, int nr, int ld, const int* active) {
+    int b = blockIdx.z;
+    if (active && !active[b]) return;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    dst.at(b)[(long)iz * ld + ir] = src.at(b)[(long)iz * ld + ir];
+}
+__global__ void k_fill(Fld dst, double v, int nz, int nr, int ld, const int* active) {
+    int b = blockIdx.z;
+    if (active && !active[b]) return;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    dst.at(b)[(long)iz * ld + ir] = v;
+}
+// Dirichlet ring from bc (core/fusion_kernel_iterative_solver.py:316-329); grid (ceil(2*(nz+nr)/256), B)
+__global__ void k_apply_bc(Fld psi, Fld bc, int nz, int nr, int ld, const int* active) {
+    int b = blockIdx.y;
+    if (active && !active[b]) return;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int iz, ir;
+    if (t < nr) { iz = 0; ir = t; }
+    else if (t < 2 * nr) { iz = nz - 1; ir = t - nr; }
+    else if (t < 2 * nr + nz) { iz = t - 2 * nr; ir = 0; }
+    else if (t < 2 * nr + 2 * nz) { iz = t - 2 * nr - nz; ir = nr - 1; }
+    else return;
+    psi.at(b)[(long)iz * ld + ir] = bc.at(b)[(long)iz * ld + ir];
+}
+
+// ---------------------------------------------------------------- red-black SOR (a1)
+// core/multigrid_solve.py:193-206: one colour pass.  Threads are colour-compacted: thread t of
+// row iz owns column ir = ir0(iz,parity) + 2t, so no lane idles on the other colour.
+// grid (ceil(ncol/64), ceil((nz-2)/4), B), block (64,4)
+template <bool CLIP>
+__global__ void k_rb_half(Fld psiF, Fld srcF, Lvl L, double omega, double om1, int parity,
+                          const int* active) {
+    int b = blockIdx.z;
+    if (active && !active[b]) return;
+    int iz = 1 + blockIdx.y * 4 + threadIdx.y;
+    int t = blockIdx.x * 64 + threadIdx.x;
+    int ir = 1 + ((iz + 1 + parity) & 1) + 2 * t;
+    if (iz >= L.nz - 1 || ir >= L.nr - 1) return;
+    double* psi = psiF.at(b);
+    const double* src = srcF.at(b);
+    long c = (long)iz * L.ld + ir;
+    double gs = (L.a_e[ir] * psi[c + 1] + L.a_w[ir] * psi[c - 1] + L.a_ns * psi[c - L.ld] +
+                 L.a_ns * psi[c + L.ld] - src[c]) /
+                L.a_c;
+    double v = om1 * psi[c] + omega * gs;
+    if (CLIP) v = fmin(fmax(v, -CAP), CAP);
+    psi[c] = v;
+}
+
+// Whole small level in LDS: n_sweeps full red-black sweeps by ONE workgroup per member
+// (levels up to SMALL_MAX points: the multigrid base case and the coarse levels).
+constexpr int SMALL_MAX = 1156;  // 34*34
+__global__ void __launch_bounds__(256) k_small_smooth(Fld psiF, Fld srcF, Lvl L, double omega,
+                                                      double om1, int n_sweeps, const int* active) {
+    __shared__ double sp[SMALL_MAX];
+    __shared__ double ss[SMALL_MAX];
+    int b = blockIdx.x;
+    if (active && !active[b]) return;
+    double* psi = psiF.at(b);
+    const double* src = srcF.at(b);
+    const int nz = L.nz, nr = L.nr, n = nz * nr;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        int iz = i / nr, ir = i - iz * nr;
+        sp[i] = psi[(long)iz * L.ld + ir];
+        ss[i] = src[(long)iz * L.ld + ir];
+    }
+    __syncthreads();
+    const int ni = nr - 2, nint = (nz - 2) * ni;
+    for (int s = 0; s < 2 * n_sweeps; ++s) {
+        int parity = s & 1;
+        for (int k = threadIdx.x; k < nint; k += 256) {
+            int iz = 1 + k / ni, ir = 1 + (k - (iz - 1) * ni);
+            if (((iz + ir) & 1) != parity) continue;
+            int c = iz * nr + ir;
+            double gs = (L.a_e[ir] * sp[c + 1] + L.a_w[ir] * sp[c - 1] + L.a_ns * sp[c - nr] +
+                         L.a_ns * sp[c + nr] - ss[c]) /
+                        L.a_c;
+            sp[c] = om1 * sp[c] + omega * gs;
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += 256) {
+        int iz = i / nr, ir = i - iz * nr;
+        psi[(long)iz * L.ld + ir] = sp[i];
+    }
+}
+
+// ---------------------------------------------------------------- residual (a2, a3)
+__device__ __forceinline__ double resid_at(const double* psi, const double* src, const Lvl& L,
+                                           int iz, int ir) {
+    // core/multigrid_solve.py:243-248
+    long c = (long)iz * L.ld + ir;
+    double p = psi[c], e = psi[c + 1], w = psi[c - 1], n = psi[c + L.ld], s = psi[c - L.ld];
+    double d2r = (e - 2.0 * p + w) / L.dr2;
+    double d1r = (e - w) / L.two_dr;
+    double d2z = (n - 2.0 * p + s) / L.dz2;
+    double lpsi = d2r - d1r / L.r_safe[ir] + d2z;
+    return lpsi - src[c];
+}
+// out = L*psi - src (zero ring); grid (ceil(nr/64), ceil(nz/4), B)
+__global__ void k_residual(Fld outF, Fld psiF, Fld srcF, Lvl L) {
+    int b = blockIdx.z;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= L.nr || iz >= L.nz) return;
+    double v = 0.0;
+    if (iz > 0 && iz < L.nz - 1 && ir > 0 && ir < L.nr - 1) v = resid_at(psiF.at(b), srcF.at(b), L, iz, ir);
+    outF.at(b)[(long)iz * L.ld + ir] = v;
+}
+// partial max|r| and sum r^2 over the interior: grid (nblk, B), 256 threads x 4 points
+__global__ void __launch_bounds__(256) k_resid_norms(Fld psiF, Fld srcF, Lvl L, double* pmax,
+                                                     double* psum, int nblk, const int* active) {
+    __shared__ double sh[4];
+    int b = blockIdx.y;
+    if (active && !active[b]) return;
+    const double* psi = psiF.at(b);
+    const double* src = srcF.at(b);
+    const int ni = L.nr - 2;
+    const long nint = (long)(L.nz - 2) * ni;
+    double m = 0.0, s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (q < nint) {
+            int iz = 1 + (int)(q / ni), ir = 1 + (int)(q - (long)(iz - 1) * ni);
+            double r = sanitize1(resid_at(psi, src, L, iz, ir));
+            m = fmax(m, fabs(r));
+            s += r * r;
+        }
+    }
+    double bm = block_max<256>(m, sh);
+    double bs = block_sum<256>(s, sh);
+    if (threadIdx.x == 0) {
+        pmax[(long)b * nblk + blockIdx.x] = bm;
+        psum[(long)b * nblk + blockIdx.x] = bs;
+    }
+}
+
+// ---------------------------------------------------------------- restriction (a4)
+__device__ __forceinline__ double fw9(double c, double up, double dn, double lf, double rt,
+                                      double ul, double ur, double dl, double dr_) {
+    // core/multigrid_solve.py:76-91
+    return (4.0 * c + 2.0 * (up + dn + lf + rt) + (ul + ur + dl + dr_)) / 16.0;
+}
+// plain full weighting of a field; grid (ceil(nr_c/64), ceil(nz_c/4), B)
+__global__ void k_restrict(Fld cF, Fld fF, int nz_f, int nr_f, int ld_f, int nz_c, int nr_c,
+                           int ld_c) {
+    int b = blockIdx.z;
+    int jc = blockIdx.x * 64 + threadIdx.x, ic = blockIdx.y * 4 + threadIdx.y;
+    if (jc >= nr_c || ic >= nz_c) return;
+    const double* f = fF.at(b);
+    double v;
+    // injection on the ring; columns override rows at the corners (multigrid_solve.py:94-97)
+    if (jc == 0) v = f[(long)(2 * ic) * ld_f];
+    else if (jc == nr_c - 1) v = f[(long)(2 * ic) * ld_f + nr_f - 1];
+    else if (ic == 0) v = f[2 * jc];
+    else if (ic == nz_c - 1) v = f[(long)(nz_f - 1) * ld_f + 2 * jc];
+    else {
+        const double* p = f + (long)(2 * ic) * ld_f + 2 * jc;
+        v = fw9(p[0], p[-ld_f], p[ld_f], p[-1], p[1], p[-ld_f - 1], p[-ld_f + 1], p[ld_f - 1], p[ld_f + 1]);
+    }
+    cF.at(b)[(long)ic * ld_c + jc] = v;
+}
+// fused: coarse rhs = restrict_full_weight(-(L*psi - src))  (multigrid_solve.py:303-306) and
+// coarse e = 0 (multigrid_solve.py:315).  Each coarse thread evaluates its 9 fine residuals.
+__global__ void k_defect_restrict(Fld rhsC, Fld eC, Fld psiF, Fld srcF, Lvl Lf, Lvl Lc,
+                                  const int* active) {
+    int b = blockIdx.z;
+    if (active && !active[b]) return;
+    int jc = blockIdx.x * 64 + threadIdx.x, ic = blockIdx.y * 4 + threadIdx.y;
+    if (jc >= Lc.nr || ic >= Lc.nz) return;
+    double v = -0.0;  // injected ring of the negated (zero-ring) residual
+    if (jc > 0 && jc < Lc.nr - 1 && ic > 0 && ic < Lc.nz - 1) {
+        const double* psi = psiF.at(b);
+        const double* src = srcF.at(b);
+        int i = 2 * ic, j = 2 * jc;
+        double c = -resid_at(psi, src, Lf, i, j);
+        double up = -resid_at(psi, src, Lf, i - 1, j), dn = -resid_at(psi, src, Lf, i + 1, j);
+        double lf = -resid_at(psi, src, Lf, i, j - 1), rt = -resid_at(psi, src, Lf, i, j + 1);
+        double ul = -resid_at(psi, src, Lf, i - 1, j - 1), ur = -resid_at(psi, src, Lf, i - 1, j + 1);
+        double dl = -resid_at(psi, src, Lf, i + 1, j - 1), dr_ = -resid_at(psi, src, Lf, i + 1, j + 1);
+        v = fw9(c, up, dn, lf, rt, ul, ur, dl, dr_);
+    }
+    rhsC.at(b)[(long)ic * Lc.ld + jc] = v;
+    eC.at(b)[(long)ic * Lc.ld + jc] = 0.0;
+}
+
+// ---------------------------------------------------------------- prolongation (a5)
+__device__ __forceinline__ double prolong_at(const double* c, int ld_c, int nz_c, int nr_c,
+                                             int nz_f, int nr_f, int i, int j) {
+    // core/multigrid_solve.py:117-143 with nz_c == (nz_f+1)/2, nr_c == (nr_f+1)/2
+    int h_end = min(2 * (nr_c - 1), nr_f - 1), v_end = min(2 * (nz_c - 1), nz_f - 1);
+    bool ie = !(i & 1), je = !(j & 1);
+    int ic = i >> 1, jc = j >> 1;
+    if (ie && je) return c[(long)ic * ld_c + jc];
+    if (ie) {  // even row, odd col
+        if (j >= h_end) return 0.0;
+        return 0.5 * (c[(long)ic * ld_c + jc] + c[(long)ic * ld_c + jc + 1]);
+    }
+    if (i >= v_end) return 0.0;
+    if (je) return 0.5 * (c[(long)ic * ld_c + jc] + c[(long)(ic + 1) * ld_c + jc]);
+    if (j >= h_end) return 0.0;
+    return 0.25 * (c[(long)ic * ld_c + jc] + c[(long)(ic + 1) * ld_c + jc] + c[(long)ic * ld_c + jc + 1] +
+                   c[(long)(ic + 1) * ld_c + jc + 1]);
+}
+// ADD: psi += P e (multigrid_solve.py:329-330) else fine = P c; grid (ceil(nr_f/64), ceil(nz_f/4), B)
+template <bool ADD>
+__global__ void k_prolong(Fld fF, Fld cF, int nz_f, int nr_f, int ld_f, int nz_c, int nr_c, int ld_c,
+                          const int* active) {
+    int b = blockIdx.z;
+    if (active && !active[b]) return;
+    int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= nr_f || i >= nz_f) return;
+    double p = prolong_at(cF.at(b), ld_c, nz_c, nr_c, nz_f, nr_f, i, j);
+    double* f = fF.at(b) + (long)i * ld_f + j;
+    if (ADD) *f = *f + p;
+    else *f = p;
+}
+
+// ---------------------------------------------------------------- Jacobi / SOR steps of the Picard driver
+// core/fusion_kernel_iterative_solver.py:54-95 (sanitize, update, clip); out != psi
+__global__ void k_jacobi(Fld outF, Fld psiF, Fld srcF, Lvl L, const int* active) {
+    int b = blockIdx.z;
+    if (active && !active[b]) return;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= L.nr || iz >= L.nz) return;
+    const double* psi = psiF.at(b);
+    const double* src = srcF.at(b);
+    long c = (long)iz * L.ld + ir;
+    double v = sanitize1(psi[c]);
+    if (iz > 0 && iz < L.nz - 1 && ir > 0 && ir < L.nr - 1) {
+        v = (L.a_e[ir] * sanitize1(psi[c + 1]) + L.a_w[ir] * sanitize1(psi[c - 1]) +
+             L.a_ns * sanitize1(psi[c - L.ld]) + L.a_ns * sanitize1(psi[c + L.ld]) - sanitize1(src[c])) /
+            L.a_c;
+        v = fmin(fmax(v, -CAP), CAP);
+    }
+    outF.at(b)[c] = v;
+}
+// damped Jacobi of the polyglot lane, core/jax_gs_solver.py:58-86 (a_NS*(S+N) association)
+__global__ void k_jacobi_damped(Fld outF, Fld psiF, Fld srcF, Lvl L, double omega_j, double om1) {
+    int b = blockIdx.z;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= L.nr || iz >= L.nz) return;
+    const double* psi = psiF.at(b);
+    long c = (long)iz * L.ld + ir;
+    double v = psi[c];
+    if (iz > 0 && iz < L.nz - 1 && ir > 0 && ir < L.nr - 1) {
+        double upd = (L.a_e[ir] * psi[c + 1] + L.a_w[ir] * psi[c - 1] + L.a_ns * (psi[c - L.ld] + psi[c + L.ld]) -
+                      srcF.at(b)[c]) /
+                     L.a_c;
+        v = om1 * v + omega_j * upd;
+    }
+    outF.at(b)[c] = v;
+}
+__global__ void k_sanitize(Fld dst, Fld src, int nz, int nr, int ld) {
+    int b = blockIdx.z;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    dst.at(b)[(long)iz * ld + ir] = sanitize1(src.at(b)[(long)iz * ld + ir]);
+}
+
+// ---------------------------------------------------------------- Picard: topology (a8)
+struct TopoPart {
+    double maxv;
+    long maxi;
+    double minb;
+    long mini;
+    double minpsi;
+    long pad;
+};
+// argmax psi, argmin |grad psi| inside the divertor rows [0, n_mask_rows), min finite psi.
+// np.gradient semantics (2nd-order centred inside, 1st-order one-sided on the array edges),
+// core/fusion_kernel.py:276-288, 342-355.  grid (nblk, B), 256 threads x 4 points.
+__global__ void __launch_bounds__(256) k_topology(Fld psiF, const Member* st, int nz, int nr, int ld,
+                                                  double dr, double dz, int n_mask_rows,
+                                                  TopoPart* part, int nblk) {
+    __shared__ VI shv[4];
+    __shared__ double shd[4];
+    int b = blockIdx.y;
+    if (!st[b].active) return;
+    const double* psi = psiF.at(b);
+    const long n = (long)nz * nr;
+    VI mx{0.0, -1}, mn{0.0, -1};
+    double minpsi = INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (q >= n) continue;
+        int iz = (int)(q / nr), ir = (int)(q - (long)iz * nr);
+        long c = (long)iz * ld + ir;
+        double p = psi[c];
+        if (p == p) mx = vi_max(mx, VI{p, q});
+        if (finite_d(p)) minpsi = fmin(minpsi, p);
+        if (iz < n_mask_rows) {
+            double gz, gr;
+            if (iz == 0) gz = (nan_to_num300(psi[c + ld]) - nan_to_num300(p)) / dz;
+            else if (iz == nz - 1) gz = (nan_to_num300(p) - nan_to_num300(psi[c - ld])) / dz;
+            else gz = (nan_to_num300(psi[c + ld]) - nan_to_num300(psi[c - ld])) / (2.0 * dz);
+            if (ir == 0) gr = (nan_to_num300(psi[c + 1]) - nan_to_num300(p)) / dr;
+            else if (ir == nr - 1) gr = (nan_to_num300(p) - nan_to_num300(psi[c - 1])) / dr;
+            else gr = (nan_to_num300(psi[c + 1]) - nan_to_num300(psi[c - 1])) / (2.0 * dr);
+            double bm = hypot(gr, gz);
+            if (finite_d(bm)) mn = vi_min(mn, VI{bm, q});
+        }
+    }
+    VI rmx = block_vi<true, 256>(mx, shv);
+    VI rmn = block_vi<false, 256>(mn, shv);
+    double rmp = -block_max<256>(-minpsi, shd);
+    if (threadIdx.x == 0) {
+        TopoPart t;
+        t.maxv = rmx.v; t.maxi = rmx.i; t.minb = rmn.v; t.mini = rmn.i; t.minpsi = rmp; t.pad = 0;
+        part[(long)b * nblk + blockIdx.x] = t;
+    }
+}
+// one block per member: finish the reductions and apply the outer-loop heuristics
+// (core/fusion_kernel.py:350-355, 288-293, 339-340; core/fusion_kernel_newton_solver.py:505-506)
+__global__ void __launch_bounds__(256) k_topology_final(Fld psiF, Member* st, const TopoPart* part, int nblk,
+                                                        int nr, int ld, const double* r_axis,
+                                                        const double* z_axis) {
+    __shared__ VI shv[4];
+    __shared__ double shd[4];
+    int b = blockIdx.x;
+    if (!st[b].active) return;
+    VI mx{0.0, -1}, mn{0.0, -1};
+    double minpsi = INFINITY;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        TopoPart t = part[(long)b * nblk + i];
+        mx = vi_max(mx, VI{t.maxv, t.maxi});
+        mn = vi_min(mn, VI{t.minb, t.mini});
+        minpsi = fmin(minpsi, t.minpsi);
+    }
+    VI rmx = block_vi<true, 256>(mx, shv);
+    VI rmn = block_vi<false, 256>(mn, shv);
+    double rmp = -block_max<256>(-minpsi, shd);
+    if (threadIdx.x == 0) {
+        Member& m = st[b];
+        const double* psi = psiF.at(b);
+        double pa = rmx.i >= 0 ? rmx.v : 0.0;
+        if (fabs(pa) < 1e-6) pa = 1e-6;
+        double pb, xr = 0.0, xz = 0.0;
+        if (rmn.i >= 0) {
+            int iz = (int)(rmn.i / nr), ir = (int)(rmn.i - (long)iz * nr);
+            pb = psi[(long)iz * ld + ir];
+            if (!finite_d(pb)) pb = nan_to_num300(pb);
+            xr = r_axis[ir];
+            xz = z_axis[iz];
+        } else {
+            pb = rmp;
+        }
+        if (fabs(pa - pb) < 0.1) pb = pa * 0.1;
+        double denom = pb - pa;  // core/fusion_kernel.py:415-417
+        if (fabs(denom) < 1e-9) denom = 1e-9;
+        m.psi_axis = pa; m.psi_bnd = pb; m.denom = denom; m.x_idx = rmn.i; m.x_r = xr; m.x_z = xz;
+    }
+}
+
+// ---------------------------------------------------------------- Picard: source (a9)
+struct Prof {
+    int hmode;
+    double ped_p[4], ped_ff[4];
+};
+__device__ __forceinline__ double mtanh1(double x, const double* p) {  // core/fusion_kernel.py:376-390
+    double y = (p[0] - x) / p[1];
+    y = fmin(fmax(y, -20.0), 20.0);
+    double pedestal = (0.5 * p[2]) * (1.0 + tanh(y));
+    double core = 0.0;
+    if (x < p[0]) {
+        double q = x / p[0];
+        core = fmax(0.0, 1.0 - q * q);
+    }
+    return pedestal + p[3] * core;
+}
+__device__ __forceinline__ double j_raw_at(double psi, double R, double inv_mu0R, double psi_axis,
+                                           double denom, const Prof& pf) {
+    // core/fusion_kernel.py:419-434
+    double pn = (psi - psi_axis) / denom;
+    double p = 0.0, ff = 0.0;
+    if (pn >= 0.0 && pn < 1.0) {
+        if (pf.hmode) { p = mtanh1(pn, pf.ped_p); ff = mtanh1(pn, pf.ped_ff); }
+        else { p = 1.0 - pn; ff = p; }
+    }
+    double j_p = R * p;
+    double j_f = inv_mu0R * ff;
+    return 0.5 * j_p + 0.5 * j_f;
+}
+// partial sums of J_raw; grid (nblk, B)
+__global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz, int nr, int ld,
+                                              const double* r_axis, const double* inv_mu0R, Prof pf,
+                                              double* part, int nblk) {
+    __shared__ double sh[4];
+    int b = blockIdx.y;
+    if (!st[b].active) return;
+    const double* psi = psiF.at(b);
+    const double pa = st[b].psi_axis, den = st[b].denom;
+    const long n = (long)nz * nr;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (q < n) {
+            int iz = (int)(q / nr), ir = (int)(q - (long)iz * nr);
+            s += j_raw_at(psi[(long)iz * ld + ir], r_axis[ir], inv_mu0R[ir], pa, den, pf);
+        }
+    }
+    double bs = block_sum<256>(s, sh);
+    if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = bs;
+}
+__global__ void __launch_bounds__(256) k_jsum_final(Member* st, const double* part, int nblk, double dr,
+                                                    double dz) {
+    __shared__ double sh[4];
+    int b = blockIdx.x;
+    if (!st[b].active) return;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += part[(long)b * nblk + i];
+    double tot = block_sum<256>(s, sh);
+    if (threadIdx.x == 0) {
+        double ic = (tot * dr) * dz;  // core/fusion_kernel.py:436
+        st[b].i_current = ic;
+        st[b].jscale = fabs(ic) > 1e-9 ? st[b].i_target / ic : 0.0;
+    }
+}
+// Source = (-mu0*R) * (J_raw * scale)  (core/fusion_kernel.py:440, newton_solver.py:513);
+// optionally stores J_phi.  grid (ceil(nr/64), ceil(nz/4), B)
+__global__ void k_source(Fld srcF, Fld jF, int write_j, Fld psiF, const Member* st, int nz, int nr, int ld,
+                         const double* r_axis, const double* inv_mu0R, const double* neg_mu0R, Prof pf) {
+    int b = blockIdx.z;
+    if (!st[b].active) return;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    long c = (long)iz * ld + ir;
+    double jr = j_raw_at(psiF.at(b)[c], r_axis[ir], inv_mu0R[ir], st[b].psi_axis, st[b].denom, pf);
+    double sc = st[b].jscale;
+    double j = sc != 0.0 ? jr * sc : 0.0;
+    srcF.at(b)[c] = neg_mu0R[ir] * j;
+    if (write_j) jF.at(b)[c] = j;
+}
+// Source from a stored J_phi (seed / external profile mode)
+__global__ void k_source_from_j(Fld srcF, Fld jF, int nz, int nr, int ld, const double* neg_mu0R,
+                                const int* active) {
+    int b = blockIdx.z;
+    if (active && !active[b]) return;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    long c = (long)iz * ld + ir;
+    srcF.at(b)[c] = neg_mu0R[ir] * jF.at(b)[c];
+}
+// J_phi = seed * (I_target / I_seed) per member (iterative_solver.py:404-406)
+__global__ void k_seed_j(Fld jF, const double* seed, const Member* st, double i_seed, int nz, int nr, int ld) {
+    int b = blockIdx.z;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    double s = seed[(long)iz * nr + ir];
+    double it = st[b].i_target;
+    double v;
+    if (fabs(it) < 1e-12) v = 0.0;
+    else v = i_seed > 0 ? s * (it / i_seed) : s;
+    jF.at(b)[(long)iz * ld + ir] = v;
+}
+
+// ---------------------------------------------------------------- Picard: blend + norms (a10)
+// nxt = (1-alpha)*cur + alpha*new with new's ring taken from bc; partial sum |new-cur|, non-finite flag
+// (core/fusion_kernel_newton_solver.py:515-537).  grid (nblk, B), 256 x 4 points
+__global__ void __launch_bounds__(256) k_blend(Fld nxtF, Fld curF, Fld newF, Fld bcF, const Member* st, int nz,
+                                               int nr, int ld, double alpha, double om_alpha, double* psum,
+                                               int* pbad, int nblk) {
+    __shared__ double sh[4];
+    __shared__ int shbad;
+    int b = blockIdx.y;
+    if (!st[b].active) return;
+    if (threadIdx.x == 0) shbad = 0;
+    __syncthreads();
+    const double* cur = curF.at(b);
+    const double* nw = newF.at(b);
+    const double* bc = bcF.at(b);
+    double* nxt = nxtF.at(b);
+    const long n = (long)nz * nr;
+    double s = 0.0;
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (q < n) {
+            int iz = (int)(q / nr), ir = (int)(q - (long)iz * nr);
+            long c = (long)iz * ld + ir;
+            bool ring = iz == 0 || iz == nz - 1 || ir == 0 || ir == nr - 1;
+            double pn = ring ? bc[c] : nw[c];
+            double pc = cur[c];
+            if (!finite_d(pn)) bad = 1;
+            s += fabs(pn - pc);
+            nxt[c] = om_alpha * pc + alpha * pn;
+        }
+    }
+    if (bad) atomicOr(&shbad, 1);
+    double bs = block_sum<256>(s, sh);
+    if (threadIdx.x == 0) {
+        psum[(long)b * nblk + blockIdx.x] = bs;
+        pbad[(long)b * nblk + blockIdx.x] = shbad;
+    }
+}
+
+struct PicardCtl {
+    double tol, gs_tol;
+    int require_gs, max_iter, iter, pad;
+    long n_total, n_interior;
+};
+// one block per member: finish diff / GS RMS, update best / ping-pong slots, convergence
+// (core/fusion_kernel_newton_solver.py:518-571)
+__global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* psum, const int* pbad,
+                                                      const double* rmax, const double* rsum, int nblk,
+                                                      int nblk_r, PicardCtl ctl, double* hist_diff,
+                                                      double* hist_gs, double* trace, int* n_active) {
+    __shared__ double sh[4];
+    __shared__ int shbad;
+    int b = blockIdx.x;
+    if (!st[b].active) return;
+    if (threadIdx.x == 0) shbad = 0;
+    __syncthreads();
+    double s = 0.0, rs = 0.0, rm = 0.0;
+    int bad = 0;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        s += psum[(long)b * nblk + i];
+        bad |= pbad[(long)b * nblk + i];
+    }
+    for (int i = threadIdx.x; i < nblk_r; i += 256) {
+        rs += rsum[(long)b * nblk_r + i];
+        rm = fmax(rm, rmax[(long)b * nblk_r + i]);
+    }
+    if (bad) atomicOr(&shbad, 1);
+    double tot = block_sum<256>(s, sh);
+    double rtot = block_sum<256>(rs, sh);
+    double rmx = block_max<256>(rm, sh);
+    if (threadIdx.x == 0) {
+        Member& m = st[b];
+        m.iterations = ctl.iter + 1;
+        if (shbad) {  // diverged: revert to best, stop (newton_solver.py:518-532)
+            m.prev = m.cur;
+            m.cur = m.best;
+            m.diverged = 1;
+            m.active = 0;
+            atomicSub(n_active, 1);
+            return;
+        }
+        double diff = tot / (double)ctl.n_total;
+        // stable_rms (fusion_kernel_numerics.py:28-37) evaluated as sqrt(sum r^2 / n); identical up to
+        // rounding for the magnitudes that occur (no overflow below 1e150)
+        double gs = rmx <= 0.0 ? 0.0 : sqrt(rtot / (double)ctl.n_interior);
+        m.diff = diff;
+        m.gs = gs;
+        if (gs < m.gs_best) m.gs_best = gs;
+        int old = m.cur;
+        m.prev = old;
+        m.cur = m.nxt;
+        if (diff < m.diff_best) { m.diff_best = diff; m.best = m.cur; }
+        int nx = 0;
+        for (int k = 0; k < 3; ++k) if (k != m.cur && k != m.best) { nx = k; break; }
+        m.nxt = nx;
+        if (hist_diff) hist_diff[(long)b * ctl.max_iter + ctl.iter] = diff;
+        if (hist_gs) hist_gs[(long)b * ctl.max_iter + ctl.iter] = gs;
+        if (trace) {
+            double* t = trace + ((long)b * ctl.max_iter + ctl.iter) * 6;
+            t[0] = m.psi_axis; t[1] = m.psi_bnd; t[2] = (double)m.x_idx; t[3] = m.i_current; t[4] = diff; t[5] = gs;
+        }
+        bool upd = diff < ctl.tol;
+        bool gsc = (!ctl.require_gs) || (gs < ctl.gs_tol);
+        if (upd && gsc) { m.converged = 1; m.active = 0; atomicSub(n_active, 1); }
+        else if (ctl.iter + 1 >= ctl.max_iter) { m.active = 0; atomicSub(n_active, 1); }
+    }
+}
+// copies the per-member slot indices into flat int arrays the kernels index (cur/nxt/best/prev/active)
+__global__ void k_publish_slots(const Member* st, int* cur, int* nxt, int* best, int* prev, int* active, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    cur[b] = st[b].cur; nxt[b] = st[b].nxt; best[b] = st[b].best; prev[b] = st[b].prev; active[b] = st[b].active;
+}
+
+// ---------------------------------------------------------------- linear multigrid_solve control (a7)
+struct MgMember {
+    double residual;
+    int n_cycles, converged, active, pad;
+};
+__global__ void __launch_bounds__(256) k_mg_final(MgMember* st, const double* rmax, int nblk, double tol,
+                                                  int max_cycles, int count_cycle, int* active, int* n_active) {
+    __shared__ double sh[4];
+    int b = blockIdx.x;
+    if (!st[b].active) return;
+    double rm = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) rm = fmax(rm, rmax[(long)b * nblk + i]);
+    double r = block_max<256>(rm, sh);
+    if (threadIdx.x == 0) {
+        MgMember& m = st[b];
+        if (count_cycle) m.n_cycles += 1;
+        m.residual = r;
+        m.converged = r < tol;
+        if (m.converged || m.n_cycles >= max_cycles) { m.active = 0; active[b] = 0; atomicSub(n_active, 1); }
+    }
+}
+
+// max |a-b| over the field (free-boundary outer diff, fusion_kernel_free_boundary.py:708); grid (nblk,B)
+__global__ void __launch_bounds__(256) k_maxabsdiff(Fld aF, Fld bF, int nz, int nr, int ld, double* pmax, int nblk) {
+    __shared__ double sh[4];
+    int b = blockIdx.y;
+    const double* a = aF.at(b);
+    const double* bb = bF.at(b);
+    const long n = (long)nz * nr;
+    double m = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (q < n) {
+            int iz = (int)(q / nr), ir = (int)(q - (long)iz * nr);
+            long c = (long)iz * ld + ir;
+            m = fmax(m, fabs(a[c] - bb[c]));
+        }
+    }
+    double bm = block_max<256>(m, sh);
+    if (threadIdx.x == 0) pmax[(long)b * nblk + blockIdx.x] = bm;
+}
+__global__ void __launch_bounds__(256) k_max_final(double* out, const double* pmax, int nblk) {
+    __shared__ double sh[4];
+    int b = blockIdx.x;
+    double m = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) m = fmax(m, pmax[(long)b * nblk + i]);
+    double r = block_max<256>(m, sh);
+    if (threadIdx.x == 0) out[b] = r;
+}
+// polyglot lane: psi_axis = max over the interior (jax_gs_solver.py:99); grid (nblk,B)
+__global__ void __launch_bounds__(256) k_max_interior(Fld aF, int nz, int nr, int ld, double* pmax, int nblk) {
+    __shared__ double sh[4];
+    int b = blockIdx.y;
+    const double* a = aF.at(b);
+    const int ni = nr - 2;
+    const long n = (long)(nz - 2) * ni;
+    double m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (q < n) {
+            int iz = 1 + (int)(q / ni), ir = 1 + (int)(q - (long)(iz - 1) * ni);
+            m = fmax(m, a[(long)iz * ld + ir]);
+        }
+    }
+    double bm = -0.0;
+    bm = block_max<256>(m, sh);
+    if (threadIdx.x == 0) pmax[(long)b * nblk + blockIdx.x] = bm;
+}
+
+// ---------------------------------------------------------------- coil Green's functions (a11)
+__device__ __forceinline__ void ellip_ke(double m, double& K, double& E) {
+    // arithmetic-geometric mean, A&S 17.6.3-4 (scipy.special.ellipk/ellipe, parameter m)
+    double a = 1.0, b = sqrt(1.0 - m), s = 0.5 * m, pw = 0.5;
+    for (int it = 0; it < 40; ++it) {
+        double c = 0.5 * (a - b);
+        double an = 0.5 * (a + b);
+        b = sqrt(a * b);
+        a = an;
+        pw *= 2.0;
+        s += pw * c * c;
+        if (fabs(c) <= 1e-17 * a) break;
+    }
+    double k = 3.14159265358979323846 / (2.0 * a);
+    K = k;
+    E = k * (1.0 - s);
+}
+constexpr double MU0_SI = 4e-7 * 3.14159265358979323846;
+__device__ __forceinline__ double green_si(double r_src, double z_src, double r_obs, double z_obs) {
+    // core/fusion_kernel_free_boundary.py:58-80
+    double dr = r_obs - r_src, dz = z_obs - z_src;
+    bool self_mask = (dr * dr + dz * dz) < 1e-24;
+    double denom = (r_obs + r_src) * (r_obs + r_src) + dz * dz;
+    double k2 = denom > 1e-30 ? ((4.0 * r_obs) * r_src) / fmax(denom, 1e-30) : 0.0;
+    k2 = fmin(fmax(k2, 1e-12), 1.0 - 1e-12);
+    double k = sqrt(k2), K, E;
+    ellip_ke(k2, K, E);
+    double prefactor = (MU0_SI / (2.0 * 3.14159265358979323846)) * sqrt(r_obs * r_src);
+    double flux = (prefactor * ((2.0 - k2) * K - 2.0 * E)) / k;
+    return self_mask ? 0.0 : flux;
+}
+// mode 0: calculate_vacuum_field (core/fusion_kernel.py:232-249); mode 1: compute_external_flux
+// ring_only: evaluate only the Dirichlet ring (the only part the free-boundary loop consumes)
+__global__ void k_coil_flux(Fld outF, int nz, int nr, int ld, const double* r_axis, const double* z_axis,
+                            int n_coils, const double* coil_r, const double* coil_z, const double* coil_i,
+                            const double* coil_turns, double mu0, int mode) {
+    int b = blockIdx.z;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    double R = r_axis[ir], Z = z_axis[iz];
+    double acc = 0.0;
+    for (int c = 0; c < n_coils; ++c) {
+        long ci = (long)b * n_coils + c;
+        double rc = coil_r[ci], zc = coil_z[ci], cur = coil_i[ci];
+        if (mode == 0) {
+            double dZ = Z - zc;
+            double rp = (R + rc) * (R + rc);
+            double k2 = ((4.0 * R) * rc) / (rp + dZ * dZ);
+            k2 = fmin(fmax(k2, 1e-12), 1.0 - 1e-12);
+            double K, E;
+            ellip_ke(k2, K, E);
+            double prefactor = (mu0 * cur) / (2.0 * 3.14159265358979323846);
+            double term = ((2.0 - k2) * K - 2.0 * E) / sqrt(k2);
+            acc += (prefactor * sqrt(R * rc)) * term;
+        } else {
+            double ieff = cur * (coil_turns ? coil_turns[ci] : 1.0);
+            acc += ieff * green_si(rc, zc, R, Z);
+        }
+    }
+    outF.at(b)[(long)iz * ld + ir] = acc;
+}
+__global__ void k_green_points(double* out, int n_coils, const double* coil_r, const double* coil_z, int n_pts,
+                               const double* pr, const double* pz) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+    if (p >= n_pts) return;
+    double rs = coil_r[c], zs = coil_z[c], ro = pr[p], zo = pz[p];
+    double v;
+    if (!finite_d(rs) || !finite_d(zs) || !finite_d(ro) || !finite_d(zo) || rs <= 0.0 || ro <= 0.0) v = NAN;
+    else v = green_si(rs, zs, ro, zo);
+    out[(long)c * n_pts + p] = v;
+}
+
+// ---------------------------------------------------------------- polyglot lane source (a13)
+// core/jax_gs_solver.py:89-123 with psi_axis from k_max_interior; two passes (sum, then source)
+__device__ __forceinline__ double np_jraw(double psi, double R, double mu0, double psi_axis, double denom,
+                                          double beta_mix) {
+    double x = (psi - psi_axis) / denom;
+    x = fmin(fmax(x, 0.0), 1.0);
+    double prof = (x >= 0.0 && x < 1.0) ? 1.0 - x : 0.0;
+    double r_safe = fmax(R, 1e-10);
+    double j_p = R * prof;
+    double j_f = prof / (mu0 * r_safe);
+    return beta_mix * j_p + (1.0 - beta_mix) * j_f;
+}
+__global__ void __launch_bounds__(256) k_np_jsum(Fld psiF, const double* scal, int nz, int nr, int ld,
+                                                 const double* r_axis, double mu0, double beta_mix, double* part,
+                                                 int nblk) {
+    __shared__ double sh[4];
+    int b = blockIdx.y;
+    const double* psi = psiF.at(b);
+    double pa = scal[0], den = scal[1];
+    const long n = (long)nz * nr;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (q < n) {
+            int iz = (int)(q / nr), ir = (int)(q - (long)iz * nr);
+            s += np_jraw(psi[(long)iz * ld + ir], r_axis[ir], mu0, pa, den, beta_mix);
+        }
+    }
+    double bs = block_sum<256>(s, sh);
+    if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = bs;
+}
+// scal[0]=psi_axis, scal[1]=denom, scal[2]=scale.  stage 0: from pmax -> axis/denom; stage 1: from psum -> scale
+__global__ void __launch_bounds__(256) k_np_final(double* scal, const double* part, int nblk, int stage, double dr,
+                                                  double dz, double ip_target) {
+    __shared__ double sh[4];
+    if (stage == 0) {
+        double m = -INFINITY;
+        for (int i = threadIdx.x; i < nblk; i += 256) m = fmax(m, part[i]);
+        double r = block_max<256>(m, sh);
+        if (threadIdx.x == 0) {
+            double denom = 0.0 - r;
+            if (fabs(denom) < 1e-9) denom = denom != 0.0 ? (denom > 0 ? 1e-9 : -1e-9) : 1e-9;
+            scal[0] = r;
+            scal[1] = denom;
+        }
+    } else {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += 256) s += part[i];
+        double tot = block_sum<256>(s, sh);
+        if (threadIdx.x == 0) {
+            double ic = (tot * dr) * dz;
+            scal[2] = ip_target / fmax(fabs(ic), 1e-9);
+        }
+    }
+}
+__global__ void k_np_source(Fld srcF, Fld psiF, const double* scal, int nz, int nr, int ld, const double* r_axis,
+                            double mu0, double beta_mix) {
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    long c = (long)iz * ld + ir;
+    double jr = np_jraw(psiF.at(0)[c], r_axis[ir], mu0, scal[0], scal[1], beta_mix);
+    srcF.at(0)[c] = ((-mu0) * r_axis[ir]) * (jr * scal[2]);
+}
+__global__ void k_axpby(Fld outF, Fld aF, Fld bF, double ca, double cb, int nz, int nr, int ld) {
+    int b = blockIdx.z;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    long c = (long)iz * ld + ir;
+    outF.at(b)[c] = ca * aF.at(b)[c] + cb * bF.at(b)[c];
+}
+
+// ---------------------------------------------------------------- legacy FastSolver ABI (a14)
+// hpc/solver.cpp:93-127,164-188: colour pass with source = -1.0*R*J built in-kernel, constant ring,
+// running max|delta| (non-negative doubles order like their bit patterns -> integer atomicMax)
+__global__ void k_fast_ring(double* psi, int nz, int nr, int ld, double v, const int* done) {
+    if (done && *done) return;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int iz, ir;
+    if (t < nr) { iz = 0; ir = t; }
+    else if (t < 2 * nr) { iz = nz - 1; ir = t - nr; }
+    else if (t < 2 * nr + nz) { iz = t - 2 * nr; ir = 0; }
+    else if (t < 2 * nr + 2 * nz) { iz = t - 2 * nr - nz; ir = nr - 1; }
+    else return;
+    psi[(long)iz * ld + ir] = v;
+}
+__global__ void __launch_bounds__(256) k_fast_half(double* psi, const double* j, int nz, int nr, int ld,
+                                                   const double* Rtab, const double* c_rp, const double* c_rm,
+                                                   double c_z, double center, double omega, double om1, int parity,
+                                                   unsigned long long* delta_bits, const int* done) {
+    __shared__ double sh[4];
+    if (done && *done) return;
+    int iz = 1 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    int ir = 1 + ((iz + 1 + parity) & 1) + 2 * t;
+    double d = 0.0;
+    if (iz < nz - 1 && ir < nr - 1) {
+        long c = (long)iz * ld + ir;
+        double source = -1.0 * Rtab[ir] * j[c];
+        double p_gs = (source + c_z * (psi[c + ld] + psi[c - ld]) + c_rp[ir] * psi[c + 1] + c_rm[ir] * psi[c - 1]) /
+                      center;
+        double old = psi[c];
+        double nw = om1 * old + omega * p_gs;
+        psi[c] = nw;
+        d = fabs(nw - old);
+        if (!(d == d)) d = 0.0;
+    }
+    double bm = block_max<256>(d, sh);
+    if (threadIdx.x == 0 && bm > 0.0) atomicMax(delta_bits, (unsigned long long)__double_as_longlong(bm));
+}
+// after a sweep: record delta, decide stop (solver.cpp:303-310)
+__global__ void k_fast_ctl(unsigned long long* delta_bits, double* last_delta, int* performed, int* done, double tol,
+                           int use_tol) {
+    if (*done) return;
+    double d = __longlong_as_double((long long)*delta_bits);
+    *last_delta = d;
+    *performed += 1;
+    *delta_bits = 0ull;
+    if (use_tol && d <= tol) *done = 1;
+}
+
+// compute_b_field, core/fusion_kernel.py:450-456
+__global__ void k_b_field(double* br, double* bz, Fld psiF, int member, int nz, int nr, int ld, double dr, double dz,
+                          const double* r_axis) {
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    const double* psi = psiF.at(member);
+    long c = (long)iz * ld + ir;
+    double gz, gr;
+    if (iz == 0) gz = (psi[c + ld] - psi[c]) / dz;
+    else if (iz == nz - 1) gz = (psi[c] - psi[c - ld]) / dz;
+    else gz = (psi[c + ld] - psi[c - ld]) / (2.0 * dz);
+    if (ir == 0) gr = (psi[c + 1] - psi[c]) / dr;
+    else if (ir == nr - 1) gr = (psi[c] - psi[c - 1]) / dr;
+    else gr = (psi[c + 1] - psi[c - 1]) / (2.0 * dr);
+    double rs = fmax(r_axis[ir], 1e-6);
+    br[(long)iz * nr + ir] = -(1.0 / rs) * gz;
+    bz[(long)iz * nr + ir] = (1.0 / rs) * gr;
+}
+
+}  // namespace gs

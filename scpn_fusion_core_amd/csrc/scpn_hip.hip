@@ -1,0 +1,1355 @@
+// scpn_hip.hip -- host driver + C ABI of libscpn_hip.so (see include/scpn_hip.h).
+//
+// Host responsibilities: multigrid hierarchy and its 1-D coefficient tables (reference
+// arithmetic, bit-exact), kernel sequencing of the V-cycle and of the Picard iteration, polling the
+// device-side convergence word.  All field data and all per-member scalars stay in HBM between
+// upload and download.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/scpn_hip.h"
+#include "gs_kernels.hip.h"
+
+using namespace gs;
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int g_device = 0;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) {                                                                        \
+            throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e__));              \
+        }                                                                                               \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline dim3 grid2d(int nr, int nz, int B) { return dim3(cdiv(nr, 64), cdiv(nz, 4), B); }
+static const dim3 BLK2D(64, 4, 1);
+
+// numpy-compatible add.reduce (8192-element chunks of pairwise sums), used for the seed integral
+static double np_pairwise(const double* a, long n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (long i = 0; i < n; ++i) r += a[i];
+        return r;
+    } else if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        long i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+}
+static double np_sum(const double* a, long n) {
+    double s = 0.0;
+    for (long i = 0; i < n; i += 8192) s = s + np_pairwise(a + i, std::min<long>(8192, n - i));
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------ device memory
+template <typename T>
+struct DBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        if (count <= n && p) return;
+        release();
+        HIP_TRY(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)));
+        n = count;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DBuf() { release(); }
+    DBuf() = default;
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+};
+
+struct LevelHost {
+    int nz, nr, ld;
+    long stride;
+    double dr, dz;
+    std::vector<double> r;  // 1-D R of this level (interior columns follow the full-weighting of the finer R)
+    DBuf<double> a_e, a_w, r_safe;
+    DBuf<double> psi, rhs;  // level >= 1: correction e and restricted defect
+    Lvl dev{};
+};
+
+static int pitch_of(int nr) { return ((nr + 7) / 8) * 8; }
+static long stride_of(int nz, int ld) { return (((long)nz * ld + 31) / 32) * 32; }
+
+// ------------------------------------------------------------------------------------------ solver handle
+struct ProfEntry {
+    hipEvent_t a, b;
+    int id;
+    long launches;
+};
+
+struct scpn_gs {
+    int nr = 0, nz = 0, B = 0, ld = 0;
+    long stride = 0;
+    double dr = 0, dz = 0;
+    std::vector<double> r_axis, z_axis;
+    hipStream_t stream = nullptr;
+
+    // multigrid hierarchies keyed by min_grid
+    std::map<int, std::vector<LevelHost*>> hier;
+    // fields (B members each)
+    DBuf<double> psi_slots;  // 3 ping-pong slots
+    DBuf<double> W, src, src2, bc, jphi, ext, old;
+    bool picard_bufs = false;
+    DBuf<double> d_r, d_z, d_inv_mu0R, d_neg_mu0R, d_seed;
+    DBuf<Member> d_st;
+    DBuf<MgMember> d_mg;
+    DBuf<int> d_cur, d_nxt, d_best, d_prev, d_active, d_nactive, d_pbad;
+    DBuf<double> d_part1, d_part2, d_part3;  // reduction partials [B][nblk]
+    DBuf<TopoPart> d_topo;
+    DBuf<double> d_scal;
+    int* h_nactive = nullptr;  // pinned
+    std::vector<double> i_target;
+    std::vector<double> vac_r, vac_z, vac_i;
+    int n_vac = 0;
+    DBuf<double> d_vac_r, d_vac_z, d_vac_i, d_fb_r, d_fb_z, d_fb_i, d_fb_t;
+    std::vector<double> seed_host;
+    bool seed_user = false;
+    double mu0_tables = NAN;
+
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfEntry> prof;
+    std::vector<std::string> prof_names;
+
+    int nblk() const { return cdiv((long)nz * nr, 1024); }
+    int nblk_int() const { return cdiv((long)(nz - 2) * (nr - 2), 1024); }
+
+    Fld slot_fld(const int* slot) { return Fld{psi_slots.p, slot, stride, B}; }
+    Fld plain(double* p) { return Fld{p, nullptr, stride, B}; }
+
+    ~scpn_gs() {
+        for (auto& kv : hier)
+            for (auto* l : kv.second) delete l;
+        for (auto& e : prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        if (h_nactive) (void)hipHostFree(h_nactive);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+static int prof_id(scpn_gs* h, const char* name) {
+    for (size_t i = 0; i < h->prof_names.size(); ++i)
+        if (h->prof_names[i] == name) return (int)i;
+    h->prof_names.push_back(name);
+    return (int)h->prof_names.size() - 1;
+}
+struct ProfScope {
+    scpn_gs* h;
+    ProfEntry e{};
+    bool on;
+    ProfScope(scpn_gs* h_, const char* name, long launches) : h(h_), on(h_->prof_on) {
+        if (!on) return;
+        HIP_TRY(hipEventCreate(&e.a));
+        HIP_TRY(hipEventCreate(&e.b));
+        e.id = prof_id(h, name);
+        e.launches = launches;
+        HIP_TRY(hipEventRecord(e.a, h->stream));
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(e.b, h->stream);
+        h->prof.push_back(e);
+    }
+};
+
+// ------------------------------------------------------------------------------------------ hierarchy
+static void build_level_tables(LevelHost* L) {
+    // core/multigrid_solve.py:181-189 (dr**2 is libm pow in CPython)
+    const double dr2 = std::pow(L->dr, 2.0), dz2 = std::pow(L->dz, 2.0);
+    std::vector<double> ae(L->nr, 0.0), aw(L->nr, 0.0), rs(L->nr, 1.0);
+    for (int ir = 0; ir < L->nr; ++ir) {
+        double r_safe = std::fmax(L->r[ir], 1e-10);
+        double t = 1.0 / ((2.0 * r_safe) * L->dr);
+        ae[ir] = 1.0 / dr2 - t;
+        aw[ir] = 1.0 / dr2 + t;
+        rs[ir] = r_safe;
+    }
+    L->a_e.alloc(L->nr);
+    L->a_w.alloc(L->nr);
+    L->r_safe.alloc(L->nr);
+    HIP_TRY(hipMemcpy(L->a_e.p, ae.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(L->a_w.p, aw.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(L->r_safe.p, rs.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
+    Lvl d;
+    d.nz = L->nz; d.nr = L->nr; d.ld = L->ld; d.stride = L->stride;
+    d.a_ns = 1.0 / dz2;
+    d.a_c = 2.0 / dr2 + 2.0 / dz2;
+    d.dr2 = dr2; d.dz2 = dz2; d.two_dr = 2.0 * L->dr; d.dr = L->dr; d.dz = L->dz;
+    d.a_e = L->a_e.p; d.a_w = L->a_w.p; d.r_safe = L->r_safe.p;
+    L->dev = d;
+}
+
+// levels of the V-cycle recursion (core/multigrid_solve.py:289-312): level k is the base case
+static std::vector<LevelHost*>& get_hierarchy(scpn_gs* h, int min_grid) {
+    auto it = h->hier.find(min_grid);
+    if (it != h->hier.end()) return it->second;
+    std::vector<LevelHost*> v;
+    auto* L0 = new LevelHost();
+    L0->nz = h->nz; L0->nr = h->nr; L0->ld = h->ld; L0->stride = h->stride;
+    L0->dr = h->dr; L0->dz = h->dz; L0->r = h->r_axis;
+    build_level_tables(L0);
+    v.push_back(L0);
+    while (!(min_grid >= v.back()->nz || min_grid >= v.back()->nr)) {
+        LevelHost* f = v.back();
+        auto* c = new LevelHost();
+        c->nz = (f->nz + 1) / 2;
+        c->nr = (f->nr + 1) / 2;
+        c->ld = pitch_of(c->nr);
+        c->stride = stride_of(c->nz, c->ld);
+        c->dr = f->dr * 2.0;
+        c->dz = f->dz * 2.0;
+        c->r.assign(c->nr, 0.0);
+        // restrict_full_weight(r_grid) of a row-constant grid (multigrid_solve.py:76-97, :307)
+        for (int jc = 1; jc < c->nr - 1; ++jc) {
+            int j = 2 * jc;
+            const double ce = f->r[j], lf = f->r[j - 1], rt = f->r[j + 1];
+            c->r[jc] = (4.0 * ce + 2.0 * (ce + ce + lf + rt) + (lf + rt + lf + rt)) / 16.0;
+        }
+        c->r[0] = f->r[0];
+        c->r[c->nr - 1] = f->r[f->nr - 1];
+        build_level_tables(c);
+        c->psi.alloc((size_t)c->stride * h->B);
+        c->rhs.alloc((size_t)c->stride * h->B);
+        HIP_TRY(hipMemsetAsync(c->psi.p, 0, sizeof(double) * c->stride * h->B, h->stream));
+        HIP_TRY(hipMemsetAsync(c->rhs.p, 0, sizeof(double) * c->stride * h->B, h->stream));
+        v.push_back(c);
+        if (v.size() > 40) break;
+    }
+    h->hier[min_grid] = v;
+    return h->hier[min_grid];
+}
+
+// ------------------------------------------------------------------------------------------ smoother / V-cycle drivers
+static void smooth(scpn_gs* h, const Lvl& L, Fld psi, Fld src, double omega, int n_sweeps, const int* active,
+                   bool clip = false) {
+    if (n_sweeps <= 0 || L.nz < 3 || L.nr < 3) return;
+    const double om1 = 1.0 - omega;
+    if (!clip && (long)L.nz * L.nr <= SMALL_MAX) {
+        ProfScope ps(h, "small_smooth", 1);
+        hipLaunchKernelGGL(k_small_smooth, dim3(h->B), dim3(256), 0, h->stream, psi, src, L, omega, om1, n_sweeps, active);
+        return;
+    }
+    ProfScope ps(h, L.nz == h->nz ? "rb_half_fine" : "rb_half_coarse", 2L * n_sweeps);
+    int ncol = (L.nr - 2 + 1) / 2;
+    dim3 g(cdiv(ncol, 64), cdiv(L.nz - 2, 4), h->B);
+    for (int s = 0; s < n_sweeps; ++s)
+        for (int parity = 0; parity < 2; ++parity) {
+            if (clip) hipLaunchKernelGGL(k_rb_half<true>, g, BLK2D, 0, h->stream, psi, src, L, omega, om1, parity, active);
+            else hipLaunchKernelGGL(k_rb_half<false>, g, BLK2D, 0, h->stream, psi, src, L, omega, om1, parity, active);
+        }
+}
+
+// one V-cycle on (psi, src) of level 0 (core/multigrid_solve.py:252-335)
+static void vcycle(scpn_gs* h, Fld psi0, Fld src0, double omega, int pre, int post, int min_grid, const int* active) {
+    auto& lv = get_hierarchy(h, min_grid);
+    const int k = (int)lv.size() - 1;
+    auto psi_of = [&](int l) { return l == 0 ? psi0 : Fld{lv[l]->psi.p, nullptr, lv[l]->stride, h->B}; };
+    auto rhs_of = [&](int l) { return l == 0 ? src0 : Fld{lv[l]->rhs.p, nullptr, lv[l]->stride, h->B}; };
+    for (int l = 0; l < k; ++l) {
+        smooth(h, lv[l]->dev, psi_of(l), rhs_of(l), omega, pre, active);
+        ProfScope ps(h, l == 0 ? "defect_restrict_fine" : "defect_restrict_coarse", 1);
+        const Lvl& Lc = lv[l + 1]->dev;
+        hipLaunchKernelGGL(k_defect_restrict, grid2d(Lc.nr, Lc.nz, h->B), BLK2D, 0, h->stream, rhs_of(l + 1), psi_of(l + 1),
+                           psi_of(l), rhs_of(l), lv[l]->dev, Lc, active);
+    }
+    smooth(h, lv[k]->dev, psi_of(k), rhs_of(k), omega, 50, active);  // base case: 50 sweeps (multigrid_solve.py:293)
+    for (int l = k - 1; l >= 0; --l) {
+        const Lvl& Lf = lv[l]->dev;
+        const Lvl& Lc = lv[l + 1]->dev;
+        {
+            ProfScope ps(h, l == 0 ? "prolong_add_fine" : "prolong_add_coarse", 1);
+            hipLaunchKernelGGL(k_prolong<true>, grid2d(Lf.nr, Lf.nz, h->B), BLK2D, 0, h->stream, psi_of(l), psi_of(l + 1), Lf.nz,
+                               Lf.nr, Lf.ld, Lc.nz, Lc.nr, Lc.ld, active);
+        }
+        smooth(h, Lf, psi_of(l), rhs_of(l), omega, post, active);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ transfers
+static void upload(scpn_gs* h, double* dst_base, int member, const double* host) {
+    // host: dense (nz, nr) [x B when member < 0]; device: pitched rows, member stride
+    if (member >= 0) {
+        HIP_TRY(hipMemcpy2DAsync(dst_base + (long)member * h->stride, sizeof(double) * h->ld, host, sizeof(double) * h->nr,
+                                 sizeof(double) * h->nr, h->nz, hipMemcpyHostToDevice, h->stream));
+    } else {
+        for (int b = 0; b < h->B; ++b)
+            HIP_TRY(hipMemcpy2DAsync(dst_base + (long)b * h->stride, sizeof(double) * h->ld, host + (long)b * h->nz * h->nr,
+                                     sizeof(double) * h->nr, sizeof(double) * h->nr, h->nz, hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+}
+static void download(scpn_gs* h, const double* src_base, int member, double* host) {
+    if (member >= 0) {
+        HIP_TRY(hipMemcpy2DAsync(host, sizeof(double) * h->nr, src_base + (long)member * h->stride, sizeof(double) * h->ld,
+                                 sizeof(double) * h->nr, h->nz, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        for (int b = 0; b < h->B; ++b)
+            HIP_TRY(hipMemcpy2DAsync(host + (long)b * h->nz * h->nr, sizeof(double) * h->nr, src_base + (long)b * h->stride,
+                                     sizeof(double) * h->ld, sizeof(double) * h->nr, h->nz, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+}
+// psi lives in ping-pong slots: member b is at slot cur[b]
+static std::vector<int> host_cur(scpn_gs* h) {
+    std::vector<int> cur(h->B, 0);
+    HIP_TRY(hipMemcpyAsync(cur.data(), h->d_cur.p, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return cur;
+}
+static double* psi_member_ptr(scpn_gs* h, const std::vector<int>& cur, int b) {
+    return h->psi_slots.p + ((long)cur[b] * h->B + b) * h->stride;
+}
+
+static void ensure_picard_bufs(scpn_gs* h) {
+    if (h->picard_bufs) return;
+    size_t n = (size_t)h->stride * h->B;
+    h->src2.alloc(n);
+    h->bc.alloc(n);
+    h->jphi.alloc(n);
+    h->ext.alloc(n);
+    h->old.alloc(n);
+    HIP_TRY(hipMemsetAsync(h->bc.p, 0, sizeof(double) * n, h->stream));
+    HIP_TRY(hipMemsetAsync(h->jphi.p, 0, sizeof(double) * n, h->stream));
+    HIP_TRY(hipMemsetAsync(h->ext.p, 0, sizeof(double) * n, h->stream));
+    h->d_topo.alloc((size_t)h->B * h->nblk());
+    h->d_part3.alloc((size_t)h->B * h->nblk());
+    h->d_pbad.alloc((size_t)h->B * h->nblk());
+    h->picard_bufs = true;
+}
+
+static void set_tables_mu0(scpn_gs* h, double mu0) {
+    if (h->mu0_tables == mu0) return;
+    std::vector<double> inv(h->nr), neg(h->nr);
+    for (int ir = 0; ir < h->nr; ++ir) {
+        inv[ir] = 1.0 / (mu0 * h->r_axis[ir]);  // core/fusion_kernel.py:431
+        neg[ir] = (-mu0) * h->r_axis[ir];       // core/fusion_kernel_newton_solver.py:513
+    }
+    h->d_inv_mu0R.alloc(h->nr);
+    h->d_neg_mu0R.alloc(h->nr);
+    HIP_TRY(hipMemcpy(h->d_inv_mu0R.p, inv.data(), sizeof(double) * h->nr, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_neg_mu0R.p, neg.data(), sizeof(double) * h->nr, hipMemcpyHostToDevice));
+    h->mu0_tables = mu0;
+}
+
+// ------------------------------------------------------------------------------------------ creation
+static scpn_gs* create_impl(int nr, int nz, int batch, const double* r_axis, const double* z_axis, double dr, double dz) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available");
+    HIP_TRY(hipSetDevice(g_device));
+    auto* h = new scpn_gs();
+    try {
+        h->nr = nr; h->nz = nz; h->B = batch;
+        h->ld = pitch_of(nr);
+        h->stride = stride_of(nz, h->ld);
+        h->dr = dr; h->dz = dz;
+        h->r_axis.assign(r_axis, r_axis + nr);
+        if (z_axis) h->z_axis.assign(z_axis, z_axis + nz);
+        else { h->z_axis.assign(nz, 0.0); for (int i = 0; i < nz; ++i) h->z_axis[i] = i * dz; }
+        HIP_TRY(hipStreamCreate(&h->stream));
+        size_t n = (size_t)h->stride * batch;
+        h->psi_slots.alloc(3 * n);
+        h->W.alloc(n);
+        h->src.alloc(n);
+        HIP_TRY(hipMemsetAsync(h->psi_slots.p, 0, sizeof(double) * 3 * n, h->stream));
+        HIP_TRY(hipMemsetAsync(h->W.p, 0, sizeof(double) * n, h->stream));
+        HIP_TRY(hipMemsetAsync(h->src.p, 0, sizeof(double) * n, h->stream));
+        h->d_r.alloc(nr);
+        h->d_z.alloc(nz);
+        HIP_TRY(hipMemcpy(h->d_r.p, h->r_axis.data(), sizeof(double) * nr, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_z.p, h->z_axis.data(), sizeof(double) * nz, hipMemcpyHostToDevice));
+        h->d_st.alloc(batch);
+        h->d_mg.alloc(batch);
+        h->d_cur.alloc(batch); h->d_nxt.alloc(batch); h->d_best.alloc(batch); h->d_prev.alloc(batch);
+        h->d_active.alloc(batch);
+        h->d_nactive.alloc(1);
+        HIP_TRY(hipMemset(h->d_cur.p, 0, sizeof(int) * batch));
+        HIP_TRY(hipMemset(h->d_nxt.p, 0, sizeof(int) * batch));
+        HIP_TRY(hipMemset(h->d_best.p, 0, sizeof(int) * batch));
+        HIP_TRY(hipMemset(h->d_prev.p, 0, sizeof(int) * batch));
+        h->d_part1.alloc((size_t)batch * h->nblk());
+        h->d_part2.alloc((size_t)batch * h->nblk());
+        h->d_scal.alloc(8);
+        HIP_TRY(hipHostMalloc((void**)&h->h_nactive, sizeof(int) * 4, hipHostMallocDefault));
+        h->i_target.assign(batch, 0.0);
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    } catch (...) {
+        delete h;
+        throw;
+    }
+    return h;
+}
+
+#define API_BEGIN try {
+#define API_END                                    \
+    }                                              \
+    catch (const std::exception& e) {              \
+        return fail(SCPN_E_DEVICE, e.what());      \
+    }                                              \
+    return SCPN_OK;
+
+static bool omega_ok(double w) { return std::isfinite(w) && w >= 1.0 && w < 2.0; }
+
+// ------------------------------------------------------------------------------------------ Picard
+static void picard_solve_impl(scpn_gs* h, const scpn_picard_params* p, scpn_picard_result* results, double* hist_diff,
+                              double* hist_gs, double* trace, const std::vector<int>* member_mask) {
+    ensure_picard_bufs(h);
+    set_tables_mu0(h, p->mu0);
+    const int B = h->B, nz = h->nz, nr = h->nr, ld = h->ld;
+    const int nblk = h->nblk(), nblk_r = h->nblk_int();
+    auto& lv = get_hierarchy(h, 5);
+    const Lvl& L0 = lv[0]->dev;
+    hipStream_t st = h->stream;
+    const int max_iter = std::max(p->max_iter, 0);
+
+    // ---- member state
+    std::vector<int> cur = host_cur(h);
+    std::vector<Member> ms(B);
+    int n_act = 0;
+    std::vector<int> zero_current(B, 0);
+    for (int b = 0; b < B; ++b) {
+        Member& m = ms[b];
+        std::memset(&m, 0, sizeof(m));
+        m.i_target = h->i_target[b];
+        m.diff_best = 1e9;
+        m.gs_best = INFINITY;
+        m.gs = INFINITY;
+        m.cur = cur[b];
+        m.best = (cur[b] + 1) % 3;  // holds the pre-seed copy (Psi_best = Psi.copy(), newton_solver.py:484)
+        m.nxt = (cur[b] + 2) % 3;
+        m.prev = cur[b];
+        m.x_idx = -1;
+        bool masked_out = member_mask && !(*member_mask)[b];
+        // zero-current short-circuit (newton_solver.py:448-465)
+        if (!masked_out && std::fabs(m.i_target) < 1e-12 && !p->preserve_initial_state) zero_current[b] = 1;
+        m.active = (!masked_out && !zero_current[b] && max_iter > 0) ? 1 : 0;
+        if (zero_current[b]) m.converged = 1;
+        n_act += m.active;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_st.p, ms.data(), sizeof(Member) * B, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_publish_slots, dim3(cdiv(B, 64)), dim3(64), 0, st, h->d_st.p, h->d_cur.p, h->d_nxt.p, h->d_best.p,
+                       h->d_prev.p, h->d_active.p, B);
+    // "all members that take part" mask for the preparation steps (active or zero-current)
+    std::vector<int> part(B);
+    for (int b = 0; b < B; ++b) part[b] = (member_mask ? (*member_mask)[b] : 1) && !zero_current[b];
+    DBuf<int> d_part;
+    d_part.alloc(B);
+    HIP_TRY(hipMemcpyAsync(d_part.p, part.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
+
+    Fld curF = h->slot_fld(h->d_cur.p), nxtF = h->slot_fld(h->d_nxt.p), bestF = h->slot_fld(h->d_best.p);
+    Fld prevF = h->slot_fld(h->d_prev.p);
+    Fld WF = h->plain(h->W.p), srcF = h->plain(h->src.p), src2F = h->plain(h->src2.p), bcF = h->plain(h->bc.p);
+    Fld jF = h->plain(h->jphi.p);
+    dim3 g2 = grid2d(nr, nz, B);
+    dim3 gring(cdiv(2L * (nz + nr), 256), B);
+
+    // ---- _prepare_initial_flux (iterative_solver.py:412-451)
+    bool need_vac = !p->has_boundary_flux && !p->preserve_initial_state;
+    bool any_zero = false;
+    for (int b = 0; b < B; ++b) any_zero |= zero_current[b] != 0;
+    if (need_vac) {
+        if (h->n_vac > 0)
+            hipLaunchKernelGGL(k_coil_flux, g2, BLK2D, 0, st, bcF, nz, nr, ld, h->d_r.p, h->d_z.p, h->n_vac, h->d_vac_r.p, h->d_vac_z.p,
+                               h->d_vac_i.p, (const double*)nullptr, p->mu0, 0);
+        else
+            hipLaunchKernelGGL(k_fill, g2, BLK2D, 0, st, bcF, 0.0, nz, nr, ld, (const int*)d_part.p);
+    } else if (!p->has_boundary_flux) {  // preserve_initial_state: the current psi is the boundary map
+        hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, bcF, curF, nz, nr, ld, (const int*)d_part.p);
+    }
+    if (p->preserve_initial_state) {
+        hipLaunchKernelGGL(k_apply_bc, gring, dim3(256), 0, st, curF, bcF, nz, nr, ld, (const int*)d_part.p);
+    } else {
+        hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, curF, bcF, nz, nr, ld, (const int*)d_part.p);
+    }
+    if (any_zero) {  // zero-current members: psi = calculate_vacuum_field() (newton_solver.py:450)
+        if (h->n_vac > 0)
+            hipLaunchKernelGGL(k_coil_flux, g2, BLK2D, 0, st, WF, nz, nr, ld, h->d_r.p, h->d_z.p, h->n_vac, h->d_vac_r.p, h->d_vac_z.p,
+                               h->d_vac_i.p, (const double*)nullptr, p->mu0, 0);
+        else
+            hipLaunchKernelGGL(k_fill, g2, BLK2D, 0, st, WF, 0.0, nz, nr, ld, (const int*)nullptr);
+        DBuf<int> d_zc;
+        d_zc.alloc(B);
+        HIP_TRY(hipMemcpyAsync(d_zc.p, zero_current.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, curF, WF, nz, nr, ld, (const int*)d_zc.p);
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    // Psi_best = Psi.copy() before seeding
+    hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, bestF, curF, nz, nr, ld, (const int*)h->d_active.p);
+
+    // ---- _seed_plasma (iterative_solver.py:384-410)
+    if (!p->skip_seed && n_act > 0) {
+        if (!h->seed_user) {
+            h->seed_host.assign((size_t)nz * nr, 0.0);
+            for (int iz = 0; iz < nz; ++iz)
+                for (int ir = 0; ir < nr; ++ir) {
+                    double a = h->r_axis[ir] - p->r_center;
+                    double dist_sq = a * a + h->z_axis[iz] * h->z_axis[iz];
+                    h->seed_host[(size_t)iz * nr + ir] = std::exp(-dist_sq / 2.0);
+                }
+        }
+        double i_seed = (np_sum(h->seed_host.data(), (long)nz * nr) * h->dr) * h->dz;
+        h->d_seed.alloc((size_t)nz * nr);
+        HIP_TRY(hipMemcpyAsync(h->d_seed.p, h->seed_host.data(), sizeof(double) * nz * nr, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_seed_j, g2, BLK2D, 0, st, jF, (const double*)h->d_seed.p, (const Member*)h->d_st.p, i_seed, nz, nr, ld);
+        // members with |I_target| < 1e-12 keep psi untouched (their J is zero)
+        std::vector<int> seed_act(B);
+        for (int b = 0; b < B; ++b) seed_act[b] = ms[b].active && std::fabs(ms[b].i_target) >= 1e-12;
+        DBuf<int> d_sa;
+        d_sa.alloc(B);
+        HIP_TRY(hipMemcpyAsync(d_sa.p, seed_act.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_source_from_j, g2, BLK2D, 0, st, srcF, jF, nz, nr, ld, (const double*)h->d_neg_mu0R.p, (const int*)d_sa.p);
+        {
+            ProfScope ps(h, "seed_jacobi", 50);
+            for (int s = 0; s < 25; ++s) {
+                hipLaunchKernelGGL(k_jacobi, g2, BLK2D, 0, st, WF, curF, srcF, L0, (const int*)d_sa.p);
+                hipLaunchKernelGGL(k_jacobi, g2, BLK2D, 0, st, curF, WF, srcF, L0, (const int*)d_sa.p);
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (p->external_profile_mode) {
+        hipLaunchKernelGGL(k_source_from_j, g2, BLK2D, 0, st, srcF, jF, nz, nr, ld, (const double*)h->d_neg_mu0R.p, (const int*)h->d_active.p);
+    }
+
+    // ---- Picard loop (newton_solver.py:499-582)
+    Prof pf;
+    pf.hmode = p->hmode;
+    for (int i = 0; i < 4; ++i) { pf.ped_p[i] = p->ped_p[i]; pf.ped_ff[i] = p->ped_ff[i]; }
+    int n_mask_rows = 0;  // rows with Z < 0.5*Z_min (fusion_kernel.py:279); Z ascending
+    for (int iz = 0; iz < nz; ++iz) if ((p->z_min_cfg * 0.5) > h->z_axis[iz]) n_mask_rows = iz + 1;
+    h->h_nactive[0] = n_act;
+    HIP_TRY(hipMemcpyAsync(h->d_nactive.p, h->h_nactive, sizeof(int), hipMemcpyHostToDevice, st));
+    DBuf<double> d_hist_diff, d_hist_gs, d_trace;
+    if (hist_diff) { d_hist_diff.alloc((size_t)B * max_iter); HIP_TRY(hipMemsetAsync(d_hist_diff.p, 0, sizeof(double) * B * max_iter, st)); }
+    if (hist_gs) { d_hist_gs.alloc((size_t)B * max_iter); HIP_TRY(hipMemsetAsync(d_hist_gs.p, 0, sizeof(double) * B * max_iter, st)); }
+    if (trace) { d_trace.alloc((size_t)B * max_iter * 6); HIP_TRY(hipMemsetAsync(d_trace.p, 0, sizeof(double) * B * max_iter * 6, st)); }
+    const int check_every = std::max(1, p->check_every);
+    const double om_alpha = 1.0 - p->alpha;
+    const int* act = h->d_active.p;
+    int k = 0;
+    while (n_act > 0 && k < max_iter) {
+        {
+            ProfScope ps(h, "topology", 2);
+            hipLaunchKernelGGL(k_topology, dim3(nblk, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, h->dr, h->dz,
+                               n_mask_rows, h->d_topo.p, nblk);
+            hipLaunchKernelGGL(k_topology_final, dim3(B), dim3(256), 0, st, curF, h->d_st.p, (const TopoPart*)h->d_topo.p, nblk, nr, ld,
+                               (const double*)h->d_r.p, (const double*)h->d_z.p);
+        }
+        if (!p->external_profile_mode) {
+            ProfScope ps(h, "source", 3);
+            hipLaunchKernelGGL(k_jsum, dim3(nblk, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_part1.p, nblk);
+            hipLaunchKernelGGL(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_part1.p, nblk, h->dr, h->dz);
+            hipLaunchKernelGGL(k_source, g2, BLK2D, 0, st, srcF, jF, 0, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
+                               (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
+        }
+        // _elliptic_solve (iterative_solver.py:361-380)
+        if (p->method == 0) {
+            { ProfScope ps(h, "copy", 1); hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, WF, curF, nz, nr, ld, act); }
+            vcycle(h, WF, srcF, p->sor_omega, 3, 3, 5, act);
+        } else if (p->method == 1) {
+            hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, WF, curF, nz, nr, ld);
+            hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, src2F, srcF, nz, nr, ld);
+            smooth(h, L0, WF, src2F, p->sor_omega, 1, act, true);
+        } else {
+            hipLaunchKernelGGL(k_jacobi, g2, BLK2D, 0, st, WF, curF, srcF, L0, act);
+        }
+        {
+            ProfScope ps(h, "blend_norms", 2);
+            hipLaunchKernelGGL(k_blend, dim3(nblk, B), dim3(256), 0, st, nxtF, curF, WF, bcF, (const Member*)h->d_st.p, nz, nr, ld, p->alpha,
+                               om_alpha, h->d_part1.p, h->d_pbad.p, nblk);
+            hipLaunchKernelGGL(k_resid_norms, dim3(nblk_r, B), dim3(256), 0, st, nxtF, srcF, L0, h->d_part2.p, h->d_part3.p, nblk_r, act);
+        }
+        PicardCtl ctl;
+        ctl.tol = p->tol; ctl.gs_tol = p->gs_tol; ctl.require_gs = p->require_gs_residual; ctl.max_iter = max_iter;
+        ctl.iter = k; ctl.pad = 0; ctl.n_total = (long)nz * nr; ctl.n_interior = (long)(nz - 2) * (nr - 2);
+        {
+            ProfScope ps(h, "picard_final", 2);
+            hipLaunchKernelGGL(k_picard_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_part1.p, (const int*)h->d_pbad.p,
+                               (const double*)h->d_part2.p, (const double*)h->d_part3.p, nblk, nblk_r, ctl, d_hist_diff.p, d_hist_gs.p,
+                               d_trace.p, h->d_nactive.p);
+            hipLaunchKernelGGL(k_publish_slots, dim3(cdiv(B, 64)), dim3(64), 0, st, (const Member*)h->d_st.p, h->d_cur.p, h->d_nxt.p,
+                               h->d_best.p, h->d_prev.p, h->d_active.p, B);
+        }
+        ++k;
+        if (k % check_every == 0 || k >= max_iter) {
+            HIP_TRY(hipMemcpyAsync(h->h_nactive, h->d_nactive.p, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            n_act = h->h_nactive[0];
+        }
+    }
+    // ---- J_phi of the last source update (recomputed from the pre-blend psi kept in slot `prev`)
+    if (!p->external_profile_mode) {
+        std::vector<Member> fin(B);
+        HIP_TRY(hipMemcpyAsync(fin.data(), h->d_st.p, sizeof(Member) * B, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<Member> tmp(fin);
+        bool any = false;
+        for (int b = 0; b < B; ++b) { tmp[b].active = (fin[b].iterations > 0) ? 1 : 0; any |= tmp[b].active != 0; }
+        if (any) {
+            DBuf<Member> d_tmp;
+            d_tmp.alloc(B);
+            HIP_TRY(hipMemcpyAsync(d_tmp.p, tmp.data(), sizeof(Member) * B, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_source, g2, BLK2D, 0, st, src2F, jF, 1, prevF, (const Member*)d_tmp.p, nz, nr, ld, (const double*)h->d_r.p,
+                               (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        for (int b = 0; b < B; ++b)
+            if (zero_current[b]) {
+                // J_phi = 0 for the vacuum short-circuit
+                HIP_TRY(hipMemsetAsync(h->jphi.p + (long)b * h->stride, 0, sizeof(double) * h->stride, st));
+            }
+    }
+    // ---- results
+    std::vector<Member> fin(B);
+    HIP_TRY(hipMemcpyAsync(fin.data(), h->d_st.p, sizeof(Member) * B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (results) {
+        for (int b = 0; b < B; ++b) {
+            const Member& m = fin[b];
+            scpn_picard_result& r = results[b];
+            std::memset(&r, 0, sizeof(r));
+            r.converged = m.converged;
+            r.iterations = zero_current[b] ? 0 : std::max(m.iterations, (member_mask && !(*member_mask)[b]) ? 0 : 1);
+            r.diverged = m.diverged;
+            r.residual = zero_current[b] ? 0.0 : m.diff_best;
+            r.gs_residual = zero_current[b] ? 0.0 : m.gs;
+            r.gs_residual_best = zero_current[b] ? 0.0 : m.gs_best;
+            r.psi_axis = m.psi_axis; r.psi_bnd = m.psi_bnd; r.x_r = m.x_r; r.x_z = m.x_z; r.i_current = m.i_current;
+        }
+    }
+    if (hist_diff) HIP_TRY(hipMemcpy(hist_diff, d_hist_diff.p, sizeof(double) * B * max_iter, hipMemcpyDeviceToHost));
+    if (hist_gs) HIP_TRY(hipMemcpy(hist_gs, d_hist_gs.p, sizeof(double) * B * max_iter, hipMemcpyDeviceToHost));
+    if (trace) HIP_TRY(hipMemcpy(trace, d_trace.p, sizeof(double) * B * max_iter * 6, hipMemcpyDeviceToHost));
+}
+
+// ------------------------------------------------------------------------------------------ legacy FastSolver handle
+struct FastSolverHip {
+    int nr, nz, ld;
+    double rmin, rmax, zmin, zmax, dr, dz;
+    double boundary_value = 0.0;
+    DBuf<double> psi, j, Rtab, c_rp, c_rm, d_last;
+    DBuf<unsigned long long> d_bits;
+    DBuf<int> d_perf, d_done;
+    hipStream_t stream = nullptr;
+    ~FastSolverHip() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
+static void fast_sweeps(FastSolverHip* s, const double* j_host, double* psi_host, int iterations, double omega, bool use_tol,
+                        double tol, int* performed, double* last_delta) {
+    hipStream_t st = s->stream;
+    const int nr = s->nr, nz = s->nz, ld = s->ld;
+    HIP_TRY(hipMemcpy2DAsync(s->j.p, sizeof(double) * ld, j_host, sizeof(double) * nr, sizeof(double) * nr, nz, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(s->d_bits.p, 0, sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->d_perf.p, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(s->d_done.p, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(s->d_last.p, 0, sizeof(double), st));
+    const double dr_sq = s->dr * s->dr, dz_sq = s->dz * s->dz;
+    const double c_z = 1.0 / dz_sq, center = 2.0 / dr_sq + 2.0 / dz_sq, om1 = 1.0 - omega;
+    int ncol = (nr - 2 + 1) / 2;
+    dim3 g(cdiv(std::max(ncol, 1), 64), cdiv(std::max(nz - 2, 1), 4));
+    dim3 gr(cdiv(2L * (nz + nr), 256));
+    for (int it = 0; it < iterations; ++it) {
+        hipLaunchKernelGGL(k_fast_ring, gr, dim3(256), 0, st, s->psi.p, nz, nr, ld, s->boundary_value, (const int*)s->d_done.p);
+        if (nz > 2 && nr > 2)
+            for (int parity = 0; parity < 2; ++parity)
+                hipLaunchKernelGGL(k_fast_half, g, dim3(256), 0, st, s->psi.p, (const double*)s->j.p, nz, nr, ld, (const double*)s->Rtab.p,
+                                   (const double*)s->c_rp.p, (const double*)s->c_rm.p, c_z, center, omega, om1, parity, s->d_bits.p,
+                                   (const int*)s->d_done.p);
+        hipLaunchKernelGGL(k_fast_ctl, dim3(1), dim3(1), 0, st, s->d_bits.p, s->d_last.p, s->d_perf.p, s->d_done.p, tol, use_tol ? 1 : 0);
+    }
+    HIP_TRY(hipMemcpy2DAsync(psi_host, sizeof(double) * nr, s->psi.p, sizeof(double) * ld, sizeof(double) * nr, nz, hipMemcpyDeviceToHost, st));
+    int perf = 0;
+    double last = 0.0;
+    HIP_TRY(hipMemcpyAsync(&perf, s->d_perf.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&last, s->d_last.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (performed) *performed = perf;
+    if (last_delta) *last_delta = last;
+}
+
+// ========================================================================================== C ABI
+extern "C" {
+
+const char* scpn_last_error(void) { return g_err.c_str(); }
+const char* scpn_version(void) { return "scpn_hip 0.1 (gfx950, fp64, fp-contract=off)"; }
+
+int scpn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int scpn_set_device(int device) {
+    int n = scpn_device_count();
+    if (device < 0 || device >= n) return fail(SCPN_E_DEVICE, "device index out of range");
+    g_device = device;
+    return hipSetDevice(device) == hipSuccess ? SCPN_OK : fail(SCPN_E_DEVICE, "hipSetDevice failed");
+}
+int scpn_device_info(char* buf, int buflen) {
+    if (!buf || buflen <= 0) return fail(SCPN_E_ARG, "bad buffer");
+    if (scpn_device_count() <= 0) return fail(SCPN_E_DEVICE, "no HIP device");
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, g_device) != hipSuccess) return fail(SCPN_E_DEVICE, "hipGetDeviceProperties failed");
+    snprintf(buf, (size_t)buflen, "%s | %s | %d CUs | %.0f GiB | HIP", pr.name, pr.gcnArchName, pr.multiProcessorCount,
+             (double)pr.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    return SCPN_OK;
+}
+
+// ---- resident handle
+int scpn_gs_create(scpn_gs** out, int nr, int nz, int batch, const double* r_axis, const double* z_axis, double dr, double dz) {
+    if (!out || !r_axis || nr < 2 || nz < 2 || batch < 1) return fail(SCPN_E_ARG, "scpn_gs_create: need nr,nz >= 2, batch >= 1");
+    if (!(dr > 0.0) || !(dz > 0.0)) return fail(SCPN_E_ARG, "scpn_gs_create: dr, dz must be > 0");
+    API_BEGIN
+    *out = create_impl(nr, nz, batch, r_axis, z_axis, dr, dz);
+    API_END
+}
+void scpn_gs_destroy(scpn_gs* h) {
+    if (!h) return;
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+static int check_member(scpn_gs* h, int member) {
+    if (!h) return fail(SCPN_E_ARG, "null handle");
+    if (member < -1 || member >= h->B) return fail(SCPN_E_ARG, "member out of range");
+    return SCPN_OK;
+}
+static int set_plain(scpn_gs* h, DBuf<double>& buf, int member, const double* host) {
+    if (check_member(h, member) || !host) return fail(SCPN_E_ARG, "bad member / null buffer");
+    API_BEGIN
+    ensure_picard_bufs(h);
+    upload(h, buf.p, member, host);
+    API_END
+}
+static int get_plain(scpn_gs* h, DBuf<double>& buf, int member, double* host) {
+    if (check_member(h, member) || !host) return fail(SCPN_E_ARG, "bad member / null buffer");
+    API_BEGIN
+    ensure_picard_bufs(h);
+    download(h, buf.p, member, host);
+    API_END
+}
+int scpn_gs_set_psi(scpn_gs* h, int member, const double* psi) {
+    if (check_member(h, member) || !psi) return fail(SCPN_E_ARG, "bad member / null buffer");
+    API_BEGIN
+    std::vector<int> cur = host_cur(h);
+    for (int b = 0; b < h->B; ++b) {
+        if (member >= 0 && b != member) continue;
+        const double* src = member >= 0 ? psi : psi + (long)b * h->nz * h->nr;
+        HIP_TRY(hipMemcpy2DAsync(psi_member_ptr(h, cur, b), sizeof(double) * h->ld, src, sizeof(double) * h->nr, sizeof(double) * h->nr,
+                                 h->nz, hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    API_END
+}
+int scpn_gs_get_psi(scpn_gs* h, int member, double* psi) {
+    if (check_member(h, member) || !psi) return fail(SCPN_E_ARG, "bad member / null buffer");
+    API_BEGIN
+    std::vector<int> cur = host_cur(h);
+    for (int b = 0; b < h->B; ++b) {
+        if (member >= 0 && b != member) continue;
+        double* dst = member >= 0 ? psi : psi + (long)b * h->nz * h->nr;
+        HIP_TRY(hipMemcpy2DAsync(dst, sizeof(double) * h->nr, psi_member_ptr(h, cur, b), sizeof(double) * h->ld, sizeof(double) * h->nr,
+                                 h->nz, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    API_END
+}
+int scpn_gs_get_jphi(scpn_gs* h, int member, double* jphi) { return get_plain(h, h->jphi, member, jphi); }
+int scpn_gs_set_jphi(scpn_gs* h, int member, const double* jphi) { return set_plain(h, h->jphi, member, jphi); }
+int scpn_gs_get_source(scpn_gs* h, int member, double* source) { return get_plain(h, h->src, member, source); }
+int scpn_gs_set_source(scpn_gs* h, int member, const double* source) { return set_plain(h, h->src, member, source); }
+int scpn_gs_set_boundary_flux(scpn_gs* h, int member, const double* bc) { return set_plain(h, h->bc, member, bc); }
+int scpn_gs_get_boundary_flux(scpn_gs* h, int member, double* bc) { return get_plain(h, h->bc, member, bc); }
+int scpn_gs_set_current_target(scpn_gs* h, int member, const double* it) {
+    if (check_member(h, member) || !it) return fail(SCPN_E_ARG, "bad member / null buffer");
+    if (member >= 0) h->i_target[member] = *it;
+    else for (int b = 0; b < h->B; ++b) h->i_target[b] = it[b];
+    return SCPN_OK;
+}
+int scpn_gs_set_vacuum_coils(scpn_gs* h, int n, const double* r, const double* z, const double* i) {
+    if (!h || n < 0 || (n > 0 && (!r || !z || !i))) return fail(SCPN_E_ARG, "bad coil arrays");
+    API_BEGIN
+    h->n_vac = n;
+    if (n > 0) {
+        size_t c = (size_t)n * h->B;
+        h->d_vac_r.alloc(c); h->d_vac_z.alloc(c); h->d_vac_i.alloc(c);
+        HIP_TRY(hipMemcpy(h->d_vac_r.p, r, sizeof(double) * c, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_vac_z.p, z, sizeof(double) * c, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_vac_i.p, i, sizeof(double) * c, hipMemcpyHostToDevice));
+    }
+    API_END
+}
+int scpn_gs_set_seed(scpn_gs* h, const double* seed) {
+    if (!h) return fail(SCPN_E_ARG, "null handle");
+    if (!seed) { h->seed_user = false; return SCPN_OK; }
+    h->seed_host.assign(seed, seed + (size_t)h->nz * h->nr);
+    h->seed_user = true;
+    return SCPN_OK;
+}
+
+int scpn_gs_picard_solve(scpn_gs* h, const scpn_picard_params* p, scpn_picard_result* results, double* hist_diff, double* hist_gs,
+                         double* trace) {
+    if (!h || !p) return fail(SCPN_E_ARG, "null handle / params");
+    if (p->method < 0 || p->method > 2) return fail(SCPN_E_ARG, "method must be 0 (multigrid), 1 (sor) or 2 (jacobi)");
+    if (p->method != 2 && !omega_ok(p->sor_omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
+    if (p->require_gs_residual && !(p->gs_tol > 0.0)) return fail(SCPN_E_ARG, "solver.gs_residual_threshold must be > 0");
+    if (h->nz < 3 || h->nr < 3) return fail(SCPN_E_ARG, "grid must be at least 3x3");
+    API_BEGIN
+    picard_solve_impl(h, p, results, hist_diff, hist_gs, trace, nullptr);
+    if (p->fail_on_diverge && results)
+        for (int b = 0; b < h->B; ++b)
+            if (results[b].diverged) return fail(SCPN_E_DIVERGED, "Equilibrium solver diverged");
+    API_END
+}
+
+int scpn_gs_free_boundary_solve(scpn_gs* h, const scpn_picard_params* p, int n_coils, const double* coil_r, const double* coil_z,
+                                const double* coil_i, const double* coil_turns, int max_outer, double tol, int* outer_iterations,
+                                double* final_diff, int* picard_iters, scpn_picard_result* results) {
+    if (!h || !p) return fail(SCPN_E_ARG, "null handle / params");
+    if (max_outer < 1) return fail(SCPN_E_ARG, "max_outer_iter must be >= 1.");
+    if (!std::isfinite(tol) || tol < 0.0) return fail(SCPN_E_ARG, "tol must be finite and >= 0.");
+    if (n_coils < 0 || (n_coils > 0 && (!coil_r || !coil_z || !coil_i))) return fail(SCPN_E_ARG, "bad coil arrays");
+    if (p->method != 2 && !omega_ok(p->sor_omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
+    API_BEGIN
+    ensure_picard_bufs(h);
+    const int B = h->B, nz = h->nz, nr = h->nr, ld = h->ld;
+    hipStream_t st = h->stream;
+    dim3 g2 = grid2d(nr, nz, B);
+    dim3 gring(cdiv(2L * (nz + nr), 256), B);
+    // psi_ext = compute_external_flux (free_boundary.py:646) -> kept in `ext`, used as boundary_flux
+    size_t c = (size_t)std::max(n_coils, 1) * B;
+    h->d_fb_r.alloc(c); h->d_fb_z.alloc(c); h->d_fb_i.alloc(c); h->d_fb_t.alloc(c);
+    if (n_coils > 0) {
+        HIP_TRY(hipMemcpyAsync(h->d_fb_r.p, coil_r, sizeof(double) * n_coils * B, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(h->d_fb_z.p, coil_z, sizeof(double) * n_coils * B, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(h->d_fb_i.p, coil_i, sizeof(double) * n_coils * B, hipMemcpyHostToDevice, st));
+        if (coil_turns) HIP_TRY(hipMemcpyAsync(h->d_fb_t.p, coil_turns, sizeof(double) * n_coils * B, hipMemcpyHostToDevice, st));
+    }
+    Fld extF = h->plain(h->ext.p), bcF = h->plain(h->bc.p), oldF = h->plain(h->old.p);
+    {
+        ProfScope ps(h, "coil_flux", 1);
+        hipLaunchKernelGGL(k_coil_flux, g2, BLK2D, 0, st, extF, nz, nr, ld, h->d_r.p, h->d_z.p, n_coils, h->d_fb_r.p, h->d_fb_z.p,
+                           h->d_fb_i.p, coil_turns ? (const double*)h->d_fb_t.p : (const double*)nullptr, 0.0, 1);
+    }
+    hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, bcF, extF, nz, nr, ld, (const int*)nullptr);
+    scpn_picard_params q = *p;
+    q.preserve_initial_state = 1;
+    q.has_boundary_flux = 1;
+    std::vector<int> mask(B, 1), outer_it(B, 0);
+    std::vector<double> fdiff(B, INFINITY), hdiff(B);
+    std::vector<scpn_picard_result> res(B), last(B);
+    DBuf<double> d_diff;
+    d_diff.alloc(B);
+    const int nblk = h->nblk();
+    for (int outer = 0; outer < max_outer; ++outer) {
+        bool any = false;
+        for (int b = 0; b < B; ++b) any |= mask[b] != 0;
+        if (!any) break;
+        DBuf<int> d_mask;
+        d_mask.alloc(B);
+        HIP_TRY(hipMemcpyAsync(d_mask.p, mask.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
+        Fld curF = h->slot_fld(h->d_cur.p);
+        hipLaunchKernelGGL(k_apply_bc, gring, dim3(256), 0, st, curF, extF, nz, nr, ld, (const int*)d_mask.p);
+        hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, oldF, curF, nz, nr, ld, (const int*)d_mask.p);
+        HIP_TRY(hipStreamSynchronize(st));
+        picard_solve_impl(h, &q, res.data(), nullptr, nullptr, nullptr, &mask);
+        curF = h->slot_fld(h->d_cur.p);
+        hipLaunchKernelGGL(k_maxabsdiff, dim3(nblk, B), dim3(256), 0, st, curF, oldF, nz, nr, ld, h->d_part1.p, nblk);
+        hipLaunchKernelGGL(k_max_final, dim3(B), dim3(256), 0, st, d_diff.p, (const double*)h->d_part1.p, nblk);
+        HIP_TRY(hipMemcpyAsync(hdiff.data(), d_diff.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int b = 0; b < B; ++b) {
+            if (!mask[b]) continue;
+            outer_it[b] = outer + 1;
+            fdiff[b] = hdiff[b];
+            last[b] = res[b];
+            if (picard_iters) picard_iters[(long)b * max_outer + outer] = res[b].iterations;
+            if (hdiff[b] < tol) mask[b] = 0;
+        }
+    }
+    for (int b = 0; b < B; ++b) {
+        if (outer_iterations) outer_iterations[b] = outer_it[b];
+        if (final_diff) final_diff[b] = fdiff[b];
+        if (results) results[b] = last[b];
+    }
+    API_END
+}
+
+int scpn_gs_rb_sor(scpn_gs* h, double omega, int n_sweeps) {
+    if (!h) return fail(SCPN_E_ARG, "null handle");
+    if (!omega_ok(omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
+    API_BEGIN
+    auto& lv = get_hierarchy(h, 5);
+    smooth(h, lv[0]->dev, h->slot_fld(h->d_cur.p), h->plain(h->src.p), omega, n_sweeps, nullptr);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    API_END
+}
+int scpn_gs_vcycle(scpn_gs* h, double omega, int pre, int post, int min_grid) {
+    if (!h) return fail(SCPN_E_ARG, "null handle");
+    if (!omega_ok(omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
+    API_BEGIN
+    vcycle(h, h->slot_fld(h->d_cur.p), h->plain(h->src.p), omega, pre, post, min_grid, nullptr);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    API_END
+}
+int scpn_gs_compute_b_field(scpn_gs* h, int member, double* b_r, double* b_z) {
+    if (!h || member < 0 || member >= h->B || !b_r || !b_z) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    size_t n = (size_t)h->nz * h->nr;
+    DBuf<double> dbr, dbz;
+    dbr.alloc(n);
+    dbz.alloc(n);
+    hipLaunchKernelGGL(k_b_field, grid2d(h->nr, h->nz, 1), BLK2D, 0, h->stream, dbr.p, dbz.p, h->slot_fld(h->d_cur.p), member, h->nz, h->nr,
+                       h->ld, h->dr, h->dz, (const double*)h->d_r.p);
+    HIP_TRY(hipMemcpyAsync(b_r, dbr.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(b_z, dbz.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    API_END
+}
+int scpn_gs_sync(scpn_gs* h) {
+    if (!h) return fail(SCPN_E_ARG, "null handle");
+    API_BEGIN
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    API_END
+}
+int scpn_gs_profile(scpn_gs* h, int enable) {
+    if (!h) return fail(SCPN_E_ARG, "null handle");
+    API_BEGIN
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (auto& e : h->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    h->prof.clear();
+    h->prof_on = enable != 0;
+    API_END
+}
+int scpn_gs_profile_read(scpn_gs* h, const char* name, double* total_ms, long* launches) {
+    if (!h || !name) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double tot = 0.0;
+    long n = 0;
+    for (auto& e : h->prof) {
+        if (h->prof_names[e.id] != name) continue;
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+        tot += ms;
+        n += e.launches;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    API_END
+}
+
+// ---- operator library on host buffers -------------------------------------------------------
+struct TempSolver {
+    scpn_gs* h = nullptr;
+    TempSolver(int nr, int nz, int batch, const double* r_axis, const double* z_axis, double dr, double dz) {
+        h = create_impl(nr, nz, batch, r_axis, z_axis, dr, dz);
+    }
+    ~TempSolver() { if (h) { (void)hipStreamSynchronize(h->stream); delete h; } }
+};
+static int check_grid(const void* a, const void* b, const double* r_axis, int nz, int nr, int batch, double dr, double dz) {
+    if (!a || !b || !r_axis) return fail(SCPN_E_ARG, "null buffer");
+    if (nz < 2 || nr < 2 || batch < 1) return fail(SCPN_E_ARG, "need nz, nr >= 2 and batch >= 1");
+    if (!(dr > 0.0) || !(dz > 0.0) || !std::isfinite(dr) || !std::isfinite(dz)) return fail(SCPN_E_ARG, "dr, dz must be finite and > 0");
+    return SCPN_OK;
+}
+
+int scpn_mg_smooth(double* psi, const double* source, const double* r_axis, int nz, int nr, int batch, double dr, double dz, double omega,
+                   int n_sweeps) {
+    if (!omega_ok(omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
+    if (check_grid(psi, source, r_axis, nz, nr, batch, dr, dz)) return SCPN_E_ARG;
+    if (n_sweeps < 0) return fail(SCPN_E_ARG, "n_sweeps must be >= 0");
+    API_BEGIN
+    TempSolver t(nr, nz, batch, r_axis, nullptr, dr, dz);
+    upload(t.h, t.h->psi_slots.p, -1, psi);
+    upload(t.h, t.h->src.p, -1, source);
+    auto& lv = get_hierarchy(t.h, 1 << 30);
+    smooth(t.h, lv[0]->dev, t.h->slot_fld(nullptr), t.h->plain(t.h->src.p), omega, n_sweeps, nullptr);
+    download(t.h, t.h->psi_slots.p, -1, psi);
+    API_END
+}
+int scpn_mg_residual(const double* psi, const double* source, const double* r_axis, int nz, int nr, int batch, double dr, double dz,
+                     double* out) {
+    if (check_grid(psi, source, r_axis, nz, nr, batch, dr, dz) || !out) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    TempSolver t(nr, nz, batch, r_axis, nullptr, dr, dz);
+    upload(t.h, t.h->psi_slots.p, -1, psi);
+    upload(t.h, t.h->src.p, -1, source);
+    auto& lv = get_hierarchy(t.h, 1 << 30);
+    hipLaunchKernelGGL(k_residual, grid2d(nr, nz, batch), BLK2D, 0, t.h->stream, t.h->plain(t.h->W.p), t.h->slot_fld(nullptr),
+                       t.h->plain(t.h->src.p), lv[0]->dev);
+    download(t.h, t.h->W.p, -1, out);
+    API_END
+}
+static void resid_norms_host(scpn_gs* h, Fld psi, Fld src, std::vector<double>& mx, std::vector<double>& ss) {
+    auto& lv = get_hierarchy(h, 1 << 30);
+    const int nb = std::max(h->nblk_int(), 1), B = h->B;
+    mx.assign(B, 0.0);
+    ss.assign(B, 0.0);
+    if (h->nz < 3 || h->nr < 3) return;
+    hipLaunchKernelGGL(k_resid_norms, dim3(nb, B), dim3(256), 0, h->stream, psi, src, lv[0]->dev, h->d_part1.p, h->d_part2.p, nb, (const int*)nullptr);
+    std::vector<double> pm((size_t)B * nb), ps((size_t)B * nb);
+    HIP_TRY(hipMemcpyAsync(pm.data(), h->d_part1.p, sizeof(double) * B * nb, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(ps.data(), h->d_part2.p, sizeof(double) * B * nb, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < nb; ++i) {
+            mx[b] = std::fmax(mx[b], pm[(size_t)b * nb + i]);
+            ss[b] += ps[(size_t)b * nb + i];
+        }
+}
+int scpn_residual_linf(const double* psi, const double* source, const double* r_axis, int nz, int nr, int batch, double dr, double dz,
+                       double* linf) {
+    if (check_grid(psi, source, r_axis, nz, nr, batch, dr, dz) || !linf) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    TempSolver t(nr, nz, batch, r_axis, nullptr, dr, dz);
+    upload(t.h, t.h->psi_slots.p, -1, psi);
+    upload(t.h, t.h->src.p, -1, source);
+    std::vector<double> mx, ss;
+    resid_norms_host(t.h, t.h->slot_fld(nullptr), t.h->plain(t.h->src.p), mx, ss);
+    for (int b = 0; b < batch; ++b) linf[b] = mx[b];
+    API_END
+}
+int scpn_gs_residual_rms(const double* psi, const double* source, const double* r_axis, int nz, int nr, int batch, double dr, double dz,
+                         double* rms) {
+    if (check_grid(psi, source, r_axis, nz, nr, batch, dr, dz) || !rms) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    TempSolver t(nr, nz, batch, r_axis, nullptr, dr, dz);
+    upload(t.h, t.h->psi_slots.p, -1, psi);
+    upload(t.h, t.h->src.p, -1, source);
+    std::vector<double> mx, ss;
+    resid_norms_host(t.h, t.h->slot_fld(nullptr), t.h->plain(t.h->src.p), mx, ss);
+    long ni = (long)(nz - 2) * (nr - 2);
+    for (int b = 0; b < batch; ++b) rms[b] = (ni <= 0 || mx[b] <= 0.0) ? 0.0 : std::sqrt(ss[b] / (double)ni);
+    API_END
+}
+int scpn_restrict_full_weight(const double* fine, int nz_f, int nr_f, int batch, double* coarse) {
+    if (!fine || !coarse || nz_f < 2 || nr_f < 2 || batch < 1) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    HIP_TRY(hipSetDevice(g_device));
+    int nz_c = (nz_f + 1) / 2, nr_c = (nr_f + 1) / 2;
+    size_t nf = (size_t)nz_f * nr_f, nc = (size_t)nz_c * nr_c;
+    DBuf<double> df, dc;
+    df.alloc(nf * batch);
+    dc.alloc(nc * batch);
+    HIP_TRY(hipMemcpy(df.p, fine, sizeof(double) * nf * batch, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_restrict, grid2d(nr_c, nz_c, batch), BLK2D, 0, 0, Fld{dc.p, nullptr, (long)nc, batch},
+                       Fld{df.p, nullptr, (long)nf, batch}, nz_f, nr_f, nr_f, nz_c, nr_c, nr_c);
+    HIP_TRY(hipMemcpy(coarse, dc.p, sizeof(double) * nc * batch, hipMemcpyDeviceToHost));
+    API_END
+}
+int scpn_prolongate_bilinear(const double* coarse, int nz_c, int nr_c, int nz_f, int nr_f, int batch, double* fine) {
+    if (!fine || !coarse || nz_f < 1 || nr_f < 1 || batch < 1) return fail(SCPN_E_ARG, "bad arguments");
+    if (nz_c != (nz_f + 1) / 2 || nr_c != (nr_f + 1) / 2)
+        return fail(SCPN_E_ARG, "coarse shape must be ((nz_f+1)//2, (nr_f+1)//2)");
+    API_BEGIN
+    HIP_TRY(hipSetDevice(g_device));
+    size_t nf = (size_t)nz_f * nr_f, nc = (size_t)nz_c * nr_c;
+    DBuf<double> df, dc;
+    df.alloc(nf * batch);
+    dc.alloc(nc * batch);
+    HIP_TRY(hipMemcpy(dc.p, coarse, sizeof(double) * nc * batch, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_prolong<false>, grid2d(nr_f, nz_f, batch), BLK2D, 0, 0, Fld{df.p, nullptr, (long)nf, batch},
+                       Fld{dc.p, nullptr, (long)nc, batch}, nz_f, nr_f, nr_f, nz_c, nr_c, nr_c, (const int*)nullptr);
+    HIP_TRY(hipMemcpy(fine, df.p, sizeof(double) * nf * batch, hipMemcpyDeviceToHost));
+    API_END
+}
+int scpn_multigrid_vcycle(double* psi, const double* source, const double* r_axis, int nz, int nr, int batch, double dr, double dz,
+                          double omega, int pre, int post, int min_grid) {
+    if (!omega_ok(omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
+    if (check_grid(psi, source, r_axis, nz, nr, batch, dr, dz)) return SCPN_E_ARG;
+    if (pre < 0 || post < 0) return fail(SCPN_E_ARG, "smoothing counts must be >= 0");
+    API_BEGIN
+    TempSolver t(nr, nz, batch, r_axis, nullptr, dr, dz);
+    upload(t.h, t.h->psi_slots.p, -1, psi);
+    upload(t.h, t.h->src.p, -1, source);
+    vcycle(t.h, t.h->slot_fld(nullptr), t.h->plain(t.h->src.p), omega, pre, post, min_grid, nullptr);
+    download(t.h, t.h->psi_slots.p, -1, psi);
+    API_END
+}
+int scpn_multigrid_solve(const double* source, double* psi, const double* r_axis, const double* z_axis, int nr, int nz, int batch,
+                         double tol, int max_cycles, double omega, int pre, int post, int min_grid, double* residual, int* n_cycles,
+                         int* converged) {
+    if (!source || !psi || !r_axis || !z_axis) return fail(SCPN_E_ARG, "null buffer");
+    if (!(std::isfinite(tol) && tol > 0.0)) return fail(SCPN_E_ARG, "tol must be finite and > 0.");
+    if (max_cycles < 1) return fail(SCPN_E_ARG, "max_cycles must be >= 1.");
+    if (!omega_ok(omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
+    if (nr < 2 || nz < 2 || batch < 1) return fail(SCPN_E_ARG, "need nz, nr >= 2 and batch >= 1");
+    API_BEGIN
+    // multigrid_solve.py:431-432: dr = r_axis[1]-r_axis[0]
+    double dr = r_axis[1] - r_axis[0], dz = z_axis[1] - z_axis[0];
+    TempSolver t(nr, nz, batch, r_axis, z_axis, dr, dz);
+    scpn_gs* h = t.h;
+    ensure_picard_bufs(h);
+    upload(h, h->psi_slots.p, -1, psi);
+    upload(h, h->src.p, -1, source);
+    hipStream_t st = h->stream;
+    const int B = batch;
+    Fld psiF = h->slot_fld(nullptr), srcF = h->plain(h->src.p), bcF = h->plain(h->bc.p);
+    hipLaunchKernelGGL(k_copy, grid2d(nr, nz, B), BLK2D, 0, st, bcF, psiF, nz, nr, h->ld, (const int*)nullptr);
+    auto& lv0 = get_hierarchy(h, 1 << 30);
+    const int nb = std::max(h->nblk_int(), 1);
+    std::vector<MgMember> ms(B);
+    std::vector<int> ones(B, 1);
+    for (auto& m : ms) { m.residual = 0; m.n_cycles = 0; m.converged = 0; m.active = 1; m.pad = 0; }
+    HIP_TRY(hipMemcpyAsync(h->d_mg.p, ms.data(), sizeof(MgMember) * B, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->d_active.p, ones.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
+    h->h_nactive[0] = B;
+    HIP_TRY(hipMemcpyAsync(h->d_nactive.p, h->h_nactive, sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(h->d_part1.p, 0, sizeof(double) * B * h->nblk(), st));
+    auto norms = [&](int count_cycle) {
+        if (nz >= 3 && nr >= 3)
+            hipLaunchKernelGGL(k_resid_norms, dim3(nb, B), dim3(256), 0, st, psiF, srcF, lv0[0]->dev, h->d_part1.p, h->d_part2.p, nb,
+                               (const int*)h->d_active.p);
+        hipLaunchKernelGGL(k_mg_final, dim3(B), dim3(256), 0, st, h->d_mg.p, (const double*)h->d_part1.p, nb, tol, max_cycles, count_cycle,
+                           h->d_active.p, h->d_nactive.p);
+    };
+    norms(0);
+    int n_act = B;
+    for (int c = 0; c < max_cycles; ++c) {
+        HIP_TRY(hipMemcpyAsync(h->h_nactive, h->d_nactive.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_act = h->h_nactive[0];
+        if (n_act <= 0) break;
+        vcycle(h, psiF, srcF, omega, pre, post, min_grid, h->d_active.p);
+        hipLaunchKernelGGL(k_apply_bc, dim3(cdiv(2L * (nz + nr), 256), B), dim3(256), 0, st, psiF, bcF, nz, nr, h->ld, (const int*)h->d_active.p);
+        norms(1);
+    }
+    HIP_TRY(hipMemcpyAsync(ms.data(), h->d_mg.p, sizeof(MgMember) * B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int b = 0; b < B; ++b) {
+        if (residual) residual[b] = ms[b].residual;
+        if (n_cycles) n_cycles[b] = ms[b].n_cycles;
+        if (converged) converged[b] = ms[b].converged;
+    }
+    download(h, h->psi_slots.p, -1, psi);
+    API_END
+}
+int scpn_jacobi_step(const double* psi, const double* source, const double* r_axis, int nz, int nr, int batch, double dr, double dz,
+                     double* out) {
+    if (check_grid(psi, source, r_axis, nz, nr, batch, dr, dz) || !out) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    TempSolver t(nr, nz, batch, r_axis, nullptr, dr, dz);
+    upload(t.h, t.h->psi_slots.p, -1, psi);
+    upload(t.h, t.h->src.p, -1, source);
+    auto& lv = get_hierarchy(t.h, 1 << 30);
+    hipLaunchKernelGGL(k_jacobi, grid2d(nr, nz, batch), BLK2D, 0, t.h->stream, t.h->plain(t.h->W.p), t.h->slot_fld(nullptr),
+                       t.h->plain(t.h->src.p), lv[0]->dev, (const int*)nullptr);
+    download(t.h, t.h->W.p, -1, out);
+    API_END
+}
+int scpn_sor_step(const double* psi, const double* source, const double* r_axis, int nz, int nr, int batch, double dr, double dz,
+                  double omega, double* out) {
+    if (!omega_ok(omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
+    if (check_grid(psi, source, r_axis, nz, nr, batch, dr, dz) || !out) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    TempSolver t(nr, nz, batch, r_axis, nullptr, dr, dz);
+    scpn_gs* h = t.h;
+    ensure_picard_bufs(h);
+    upload(h, h->psi_slots.p, -1, psi);
+    upload(h, h->src.p, -1, source);
+    auto& lv = get_hierarchy(h, 1 << 30);
+    dim3 g2 = grid2d(nr, nz, batch);
+    hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, h->stream, h->plain(h->W.p), h->slot_fld(nullptr), nz, nr, h->ld);
+    hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, h->stream, h->plain(h->src2.p), h->plain(h->src.p), nz, nr, h->ld);
+    smooth(h, lv[0]->dev, h->plain(h->W.p), h->plain(h->src2.p), omega, 1, nullptr, true);
+    download(h, h->W.p, -1, out);
+    API_END
+}
+int scpn_coil_flux(const double* r_axis, const double* z_axis, int nz, int nr, int batch, int n_coils, const double* coil_r,
+                   const double* coil_z, const double* coil_i, const double* coil_turns, double mu0, int mode, double* out) {
+    if (!r_axis || !z_axis || !out || nz < 1 || nr < 1 || batch < 1 || n_coils < 0) return fail(SCPN_E_ARG, "bad arguments");
+    if (n_coils > 0 && (!coil_r || !coil_z || !coil_i)) return fail(SCPN_E_ARG, "null coil arrays");
+    if (mode != 0 && mode != 1) return fail(SCPN_E_ARG, "mode must be 0 or 1");
+    API_BEGIN
+    HIP_TRY(hipSetDevice(g_device));
+    size_t n = (size_t)nz * nr, c = (size_t)std::max(n_coils, 1) * batch;
+    DBuf<double> dout, dr_, dz_, cr, cz, ci, ct;
+    dout.alloc(n * batch); dr_.alloc(nr); dz_.alloc(nz); cr.alloc(c); cz.alloc(c); ci.alloc(c); ct.alloc(c);
+    HIP_TRY(hipMemcpy(dr_.p, r_axis, sizeof(double) * nr, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dz_.p, z_axis, sizeof(double) * nz, hipMemcpyHostToDevice));
+    if (n_coils > 0) {
+        HIP_TRY(hipMemcpy(cr.p, coil_r, sizeof(double) * n_coils * batch, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(cz.p, coil_z, sizeof(double) * n_coils * batch, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ci.p, coil_i, sizeof(double) * n_coils * batch, hipMemcpyHostToDevice));
+        if (coil_turns) HIP_TRY(hipMemcpy(ct.p, coil_turns, sizeof(double) * n_coils * batch, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_coil_flux, grid2d(nr, nz, batch), BLK2D, 0, 0, Fld{dout.p, nullptr, (long)n, batch}, nz, nr, nr, (const double*)dr_.p,
+                       (const double*)dz_.p, n_coils, (const double*)cr.p, (const double*)cz.p, (const double*)ci.p,
+                       coil_turns ? (const double*)ct.p : (const double*)nullptr, mu0, mode);
+    HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * n * batch, hipMemcpyDeviceToHost));
+    API_END
+}
+int scpn_green_points(int n_coils, const double* coil_r, const double* coil_z, int n_pts, const double* pts_r, const double* pts_z,
+                      double* out) {
+    if (n_coils < 1 || n_pts < 1 || !coil_r || !coil_z || !pts_r || !pts_z || !out) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    HIP_TRY(hipSetDevice(g_device));
+    DBuf<double> cr, cz, pr, pz, dout;
+    cr.alloc(n_coils); cz.alloc(n_coils); pr.alloc(n_pts); pz.alloc(n_pts); dout.alloc((size_t)n_coils * n_pts);
+    HIP_TRY(hipMemcpy(cr.p, coil_r, sizeof(double) * n_coils, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(cz.p, coil_z, sizeof(double) * n_coils, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pr.p, pts_r, sizeof(double) * n_pts, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pz.p, pts_z, sizeof(double) * n_pts, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_green_points, dim3(cdiv(n_pts, 256), n_coils), dim3(256), 0, 0, dout.p, n_coils, (const double*)cr.p,
+                       (const double*)cz.p, n_pts, (const double*)pr.p, (const double*)pz.p);
+    HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * n_coils * n_pts, hipMemcpyDeviceToHost));
+    API_END
+}
+int scpn_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int nr, int nz, const double* r_axis, const double* z_axis,
+                     const double* psi_seed, double ip_target, double mu0, int n_picard, int n_jacobi, double alpha, double omega_j,
+                     double beta_mix, double* psi_out) {
+    (void)r_max; (void)z_min; (void)z_max;
+    if (!r_axis || !z_axis || !psi_out || nr < 3 || nz < 3 || n_picard < 0 || n_jacobi < 0) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    double dr = r_axis[1] - r_axis[0], dz = z_axis[1] - z_axis[0];
+    TempSolver t(nr, nz, 1, r_axis, z_axis, dr, dz);
+    scpn_gs* h = t.h;
+    ensure_picard_bufs(h);
+    std::vector<double> seed((size_t)nz * nr);
+    if (psi_seed) std::copy(psi_seed, psi_seed + (size_t)nz * nr, seed.begin());
+    else {
+        double r_center = 0.5 * (r_min + r_axis[nr - 1]);
+        for (int iz = 0; iz < nz; ++iz)
+            for (int ir = 0; ir < nr; ++ir) {
+                double a = r_axis[ir] - r_center;
+                bool ring = iz == 0 || iz == nz - 1 || ir == 0 || ir == nr - 1;
+                seed[(size_t)iz * nr + ir] = ring ? 0.0 : std::exp(-(a * a) / 0.5) * 0.01;
+            }
+    }
+    upload(h, h->psi_slots.p, 0, seed.data());
+    // jax_gs_solver.py:67-74 uses dR*dR (not dR**2); identical to pow(dR, 2) in IEEE arithmetic
+    auto& lv = get_hierarchy(h, 1 << 30);
+    Lvl L = lv[0]->dev;
+    hipStream_t st = h->stream;
+    Fld psiF = h->slot_fld(nullptr), srcF = h->plain(h->src.p), aF = h->plain(h->W.p), bF = h->plain(h->src2.p);
+    dim3 g2 = grid2d(nr, nz, 1);
+    const int nb = h->nblk(), nbi = std::max(h->nblk_int(), 1);
+    for (int it = 0; it < n_picard; ++it) {
+        hipLaunchKernelGGL(k_max_interior, dim3(nbi, 1), dim3(256), 0, st, psiF, nz, nr, h->ld, h->d_part1.p, nbi);
+        hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, h->d_scal.p, (const double*)h->d_part1.p, nbi, 0, dr, dz, ip_target);
+        hipLaunchKernelGGL(k_np_jsum, dim3(nb, 1), dim3(256), 0, st, psiF, (const double*)h->d_scal.p, nz, nr, h->ld, (const double*)h->d_r.p, mu0,
+                           beta_mix, h->d_part2.p, nb);
+        hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, h->d_scal.p, (const double*)h->d_part2.p, nb, 1, dr, dz, ip_target);
+        hipLaunchKernelGGL(k_np_source, g2, BLK2D, 0, st, srcF, psiF, (const double*)h->d_scal.p, nz, nr, h->ld, (const double*)h->d_r.p, mu0,
+                           beta_mix);
+        hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, aF, psiF, nz, nr, h->ld, (const int*)nullptr);
+        Fld in = aF, out = bF;
+        for (int j = 0; j < n_jacobi; ++j) {
+            hipLaunchKernelGGL(k_jacobi_damped, g2, BLK2D, 0, st, out, in, srcF, L, omega_j, 1.0 - omega_j);
+            std::swap(in, out);
+        }
+        hipLaunchKernelGGL(k_axpby, g2, BLK2D, 0, st, psiF, psiF, in, 1.0 - alpha, alpha, nz, nr, h->ld);
+    }
+    download(h, h->psi_slots.p, 0, psi_out);
+    API_END
+}
+
+// ---- legacy libscpn_solver symbols (hpc/solver.cpp:200-335) ---------------------------------
+void* create_solver(int nr, int nz, double rmin, double rmax, double zmin, double zmax) {
+    if (nr < 2 || nz < 2) return nullptr;
+    if (rmin >= rmax || zmin >= zmax) return nullptr;
+    try {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nullptr;
+        HIP_TRY(hipSetDevice(g_device));
+        auto* s = new FastSolverHip();
+        s->nr = nr; s->nz = nz; s->ld = pitch_of(nr);
+        s->rmin = rmin; s->rmax = rmax; s->zmin = zmin; s->zmax = zmax;
+        s->dr = (rmax - rmin) / (nr - 1);  // solver.cpp:73-74
+        s->dz = (zmax - zmin) / (nz - 1);
+        HIP_TRY(hipStreamCreate(&s->stream));
+        size_t n = (size_t)nz * s->ld;
+        s->psi.alloc(n); s->j.alloc(n);
+        HIP_TRY(hipMemset(s->psi.p, 0, sizeof(double) * n));
+        HIP_TRY(hipMemset(s->j.p, 0, sizeof(double) * n));
+        std::vector<double> R(nr), crp(nr), crm(nr);
+        const double dr_sq = s->dr * s->dr;
+        for (int r = 0; r < nr; ++r) {
+            R[r] = rmin + r * s->dr;  // solver.cpp:85
+            crp[r] = 1.0 / dr_sq - 1.0 / (2.0 * R[r] * s->dr);  // solver.cpp:170-171
+            crm[r] = 1.0 / dr_sq + 1.0 / (2.0 * R[r] * s->dr);
+        }
+        s->Rtab.alloc(nr); s->c_rp.alloc(nr); s->c_rm.alloc(nr);
+        HIP_TRY(hipMemcpy(s->Rtab.p, R.data(), sizeof(double) * nr, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->c_rp.p, crp.data(), sizeof(double) * nr, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->c_rm.p, crm.data(), sizeof(double) * nr, hipMemcpyHostToDevice));
+        s->d_bits.alloc(1); s->d_perf.alloc(1); s->d_done.alloc(1); s->d_last.alloc(1);
+        return s;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+void set_boundary_dirichlet(void* solver, double v) {
+    if (!solver) return;
+    auto* s = static_cast<FastSolverHip*>(solver);
+    s->boundary_value = v;
+    try {
+        hipLaunchKernelGGL(k_fast_ring, dim3(cdiv(2L * (s->nz + s->nr), 256)), dim3(256), 0, s->stream, s->psi.p, s->nz, s->nr, s->ld, v,
+                           (const int*)nullptr);
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    } catch (const std::exception& e) { g_err = e.what(); }
+}
+void run_step(void* solver, const double* j, double* psi, int size, int iterations) {
+    if (!solver || !j || !psi || size <= 0) return;
+    auto* s = static_cast<FastSolverHip*>(solver);
+    if ((long)size != (long)s->nr * s->nz) return;
+    try {
+        fast_sweeps(s, j, psi, std::max(iterations, 1), 1.8, false, 0.0, nullptr, nullptr);
+    } catch (const std::exception& e) { g_err = e.what(); }
+}
+int run_step_converged(void* solver, const double* j, double* psi, int size, int max_iterations, double omega, double tolerance,
+                       double* final_delta_out) {
+    if (!solver || !j || !psi || size <= 0) { if (final_delta_out) *final_delta_out = 0.0; return 0; }
+    auto* s = static_cast<FastSolverHip*>(solver);
+    if ((long)size != (long)s->nr * s->nz) { if (final_delta_out) *final_delta_out = 0.0; return 0; }
+    const int n_iter = std::max(max_iterations, 1);
+    const double omega_safe = std::isfinite(omega) ? omega : 1.8;
+    const double tol_safe = std::isfinite(tolerance) ? tolerance : 0.0;
+    const double omega_c = std::min(std::max(omega_safe, 0.1), 1.99);
+    const double tol = std::max(tol_safe, 0.0);
+    int performed = 0;
+    double last = 0.0;
+    try {
+        fast_sweeps(s, j, psi, n_iter, omega_c, true, tol, &performed, &last);
+    } catch (const std::exception& e) { g_err = e.what(); return 0; }
+    if (final_delta_out) *final_delta_out = last;
+    return performed;
+}
+void destroy_solver(void* solver) {
+    if (!solver) return;
+    auto* s = static_cast<FastSolverHip*>(solver);
+    (void)hipStreamSynchronize(s->stream);
+    delete s;
+}
+void delete_solver(void* solver) { destroy_solver(solver); }
+
+}  // extern "C"

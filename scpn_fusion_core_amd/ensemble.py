@@ -1,0 +1,276 @@
+"""Resident ensemble solver: ``batch`` independent Grad-Shafranov equilibria on one MI355X.
+
+Thin Python face of the ``scpn_gs_*`` handle API (include/scpn_hip.h, group 3).  Fields are uploaded
+once, the whole Picard / free-boundary iteration runs on the device (per-member scalars, convergence
+flags and ping-pong state never leave HBM) and results are downloaded once.  The reference has no
+NumPy ensemble driver; the per-member semantics are exactly those of
+``FusionKernel.solve_equilibrium`` / ``solve_free_boundary``
+(core/fusion_kernel_newton_solver.py:390-615, core/fusion_kernel_free_boundary.py:623-739).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import PicardParams, PicardResult, as_f64, check, ptr
+
+_METHODS = {"multigrid": 0, "sor": 1, "jacobi": 2}
+_PED_DEFAULT = {"ped_top": 0.92, "ped_width": 0.05, "ped_height": 1.0, "core_alpha": 0.3}  # core/fusion_kernel.py:181-192
+
+
+def picard_params_from_cfg(cfg: dict, *, preserve_initial_state=False, has_boundary_flux=False,
+                           external_profile_mode=False, check_every=8) -> PicardParams:
+    """Translate a reference-style config dict (core/config_schema.py) into the C parameter block."""
+    dims, phys, sol = cfg["dimensions"], cfg["physics"], cfg.get("solver", {})
+    method = sol.get("solver_method", "multigrid")
+    if method not in _METHODS:
+        raise NotImplementedError(f"solver_method={method!r} is not on the HIP path (multigrid, sor, jacobi are)")
+    p = PicardParams()
+    p.z_min_cfg = dims["Z_min"]
+    p.r_center = (dims["R_min"] + dims["R_max"]) / 2.0
+    p.mu0 = phys["vacuum_permeability"]
+    p.method = _METHODS[method]
+    p.sor_omega = sol.get("sor_omega", 1.6)
+    p.alpha = sol.get("relaxation_factor", 0.1)
+    p.tol = sol["convergence_threshold"]
+    p.max_iter = sol["max_iterations"]
+    p.require_gs_residual = int(bool(sol.get("require_gs_residual", False)))
+    p.gs_tol = float(sol.get("gs_residual_threshold", p.tol))
+    if p.require_gs_residual and p.gs_tol <= 0.0:
+        raise ValueError("solver.gs_residual_threshold must be > 0")
+    prof = phys.get("profiles") or {}
+    p.hmode = int(prof.get("mode", "l-mode") in ("h-mode", "H-mode", "hmode"))
+    pp, pf = dict(_PED_DEFAULT), dict(_PED_DEFAULT)
+    pp.update(prof.get("p_prime", {}))
+    pf.update(prof.get("ff_prime", {}))
+    keys = ("ped_top", "ped_width", "ped_height", "core_alpha")
+    p.ped_p = (C.c_double * 4)(*[pp[k] for k in keys])
+    p.ped_ff = (C.c_double * 4)(*[pf[k] for k in keys])
+    p.preserve_initial_state = int(preserve_initial_state)
+    p.has_boundary_flux = int(has_boundary_flux)
+    p.external_profile_mode = int(external_profile_mode)
+    p.check_every = int(check_every)
+    p.fail_on_diverge = int(bool(sol.get("fail_on_diverge", False)))
+    p.skip_seed = 0
+    return p
+
+
+def _result_dict(r: PicardResult) -> dict[str, Any]:
+    return {"converged": bool(r.converged), "iterations": int(r.iterations), "diverged": bool(r.diverged),
+            "residual": r.residual, "gs_residual": r.gs_residual, "gs_residual_best": r.gs_residual_best,
+            "psi_axis": r.psi_axis, "psi_boundary": r.psi_bnd, "x_point": (r.x_r, r.x_z), "i_current": r.i_current}
+
+
+class EnsembleSolver:
+    """``batch`` equilibria sharing one (R, Z) grid and one solver configuration.
+
+    Parameters
+    ----------
+    cfg : dict
+        Reference-style configuration (grid_resolution, dimensions, physics, coils, solver).
+    batch : int
+        Number of ensemble members resident on this GPU.
+    coil_currents : array (batch, n_coils), optional
+        Per-member currents of ``cfg["coils"]`` (default: the config's currents for every member).
+    current_targets : array (batch,), optional
+        Per-member ``plasma_current_target``.
+    """
+
+    def __init__(self, cfg: dict, batch: int = 1, coil_currents=None, current_targets=None, device: int | None = None):
+        self._L = _lib.require_gpu()
+        if device is not None:
+            check(self._L.scpn_set_device(int(device)))
+        self.cfg = cfg
+        self.batch = int(batch)
+        self.NR, self.NZ = (int(v) for v in cfg["grid_resolution"])
+        d = cfg["dimensions"]
+        self.R = np.linspace(d["R_min"], d["R_max"], self.NR)  # core/fusion_kernel.py:165-168
+        self.Z = np.linspace(d["Z_min"], d["Z_max"], self.NZ)
+        self.dR = float(self.R[1] - self.R[0])
+        self.dZ = float(self.Z[1] - self.Z[0])
+        h = C.c_void_p()
+        check(self._L.scpn_gs_create(C.byref(h), self.NR, self.NZ, self.batch, self.R, self.Z, self.dR, self.dZ))
+        self._h = h
+        coils = cfg.get("coils", [])
+        self.n_coils = len(coils)
+        self.coil_r = np.tile(np.array([c["r"] for c in coils], dtype=np.float64), (self.batch, 1))
+        self.coil_z = np.tile(np.array([c["z"] for c in coils], dtype=np.float64), (self.batch, 1))
+        base_i = np.array([c["current"] for c in coils], dtype=np.float64)
+        self.coil_i = np.tile(base_i, (self.batch, 1)) if coil_currents is None else as_f64(coil_currents).reshape(self.batch, -1)
+        if self.coil_i.shape != (self.batch, self.n_coils):
+            raise ValueError("coil_currents must have shape (batch, n_coils)")
+        self._push_vacuum_coils()
+        it = cfg["physics"]["plasma_current_target"]
+        self.current_targets = np.full(self.batch, float(it)) if current_targets is None else as_f64(current_targets).reshape(-1)
+        if self.current_targets.shape != (self.batch,):
+            raise ValueError("current_targets must have shape (batch,)")
+        check(self._L.scpn_gs_set_current_target(self._h, -1, self.current_targets))
+        self.external_profile_mode = False
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.scpn_gs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- state transfer -------------------------------------------------------------------------
+    def _push_vacuum_coils(self):
+        if self.n_coils:
+            self.coil_r, self.coil_z, self.coil_i = (np.ascontiguousarray(a) for a in (self.coil_r, self.coil_z, self.coil_i))
+            check(self._L.scpn_gs_set_vacuum_coils(self._h, self.n_coils, ptr(self.coil_r), ptr(self.coil_z), ptr(self.coil_i)))
+        else:
+            check(self._L.scpn_gs_set_vacuum_coils(self._h, 0, None, None, None))
+
+    def _field(self, arr, member):
+        a = as_f64(arr)
+        want = (self.NZ, self.NR) if member >= 0 else (self.batch, self.NZ, self.NR)
+        if a.shape != want:
+            raise ValueError(f"field shape {a.shape} must be {want}")
+        return np.ascontiguousarray(a)
+
+    def _get(self, fn, member):
+        out = np.empty((self.NZ, self.NR) if member >= 0 else (self.batch, self.NZ, self.NR))
+        check(fn(self._h, member, out))
+        return out
+
+    def set_psi(self, psi, member=-1):
+        check(self._L.scpn_gs_set_psi(self._h, member, self._field(psi, member)))
+
+    def get_psi(self, member=-1):
+        return self._get(self._L.scpn_gs_get_psi, member)
+
+    def get_jphi(self, member=-1):
+        return self._get(self._L.scpn_gs_get_jphi, member)
+
+    def set_jphi(self, j, member=-1):
+        check(self._L.scpn_gs_set_jphi(self._h, member, self._field(j, member)))
+
+    def get_source(self, member=-1):
+        return self._get(self._L.scpn_gs_get_source, member)
+
+    def set_source(self, s, member=-1):
+        check(self._L.scpn_gs_set_source(self._h, member, self._field(s, member)))
+
+    def set_boundary_flux(self, bc, member=-1):
+        check(self._L.scpn_gs_set_boundary_flux(self._h, member, self._field(bc, member)))
+
+    def get_boundary_flux(self, member=-1):
+        return self._get(self._L.scpn_gs_get_boundary_flux, member)
+
+    def set_seed(self, seed_j):
+        """Optional host-computed Gaussian seed (core/fusion_kernel_iterative_solver.py:400-402)."""
+        if seed_j is None:
+            check(self._L.scpn_gs_set_seed(self._h, None))
+        else:
+            s = self._field(seed_j, 0)
+            check(self._L.scpn_gs_set_seed(self._h, ptr(s)))
+
+    # -- solves ---------------------------------------------------------------------------------
+    def solve_equilibrium(self, preserve_initial_state=False, boundary_flux=None, *, history=False, trace=False,
+                          check_every=8) -> list[dict[str, Any]]:
+        """Picard solve of every member (core/fusion_kernel_newton_solver.py:390-615)."""
+        if boundary_flux is not None:
+            bf = as_f64(boundary_flux)
+            if bf.shape == (self.NZ, self.NR):
+                bf = np.broadcast_to(bf, (self.batch, self.NZ, self.NR))
+            if bf.shape != (self.batch, self.NZ, self.NR):
+                raise ValueError(f"boundary_flux shape {bf.shape} must match Psi shape {(self.NZ, self.NR)}")
+            self.set_boundary_flux(np.ascontiguousarray(bf))
+        p = picard_params_from_cfg(self.cfg, preserve_initial_state=preserve_initial_state,
+                                   has_boundary_flux=boundary_flux is not None,
+                                   external_profile_mode=self.external_profile_mode, check_every=check_every)
+        res = (PicardResult * self.batch)()
+        mi = max(int(p.max_iter), 1)
+        hd = np.zeros((self.batch, mi)) if history else None
+        hg = np.zeros((self.batch, mi)) if history else None
+        tr = np.zeros((self.batch, mi, 6)) if trace else None
+        check(self._L.scpn_gs_picard_solve(self._h, C.byref(p), res, ptr(hd), ptr(hg), ptr(tr)))
+        out = []
+        for b in range(self.batch):
+            d = _result_dict(res[b])
+            n = d["iterations"]
+            if history:
+                d["residual_history"] = hd[b, :n].tolist()
+                d["gs_residual_history"] = hg[b, :n].tolist()
+            if trace:
+                d["trace"] = tr[b, :n].copy()
+            out.append(d)
+        return out
+
+    def solve_free_boundary(self, coil_r=None, coil_z=None, coil_currents=None, turns=None, *, max_outer_iter=20, tol=1e-4,
+                            check_every=8) -> list[dict[str, Any]]:
+        """``solve_free_boundary(optimize_shape=False)`` of every member
+        (core/fusion_kernel_free_boundary.py:623-739).  Coil arrays are ``(batch, n)`` (1-D arrays are
+        broadcast to every member); defaults: the config's coil set, one turn each."""
+        if max_outer_iter < 1:
+            raise ValueError("max_outer_iter must be >= 1.")
+        if not np.isfinite(tol) or tol < 0.0:
+            raise ValueError("tol must be finite and >= 0.")
+
+        def bc(a, default):
+            a = default if a is None else as_f64(a)
+            if a.ndim == 1:
+                a = np.tile(a, (self.batch, 1))
+            return np.ascontiguousarray(a)
+
+        cr, cz, ci = bc(coil_r, self.coil_r), bc(coil_z, self.coil_z), bc(coil_currents, self.coil_i)
+        n = cr.shape[1]
+        ct = bc(turns, np.ones((self.batch, n)))
+        for a in (cz, ci, ct):
+            if a.shape != (self.batch, n):
+                raise ValueError("coil arrays must share the shape (batch, n_coils)")
+        p = picard_params_from_cfg(self.cfg, preserve_initial_state=True, has_boundary_flux=True,
+                                   external_profile_mode=self.external_profile_mode, check_every=check_every)
+        res = (PicardResult * self.batch)()
+        outer = np.zeros(self.batch, dtype=np.int32)
+        fdiff = np.zeros(self.batch)
+        pits = np.zeros((self.batch, max_outer_iter), dtype=np.int32)
+        check(self._L.scpn_gs_free_boundary_solve(self._h, C.byref(p), n, ptr(cr), ptr(cz), ptr(ci), ptr(ct), int(max_outer_iter),
+                                                  float(tol), ptr(outer), ptr(fdiff), ptr(pits), res))
+        out = []
+        for b in range(self.batch):
+            d = _result_dict(res[b])
+            d.update(outer_iterations=int(outer[b]), final_diff=float(fdiff[b]),
+                     picard_iterations=[int(v) for v in pits[b, : outer[b]]], coil_currents=ci[b].copy())
+            out.append(d)
+        return out
+
+    # -- resident operators (zero-copy smoother benchmark path) ------------------------------------
+    def rb_sor(self, omega: float, n_sweeps: int):
+        check(self._L.scpn_gs_rb_sor(self._h, float(omega), int(n_sweeps)))
+
+    def vcycle(self, omega=1.0, pre_smooth=3, post_smooth=3, min_grid=5):
+        check(self._L.scpn_gs_vcycle(self._h, float(omega), int(pre_smooth), int(post_smooth), int(min_grid)))
+
+    def compute_b_field(self, member=0):
+        br, bz = np.empty((self.NZ, self.NR)), np.empty((self.NZ, self.NR))
+        check(self._L.scpn_gs_compute_b_field(self._h, int(member), br, bz))
+        return br, bz
+
+    # -- device timing (bench.py) -------------------------------------------------------------------
+    def profile(self, enable: bool):
+        check(self._L.scpn_gs_profile(self._h, int(bool(enable))))
+
+    def profile_read(self, name: str):
+        ms, n = C.c_double(), C.c_long()
+        check(self._L.scpn_gs_profile_read(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def sync(self):
+        check(self._L.scpn_gs_sync(self._h))

@@ -1,0 +1,335 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden fixtures generated from the
+reference and against the CPU oracle on seeded inputs.
+
+Bars: bit-exact (array_equal) for the linear elliptic operators (smoother, residual, restriction,
+prolongation, V-cycle, multigrid_solve, Jacobi/SOR steps, legacy FastSolver ABI); for the nonlinear
+Picard / free-boundary solves -- whose global sums are reduced in a different (fixed) order than
+NumPy's pairwise sum -- psi within 1e-11 * max|psi| and identical iteration counts; Green's
+functions within 1e-12 relative (SciPy's Cephes polynomials vs AGM).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests._problems import bench_problem, configs_from, grid, iter_like_cfg, operator_problem  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import scpn_fusion_core_amd as pkg
+    from scpn_fusion_core_amd import _lib
+
+    _lib.require_gpu()  # fail loudly: no fallback path exists
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def mgs(hip):
+    from scpn_fusion_core_amd import multigrid_solve
+
+    return multigrid_solve
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+
+    return oracle
+
+
+# ----------------------------------------------------------------------------- a1 smoother
+def test_smooth_golden_bit_exact(mgs, golden):
+    g = golden("smooth.npz")
+    for nz, nr, omega, sweeps in g["cases"]:
+        nz, nr, sweeps = int(nz), int(nr), int(sweeps)
+        psi0, source, rr, r, z = bench_problem(nz, nr)
+        dr, dz = 4.0 / (nr - 1), 8.0 / (nz - 1)
+        out = mgs.mg_smooth(psi0.copy(), source, rr, dr, dz, omega, sweeps)
+        assert np.array_equal(out, g[f"out_{nz}x{nr}_w{omega}_s{sweeps}"]), (nz, nr, omega, sweeps)
+
+
+@pytest.mark.parametrize("n", [65, 129, 257])
+def test_smooth_vs_oracle_bit_exact(mgs, orc, n):
+    psi0, source, rr, r, z = bench_problem(n, n)
+    dr, dz = 4.0 / (n - 1), 8.0 / (n - 1)
+    ref = orc.mg_smooth(psi0, source, rr, dr, dz, 1.3, 20)
+    out = mgs.mg_smooth(psi0.copy(), source, rr, dr, dz, 1.3, 20)
+    assert np.array_equal(out, ref)
+
+
+def test_smooth_input_semantics_and_errors(mgs):
+    psi0, source, rr, r, z = bench_problem(17, 17)
+    p = psi0.copy()
+    out = mgs.mg_smooth(p, source, rr, 0.25, 0.5, 1.0, 1)
+    assert out is p  # in place + returned, like the reference
+    assert np.array_equal(out[0], psi0[0]) and np.array_equal(out[:, -1], psi0[:, -1])  # ring untouched
+    for w in (0.5, 2.0, float("nan")):
+        with pytest.raises(ValueError):
+            mgs.mg_smooth(psi0.copy(), source, rr, 0.25, 0.5, w, 1)
+
+
+def test_smooth_batch_members_independent(mgs, orc):
+    a = bench_problem(33, 33, seed=1)
+    b = bench_problem(33, 33, seed=2)
+    psi = np.stack([a[0], b[0], a[0]])
+    src = np.stack([a[1], 2.0 * b[1], a[1]])
+    out = mgs.mg_smooth(psi.copy(), src, a[2], 0.125, 0.25, 1.6, 7)
+    assert np.array_equal(out[0], out[2])
+    assert np.array_equal(out[0], orc.mg_smooth(a[0], a[1], a[2], 0.125, 0.25, 1.6, 7))
+    assert np.array_equal(out[1], orc.mg_smooth(b[0], 2.0 * b[1], a[2], 0.125, 0.25, 1.6, 7))
+
+
+def test_discrete_solution_is_fixed_point(mgs):
+    # reference tests/test_fusion_kernel_solver_mixins.py:113-134 (fixed point to 1e-12)
+    n = 65
+    psi0, _, rr, r, z = bench_problem(n, n)
+    dr, dz = float(r[1] - r[0]), float(z[1] - z[0])
+    psi = np.sin(rr) * np.cos(0.5 * np.repeat(z[:, None], n, axis=1))
+    src = mgs.mg_residual(psi, np.zeros_like(psi), rr, dr, dz)  # L*psi
+    out = mgs.mg_smooth(psi.copy(), src, rr, dr, dz, 1.6, 3)
+    assert np.abs(out - psi).max() < 1e-12
+
+
+# ----------------------------------------------------------------------------- a2-a6 operators
+def test_operators_golden_bit_exact(mgs, golden):
+    g = golden("operators.npz")
+    for nz, nr in g["shapes"]:
+        nz, nr = int(nz), int(nr)
+        tag = f"{nz}x{nr}"
+        psi, source, rr, dr, dz = operator_problem(nz, nr)
+        assert np.array_equal(mgs.mg_residual(psi, source, rr, dr, dz), g[f"res_{tag}"]), tag
+        assert mgs.residual_linf(psi, source, rr, dr, dz) == float(g[f"linf_{tag}"]), tag
+        fine = g[f"fine_{tag}"]
+        c = mgs.restrict_full_weight(fine)
+        assert np.array_equal(c, g[f"restrict_{tag}"]), tag
+        assert np.array_equal(mgs.prolongate_bilinear(c, nz, nr), g[f"prolong_{tag}"]), tag
+        if min(nz, nr) >= 5:
+            for omega in (1.0, 1.6):
+                v = mgs.multigrid_vcycle(psi, source, rr, dr, dz, omega=omega)
+                assert np.array_equal(v, g[f"vcycle_{tag}_w{omega}"]), (tag, omega)
+
+
+def test_restrict_prolong_shape_contract(mgs):
+    with pytest.raises(ValueError):
+        mgs.prolongate_bilinear(np.zeros((5, 5)), 17, 17)
+    assert mgs.restrict_full_weight(np.zeros((3, 33, 65))).shape == (3, 17, 33)
+
+
+@pytest.mark.parametrize("shape", [(129, 129), (257, 257), (200, 141), (513, 513)])
+def test_vcycle_vs_oracle_bit_exact(mgs, orc, shape):
+    nz, nr = shape
+    psi, source, rr, dr, dz = operator_problem(nz, nr)
+    ref = orc.multigrid_vcycle(psi, source, rr, dr, dz, omega=1.0)
+    out = mgs.multigrid_vcycle(psi, source, rr, dr, dz, omega=1.0)
+    assert np.array_equal(out, ref)
+    assert mgs.residual_linf(out, source, rr, dr, dz) == orc.residual_linf(ref, source, rr, dr, dz)
+
+
+def test_gs_residual_rms(mgs, golden):
+    g = golden("pieces.npz")
+    psi = g["psi"]
+    r0, r1, z0, z1, dr, dz, _ = g["dims"]
+    r = np.linspace(r0, r1, psi.shape[1])
+    assert mgs.gs_residual_rms(psi, g["source"], r, dr, dz) == pytest.approx(float(g["gs_rms"]), rel=1e-13)
+
+
+# ----------------------------------------------------------------------------- a7 multigrid_solve
+def test_multigrid_solve_golden_bit_exact(mgs, golden):
+    g = golden("mgsolve.npz")
+    for n in (33, 65):
+        psi, res, ncy, conv = mgs.multigrid_solve(g[f"gauss{n}_source"], np.zeros((n, n)), 1.2, 2.2, -0.5, 0.5, n, n, tol=1e-6)
+        assert np.array_equal(psi, g[f"gauss{n}_psi"])
+        assert [res, ncy, float(conv)] == list(g[f"gauss{n}_stats"])
+    for n in (33, 65, 97):
+        r_min, r_max, z_min, z_max = g[f"solovev{n}_extent"]
+        r, z, rr, zz = grid(n, n, r_min, r_max, z_min, z_max)
+        exact = rr**4 / 8.0 + 0.5 * zz**2
+        source = rr**2 + 1.0
+        bc = np.zeros((n, n))
+        bc[0, :], bc[-1, :], bc[:, 0], bc[:, -1] = exact[0, :], exact[-1, :], exact[:, 0], exact[:, -1]
+        psi, res, ncy, conv = mgs.multigrid_solve(source, bc, r_min, r_max, z_min, z_max, n, n, tol=1e-9, max_cycles=200)
+        assert np.array_equal(psi, g[f"solovev{n}_psi"]), n
+        assert [res, ncy, float(conv)] == list(g[f"solovev{n}_stats"])
+    ext = g["solovev65_extent"]
+    source65 = grid(65, 65, *ext)[2] ** 2 + 1.0
+    psi2, res2, ncy2, conv2 = mgs.multigrid_solve(source65, _solovev_bc(65, ext), *ext, 65, 65, tol=1e-9, max_cycles=200,
+                                                 omega=1.6, pre_smooth=2, post_smooth=1)
+    assert np.array_equal(psi2, g["solovev65_w16_psi"])
+    assert [res2, ncy2, float(conv2)] == list(g["solovev65_w16_stats"])
+
+
+def _solovev_bc(n, extent):
+    r, z, rr, zz = grid(n, n, *extent)
+    exact = rr**4 / 8.0 + 0.5 * zz**2
+    bc = np.zeros((n, n))
+    bc[0, :], bc[-1, :], bc[:, 0], bc[:, -1] = exact[0, :], exact[-1, :], exact[:, 0], exact[:, -1]
+    return bc
+
+
+def test_multigrid_solve_batch_and_errors(mgs, golden):
+    g = golden("mgsolve.npz")
+    src = g["gauss33_source"]
+    srcs = np.stack([src, 0.0 * src, 3.0 * src])
+    psi, res, ncy, conv = mgs.multigrid_solve(srcs, np.zeros_like(srcs), 1.2, 2.2, -0.5, 0.5, 33, 33, tol=1e-6)
+    assert np.array_equal(psi[0], g["gauss33_psi"]) and ncy[0] == int(g["gauss33_stats"][1])
+    assert ncy[1] == 0 and conv[1] and np.all(psi[1] == 0.0)  # already converged member does no cycle
+    assert conv.all()
+    z = np.zeros((9, 9))
+    for kw in (dict(tol=0.0), dict(tol=float("inf")), dict(max_cycles=0), dict(omega=2.0)):
+        with pytest.raises(ValueError):
+            mgs.multigrid_solve(z, z, 1.0, 2.0, -1.0, 1.0, 9, 9, **kw)
+    with pytest.raises(ValueError):
+        mgs.multigrid_solve(z, z, 1.0, 2.0, -1.0, 1.0, 9, 8)
+
+
+def test_multigrid_solve_513_properties(mgs):
+    # full BASELINE size: grid-independent cycle count (<12, reference multigrid.rs:343-460) and exact ring
+    n = 513
+    r, z, rr, zz = grid(n, n, 1.2, 2.2, -0.5, 0.5)
+    source = -rr * np.exp(-((rr - 1.7) ** 2 + zz**2) / 0.05)
+    rng = np.random.default_rng(5)
+    bc = np.zeros((n, n))
+    bc[0, :], bc[-1, :], bc[:, 0], bc[:, -1] = rng.normal(size=n) * 1e-3, 0.0, 0.0, 0.0
+    bc[0, 0] = bc[0, -1] = 0.0
+    psi, res, ncy, conv = mgs.multigrid_solve(source, bc, 1.2, 2.2, -0.5, 0.5, n, n, tol=1e-8)
+    assert conv and ncy < 16 and res < 1e-8
+    assert np.array_equal(psi[0], bc[0]) and np.array_equal(psi[-1], bc[-1]) and np.array_equal(psi[:, 0], bc[:, 0])
+    assert mgs.residual_linf(psi, source, rr, float(r[1] - r[0]), float(z[1] - z[0])) == res
+    # linearity: solving for 2*source with 2*bc gives 2*psi up to rounding of the stopping rule
+    psi2, _, ncy2, _ = mgs.multigrid_solve(2.0 * source, 2.0 * bc, 1.2, 2.2, -0.5, 0.5, n, n, tol=2e-8)
+    assert ncy2 == ncy and np.array_equal(psi2, 2.0 * psi)
+
+
+# ----------------------------------------------------------------------------- Jacobi / SOR steps
+def test_jacobi_sor_steps_golden(mgs, golden):
+    g = golden("pieces.npz")
+    psi = g["psi"]
+    r0, r1, z0, z1, dr, dz, _ = g["dims"]
+    r = np.linspace(r0, r1, psi.shape[1])
+    assert np.array_equal(mgs.jacobi_step(psi, g["source"], r, dr, dz), g["jacobi"])
+    assert np.array_equal(mgs.sor_step(psi, g["source"], r, dr, dz, 1.6), g["sor_w16"])
+    bad = psi.copy()
+    bad[5, 5] = np.nan
+    bad[6, 6] = np.inf
+    out = mgs.jacobi_step(bad, g["source"], r, dr, dz)
+    assert np.isfinite(out).all()
+
+
+# ----------------------------------------------------------------------------- a11 Green's functions
+def test_coil_flux_golden(hip, golden):
+    from scpn_fusion_core_amd import free_boundary as fb
+
+    g = golden("green.npz")
+    co = g["coils"]
+    r, z = np.linspace(2.2, 10.2, 33), np.linspace(-6.8, 6.8, 33)
+    vac = fb.coil_flux_grid(r, z, co[:, 0], co[:, 1], co[:, 2], mu0=1.0, mode="vacuum")
+    np.testing.assert_allclose(vac, g["vacuum33"], rtol=1e-12, atol=1e-14)
+    ext = fb.coil_flux_grid(r, z, co[:, 0], co[:, 1], co[:, 2], turns=g["turns"], mode="external")
+    np.testing.assert_allclose(ext, g["ext33"], rtol=1e-12, atol=1e-20)
+    for p, v in zip(g["green_pts"], g["green_vals"]):
+        assert fb.green_function(*p) == pytest.approx(v, rel=1e-12, abs=1e-22)
+    assert fb.green_function(9.2, 4.08, 9.2, 4.08) == 0.0
+    with pytest.raises(ValueError):
+        fb.green_function(-1.0, 0.0, 1.0, 0.0)
+
+
+# ----------------------------------------------------------------------------- a8-a10 Picard
+PICARD_CASES = ["iter33_mg_w10", "iter65_mg_w10", "iter33_mg_w16", "iter33_sor", "iter33_jacobi", "iter33_hmode",
+                "d3d33_mg", "iter32_even_mg"]
+
+
+@pytest.mark.parametrize("name", PICARD_CASES)
+def test_picard_golden(hip, golden, name):
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    g = golden("picard.npz")
+    cfg = configs_from(g)[name]
+    with EnsembleSolver(cfg, batch=1) as es:
+        res = es.solve_equilibrium(history=True, trace=True, check_every=1)[0]
+        psi = es.get_psi(0)
+        jphi = es.get_jphi(0)
+    conv, its, resid, gs, gs_best = g[f"{name}_stats"]
+    assert res["iterations"] == int(its) and res["converged"] == bool(conv)
+    tr = res["trace"]
+    np.testing.assert_allclose(tr[:, 0:2], g[f"{name}_axis_bnd"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(res["residual_history"], g[f"{name}_diff"], rtol=1e-6, atol=1e-15)
+    np.testing.assert_allclose(res["gs_residual_history"], g[f"{name}_gs"], rtol=1e-5, atol=1e-13)
+    scale = np.abs(g[f"{name}_psi"]).max()
+    assert np.abs(psi - g[f"{name}_psi"]).max() <= 1e-11 * scale
+    jscale = np.abs(g[f"{name}_jphi"]).max()
+    assert np.abs(jphi - g[f"{name}_jphi"]).max() <= 1e-9 * jscale
+    assert res["residual"] == pytest.approx(resid, rel=1e-5)
+
+
+def test_picard_ensemble_members_match_single_solves(hip, orc):
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    cfg = iter_like_cfg(33, tol=1e-7, max_iter=400)
+    base = np.array([c["current"] for c in cfg["coils"]])
+    rng = np.random.default_rng(2026)
+    currents = base * (1.0 + 0.1 * rng.uniform(-1, 1, size=(4, base.size)))
+    targets = np.array([15.0, 14.0, 0.0, 16.0])  # member 2: zero-current vacuum short-circuit
+    with EnsembleSolver(cfg, batch=4, coil_currents=currents, current_targets=targets) as es:
+        res = es.solve_equilibrium(check_every=5)
+        psi = es.get_psi()
+        jphi = es.get_jphi()
+    for b in range(4):
+        c = {**cfg, "coils": [dict(co, current=float(currents[b, i])) for i, co in enumerate(cfg["coils"])],
+             "physics": dict(cfg["physics"], plasma_current_target=float(targets[b]))}
+        ref = orc.picard_solve(c)
+        assert res[b]["iterations"] == ref["iterations"] and res[b]["converged"] == ref["converged"], b
+        scale = max(np.abs(ref["psi"]).max(), 1e-30)
+        assert np.abs(psi[b] - ref["psi"]).max() <= 1e-10 * scale, b
+        assert np.abs(jphi[b] - ref["j_phi"]).max() <= 1e-9 * max(np.abs(ref["j_phi"]).max(), 1e-30), b
+    assert res[2]["iterations"] == 0 and res[2]["converged"]
+
+
+@pytest.mark.parametrize("name", ["iter33", "d3d33", "iter65"])
+def test_free_boundary_golden(hip, golden, name):
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    g = golden("free_boundary.npz")
+    cfg = configs_from(g)[name]
+    with EnsembleSolver(cfg, batch=1) as es:
+        res = es.solve_free_boundary(max_outer_iter=20, tol=1e-4)[0]
+        psi = es.get_psi(0)
+    st = g[f"{name}_stats"]
+    assert res["outer_iterations"] == int(st[0])
+    assert res["picard_iterations"] == [int(v) for v in st[2:]]
+    scale = np.abs(g[f"{name}_psi"]).max()
+    assert np.abs(psi - g[f"{name}_psi"]).max() <= 1e-11 * scale
+    assert res["final_diff"] < 1e-4
+
+
+def test_polyglot_lane_golden(hip, golden):
+    from scpn_fusion_core_amd.polyglot import gs_solve_hip
+
+    g = golden("polyglot.npz")
+    p = g["params"]
+    for n in (17, 65):
+        psi = gs_solve_hip(p[0], p[1], p[2], p[3], n, n, p[4], mu0=p[5], n_picard=int(p[6]), n_jacobi=int(p[7]), alpha=p[8],
+                           omega_j=p[9], beta_mix=p[10])
+        np.testing.assert_allclose(psi, g[f"psi{n}"], rtol=1e-12, atol=0)
+        if n == 17:  # published golden: validation/reports/polyglot_gs_solver_comparison.json:117
+            assert abs(psi.max() - 0.042651828900105285) < 1e-13
+
+
+# ----------------------------------------------------------------------------- a14 legacy ABI
+def test_legacy_abi_golden_bit_exact(hip, golden):
+    from scpn_fusion_core_amd.hpc_bridge import HPCBridge
+
+    g = golden("fastsolver.npz")
+    j = g["j"]
+    nz, nr = j.shape
+    ext = g["extent"]
+    br = HPCBridge()
+    assert br.is_available()
+    br.initialize(nr, nz, (ext[0], ext[1]), (ext[2], ext[3]))
+    assert np.array_equal(br.solve(j, iterations=50), g["run50_a"])
+    assert np.array_equal(br.solve(j, iterations=50), g["run50_b"])  # warm psi state inside the handle
+    br.set_boundary_dirichlet(0.25)
+    assert np.array_equal(br.solve(j, iterations=7), g["run7_bc"])
+    psi, n, fd = br.solve_until_converged(j, max_iterations=500, tolerance=1e-9, omega=1.5)
+    assert np.array_equal(psi, g["conv_psi"]) and [n, fd] == list(g["conv_stats"])
+    br.close()
