@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- converged free-boundary Grad-Shafranov equilibria / s on MI355X.
+
+Metric (BASELINE.json): converged equilibria/s, 513x513 free-boundary, Picard tol 1e-8.
+Workload: an ensemble of `--batch` (default 32 = 256 / 8 GPUs, BASELINE config 5) independent
+ITER-like free-boundary equilibria per GPU on a 513x513 grid (validation/benchmark_vs_freegs.py:157
+geometry, coil currents I_k*(1+0.1u), u~U(-1,1), rng 2026), each solved exactly as the reference's
+``solve_free_boundary(coils, max_outer_iter=20, tol=1e-4, optimize_shape=False)`` with
+``solver_method="multigrid"``, sor_omega=1.0, relaxation_factor=0.12, convergence_threshold=1e-8.
+One "step" = one full solve of the resident ensemble (Green's-function boundary flux, seed, ~2 outer
+x ~240 Picard iterations of one V-cycle each, all on the device).  Inputs (coil table, psi=0) are
+resident in HBM before the timed region; results stay in HBM (the RCCL gather for N>1 is inside).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timed on the
+solver's own stream) and "cpu_baseline" (the CPU oracle on the host cores, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def make_cfg(n: int) -> dict:
+    from tests._problems import iter_like_cfg
+
+    return iter_like_cfg(n, method="multigrid", omega=1.0, tol=1e-8, max_iter=1000, alpha=0.12)
+
+
+def member_currents(cfg: dict, total: int) -> np.ndarray:
+    base = np.array([c["current"] for c in cfg["coils"]], dtype=np.float64)
+    rng = np.random.default_rng(2026)
+    return base[None, :] * (1.0 + 0.1 * rng.uniform(-1.0, 1.0, size=(total, base.size)))
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="ensemble members per GPU")
+    ap.add_argument("--grid", type=int, default=513)
+    ap.add_argument("--check-every", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist  # rendezvous + RCCL gather only; the solver itself is torch-free
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from scpn_fusion_core_amd import _lib
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    _lib.require_gpu()
+    cfg = make_cfg(args.grid)
+    B = args.batch
+    currents = member_currents(cfg, B * world)[rank * B:(rank + 1) * B]
+    es = EnsembleSolver(cfg, batch=B, coil_currents=currents, device=local_rank)
+    n_pts = args.grid * args.grid
+
+    def barrier():
+        es.sync()
+        if dist is not None:
+            import torch
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    gather_buf = None
+
+    def step():
+        es.fill_psi(0.0)
+        res = es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
+        if dist is not None:  # ensemble gather of psi over RCCL/xGMI (the path's only exchange step)
+            import torch
+
+            nonlocal gather_buf
+            ptr = es.pack_psi_device()
+
+            class _Dev:
+                __cuda_array_interface__ = {"shape": (B, args.grid, args.grid), "typestr": "<f8", "data": (ptr, False),
+                                            "version": 3, "strides": None}
+
+            send = torch.as_tensor(_Dev(), device=f"cuda:{local_rank}")
+            if gather_buf is None:
+                gather_buf = torch.empty((world * B, args.grid, args.grid), dtype=torch.float64, device=send.device)
+            dist.all_gather_into_tensor(gather_buf, send)
+        return res
+
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_conv = sum(int(r["converged"]) for r in res)
+    picard_total = [sum(r["picard_iterations"]) for r in res]
+    outer = [r["outer_iterations"] for r in res]
+    value = args.steps * B * world / elapsed
+
+    # ---- roofline of the dominant kernel (red-black colour pass on the 513^2 level), HIP events on
+    #      the solver stream, in a separate pass so the event records do not perturb the timed region
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        es.fill_psi(0.0)
+        es.profile(True)
+        es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
+        fam = {}
+        for name in ("rb_half_fine", "rb_half_coarse", "small_smooth", "defect_restrict_fine", "defect_restrict_coarse",
+                     "prolong_add_fine", "prolong_add_coarse", "topology", "source", "copy", "blend_norms", "picard_final",
+                     "seed_jacobi", "coil_flux", "smooth_tile_fine", "vcycle_coarse"):
+            ms, n = es.profile_read(name)
+            if n:
+                fam[name] = {"ms": round(ms, 3), "launches": int(n)}
+        es.profile(False)
+        dom = max(fam, key=lambda k: fam[k]["ms"]) if fam else None
+        if dom:
+            # algorithmic bytes per launch (DESIGN.md "Kernels"): one colour pass reads the 4 neighbours
+            # (the other colour: N/2 values), own old value, source and writes the colour: 16 B per grid
+            # point per launch (= SURVEY 8d "two-pass colour kernels: 32 B/pt/sweep"), x B members.
+            per_pt = {"rb_half_fine": 16.0, "smooth_tile_fine": 24.0}.get(dom, 16.0)
+            avg_s = fam[dom]["ms"] * 1e-3 / fam[dom]["launches"]
+            alg_bytes = per_pt * n_pts * B
+            ach = alg_bytes / avg_s / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_us": round(avg_s * 1e6, 2), "alg_bytes_per_launch": alg_bytes,
+                        "families_ms": fam}
+
+    # ---- CPU baseline: the C oracle (port of the reference algorithm), one full free-boundary solve of
+    #      member 0 on one host core
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        from oracle import oracle as orc
+
+        c0 = {**cfg, "coils": [dict(co, current=float(currents[0, i])) for i, co in enumerate(cfg["coils"])]}
+        co = c0["coils"]
+        tc = time.perf_counter()
+        ref = orc.free_boundary_solve(c0, [c["r"] for c in co], [c["z"] for c in co], [c["current"] for c in co],
+                                      [1.0] * len(co), max_outer=20, tol=1e-4)
+        dt = time.perf_counter() - tc
+        psi0 = es.get_psi(0) if roofline is None else None
+        cpu = {"value": round(1.0 / dt, 5), "unit": "equilibria/s", "cores": 1, "kind": "port",
+               "sample": f"one full {args.grid}x{args.grid} free-boundary solve of ensemble member 0 "
+                         f"({ref['outer_iterations']} outer, {sum(ref['picard_iterations'])} Picard iterations, {dt:.1f} s) "
+                         "by oracle/gs_oracle.c on one host core",
+               "picard_iterations": ref["picard_iterations"]}
+        if psi0 is not None:
+            cpu["psi_rel_linf_vs_gpu"] = float(np.abs(psi0 - ref["psi"]).max() / np.abs(ref["psi"]).max())
+
+    if rank == 0:
+        line = {
+            "metric": "converged equilibria/s (513x513 free-boundary, Picard tol 1e-8)",
+            "value": round(value, 3), "unit": "equilibria/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"ensemble of {B} ITER-like free-boundary equilibria per GPU, {args.grid}x{args.grid}, "
+                                   "PF-coil Green's-function boundary, Picard+V-cycle tol 1e-8 (BASELINE configs[2]/[4])",
+                       "grid": args.grid, "members_per_gpu": B, "global_members": B * world,
+                       "parallelism": f"ensemble-sharded x{world}",
+                       "converged_members_rank0": n_conv, "outer_iterations": [min(outer), max(outer)],
+                       "picard_iterations_per_member": [min(picard_total), max(picard_total)]},
+        }
+        if roofline is not None:
+            line["roofline"] = roofline
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+    es.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -199,6 +199,13 @@ int scpn_gs_vcycle(scpn_gs *h, double omega, int pre_smooth, int post_smooth, in
 /* post-solve products core/fusion_kernel.py:450-456 compute_b_field */
 int scpn_gs_compute_b_field(scpn_gs *h, int member, double *b_r, double *b_z);
 
+/* psi <- value on every member, on the device (ensemble re-runs without a host upload) */
+int scpn_gs_fill_psi(scpn_gs *h, double value);
+/* pack the current psi of all members into one dense device buffer [batch][nz][nr] owned by the
+ * handle and return its DEVICE address (valid until the next pack / destroy): the send buffer of the
+ * RCCL ensemble gather */
+int scpn_gs_pack_psi_device(scpn_gs *h, void **device_ptr);
+
 /* timing hooks for bench.py: average device time (ms) of the named kernel family since the last
  * reset, measured with hipEvents on the handle's stream when profiling is enabled */
 int scpn_gs_profile(scpn_gs *h, int enable);

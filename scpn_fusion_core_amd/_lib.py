@@ -100,6 +100,8 @@ SIGNATURES = {
     "scpn_gs_rb_sor": (_i, [_vp, _d, _i]),
     "scpn_gs_vcycle": (_i, [_vp, _d, _i, _i, _i]),
     "scpn_gs_compute_b_field": (_i, [_vp, _i, _dp, _dp]),
+    "scpn_gs_fill_psi": (_i, [_vp, _d]),
+    "scpn_gs_pack_psi_device": (_i, [_vp, C.POINTER(_vp)]),
     "scpn_gs_profile": (_i, [_vp, _i]),
     "scpn_gs_profile_read": (_i, [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(C.c_long)]),
     "scpn_gs_sync": (_i, [_vp]),

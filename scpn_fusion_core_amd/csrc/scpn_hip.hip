@@ -118,7 +118,7 @@ struct scpn_gs {
     std::map<int, std::vector<LevelHost*>> hier;
     // fields (B members each)
     DBuf<double> psi_slots;  // 3 ping-pong slots
-    DBuf<double> W, src, src2, bc, jphi, ext, old;
+    DBuf<double> W, src, src2, bc, jphi, ext, old, dense;
     bool picard_bufs = false;
     DBuf<double> d_r, d_z, d_inv_mu0R, d_neg_mu0R, d_seed;
     DBuf<Member> d_st;
@@ -931,6 +931,27 @@ int scpn_gs_compute_b_field(scpn_gs* h, int member, double* b_r, double* b_z) {
     HIP_TRY(hipMemcpyAsync(b_r, dbr.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(b_z, dbz.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    API_END
+}
+int scpn_gs_fill_psi(scpn_gs* h, double value) {
+    if (!h) return fail(SCPN_E_ARG, "null handle");
+    API_BEGIN
+    hipLaunchKernelGGL(k_fill, grid2d(h->nr, h->nz, h->B), BLK2D, 0, h->stream, h->slot_fld(h->d_cur.p), value, h->nz, h->nr, h->ld,
+                       (const int*)nullptr);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    API_END
+}
+int scpn_gs_pack_psi_device(scpn_gs* h, void** device_ptr) {
+    if (!h || !device_ptr) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    size_t n = (size_t)h->nz * h->nr;
+    h->dense.alloc(n * h->B);
+    std::vector<int> cur = host_cur(h);
+    for (int b = 0; b < h->B; ++b)
+        HIP_TRY(hipMemcpy2DAsync(h->dense.p + n * b, sizeof(double) * h->nr, psi_member_ptr(h, cur, b), sizeof(double) * h->ld,
+                                 sizeof(double) * h->nr, h->nz, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *device_ptr = h->dense.p;
     API_END
 }
 int scpn_gs_sync(scpn_gs* h) {

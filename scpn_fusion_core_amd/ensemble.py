@@ -263,6 +263,16 @@ class EnsembleSolver:
         check(self._L.scpn_gs_compute_b_field(self._h, int(member), br, bz))
         return br, bz
 
+    def fill_psi(self, value: float = 0.0):
+        """psi <- value on every member, on the device."""
+        check(self._L.scpn_gs_fill_psi(self._h, float(value)))
+
+    def pack_psi_device(self) -> int:
+        """Dense [batch][nz][nr] device copy of the current psi; returns the device address (RCCL send buffer)."""
+        p = C.c_void_p()
+        check(self._L.scpn_gs_pack_psi_device(self._h, C.byref(p)))
+        return int(p.value)
+
     # -- device timing (bench.py) -------------------------------------------------------------------
     def profile(self, enable: bool):
         check(self._L.scpn_gs_profile(self._h, int(bool(enable))))
