@@ -135,20 +135,15 @@ def main() -> int:
         es.fill_psi(0.0)
         es.profile(True)
         es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
-        fam = {}
-        for name in ("rb_half_fine", "rb_half_coarse", "small_smooth", "defect_restrict_fine", "defect_restrict_coarse",
-                     "prolong_add_fine", "prolong_add_coarse", "topology", "source", "copy", "blend_norms", "picard_final",
-                     "seed_jacobi", "coil_flux", "smooth_tile_fine", "vcycle_coarse"):
-            ms, n = es.profile_read(name)
-            if n:
-                fam[name] = {"ms": round(ms, 3), "launches": int(n)}
+        fam = es.profile_report()
         es.profile(False)
         dom = max(fam, key=lambda k: fam[k]["ms"]) if fam else None
         if dom:
             # algorithmic bytes per launch (DESIGN.md "Kernels"): one colour pass reads the 4 neighbours
             # (the other colour: N/2 values), own old value, source and writes the colour: 16 B per grid
             # point per launch (= SURVEY 8d "two-pass colour kernels: 32 B/pt/sweep"), x B members.
-            per_pt = {"rb_half_fine": 16.0, "smooth_tile_fine": 24.0}.get(dom, 16.0)
+            # the LDS-tiled kernel does 3 sweeps per launch with compulsory traffic read psi + read src + write psi
+            per_pt = 24.0 if dom.startswith("smooth_tile") else 16.0
             avg_s = fam[dom]["ms"] * 1e-3 / fam[dom]["launches"]
             alg_bytes = per_pt * n_pts * B
             ach = alg_bytes / avg_s / 1e9

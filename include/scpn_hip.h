@@ -210,6 +210,7 @@ int scpn_gs_pack_psi_device(scpn_gs *h, void **device_ptr);
  * reset, measured with hipEvents on the handle's stream when profiling is enabled */
 int scpn_gs_profile(scpn_gs *h, int enable);
 int scpn_gs_profile_read(scpn_gs *h, const char *name, double *total_ms, long *launches);
+int scpn_gs_profile_names(scpn_gs *h, char *buf, int buflen); /* comma-separated family names seen so far */
 int scpn_gs_sync(scpn_gs *h);
 
 #ifdef __cplusplus

@@ -104,6 +104,7 @@ SIGNATURES = {
     "scpn_gs_pack_psi_device": (_i, [_vp, C.POINTER(_vp)]),
     "scpn_gs_profile": (_i, [_vp, _i]),
     "scpn_gs_profile_read": (_i, [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(C.c_long)]),
+    "scpn_gs_profile_names": (_i, [_vp, C.c_char_p, _i]),
     "scpn_gs_sync": (_i, [_vp]),
 }
 

@@ -21,10 +21,26 @@ struct Lvl {
     int nz, nr, ld;
     long stride;
     double a_ns, a_c, dr2, dz2, two_dr, dr, dz;
+    double inv_a_c, inv_dr2, inv_dz2, inv_two_dr;  // correctly rounded reciprocals (host IEEE division) for divc()
     const double* a_e;
     const double* a_w;
     const double* r_safe;
+    const double* r_inv;  // RN(1/r_safe[ir])
 };
+
+// x / d for a divisor whose correctly rounded reciprocal r = RN(1/d) is known.  q0 = RN(x*r) is within
+// 1.5 ulp; one FMA correction makes it faithful (< 1 ulp), and Markstein's theorem (Handbook of Floating-Point
+// Arithmetic, Newton-Raphson division with FMA) then makes the second correction the correctly rounded
+// quotient -- bit-identical to IEEE division for all finite x away from under/overflow (the only difference
+// is the sign of a zero result, and NaN instead of Inf for infinite x).  5 full-rate instructions instead
+// of the ~14 of the IEEE sequence; verified against x/d on 2e9 random + near-midpoint inputs.
+__device__ __forceinline__ double divc(double x, double d, double r) {
+    double q = x * r;
+    double e = __builtin_fma(-q, d, x);
+    q = __builtin_fma(e, r, q);
+    e = __builtin_fma(-q, d, x);
+    return __builtin_fma(e, r, q);
+}
 
 // A batched field whose member b may live in one of several ping-pong slots.
 struct Fld {
@@ -40,7 +56,7 @@ struct Fld {
 
 // per-member solver state kept on the device for the whole Picard solve
 struct Member {
-    double psi_axis, psi_bnd, denom;  // topology of the current iteration
+    double psi_axis, psi_bnd, denom, inv_denom;  // topology of the current iteration
     double x_r, x_z;
     long x_idx;
     double i_current, jscale;
@@ -191,9 +207,8 @@ __global__ void k_rb_half(Fld psiF, Fld srcF, Lvl L, double omega, double om1, i
     double* psi = psiF.at(b);
     const double* src = srcF.at(b);
     long c = (long)iz * L.ld + ir;
-    double gs = (L.a_e[ir] * psi[c + 1] + L.a_w[ir] * psi[c - 1] + L.a_ns * psi[c - L.ld] +
-                 L.a_ns * psi[c + L.ld] - src[c]) /
-                L.a_c;
+    double num = L.a_e[ir] * psi[c + 1] + L.a_w[ir] * psi[c - 1] + L.a_ns * psi[c - L.ld] + L.a_ns * psi[c + L.ld] - src[c];
+    double gs = CLIP ? num / L.a_c : divc(num, L.a_c, L.inv_a_c);  // the clipped (_sor_step) form keeps IEEE Inf semantics
     double v = om1 * psi[c] + omega * gs;
     if (CLIP) v = fmin(fmax(v, -CAP), CAP);
     psi[c] = v;
@@ -224,9 +239,8 @@ __global__ void __launch_bounds__(256) k_small_smooth(Fld psiF, Fld srcF, Lvl L,
             int iz = 1 + k / ni, ir = 1 + (k - (iz - 1) * ni);
             if (((iz + ir) & 1) != parity) continue;
             int c = iz * nr + ir;
-            double gs = (L.a_e[ir] * sp[c + 1] + L.a_w[ir] * sp[c - 1] + L.a_ns * sp[c - nr] +
-                         L.a_ns * sp[c + nr] - ss[c]) /
-                        L.a_c;
+            double gs = divc(L.a_e[ir] * sp[c + 1] + L.a_w[ir] * sp[c - 1] + L.a_ns * sp[c - nr] + L.a_ns * sp[c + nr] - ss[c],
+                             L.a_c, L.inv_a_c);
             sp[c] = om1 * sp[c] + omega * gs;
         }
         __syncthreads();
@@ -243,10 +257,10 @@ __device__ __forceinline__ double resid_at(const double* psi, const double* src,
     // core/multigrid_solve.py:243-248
     long c = (long)iz * L.ld + ir;
     double p = psi[c], e = psi[c + 1], w = psi[c - 1], n = psi[c + L.ld], s = psi[c - L.ld];
-    double d2r = (e - 2.0 * p + w) / L.dr2;
-    double d1r = (e - w) / L.two_dr;
-    double d2z = (n - 2.0 * p + s) / L.dz2;
-    double lpsi = d2r - d1r / L.r_safe[ir] + d2z;
+    double d2r = divc(e - 2.0 * p + w, L.dr2, L.inv_dr2);
+    double d1r = divc(e - w, L.two_dr, L.inv_two_dr);
+    double d2z = divc(n - 2.0 * p + s, L.dz2, L.inv_dz2);
+    double lpsi = d2r - divc(d1r, L.r_safe[ir], L.r_inv[ir]) + d2z;
     return lpsi - src[c];
 }
 // out = L*psi - src (zero ring); grid (ceil(nr/64), ceil(nz/4), B)
@@ -354,6 +368,254 @@ __device__ __forceinline__ double prolong_at(const double* c, int ld_c, int nz_c
     return 0.25 * (c[(long)ic * ld_c + jc] + c[(long)(ic + 1) * ld_c + jc] + c[(long)ic * ld_c + jc + 1] +
                    c[(long)(ic + 1) * ld_c + jc + 1]);
 }
+// ---------------------------------------------------------------- LDS-tiled multi-sweep smoother
+// S full red-black sweeps per launch with temporal blocking.  A 512-thread workgroup stages a
+// TILE_LZ x 128 tile of psi (halo H = 2S) in LDS, de-interleaved into two colour planes so that every
+// wave access is 64 consecutive doubles (no stride-2 bank conflicts); lane l owns the column pair
+// (2l, 2l+1) of each of its rows, so source values and the a_e/a_w coefficients of the pair stay in
+// registers for all sweeps.  Each colour pass invalidates one more cell from every interior tile edge;
+// after 2S passes the centre (TILE_LZ-4S) x (128-4S) window is exact and is written to `out`
+// (out-of-place: neighbouring tiles read the halo from `in`).  Results are bit-identical to the
+// one-pass-per-launch kernel because a colour pass only reads the other colour.
+// Inactive members are passed through (out = in).  grid (tiles_r, tiles_z, B), dynamic LDS = TILE_LZ KiB.
+constexpr int TILE_LZ = 78;
+template <int S>
+__global__ void __launch_bounds__(512) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
+                                                     const int* active) {
+    constexpr int LZ = TILE_LZ, H = 2 * S, NROWS = (LZ + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* A0 = lds;            // colour 0: (iz + ir) even
+    double* A1 = lds + LZ * 64;  // colour 1
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int z0 = blockIdx.y * (LZ - 2 * H) - H, r0 = blockIdx.x * (128 - 2 * H) - H;  // both even
+    const int nz = L.nz, nr = L.nr, ld = L.ld;
+    const double* in = inF.at(b);
+    double* out = outF.at(b);
+    const int c0 = r0 + 2 * lane;  // global column of the lane's even element
+    const bool pass = active && !active[b];
+    if (pass) {
+#pragma unroll
+        for (int i = 0; i < NROWS; ++i) {
+            int lz = w + 8 * i, gz = z0 + lz;
+            if (lz >= H && lz < LZ - H && gz < nz) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    int col = 2 * lane + p, gc = c0 + p;
+                    if (col >= H && col < 128 - H && gc < nr) out[(long)gz * ld + gc] = in[(long)gz * ld + gc];
+                }
+            }
+        }
+        return;
+    }
+    const double* src = srcF.at(b);
+    double ae0 = 0.0, ae1 = 0.0, aw0 = 0.0, aw1 = 0.0;
+    if (c0 >= 1 && c0 <= nr - 2) { ae0 = L.a_e[c0]; aw0 = L.a_w[c0]; }
+    if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { ae1 = L.a_e[c0 + 1]; aw1 = L.a_w[c0 + 1]; }
+    const double a_ns = L.a_ns, a_c = L.a_c, inv_a_c = L.inv_a_c;
+    // every row of this wave has the parity of w (lz = w + 8i), so the lane's element (0: even column, 1: odd
+    // column) that carries colour c is e(c) = (c + w) & 1 for all rows: per-colour registers, no per-row selects
+    const int e0 = w & 1;  // element index of colour 0
+    const double aeC0 = e0 ? ae1 : ae0, awC0 = e0 ? aw1 : aw0, aeC1 = e0 ? ae0 : ae1, awC1 = e0 ? aw0 : aw1;
+    double sC0[NROWS], sC1[NROWS];
+    const bool vec_ok = c0 >= 0 && c0 + 1 < nr;
+#pragma unroll
+    for (int i = 0; i < NROWS; ++i) {
+        int lz = w + 8 * i;
+        sC0[i] = 0.0;
+        sC1[i] = 0.0;
+        if (lz < LZ) {
+            int gz = z0 + lz;
+            double vx = 0.0, vy = 0.0, sx = 0.0, sy = 0.0;
+            if (gz >= 0 && gz < nz) {
+                long o = (long)gz * ld + c0;
+                if (vec_ok) {
+                    double2 v = *reinterpret_cast<const double2*>(in + o);
+                    double2 sv = *reinterpret_cast<const double2*>(src + o);
+                    vx = v.x; vy = v.y; sx = sv.x; sy = sv.y;
+                } else {
+                    if (c0 >= 0 && c0 < nr) { vx = in[o]; sx = src[o]; }
+                    if (c0 + 1 >= 0 && c0 + 1 < nr) { vy = in[o + 1]; sy = src[o + 1]; }
+                }
+            }
+            // even column has colour (gz & 1) == (lz & 1) == e0 ? 1 : 0 since z0, c0 are even
+            if (e0) { A1[lz * 64 + lane] = vx; A0[lz * 64 + lane] = vy; sC1[i] = sx; sC0[i] = sy; }
+            else { A0[lz * 64 + lane] = vx; A1[lz * 64 + lane] = vy; sC0[i] = sx; sC1[i] = sy; }
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int hs = 0; hs < 2 * S; ++hs) {
+        const int c = hs & 1;
+        double* mine = c ? A1 : A0;
+        const double* oth = c ? A0 : A1;
+        const int pr = (c + w) & 1;  // column parity of colour c in this wave's rows
+        const double ae = c ? aeC1 : aeC0, aw = c ? awC1 : awC0;
+        const int col = 2 * lane + pr, gc = r0 + col;
+        const bool colok = col >= 1 && col <= 126 && gc >= 1 && gc <= nr - 2;
+        // rows still needed for the final window shrink by one per pass: [hs+1, LZ-2-hs]
+#pragma unroll
+        for (int i = 0; i < NROWS; ++i) {
+            const int lz = w + 8 * i, gz = z0 + lz;
+            if (lz >= hs + 1 && lz <= LZ - 2 - hs && gz >= 1 && gz <= nz - 2) {  // wave-uniform
+                const double W = oth[lz * 64 + lane - 1 + pr], E = oth[lz * 64 + lane + pr];
+                const double Sv = oth[(lz - 1) * 64 + lane], N = oth[(lz + 1) * 64 + lane];
+                const double C = mine[lz * 64 + lane];
+                const double sv = c ? sC1[i] : sC0[i];
+                const double gsv = divc(ae * E + aw * W + a_ns * Sv + a_ns * N - sv, a_c, inv_a_c);
+                const double nw = om1 * C + omega * gsv;
+                if (colok) mine[lz * 64 + lane] = nw;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NROWS; ++i) {
+        const int lz = w + 8 * i, gz = z0 + lz;
+        if (lz >= H && lz < LZ - H && gz < nz) {
+            double vx, vy;
+            if (e0) { vx = A1[lz * 64 + lane]; vy = A0[lz * 64 + lane]; }
+            else { vx = A0[lz * 64 + lane]; vy = A1[lz * 64 + lane]; }
+            const int col = 2 * lane;
+            long o = (long)gz * ld + c0;
+            if (col >= H && col + 1 < 128 - H && c0 + 1 < nr) {
+                *reinterpret_cast<double2*>(out + o) = double2{vx, vy};
+            } else {
+                if (col >= H && col < 128 - H && c0 < nr) out[o] = vx;
+                if (col + 1 >= H && col + 1 < 128 - H && c0 + 1 < nr) out[o + 1] = vy;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- whole coarse V-cycle in LDS
+// One 1024-thread workgroup per member runs the complete recursion from level `lc` down to the base
+// case and back (core/multigrid_solve.py:289-335) with every level resident in LDS: e_lc = Vcycle(0, rhs_lc).
+constexpr int CV_MAX = 8;
+struct CoarseV {
+    int n;                 // number of levels held (last one is the base case)
+    int nz[CV_MAX], nr[CV_MAX];
+    int off_psi[CV_MAX], off_rhs[CV_MAX], off_tab[CV_MAX];  // LDS offsets (doubles); tab = a_e, a_w, r_safe, r_inv (4*nr)
+    double a_ns[CV_MAX], a_c[CV_MAX], dr2[CV_MAX], dz2[CV_MAX], two_dr[CV_MAX];
+    double inv_a_c[CV_MAX], inv_dr2[CV_MAX], inv_dz2[CV_MAX], inv_two_dr[CV_MAX];
+    const double* r_inv[CV_MAX];
+    const double* a_e[CV_MAX];
+    const double* a_w[CV_MAX];
+    const double* r_safe[CV_MAX];
+    int ld0;       // pitch of the global level-lc arrays
+    long stride0;
+};
+__device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const double* tab, int nz, int nr, double a_ns,
+                                          double a_c, double inv_a_c, double omega, double om1, int n_sweeps) {
+    const int hw = (nr - 2 + 1) / 2, tot = (nz - 2) * hw;
+    const double* a_e = tab;
+    const double* a_w = tab + nr;
+    for (int s = 0; s < 2 * n_sweeps; ++s) {
+        const int parity = s & 1;
+        for (int t = threadIdx.x; t < tot; t += blockDim.x) {
+            int iz = 1 + t / hw, k = t - (iz - 1) * hw;
+            int ir = 1 + ((iz + 1 + parity) & 1) + 2 * k;
+            if (ir <= nr - 2) {
+                int c = iz * nr + ir;
+                double gs = divc(a_e[ir] * psi[c + 1] + a_w[ir] * psi[c - 1] + a_ns * psi[c - nr] + a_ns * psi[c + nr] - rhs[c], a_c, inv_a_c);
+                psi[c] = om1 * psi[c] + omega * gs;
+            }
+        }
+        __syncthreads();
+    }
+}
+struct CvC { double dr2, dz2, two_dr, inv_dr2, inv_dz2, inv_two_dr; };
+__device__ __forceinline__ double cv_resid(const double* psi, const double* rhs, const double* rs, int nr, const CvC& k, int iz,
+                                           int ir) {
+    int c = iz * nr + ir;  // rs = r_safe table, rs + nr = its reciprocals
+    double p = psi[c], e = psi[c + 1], w = psi[c - 1], n = psi[c + nr], s = psi[c - nr];
+    double d2r = divc(e - 2.0 * p + w, k.dr2, k.inv_dr2);
+    double d1r = divc(e - w, k.two_dr, k.inv_two_dr);
+    double d2z = divc(n - 2.0 * p + s, k.dz2, k.inv_dz2);
+    double lpsi = d2r - divc(d1r, rs[ir], rs[nr + ir]) + d2z;
+    return lpsi - rhs[c];
+}
+__global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, CoarseV V, double omega, double om1, int pre,
+                                                        int post, const int* active) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    // stage the coefficient tables of every level and the top-level rhs
+    for (int l = 0; l < V.n; ++l) {
+        double* tab = lds + V.off_tab[l];
+        for (int i = threadIdx.x; i < V.nr[l]; i += blockDim.x) {
+            tab[i] = V.a_e[l][i];
+            tab[V.nr[l] + i] = V.a_w[l][i];
+            tab[2 * V.nr[l] + i] = V.r_safe[l][i];
+            tab[3 * V.nr[l] + i] = V.r_inv[l][i];
+        }
+    }
+    {
+        const double* g = rhsF.at(b);
+        double* rhs = lds + V.off_rhs[0];
+        double* psi = lds + V.off_psi[0];
+        const int nz = V.nz[0], nr = V.nr[0], n = nz * nr;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            int iz = i / nr, ir = i - iz * nr;
+            rhs[i] = g[(long)iz * V.ld0 + ir];
+            psi[i] = 0.0;
+        }
+    }
+    __syncthreads();
+    for (int l = 0; l < V.n - 1; ++l) {
+        double* psi = lds + V.off_psi[l];
+        const double* rhs = lds + V.off_rhs[l];
+        const double* tab = lds + V.off_tab[l];
+        cv_smooth(psi, rhs, tab, V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], omega, om1, pre);
+        // coarse rhs = restrict_full_weight(-(L*psi - rhs)); coarse e = 0
+        double* rc = lds + V.off_rhs[l + 1];
+        double* pc = lds + V.off_psi[l + 1];
+        const int nzc = V.nz[l + 1], nrc = V.nr[l + 1], nrf = V.nr[l], nc = nzc * nrc;
+        const double* rs = tab + 2 * nrf;
+        for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+            int ic = i / nrc, jc = i - ic * nrc;
+            double v = -0.0;
+            if (jc > 0 && jc < nrc - 1 && ic > 0 && ic < nzc - 1) {
+                int ii = 2 * ic, jj = 2 * jc;
+                const CvC kk{V.dr2[l], V.dz2[l], V.two_dr[l], V.inv_dr2[l], V.inv_dz2[l], V.inv_two_dr[l]};
+                double c = -cv_resid(psi, rhs, rs, nrf, kk, ii, jj);
+                double up = -cv_resid(psi, rhs, rs, nrf, kk, ii - 1, jj), dn = -cv_resid(psi, rhs, rs, nrf, kk, ii + 1, jj);
+                double lf = -cv_resid(psi, rhs, rs, nrf, kk, ii, jj - 1), rt = -cv_resid(psi, rhs, rs, nrf, kk, ii, jj + 1);
+                double ul = -cv_resid(psi, rhs, rs, nrf, kk, ii - 1, jj - 1), ur = -cv_resid(psi, rhs, rs, nrf, kk, ii - 1, jj + 1);
+                double dl = -cv_resid(psi, rhs, rs, nrf, kk, ii + 1, jj - 1), dr_ = -cv_resid(psi, rhs, rs, nrf, kk, ii + 1, jj + 1);
+                v = fw9(c, up, dn, lf, rt, ul, ur, dl, dr_);
+            }
+            rc[i] = v;
+            pc[i] = 0.0;
+        }
+        __syncthreads();
+    }
+    {
+        const int l = V.n - 1;  // base case: 50 sweeps (multigrid_solve.py:293)
+        cv_smooth(lds + V.off_psi[l], lds + V.off_rhs[l], lds + V.off_tab[l], V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], omega, om1, 50);
+    }
+    for (int l = V.n - 2; l >= 0; --l) {
+        double* psi = lds + V.off_psi[l];
+        const double* pc = lds + V.off_psi[l + 1];
+        const int nzf = V.nz[l], nrf = V.nr[l], nzc = V.nz[l + 1], nrc = V.nr[l + 1], n = nzf * nrf;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            int iz = i / nrf, ir = i - iz * nrf;
+            psi[i] = psi[i] + prolong_at(pc, nrc, nzc, nrc, nzf, nrf, iz, ir);
+        }
+        __syncthreads();
+        cv_smooth(psi, lds + V.off_rhs[l], lds + V.off_tab[l], nzf, nrf, V.a_ns[l], V.a_c[l], V.inv_a_c[l], omega, om1, post);
+    }
+    {
+        double* g = eF.at(b);
+        const double* psi = lds + V.off_psi[0];
+        const int nz = V.nz[0], nr = V.nr[0], n = nz * nr;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            int iz = i / nr, ir = i - iz * nr;
+            g[(long)iz * V.ld0 + ir] = psi[i];
+        }
+    }
+}
+
 // ADD: psi += P e (multigrid_solve.py:329-330) else fine = P c; grid (ceil(nr_f/64), ceil(nz_f/4), B)
 template <bool ADD>
 __global__ void k_prolong(Fld fF, Fld cF, int nz_f, int nr_f, int ld_f, int nz_c, int nr_c, int ld_c,
@@ -501,7 +763,7 @@ __global__ void __launch_bounds__(256) k_topology_final(Fld psiF, Member* st, co
         if (fabs(pa - pb) < 0.1) pb = pa * 0.1;
         double denom = pb - pa;  // core/fusion_kernel.py:415-417
         if (fabs(denom) < 1e-9) denom = 1e-9;
-        m.psi_axis = pa; m.psi_bnd = pb; m.denom = denom; m.x_idx = rmn.i; m.x_r = xr; m.x_z = xz;
+        m.psi_axis = pa; m.psi_bnd = pb; m.denom = denom; m.inv_denom = 1.0 / denom; m.x_idx = rmn.i; m.x_r = xr; m.x_z = xz;
     }
 }
 
@@ -522,9 +784,9 @@ __device__ __forceinline__ double mtanh1(double x, const double* p) {  // core/f
     return pedestal + p[3] * core;
 }
 __device__ __forceinline__ double j_raw_at(double psi, double R, double inv_mu0R, double psi_axis,
-                                           double denom, const Prof& pf) {
+                                           double denom, double inv_denom, const Prof& pf) {
     // core/fusion_kernel.py:419-434
-    double pn = (psi - psi_axis) / denom;
+    double pn = divc(psi - psi_axis, denom, inv_denom);
     double p = 0.0, ff = 0.0;
     if (pn >= 0.0 && pn < 1.0) {
         if (pf.hmode) { p = mtanh1(pn, pf.ped_p); ff = mtanh1(pn, pf.ped_ff); }
@@ -542,7 +804,7 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
     int b = blockIdx.y;
     if (!st[b].active) return;
     const double* psi = psiF.at(b);
-    const double pa = st[b].psi_axis, den = st[b].denom;
+    const double pa = st[b].psi_axis, den = st[b].denom, iden = st[b].inv_denom;
     const long n = (long)nz * nr;
     double s = 0.0;
 #pragma unroll
@@ -550,7 +812,7 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
         long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
         if (q < n) {
             int iz = (int)(q / nr), ir = (int)(q - (long)iz * nr);
-            s += j_raw_at(psi[(long)iz * ld + ir], r_axis[ir], inv_mu0R[ir], pa, den, pf);
+            s += j_raw_at(psi[(long)iz * ld + ir], r_axis[ir], inv_mu0R[ir], pa, den, iden, pf);
         }
     }
     double bs = block_sum<256>(s, sh);
@@ -579,7 +841,7 @@ __global__ void k_source(Fld srcF, Fld jF, int write_j, Fld psiF, const Member* 
     int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
     if (ir >= nr || iz >= nz) return;
     long c = (long)iz * ld + ir;
-    double jr = j_raw_at(psiF.at(b)[c], r_axis[ir], inv_mu0R[ir], st[b].psi_axis, st[b].denom, pf);
+    double jr = j_raw_at(psiF.at(b)[c], r_axis[ir], inv_mu0R[ir], st[b].psi_axis, st[b].denom, st[b].inv_denom, pf);
     double sc = st[b].jscale;
     double j = sc != 0.0 ? jr * sc : 0.0;
     srcF.at(b)[c] = neg_mu0R[ir] * j;

@@ -92,9 +92,15 @@ struct LevelHost {
     long stride;
     double dr, dz;
     std::vector<double> r;  // 1-D R of this level (interior columns follow the full-weighting of the finer R)
-    DBuf<double> a_e, a_w, r_safe;
-    DBuf<double> psi, rhs;  // level >= 1: correction e and restricted defect
+    DBuf<double> a_e, a_w, r_safe, r_inv;
+    DBuf<double> psi, psi2, rhs;  // level >= 1: correction e (+ ping-pong twin) and restricted defect
     Lvl dev{};
+};
+struct Hier {
+    std::vector<LevelHost*> lv;
+    int lc = -1;          // first level handled by the in-LDS coarse V-cycle kernel (-1: none)
+    CoarseV cv{};
+    size_t cv_lds = 0;    // dynamic LDS bytes of k_vcycle_coarse
 };
 
 static int pitch_of(int nr) { return ((nr + 7) / 8) * 8; }
@@ -115,10 +121,11 @@ struct scpn_gs {
     hipStream_t stream = nullptr;
 
     // multigrid hierarchies keyed by min_grid
-    std::map<int, std::vector<LevelHost*>> hier;
+    std::map<int, Hier> hier;
+    bool use_fused = true;  // SCPN_HIP_FUSED=0 selects the one-pass-per-launch kernels (A/B testing)
     // fields (B members each)
     DBuf<double> psi_slots;  // 3 ping-pong slots
-    DBuf<double> W, src, src2, bc, jphi, ext, old, dense;
+    DBuf<double> W, W2, src, src2, bc, jphi, ext, old, dense;
     bool picard_bufs = false;
     DBuf<double> d_r, d_z, d_inv_mu0R, d_neg_mu0R, d_seed;
     DBuf<Member> d_st;
@@ -149,7 +156,7 @@ struct scpn_gs {
 
     ~scpn_gs() {
         for (auto& kv : hier)
-            for (auto* l : kv.second) delete l;
+            for (auto* l : kv.second.lv) delete l;
         for (auto& e : prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         if (h_nactive) (void)hipHostFree(h_nactive);
         if (stream) (void)hipStreamDestroy(stream);
@@ -185,17 +192,20 @@ struct ProfScope {
 static void build_level_tables(LevelHost* L) {
     // core/multigrid_solve.py:181-189 (dr**2 is libm pow in CPython)
     const double dr2 = std::pow(L->dr, 2.0), dz2 = std::pow(L->dz, 2.0);
-    std::vector<double> ae(L->nr, 0.0), aw(L->nr, 0.0), rs(L->nr, 1.0);
+    std::vector<double> ae(L->nr, 0.0), aw(L->nr, 0.0), rs(L->nr, 1.0), ri(L->nr, 1.0);
     for (int ir = 0; ir < L->nr; ++ir) {
         double r_safe = std::fmax(L->r[ir], 1e-10);
         double t = 1.0 / ((2.0 * r_safe) * L->dr);
         ae[ir] = 1.0 / dr2 - t;
         aw[ir] = 1.0 / dr2 + t;
         rs[ir] = r_safe;
+        ri[ir] = 1.0 / r_safe;
     }
     L->a_e.alloc(L->nr);
     L->a_w.alloc(L->nr);
     L->r_safe.alloc(L->nr);
+    L->r_inv.alloc(L->nr);
+    HIP_TRY(hipMemcpy(L->r_inv.p, ri.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(L->a_e.p, ae.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(L->a_w.p, aw.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(L->r_safe.p, rs.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
@@ -204,15 +214,17 @@ static void build_level_tables(LevelHost* L) {
     d.a_ns = 1.0 / dz2;
     d.a_c = 2.0 / dr2 + 2.0 / dz2;
     d.dr2 = dr2; d.dz2 = dz2; d.two_dr = 2.0 * L->dr; d.dr = L->dr; d.dz = L->dz;
-    d.a_e = L->a_e.p; d.a_w = L->a_w.p; d.r_safe = L->r_safe.p;
+    d.inv_a_c = 1.0 / d.a_c; d.inv_dr2 = 1.0 / dr2; d.inv_dz2 = 1.0 / dz2; d.inv_two_dr = 1.0 / d.two_dr;
+    d.a_e = L->a_e.p; d.a_w = L->a_w.p; d.r_safe = L->r_safe.p; d.r_inv = L->r_inv.p;
     L->dev = d;
 }
 
 // levels of the V-cycle recursion (core/multigrid_solve.py:289-312): level k is the base case
-static std::vector<LevelHost*>& get_hierarchy(scpn_gs* h, int min_grid) {
+static Hier& get_hier(scpn_gs* h, int min_grid) {
     auto it = h->hier.find(min_grid);
     if (it != h->hier.end()) return it->second;
-    std::vector<LevelHost*> v;
+    Hier H;
+    std::vector<LevelHost*>& v = H.lv;
     auto* L0 = new LevelHost();
     L0->nz = h->nz; L0->nr = h->nr; L0->ld = h->ld; L0->stride = h->stride;
     L0->dr = h->dr; L0->dz = h->dz; L0->r = h->r_axis;
@@ -238,60 +250,174 @@ static std::vector<LevelHost*>& get_hierarchy(scpn_gs* h, int min_grid) {
         c->r[c->nr - 1] = f->r[f->nr - 1];
         build_level_tables(c);
         c->psi.alloc((size_t)c->stride * h->B);
+        c->psi2.alloc((size_t)c->stride * h->B);
         c->rhs.alloc((size_t)c->stride * h->B);
         HIP_TRY(hipMemsetAsync(c->psi.p, 0, sizeof(double) * c->stride * h->B, h->stream));
+        HIP_TRY(hipMemsetAsync(c->psi2.p, 0, sizeof(double) * c->stride * h->B, h->stream));
         HIP_TRY(hipMemsetAsync(c->rhs.p, 0, sizeof(double) * c->stride * h->B, h->stream));
         v.push_back(c);
         if (v.size() > 40) break;
     }
-    h->hier[min_grid] = v;
+    // in-LDS coarse V-cycle: the deepest suffix of levels (starting at >= 1) that fits 150 KiB
+    const int k = (int)v.size() - 1;
+    if (k >= 1) {
+        const size_t budget = 150 * 1024 / sizeof(double);
+        int lc = k;
+        auto need = [&](int from) {
+            size_t tot = 0;
+            for (int l = from; l <= k; ++l) tot += 2 * (size_t)v[l]->nz * v[l]->nr + 4 * (size_t)v[l]->nr + 8;
+            return tot;
+        };
+        while (lc - 1 >= 1 && (k - (lc - 1) + 1) <= CV_MAX && need(lc - 1) <= budget) --lc;
+        if (need(lc) <= budget && (k - lc + 1) <= CV_MAX) {
+            H.lc = lc;
+            CoarseV& V = H.cv;
+            V.n = k - lc + 1;
+            int off = 0;
+            auto al = [&](int nd) { int o = off; off += (nd + 1) & ~1; return o; };
+            for (int i = 0; i < V.n; ++i) {
+                LevelHost* L = v[lc + i];
+                V.nz[i] = L->nz; V.nr[i] = L->nr;
+                V.off_psi[i] = al(L->nz * L->nr);
+                V.off_rhs[i] = al(L->nz * L->nr);
+                V.off_tab[i] = al(4 * L->nr);
+                V.a_ns[i] = L->dev.a_ns; V.a_c[i] = L->dev.a_c; V.dr2[i] = L->dev.dr2; V.dz2[i] = L->dev.dz2; V.two_dr[i] = L->dev.two_dr;
+                V.inv_a_c[i] = L->dev.inv_a_c; V.inv_dr2[i] = L->dev.inv_dr2; V.inv_dz2[i] = L->dev.inv_dz2; V.inv_two_dr[i] = L->dev.inv_two_dr;
+                V.a_e[i] = L->dev.a_e; V.a_w[i] = L->dev.a_w; V.r_safe[i] = L->dev.r_safe; V.r_inv[i] = L->dev.r_inv;
+            }
+            V.ld0 = v[lc]->ld;
+            V.stride0 = v[lc]->stride;
+            H.cv_lds = (size_t)off * sizeof(double);
+        }
+    }
+    h->hier[min_grid] = H;
     return h->hier[min_grid];
 }
+static std::vector<LevelHost*>& get_hierarchy(scpn_gs* h, int min_grid) { return get_hier(h, min_grid).lv; }
 
 // ------------------------------------------------------------------------------------------ smoother / V-cycle drivers
-static void smooth(scpn_gs* h, const Lvl& L, Fld psi, Fld src, double omega, int n_sweeps, const int* active,
-                   bool clip = false) {
-    if (n_sweeps <= 0 || L.nz < 3 || L.nr < 3) return;
+template <int S>
+static void launch_tile(scpn_gs* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active) {
+    static bool attr_done = false;
+    const size_t lds = (size_t)TILE_LZ * 128 * sizeof(double);
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_tile<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    dim3 g(cdiv(L.nr, 128 - 4 * S), cdiv(L.nz, TILE_LZ - 4 * S), h->B);
+    hipLaunchKernelGGL(k_smooth_tile<S>, g, dim3(512), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active);
+}
+
+// n_sweeps red-black SOR sweeps of (in, src).  Returns the field that holds the result: `in` itself for the
+// in-place kernels, or `in`/`alt` alternately for the out-of-place LDS-tiled kernel (`alt` must not alias `in`).
+static std::string lname(const char* kind, int lvl) { return std::string(kind) + "_L" + std::to_string(lvl); }
+static Fld smooth(scpn_gs* h, const Lvl& L, Fld in, Fld alt, Fld src, double omega, int n_sweeps, const int* active,
+                  bool clip = false, int lvl = 0) {
+    if (n_sweeps <= 0 || L.nz < 3 || L.nr < 3) return in;
     const double om1 = 1.0 - omega;
     if (!clip && (long)L.nz * L.nr <= SMALL_MAX) {
-        ProfScope ps(h, "small_smooth", 1);
-        hipLaunchKernelGGL(k_small_smooth, dim3(h->B), dim3(256), 0, h->stream, psi, src, L, omega, om1, n_sweeps, active);
-        return;
+        ProfScope ps(h, lname("small_smooth", lvl).c_str(), 1);
+        hipLaunchKernelGGL(k_small_smooth, dim3(h->B), dim3(256), 0, h->stream, in, src, L, omega, om1, n_sweeps, active);
+        return in;
     }
-    ProfScope ps(h, L.nz == h->nz ? "rb_half_fine" : "rb_half_coarse", 2L * n_sweeps);
+    if (!clip && h->use_fused && alt.base != nullptr) {
+        ProfScope ps(h, lname("smooth_tile", lvl).c_str(), (n_sweeps + 2) / 3);
+        Fld a = in, b = alt;
+        int left = n_sweeps;
+        while (left > 0) {
+            const int S = std::min(3, left);
+            if (S == 3) launch_tile<3>(h, L, b, a, src, omega, active);
+            else if (S == 2) launch_tile<2>(h, L, b, a, src, omega, active);
+            else launch_tile<1>(h, L, b, a, src, omega, active);
+            std::swap(a, b);
+            left -= S;
+        }
+        return a;
+    }
+    ProfScope ps(h, lname("rb_half", lvl).c_str(), 2L * n_sweeps);
     int ncol = (L.nr - 2 + 1) / 2;
     dim3 g(cdiv(ncol, 64), cdiv(L.nz - 2, 4), h->B);
     for (int s = 0; s < n_sweeps; ++s)
         for (int parity = 0; parity < 2; ++parity) {
-            if (clip) hipLaunchKernelGGL(k_rb_half<true>, g, BLK2D, 0, h->stream, psi, src, L, omega, om1, parity, active);
-            else hipLaunchKernelGGL(k_rb_half<false>, g, BLK2D, 0, h->stream, psi, src, L, omega, om1, parity, active);
+            if (clip) hipLaunchKernelGGL(k_rb_half<true>, g, BLK2D, 0, h->stream, in, src, L, omega, om1, parity, active);
+            else hipLaunchKernelGGL(k_rb_half<false>, g, BLK2D, 0, h->stream, in, src, L, omega, om1, parity, active);
         }
+    return in;
 }
 
-// one V-cycle on (psi, src) of level 0 (core/multigrid_solve.py:252-335)
-static void vcycle(scpn_gs* h, Fld psi0, Fld src0, double omega, int pre, int post, int min_grid, const int* active) {
-    auto& lv = get_hierarchy(h, min_grid);
+// One V-cycle (core/multigrid_solve.py:252-335) of (in0, src0) on level 0.  in0 is left untouched; the improved
+// estimate is produced in bufA or bufB (returned).  `active` (may be null) freezes members.
+static Fld vcycle(scpn_gs* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega, int pre, int post, int min_grid,
+                  const int* active) {
+    Hier& H = get_hier(h, min_grid);
+    auto& lv = H.lv;
     const int k = (int)lv.size() - 1;
-    auto psi_of = [&](int l) { return l == 0 ? psi0 : Fld{lv[l]->psi.p, nullptr, lv[l]->stride, h->B}; };
-    auto rhs_of = [&](int l) { return l == 0 ? src0 : Fld{lv[l]->rhs.p, nullptr, lv[l]->stride, h->B}; };
-    for (int l = 0; l < k; ++l) {
-        smooth(h, lv[l]->dev, psi_of(l), rhs_of(l), omega, pre, active);
-        ProfScope ps(h, l == 0 ? "defect_restrict_fine" : "defect_restrict_coarse", 1);
-        const Lvl& Lc = lv[l + 1]->dev;
-        hipLaunchKernelGGL(k_defect_restrict, grid2d(Lc.nr, Lc.nz, h->B), BLK2D, 0, h->stream, rhs_of(l + 1), psi_of(l + 1),
-                           psi_of(l), rhs_of(l), lv[l]->dev, Lc, active);
+    const int B = h->B;
+    const bool fused = h->use_fused;
+    auto lvf = [&](DBuf<double>& d, int l) { return Fld{d.p, nullptr, lv[l]->stride, B}; };
+    std::vector<Fld> cur(k + 1);
+    // level 0: first smoothing pass reads in0 and writes a work buffer
+    {
+        const Lvl& L0 = lv[0]->dev;
+        const int n0 = (k == 0) ? 50 : pre;  // base case: 50 sweeps (multigrid_solve.py:292-293)
+        const bool tile0 = fused && (long)L0.nz * L0.nr > SMALL_MAX && n0 > 0;
+        if (tile0) {
+            Fld r = smooth(h, L0, in0, bufA, src0, omega, std::min(3, n0), active);  // in0 -> bufA
+            if (n0 > 3) r = smooth(h, L0, bufA, bufB, src0, omega, n0 - 3, active);
+            cur[0] = r;
+        } else {
+            ProfScope ps(h, "copy", 1);
+            hipLaunchKernelGGL(k_copy, grid2d(L0.nr, L0.nz, B), BLK2D, 0, h->stream, bufA, in0, L0.nz, L0.nr, L0.ld, (const int*)nullptr);
+            cur[0] = bufA;
+            if (n0 > 0) cur[0] = smooth(h, L0, bufA, bufB, src0, omega, n0, active);
+        }
+        if (k == 0) return cur[0];
     }
-    smooth(h, lv[k]->dev, psi_of(k), rhs_of(k), omega, 50, active);  // base case: 50 sweeps (multigrid_solve.py:293)
-    for (int l = k - 1; l >= 0; --l) {
+    const int lc = (fused && H.lc >= 1) ? H.lc : k + 1;  // levels >= lc run inside k_vcycle_coarse
+    auto rhs_of = [&](int l) { return l == 0 ? src0 : lvf(lv[l]->rhs, l); };
+    auto other_of = [&](int l, Fld f) {
+        if (l == 0) return f.base == bufA.base && f.slot == bufA.slot ? bufB : bufA;
+        return f.base == lv[l]->psi.p ? lvf(lv[l]->psi2, l) : lvf(lv[l]->psi, l);
+    };
+    for (int l = 0; l < k && l < lc; ++l) {
+        if (l > 0) cur[l] = smooth(h, lv[l]->dev, cur[l], other_of(l, cur[l]), rhs_of(l), omega, pre, active, false, l);
+        ProfScope ps(h, lname("defect_restrict", l).c_str(), 1);
+        const Lvl& Lc = lv[l + 1]->dev;
+        cur[l + 1] = lvf(lv[l + 1]->psi, l + 1);
+        hipLaunchKernelGGL(k_defect_restrict, grid2d(Lc.nr, Lc.nz, B), BLK2D, 0, h->stream, rhs_of(l + 1), cur[l + 1], cur[l], rhs_of(l),
+                           lv[l]->dev, Lc, active);
+    }
+    int top;  // coarsest level solved so far
+    if (lc <= k) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vcycle_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_done = true;
+        }
+        ProfScope ps(h, "vcycle_coarse", 1);
+        hipLaunchKernelGGL(k_vcycle_coarse, dim3(B), dim3(1024), H.cv_lds, h->stream, cur[lc], rhs_of(lc), H.cv, omega, 1.0 - omega, pre, post, active);
+        top = lc;
+    } else {
+        cur[k] = smooth(h, lv[k]->dev, cur[k], other_of(k, cur[k]), rhs_of(k), omega, 50, active, false, k);
+        top = k;
+    }
+    for (int l = top - 1; l >= 0; --l) {
         const Lvl& Lf = lv[l]->dev;
         const Lvl& Lc = lv[l + 1]->dev;
         {
-            ProfScope ps(h, l == 0 ? "prolong_add_fine" : "prolong_add_coarse", 1);
-            hipLaunchKernelGGL(k_prolong<true>, grid2d(Lf.nr, Lf.nz, h->B), BLK2D, 0, h->stream, psi_of(l), psi_of(l + 1), Lf.nz,
-                               Lf.nr, Lf.ld, Lc.nz, Lc.nr, Lc.ld, active);
+            ProfScope ps(h, lname("prolong_add", l).c_str(), 1);
+            hipLaunchKernelGGL(k_prolong<true>, grid2d(Lf.nr, Lf.nz, B), BLK2D, 0, h->stream, cur[l], cur[l + 1], Lf.nz, Lf.nr, Lf.ld, Lc.nz,
+                               Lc.nr, Lc.ld, active);
         }
-        smooth(h, Lf, psi_of(l), rhs_of(l), omega, post, active);
+        cur[l] = smooth(h, Lf, cur[l], other_of(l, cur[l]), rhs_of(l), omega, post, active, false, l);
     }
+    return cur[0];
+}
+
+static bool same_fld(const Fld& a, const Fld& b) { return a.base == b.base && a.slot == b.slot; }
+static void copy_back(scpn_gs* h, Fld dst, Fld res, const int* active) {
+    if (same_fld(dst, res)) return;
+    hipLaunchKernelGGL(k_copy, grid2d(h->nr, h->nz, h->B), BLK2D, 0, h->stream, dst, res, h->nz, h->nr, h->ld, active);
 }
 
 // ------------------------------------------------------------------------------------------ transfers
@@ -378,9 +504,15 @@ static scpn_gs* create_impl(int nr, int nz, int batch, const double* r_axis, con
         size_t n = (size_t)h->stride * batch;
         h->psi_slots.alloc(3 * n);
         h->W.alloc(n);
+        h->W2.alloc(n);
         h->src.alloc(n);
+        {
+            const char* e = std::getenv("SCPN_HIP_FUSED");
+            h->use_fused = !(e && e[0] == '0');
+        }
         HIP_TRY(hipMemsetAsync(h->psi_slots.p, 0, sizeof(double) * 3 * n, h->stream));
         HIP_TRY(hipMemsetAsync(h->W.p, 0, sizeof(double) * n, h->stream));
+        HIP_TRY(hipMemsetAsync(h->W2.p, 0, sizeof(double) * n, h->stream));
         HIP_TRY(hipMemsetAsync(h->src.p, 0, sizeof(double) * n, h->stream));
         h->d_r.alloc(nr);
         h->d_z.alloc(nz);
@@ -466,7 +598,7 @@ static void picard_solve_impl(scpn_gs* h, const scpn_picard_params* p, scpn_pica
 
     Fld curF = h->slot_fld(h->d_cur.p), nxtF = h->slot_fld(h->d_nxt.p), bestF = h->slot_fld(h->d_best.p);
     Fld prevF = h->slot_fld(h->d_prev.p);
-    Fld WF = h->plain(h->W.p), srcF = h->plain(h->src.p), src2F = h->plain(h->src2.p), bcF = h->plain(h->bc.p);
+    Fld WF = h->plain(h->W.p), W2F = h->plain(h->W2.p), srcF = h->plain(h->src.p), src2F = h->plain(h->src2.p), bcF = h->plain(h->bc.p);
     Fld jF = h->plain(h->jphi.p);
     dim3 g2 = grid2d(nr, nz, B);
     dim3 gring(cdiv(2L * (nz + nr), 256), B);
@@ -572,19 +704,19 @@ static void picard_solve_impl(scpn_gs* h, const scpn_picard_params* p, scpn_pica
                                (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
         }
         // _elliptic_solve (iterative_solver.py:361-380)
+        Fld newF = WF;
         if (p->method == 0) {
-            { ProfScope ps(h, "copy", 1); hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, WF, curF, nz, nr, ld, act); }
-            vcycle(h, WF, srcF, p->sor_omega, 3, 3, 5, act);
+            newF = vcycle(h, curF, WF, W2F, srcF, p->sor_omega, 3, 3, 5, act);
         } else if (p->method == 1) {
             hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, WF, curF, nz, nr, ld);
             hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, src2F, srcF, nz, nr, ld);
-            smooth(h, L0, WF, src2F, p->sor_omega, 1, act, true);
+            smooth(h, L0, WF, Fld{nullptr, nullptr, 0, 0}, src2F, p->sor_omega, 1, act, true);
         } else {
             hipLaunchKernelGGL(k_jacobi, g2, BLK2D, 0, st, WF, curF, srcF, L0, act);
         }
         {
             ProfScope ps(h, "blend_norms", 2);
-            hipLaunchKernelGGL(k_blend, dim3(nblk, B), dim3(256), 0, st, nxtF, curF, WF, bcF, (const Member*)h->d_st.p, nz, nr, ld, p->alpha,
+            hipLaunchKernelGGL(k_blend, dim3(nblk, B), dim3(256), 0, st, nxtF, curF, newF, bcF, (const Member*)h->d_st.p, nz, nr, ld, p->alpha,
                                om_alpha, h->d_part1.p, h->d_pbad.p, nblk);
             hipLaunchKernelGGL(k_resid_norms, dim3(nblk_r, B), dim3(256), 0, st, nxtF, srcF, L0, h->d_part2.p, h->d_part3.p, nblk_r, act);
         }
@@ -907,7 +1039,9 @@ int scpn_gs_rb_sor(scpn_gs* h, double omega, int n_sweeps) {
     if (!omega_ok(omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
     API_BEGIN
     auto& lv = get_hierarchy(h, 5);
-    smooth(h, lv[0]->dev, h->slot_fld(h->d_cur.p), h->plain(h->src.p), omega, n_sweeps, nullptr);
+    Fld curF = h->slot_fld(h->d_cur.p);
+    Fld res = smooth(h, lv[0]->dev, curF, h->plain(h->W.p), h->plain(h->src.p), omega, n_sweeps, nullptr);
+    copy_back(h, curF, res, nullptr);
     HIP_TRY(hipStreamSynchronize(h->stream));
     API_END
 }
@@ -915,7 +1049,9 @@ int scpn_gs_vcycle(scpn_gs* h, double omega, int pre, int post, int min_grid) {
     if (!h) return fail(SCPN_E_ARG, "null handle");
     if (!omega_ok(omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
     API_BEGIN
-    vcycle(h, h->slot_fld(h->d_cur.p), h->plain(h->src.p), omega, pre, post, min_grid, nullptr);
+    Fld curF = h->slot_fld(h->d_cur.p);
+    Fld res = vcycle(h, curF, h->plain(h->W.p), h->plain(h->W2.p), h->plain(h->src.p), omega, pre, post, min_grid, nullptr);
+    copy_back(h, curF, res, nullptr);
     HIP_TRY(hipStreamSynchronize(h->stream));
     API_END
 }
@@ -969,6 +1105,13 @@ int scpn_gs_profile(scpn_gs* h, int enable) {
     h->prof_on = enable != 0;
     API_END
 }
+int scpn_gs_profile_names(scpn_gs* h, char* buf, int buflen) {
+    if (!h || !buf || buflen <= 0) return fail(SCPN_E_ARG, "bad arguments");
+    std::string all;
+    for (auto& n : h->prof_names) { if (!all.empty()) all += ","; all += n; }
+    snprintf(buf, (size_t)buflen, "%s", all.c_str());
+    return SCPN_OK;
+}
 int scpn_gs_profile_read(scpn_gs* h, const char* name, double* total_ms, long* launches) {
     if (!h || !name) return fail(SCPN_E_ARG, "bad arguments");
     API_BEGIN
@@ -1012,7 +1155,8 @@ int scpn_mg_smooth(double* psi, const double* source, const double* r_axis, int 
     upload(t.h, t.h->psi_slots.p, -1, psi);
     upload(t.h, t.h->src.p, -1, source);
     auto& lv = get_hierarchy(t.h, 1 << 30);
-    smooth(t.h, lv[0]->dev, t.h->slot_fld(nullptr), t.h->plain(t.h->src.p), omega, n_sweeps, nullptr);
+    Fld res = smooth(t.h, lv[0]->dev, t.h->slot_fld(nullptr), t.h->plain(t.h->W.p), t.h->plain(t.h->src.p), omega, n_sweeps, nullptr);
+    copy_back(t.h, t.h->slot_fld(nullptr), res, nullptr);
     download(t.h, t.h->psi_slots.p, -1, psi);
     API_END
 }
@@ -1111,7 +1255,9 @@ int scpn_multigrid_vcycle(double* psi, const double* source, const double* r_axi
     TempSolver t(nr, nz, batch, r_axis, nullptr, dr, dz);
     upload(t.h, t.h->psi_slots.p, -1, psi);
     upload(t.h, t.h->src.p, -1, source);
-    vcycle(t.h, t.h->slot_fld(nullptr), t.h->plain(t.h->src.p), omega, pre, post, min_grid, nullptr);
+    Fld res = vcycle(t.h, t.h->slot_fld(nullptr), t.h->plain(t.h->W.p), t.h->plain(t.h->W2.p), t.h->plain(t.h->src.p), omega, pre, post,
+                     min_grid, nullptr);
+    copy_back(t.h, t.h->slot_fld(nullptr), res, nullptr);
     download(t.h, t.h->psi_slots.p, -1, psi);
     API_END
 }
@@ -1159,7 +1305,8 @@ int scpn_multigrid_solve(const double* source, double* psi, const double* r_axis
         HIP_TRY(hipStreamSynchronize(st));
         n_act = h->h_nactive[0];
         if (n_act <= 0) break;
-        vcycle(h, psiF, srcF, omega, pre, post, min_grid, h->d_active.p);
+        Fld res = vcycle(h, psiF, h->plain(h->W.p), h->plain(h->W2.p), srcF, omega, pre, post, min_grid, h->d_active.p);
+        copy_back(h, psiF, res, (const int*)h->d_active.p);
         hipLaunchKernelGGL(k_apply_bc, dim3(cdiv(2L * (nz + nr), 256), B), dim3(256), 0, st, psiF, bcF, nz, nr, h->ld, (const int*)h->d_active.p);
         norms(1);
     }
@@ -1200,7 +1347,7 @@ int scpn_sor_step(const double* psi, const double* source, const double* r_axis,
     dim3 g2 = grid2d(nr, nz, batch);
     hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, h->stream, h->plain(h->W.p), h->slot_fld(nullptr), nz, nr, h->ld);
     hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, h->stream, h->plain(h->src2.p), h->plain(h->src.p), nz, nr, h->ld);
-    smooth(h, lv[0]->dev, h->plain(h->W.p), h->plain(h->src2.p), omega, 1, nullptr, true);
+    smooth(h, lv[0]->dev, h->plain(h->W.p), Fld{nullptr, nullptr, 0, 0}, h->plain(h->src2.p), omega, 1, nullptr, true);
     download(h, h->W.p, -1, out);
     API_END
 }

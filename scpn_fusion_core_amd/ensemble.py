@@ -282,5 +282,16 @@ class EnsembleSolver:
         check(self._L.scpn_gs_profile_read(self._h, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_report(self) -> dict:
+        """{family: {"ms": total device ms, "launches": n}} for every kernel family timed since profile(True)."""
+        buf = C.create_string_buffer(4096)
+        check(self._L.scpn_gs_profile_names(self._h, buf, 4096))
+        out = {}
+        for name in filter(None, buf.value.decode().split(",")):
+            ms, n = self.profile_read(name)
+            if n:
+                out[name] = {"ms": round(ms, 3), "launches": int(n)}
+        return out
+
     def sync(self):
         check(self._L.scpn_gs_sync(self._h))
