@@ -145,10 +145,10 @@ def main() -> int:
             # the LDS-tiled kernel does 3 sweeps per launch with compulsory traffic read psi + read src + write psi
             per_pt = 24.0 if dom.startswith("smooth_tile") else 16.0
             avg_s = fam[dom]["ms"] * 1e-3 / fam[dom]["launches"]
-            alg_bytes = per_pt * n_pts * B
+            alg_bytes = per_pt * n_pts * B / es.num_groups  # one launch covers one group's members
             ach = alg_bytes / avg_s / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "groups": es.num_groups,
                         "avg_launch_us": round(avg_s * 1e6, 2), "alg_bytes_per_launch": alg_bytes,
                         "families_ms": fam}
 

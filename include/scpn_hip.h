@@ -212,6 +212,10 @@ int scpn_gs_profile(scpn_gs *h, int enable);
 int scpn_gs_profile_read(scpn_gs *h, const char *name, double *total_ms, long *launches);
 int scpn_gs_profile_names(scpn_gs *h, char *buf, int buflen); /* comma-separated family names seen so far */
 int scpn_gs_sync(scpn_gs *h);
+/* the ensemble is split into this many independent groups (own HIP stream + host thread each; env
+ * SCPN_HIP_GROUPS overrides the default of 2 for batch >= 16) so latency-bound coarse-level kernels of one
+ * group overlap bandwidth-bound fine-level kernels of another */
+int scpn_gs_num_groups(scpn_gs *h);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,7 @@ SIGNATURES = {
     "scpn_gs_profile_read": (_i, [_vp, C.c_char_p, C.POINTER(_d), C.POINTER(C.c_long)]),
     "scpn_gs_profile_names": (_i, [_vp, C.c_char_p, _i]),
     "scpn_gs_sync": (_i, [_vp]),
+    "scpn_gs_num_groups": (_i, [_vp]),
 }
 
 

@@ -379,9 +379,11 @@ __device__ __forceinline__ double prolong_at(const double* c, int ld_c, int nz_c
 // one-pass-per-launch kernel because a colour pass only reads the other colour.
 // Inactive members are passed through (out = in).  grid (tiles_r, tiles_z, B), dynamic LDS = TILE_LZ KiB.
 constexpr int TILE_LZ = 78;
-template <int S>
+// PROLONG: the tile is loaded as in + P(coarse) (bilinear prolongation of the coarse-grid correction,
+// multigrid_solve.py:329-330) -- the separate prolong-add pass over the fine grid disappears.
+template <int S, bool PROLONG>
 __global__ void __launch_bounds__(512) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
-                                                     const int* active) {
+                                                     const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c) {
     constexpr int LZ = TILE_LZ, H = 2 * S, NROWS = (LZ + 7) / 8;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* A0 = lds;            // colour 0: (iz + ir) even
@@ -437,6 +439,11 @@ __global__ void __launch_bounds__(512) k_smooth_tile(Fld outF, Fld inF, Fld srcF
                     if (c0 >= 0 && c0 < nr) { vx = in[o]; sx = src[o]; }
                     if (c0 + 1 >= 0 && c0 + 1 < nr) { vy = in[o + 1]; sy = src[o + 1]; }
                 }
+            }
+            if (PROLONG && gz >= 0 && gz < nz) {
+                const double* cc = coarseF.at(b);
+                if (c0 >= 0 && c0 < nr) vx = vx + prolong_at(cc, ld_c, nz_c, nr_c, nz, nr, gz, c0);
+                if (c0 + 1 >= 0 && c0 + 1 < nr) vy = vy + prolong_at(cc, ld_c, nz_c, nr_c, nz, nr, gz, c0 + 1);
             }
             // even column has colour (gz & 1) == (lz & 1) == e0 ? 1 : 0 since z0, c0 are even
             if (e0) { A1[lz * 64 + lane] = vx; A0[lz * 64 + lane] = vy; sC1[i] = sx; sC0[i] = sy; }
@@ -510,6 +517,28 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
     const int hw = (nr - 2 + 1) / 2, tot = (nz - 2) * hw;
     const double* a_e = tab;
     const double* a_w = tab + nr;
+    if (tot <= 128) {
+        // tiny level (base case, 9x9, ...): one wave does every colour pass; LDS accesses of a single wave are
+        // executed in order, so a wave-local fence replaces the 16-wave workgroup barrier of each pass
+        if (threadIdx.x < 64) {
+            for (int s = 0; s < 2 * n_sweeps; ++s) {
+                const int parity = s & 1;
+                for (int t = threadIdx.x; t < tot; t += 64) {
+                    int iz = 1 + t / hw, k = t - (iz - 1) * hw;
+                    int ir = 1 + ((iz + 1 + parity) & 1) + 2 * k;
+                    if (ir <= nr - 2) {
+                        int c = iz * nr + ir;
+                        double gs = divc(a_e[ir] * psi[c + 1] + a_w[ir] * psi[c - 1] + a_ns * psi[c - nr] + a_ns * psi[c + nr] - rhs[c], a_c, inv_a_c);
+                        psi[c] = om1 * psi[c] + omega * gs;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS stores of this pass visible to the next (same wave)
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        return;
+    }
     for (int s = 0; s < 2 * n_sweeps; ++s) {
         const int parity = s & 1;
         for (int t = threadIdx.x; t < tot; t += blockDim.x) {
@@ -911,6 +940,108 @@ __global__ void __launch_bounds__(256) k_blend(Fld nxtF, Fld curF, Fld newF, Fld
     }
 }
 
+// Fused tail of a Picard iteration (one pass over the fine grid instead of three):
+//   nxt = (1-alpha)*cur + alpha*new (new's ring from bc)            newton_solver.py:515-537
+//   partial sum |new-cur|, non-finite flag                             newton_solver.py:518,535
+//   partial max|r|, sum r^2 of r = L*nxt - src over the interior       fusion_kernel_solver_runtime.py:25-51
+//   topology partials of nxt for the NEXT iteration (argmax psi, masked argmin |grad psi|, min psi)
+// A 256-thread workgroup blends a (16+2) x (64+2) tile into LDS (1-cell halo recomputed from cur/new) and
+// evaluates the residual / np.gradient stencils from LDS.  grid (ceil(nr/64), ceil(nz/16), B).
+constexpr int BT_Z = 16, BT_R = 64;
+__global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
+                                                     double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
+                                                     double* rmax, double* rsum, TopoPart* topo, int nblk) {
+    __shared__ double t[BT_Z + 2][BT_R + 2 + 1];
+    __shared__ VI shv[4];
+    __shared__ double shd[4];
+    __shared__ int shbad;
+    const int b = blockIdx.z;
+    if (!st[b].active) return;
+    const int tid = threadIdx.x;
+    if (tid == 0) shbad = 0;
+    const int nz = L.nz, nr = L.nr, ld = L.ld;
+    const int z0 = blockIdx.y * BT_Z - 1, r0 = blockIdx.x * BT_R - 1;
+    const double* cur = curF.at(b);
+    const double* nw = newF.at(b);
+    const double* bc = bcF.at(b);
+    const double* src = srcF.at(b);
+    double* nxt = nxtF.at(b);
+    double dsum = 0.0, minpsi = INFINITY;
+    int bad = 0;
+    VI mx{0.0, -1}, mn{0.0, -1};
+    __syncthreads();
+    for (int i = tid; i < (BT_Z + 2) * (BT_R + 2); i += 256) {
+        const int lz = i / (BT_R + 2), lr = i - lz * (BT_R + 2);
+        const int gz = z0 + lz, gr = r0 + lr;
+        double v = 0.0;
+        if (gz >= 0 && gz < nz && gr >= 0 && gr < nr) {
+            const long c = (long)gz * ld + gr;
+            const bool ring = gz == 0 || gz == nz - 1 || gr == 0 || gr == nr - 1;
+            const double pn = ring ? bc[c] : nw[c];
+            const double pc = cur[c];
+            v = om_alpha * pc + alpha * pn;
+            if (lz >= 1 && lz <= BT_Z && lr >= 1 && lr <= BT_R) {  // owned point
+                if (!finite_d(pn)) bad = 1;
+                dsum += fabs(pn - pc);
+                nxt[c] = v;
+                const long q = (long)gz * nr + gr;
+                if (v == v) mx = vi_max(mx, VI{v, q});
+                if (finite_d(v)) minpsi = fmin(minpsi, v);
+            }
+        }
+        t[lz][lr] = v;
+    }
+    if (bad) atomicOr(&shbad, 1);
+    __syncthreads();
+    double m = 0.0, s2 = 0.0;
+    const int tx = tid & 63, ty = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < BT_Z / 4; ++k) {
+        const int lz = 1 + ty + 4 * k, lr = 1 + tx;
+        const int gz = z0 + lz, gr = r0 + lr;
+        if (gz >= nz || gr >= nr) continue;
+        const double p = t[lz][lr];
+        if (gz >= 1 && gz <= nz - 2 && gr >= 1 && gr <= nr - 2) {
+            const double e = t[lz][lr + 1], w = t[lz][lr - 1], n = t[lz + 1][lr], so = t[lz - 1][lr];
+            const double d2r = divc(e - 2.0 * p + w, L.dr2, L.inv_dr2);
+            const double d1r = divc(e - w, L.two_dr, L.inv_two_dr);
+            const double d2z = divc(n - 2.0 * p + so, L.dz2, L.inv_dz2);
+            const double lpsi = d2r - divc(d1r, L.r_safe[gr], L.r_inv[gr]) + d2z;
+            const double r = sanitize1(lpsi - src[(long)gz * ld + gr]);
+            m = fmax(m, fabs(r));
+            s2 += r * r;
+        }
+        if (gz < n_mask_rows) {  // np.gradient + hypot inside the divertor rows (fusion_kernel.py:276-288)
+            double gzv, grv;
+            const double ps = nan_to_num300(p);
+            if (gz == 0) gzv = (nan_to_num300(t[lz + 1][lr]) - ps) / L.dz;
+            else if (gz == nz - 1) gzv = (ps - nan_to_num300(t[lz - 1][lr])) / L.dz;
+            else gzv = (nan_to_num300(t[lz + 1][lr]) - nan_to_num300(t[lz - 1][lr])) / (2.0 * L.dz);
+            if (gr == 0) grv = (nan_to_num300(t[lz][lr + 1]) - ps) / L.dr;
+            else if (gr == nr - 1) grv = (ps - nan_to_num300(t[lz][lr - 1])) / L.dr;
+            else grv = (nan_to_num300(t[lz][lr + 1]) - nan_to_num300(t[lz][lr - 1])) / (2.0 * L.dr);
+            const double bm = hypot(grv, gzv);
+            if (finite_d(bm)) mn = vi_min(mn, VI{bm, (long)gz * nr + gr});
+        }
+    }
+    const double bsum = block_sum<256>(dsum, shd);
+    const double bmax = block_max<256>(m, shd);
+    const double bs2 = block_sum<256>(s2, shd);
+    const double bminp = -block_max<256>(-minpsi, shd);
+    const VI rmx = block_vi<true, 256>(mx, shv);
+    const VI rmn = block_vi<false, 256>(mn, shv);
+    if (tid == 0) {
+        const long o = (long)b * nblk + (long)blockIdx.y * gridDim.x + blockIdx.x;
+        psum[o] = bsum;
+        pbad[o] = shbad;
+        rmax[o] = bmax;
+        rsum[o] = bs2;
+        TopoPart tp;
+        tp.maxv = rmx.v; tp.maxi = rmx.i; tp.minb = rmn.v; tp.mini = rmn.i; tp.minpsi = bminp; tp.pad = 0;
+        topo[o] = tp;
+    }
+}
+
 struct PicardCtl {
     double tol, gs_tol;
     int require_gs, max_iter, iter, pad;
@@ -944,7 +1075,8 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
     double rmx = block_max<256>(rm, sh);
     if (threadIdx.x == 0) {
         Member& m = st[b];
-        m.iterations = ctl.iter + 1;
+        const int it = m.iterations;  // iteration index lives on the device: kernel arguments stay constant (HIP graph replay)
+        m.iterations = it + 1;
         if (shbad) {  // diverged: revert to best, stop (newton_solver.py:518-532)
             m.prev = m.cur;
             m.cur = m.best;
@@ -967,16 +1099,16 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
         int nx = 0;
         for (int k = 0; k < 3; ++k) if (k != m.cur && k != m.best) { nx = k; break; }
         m.nxt = nx;
-        if (hist_diff) hist_diff[(long)b * ctl.max_iter + ctl.iter] = diff;
-        if (hist_gs) hist_gs[(long)b * ctl.max_iter + ctl.iter] = gs;
+        if (hist_diff) hist_diff[(long)b * ctl.max_iter + it] = diff;
+        if (hist_gs) hist_gs[(long)b * ctl.max_iter + it] = gs;
         if (trace) {
-            double* t = trace + ((long)b * ctl.max_iter + ctl.iter) * 6;
+            double* t = trace + ((long)b * ctl.max_iter + it) * 6;
             t[0] = m.psi_axis; t[1] = m.psi_bnd; t[2] = (double)m.x_idx; t[3] = m.i_current; t[4] = diff; t[5] = gs;
         }
         bool upd = diff < ctl.tol;
         bool gsc = (!ctl.require_gs) || (gs < ctl.gs_tol);
         if (upd && gsc) { m.converged = 1; m.active = 0; atomicSub(n_active, 1); }
-        else if (ctl.iter + 1 >= ctl.max_iter) { m.active = 0; atomicSub(n_active, 1); }
+        else if (it + 1 >= ctl.max_iter) { m.active = 0; atomicSub(n_active, 1); }
     }
 }
 // copies the per-member slot indices into flat int arrays the kernels index (cur/nxt/best/prev/active)

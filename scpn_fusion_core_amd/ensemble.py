@@ -293,5 +293,9 @@ class EnsembleSolver:
                 out[name] = {"ms": round(ms, 3), "launches": int(n)}
         return out
 
+    @property
+    def num_groups(self) -> int:
+        return int(self._L.scpn_gs_num_groups(self._h))
+
     def sync(self):
         check(self._L.scpn_gs_sync(self._h))
