@@ -1,0 +1,61 @@
+"""CPU, world_size 2 (gloo): the N>1 path -- member sharding + the final all-gather of psi blocks and the scalar table.
+
+The per-rank device solve is replaced by the CPU oracle (test infrastructure) so the sharding / gather plumbing that
+bench.py and a multi-GPU user run is exercised exactly, without a GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+from tests._problems import iter_like_cfg  # noqa: E402
+
+TOTAL = 3  # odd on purpose: the last rank's block is padded
+
+
+def member_cfg(i):
+    cfg = iter_like_cfg(17, tol=1e-5, max_iter=60)
+    cfg["physics"]["plasma_current_target"] = 15.0 * (1.0 + 0.05 * i)
+    return cfg
+
+
+def solve_block(start, stop):
+    from oracle import oracle as orc
+
+    psi, table = [], []
+    for i in range(start, stop):
+        r = orc.picard_solve(member_cfg(i))
+        psi.append(r["psi"])
+        table.append([float(r["converged"]), r["iterations"], r["residual"], r["psi_axis"]])
+    return np.array(psi).reshape(-1, 17, 17), np.array(table).reshape(-1, 4)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scpn_fusion_core_amd.distributed import gather_blocks, shard_range
+
+    a, b = shard_range(TOTAL, rank, world)
+    psi, table = solve_block(a, b)
+    all_psi = gather_blocks(psi, TOTAL)
+    all_tab = gather_blocks(table, TOTAL)
+    dist.barrier()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), psi=all_psi, table=all_tab)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_ensemble_matches_serial(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    psi_ref, tab_ref = solve_block(0, TOTAL)
+    for rank in range(2):
+        got = np.load(tmp_path / f"rank{rank}.npz")
+        assert got["psi"].shape == (TOTAL, 17, 17)
+        assert np.array_equal(got["psi"], psi_ref) and np.array_equal(got["table"], tab_ref)

@@ -1,0 +1,165 @@
+"""CPU: host-side logic of the package -- dispatcher seam, trust gate, config contract, sharding helpers."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from scpn_fusion_core_amd import _lib
+from scpn_fusion_core_amd import multi_compat as multi
+from tests._problems import iter_like_cfg
+
+
+def test_backend_tier_order_and_registration(monkeypatch):
+    assert [t.name for t in sorted(multi.BackendTier)] == ["RUST", "GPU", "MOJO", "JULIA", "GO", "JAX", "NUMPY"]
+    multi._ensure_probed()
+    calls = []
+    multi.register_kernel("unit_test_kernel", multi.BackendTier.NUMPY, lambda: calls.append("numpy") or "numpy")
+    multi.register_kernel("unit_test_kernel", multi.BackendTier.GPU, lambda: calls.append("gpu") or "gpu")
+    monkeypatch.setitem(multi._availability, multi.BackendTier.GPU, False)
+    monkeypatch.setitem(multi._availability, multi.BackendTier.NUMPY, True)
+    multi._dispatch_cache.pop("unit_test_kernel", None)
+    assert multi.dispatch("unit_test_kernel")() == "numpy"
+    monkeypatch.setitem(multi._availability, multi.BackendTier.GPU, True)
+    multi._dispatch_cache.pop("unit_test_kernel", None)
+    assert multi.dispatch("unit_test_kernel")() == "gpu"  # lower enum value preferred
+    with pytest.raises(KeyError):
+        multi.dispatch("no_such_kernel")
+    multi._dispatch_cache.pop("unit_test_kernel", None)
+
+
+def test_gpu_tier_registered_for_the_three_seams(monkeypatch):
+    assert any(t == multi.BackendTier.GPU for t, _ in multi._registry["gs_rb_sor_smooth"])
+    assert any(t == multi.BackendTier.GPU for t, _ in multi._registry["multigrid_solve"])
+    assert any(t == multi.BackendTier.GPU for t, _ in multi._class_registry["equilibrium_kernel"])
+    monkeypatch.setenv("SCPN_DISABLE_GPU", "1")
+    assert not _lib.gpu_available()  # core/_multi_compat.py:109-113
+    if _lib.device_count() == 0:
+        multi.reset_probe_cache()
+        with pytest.raises(RuntimeError):
+            multi.dispatch("multigrid_solve")
+        with pytest.raises(RuntimeError):
+            multi.dispatch_kernel_class("equilibrium_kernel")
+
+
+def test_gpu_tier_surface_without_device():
+    from scpn_fusion_core_amd import gpu_tier
+
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    assert gpu_tier.py_gpu_available() is False and gpu_tier.py_gpu_info() is None
+    with pytest.raises(RuntimeError):
+        gpu_tier.PyGpuSolver(65, 65, 4.0, 8.0, -4.0, 4.0)
+    with pytest.raises(RuntimeError):
+        gpu_tier.PyGpuSolver(3, 65, 4.0, 8.0, -4.0, 4.0)
+
+
+def test_trust_gate(tmp_path, monkeypatch):
+    from scpn_fusion_core_amd import hpc_bridge as hb
+
+    for var in ("SCPN_SOLVER_LIB", "SCPN_SOLVER_LIB_SHA256", "SCPN_SOLVER_TRUST_MANIFEST"):
+        monkeypatch.delenv(var, raising=False)
+    lib = tmp_path / "libscpn_solver.so"
+    shutil.copy(_lib.LIB_PATH, lib)
+    with pytest.raises(ValueError, match="trust metadata is required"):
+        hb.HPCBridge(lib_path=str(lib))
+    hb.write_sha256_sidecar(lib)
+    br = hb.HPCBridge(lib_path=str(lib))
+    assert br.loaded
+    assert br.is_available() == (_lib.device_count() > 0)
+    monkeypatch.setenv("SCPN_SOLVER_LIB_SHA256", "0" * 64)
+    with pytest.raises(ValueError, match="does not match"):
+        hb.HPCBridge(lib_path=str(lib))
+    monkeypatch.delenv("SCPN_SOLVER_LIB_SHA256")
+    with pytest.raises(ValueError, match="absolute"):
+        hb.HPCBridge(lib_path="libscpn_solver.so")
+    link = tmp_path / "link.so"
+    os.symlink(lib, link)
+    with pytest.raises(ValueError, match="symlink"):
+        hb.HPCBridge(lib_path=str(link))
+    with pytest.raises(ValueError, match="does not exist"):
+        hb.HPCBridge(lib_path=str(tmp_path / "missing.so"))
+    # manifest route
+    (tmp_path / "libscpn_solver.so.sha256").unlink()
+    man = tmp_path / "manifest.json"
+    man.write_text('{"libraries": {"libscpn_solver.so": "%s"}}' % hb._sha256_file(lib))
+    monkeypatch.setenv("SCPN_SOLVER_TRUST_MANIFEST", str(man))
+    assert hb.HPCBridge(lib_path=str(lib)).loaded
+
+
+def test_bridge_input_validation():
+    from scpn_fusion_core_amd import hpc_bridge as hb
+
+    br = hb.HPCBridge()
+    br.nr, br.nz = 5, 4
+    with pytest.raises(ValueError):
+        br._prepare_inputs(np.zeros((5, 4)))
+    with pytest.raises(ValueError):
+        br._prepare_inputs(np.full((4, 5), np.nan))
+    with pytest.raises(ValueError):
+        br._prepare_inputs(np.zeros(20))
+    assert br._prepare_inputs(np.zeros((4, 5))).flags.c_contiguous
+
+
+def test_config_contract_and_param_block():
+    from scpn_fusion_core_amd.ensemble import picard_params_from_cfg
+    from scpn_fusion_core_amd.fusion_kernel import validate_config
+
+    cfg = validate_config(iter_like_cfg(33))
+    assert cfg["grid_resolution"] == [33, 33] and cfg["physics"]["vacuum_permeability"] == 1.0
+    for bad in ({"grid_resolution": [3, 33]}, {"dimensions": {"R_min": -1.0, "R_max": 2.0, "Z_min": -1, "Z_max": 1}},
+                {"dimensions": {"R_min": 2.0, "R_max": 1.0, "Z_min": -1, "Z_max": 1}}):
+        with pytest.raises(ValueError):
+            validate_config({**iter_like_cfg(33), **bad})
+    with pytest.raises(ValueError):
+        validate_config({"reactor_name": "x"})
+    p = picard_params_from_cfg(cfg, preserve_initial_state=True, has_boundary_flux=True)
+    assert p.method == 0 and p.sor_omega == 1.0 and p.alpha == 0.12 and p.tol == 1e-8 and p.max_iter == 1000
+    assert p.z_min_cfg == -6.8 and p.r_center == (2.2 + 10.2) / 2.0 and p.preserve_initial_state == 1 and p.hmode == 0
+    assert list(p.ped_p) == [0.92, 0.05, 1.0, 0.3]
+    cfg["physics"]["profiles"] = {"mode": "h-mode", "p_prime": {"ped_top": 0.9}}
+    cfg["solver"]["solver_method"] = "sor"
+    p = picard_params_from_cfg(cfg)
+    assert p.hmode == 1 and p.ped_p[0] == 0.9 and p.ped_ff[0] == 0.92 and p.method == 1 and p.sor_omega == 1.0
+    cfg["solver"]["solver_method"] = "newton"
+    with pytest.raises(NotImplementedError):
+        picard_params_from_cfg(cfg)
+    cfg["solver"].update(solver_method="multigrid", require_gs_residual=True, gs_residual_threshold=0.0)
+    with pytest.raises(ValueError):
+        picard_params_from_cfg(cfg)
+
+
+def test_operator_argument_validation_precedes_the_device():
+    from scpn_fusion_core_amd import multigrid_solve as mgs
+    from scpn_fusion_core_amd import free_boundary as fb
+
+    z = np.zeros((9, 9))
+    for kw in (dict(tol=0.0), dict(tol=float("nan")), dict(max_cycles=0), dict(omega=0.5)):
+        with pytest.raises(ValueError):
+            mgs.multigrid_solve(z, z, 1.0, 2.0, -1.0, 1.0, 9, 9, **kw)
+    with pytest.raises(ValueError):
+        mgs.multigrid_solve(z, z, 1.0, 2.0, -1.0, 1.0, 9, 8)
+    assert mgs.validate_sor_omega(1.0) == 1.0
+    for w in (0.99, 2.0, float("inf")):
+        with pytest.raises(ValueError):
+            mgs.validate_sor_omega(w)
+    with pytest.raises(ValueError):
+        fb.green_function(-1.0, 0.0, 1.0, 0.0)
+    with pytest.raises(ValueError):
+        fb.green_function(1.0, float("nan"), 1.0, 0.0)
+    cs = fb.CoilSet(positions=[(1.0, 0.0), (2.0, 1.0), (3.0, 0.0)], currents=np.ones(3), turns=[4, 2])
+    assert list(cs.turns_array()) == [4.0, 2.0, 1.0]
+
+
+def test_shard_ranges():
+    from scpn_fusion_core_amd.distributed import shard_range, shard_sizes
+
+    assert [shard_range(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
+    assert shard_sizes(10, 4) == [3, 3, 3, 1] and shard_sizes(3, 4) == [1, 1, 1, 0]
+    cover = []
+    for r in range(3):
+        a, b = shard_range(7, r, 3)
+        cover += list(range(a, b))
+    assert cover == list(range(7))
+    with pytest.raises(ValueError):
+        shard_range(4, 4, 4)
