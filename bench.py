@@ -4,7 +4,7 @@
 Metric (BASELINE.json): converged equilibria/s, 513x513 free-boundary, Picard tol 1e-8.
 Workload: an ensemble of `--batch` (default 32 = 256 / 8 GPUs, BASELINE config 5) independent
 ITER-like free-boundary equilibria per GPU on a 513x513 grid (validation/benchmark_vs_freegs.py:157
-geometry, coil currents I_k*(1+0.1u), u~U(-1,1), rng 2026), each solved exactly as the reference's
+geometry; coil currents I_k*(1+0.1u) and plasma current Ip*(1+0.1u), u~U(-1,1), rng 2026), each solved exactly as the reference's
 ``solve_free_boundary(coils, max_outer_iter=20, tol=1e-4, optimize_shape=False)`` with
 ``solver_method="multigrid"``, sor_omega=1.0, relaxation_factor=0.12, convergence_threshold=1e-8.
 One "step" = one full solve of the resident ensemble (Green's-function boundary flux, seed, ~2 outer
@@ -40,10 +40,13 @@ def make_cfg(n: int) -> dict:
     return iter_like_cfg(n, method="multigrid", omega=1.0, tol=1e-8, max_iter=1000, alpha=0.12)
 
 
-def member_currents(cfg: dict, total: int) -> np.ndarray:
+def member_table(cfg: dict, total: int) -> tuple[np.ndarray, np.ndarray]:
+    """Coil/shape scan of BASELINE config 5: coil currents I_k*(1+0.1u) and plasma current Ip*(1+0.1u), u~U(-1,1)."""
     base = np.array([c["current"] for c in cfg["coils"]], dtype=np.float64)
     rng = np.random.default_rng(2026)
-    return base[None, :] * (1.0 + 0.1 * rng.uniform(-1.0, 1.0, size=(total, base.size)))
+    currents = base[None, :] * (1.0 + 0.1 * rng.uniform(-1.0, 1.0, size=(total, base.size)))
+    targets = cfg["physics"]["plasma_current_target"] * (1.0 + 0.1 * rng.uniform(-1.0, 1.0, size=total))
+    return currents, targets
 
 
 def main() -> int:
@@ -75,8 +78,12 @@ def main() -> int:
     _lib.require_gpu()
     cfg = make_cfg(args.grid)
     B = args.batch
-    currents = member_currents(cfg, B * world)[rank * B:(rank + 1) * B]
-    es = EnsembleSolver(cfg, batch=B, coil_currents=currents, device=local_rank)
+    from scpn_fusion_core_amd.distributed import DevicePointer, gather_blocks, shard_range
+
+    lo, hi = shard_range(B * world, rank, world)
+    all_currents, all_targets = member_table(cfg, B * world)
+    currents, targets = all_currents[lo:hi], all_targets[lo:hi]
+    es = EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, device=local_rank)
     n_pts = args.grid * args.grid
 
     def barrier():
@@ -87,25 +94,14 @@ def main() -> int:
             dist.barrier()
             torch.cuda.synchronize()
 
-    gather_buf = None
-
     def step():
         es.fill_psi(0.0)
         res = es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
-        if dist is not None:  # ensemble gather of psi over RCCL/xGMI (the path's only exchange step)
+        if dist is not None:  # ensemble gather of the psi blocks over RCCL/xGMI (the path's only exchange step)
             import torch
 
-            nonlocal gather_buf
-            ptr = es.pack_psi_device()
-
-            class _Dev:
-                __cuda_array_interface__ = {"shape": (B, args.grid, args.grid), "typestr": "<f8", "data": (ptr, False),
-                                            "version": 3, "strides": None}
-
-            send = torch.as_tensor(_Dev(), device=f"cuda:{local_rank}")
-            if gather_buf is None:
-                gather_buf = torch.empty((world * B, args.grid, args.grid), dtype=torch.float64, device=send.device)
-            dist.all_gather_into_tensor(gather_buf, send)
+            send = torch.as_tensor(DevicePointer(es.pack_psi_device(), (B, args.grid, args.grid)), device=f"cuda:{local_rank}")
+            gather_blocks(send, B * world)
         return res
 
     for _ in range(args.warmup):
@@ -147,8 +143,16 @@ def main() -> int:
             avg_s = fam[dom]["ms"] * 1e-3 / fam[dom]["launches"]
             alg_bytes = per_pt * n_pts * B / es.num_groups  # one launch covers one group's members
             ach = alg_bytes / avg_s / 1e9
+            traffic = None  # HBM bytes per launch from the committed PMC passes (same kernel, same grid)
+            try:
+                pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+                if pmc.get("grid") == args.grid and dom in pmc["hbm_bytes_per_member_launch"]:
+                    traffic = round(pmc["hbm_bytes_per_member_launch"][dom] * B / es.num_groups)
+            except (OSError, ValueError, KeyError):
+                pass
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "groups": es.num_groups,
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "groups": es.num_groups,
+                        "members_per_launch": B // es.num_groups, "isolated_kernel_timing": True,
                         "avg_launch_us": round(avg_s * 1e6, 2), "alg_bytes_per_launch": alg_bytes,
                         "families_ms": fam}
 
@@ -158,7 +162,8 @@ def main() -> int:
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         from oracle import oracle as orc
 
-        c0 = {**cfg, "coils": [dict(co, current=float(currents[0, i])) for i, co in enumerate(cfg["coils"])]}
+        c0 = {**cfg, "coils": [dict(co, current=float(currents[0, i])) for i, co in enumerate(cfg["coils"])],
+              "physics": dict(cfg["physics"], plasma_current_target=float(targets[0]))}
         co = c0["coils"]
         tc = time.perf_counter()
         ref = orc.free_boundary_solve(c0, [c["r"] for c in co], [c["z"] for c in co], [c["current"] for c in co],

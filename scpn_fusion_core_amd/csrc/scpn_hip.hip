@@ -1205,7 +1205,15 @@ struct scpn_gs {
 template <class F>
 static int run_groups(scpn_gs* g, F f) {
     const int n = (int)g->kids.size();
-    if (n == 1) return f(0, g->kids[0]);
+    bool profiling = false;  // kernel timing wants isolated kernels: run the groups one after the other
+    for (auto* k : g->kids) profiling |= k->prof_on;
+    if (n == 1 || profiling) {
+        for (int gi = 0; gi < n; ++gi) {
+            int rc = f(gi, g->kids[gi]);
+            if (rc) return rc;
+        }
+        return SCPN_OK;
+    }
     std::vector<int> rc(n, 0);
     std::vector<std::string> err(n);
     std::vector<std::thread> th;
