@@ -517,9 +517,31 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
     const int hw = (nr - 2 + 1) / 2, tot = (nz - 2) * hw;
     const double* a_e = tab;
     const double* a_w = tab + nr;
-    if (tot <= 128) {
-        // tiny level (base case, 9x9, ...): one wave does every colour pass; LDS accesses of a single wave are
-        // executed in order, so a wave-local fence replaces the 16-wave workgroup barrier of each pass
+    if (nz * nr <= 64) {
+        // the whole level fits one wave (the 5x5 / 4x4 base case: 50 sweeps): one grid point per lane, value in a
+        // register, neighbours by wave shuffles -- no LDS round trip and no barrier per colour pass
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x, n = nz * nr;
+            const int iz = lane / nr, ir = lane - iz * nr;
+            const bool in = lane < n, interior = in && iz >= 1 && iz <= nz - 2 && ir >= 1 && ir <= nr - 2;
+            double v = in ? psi[lane] : 0.0;
+            const double ae = interior ? a_e[ir] : 0.0, aw = interior ? a_w[ir] : 0.0, sv = interior ? rhs[lane] : 0.0;
+            const int par = (iz + ir) & 1;
+            for (int s = 0; s < 2 * n_sweeps; ++s) {
+                const double E = __shfl(v, lane + 1, 64), W = __shfl(v, lane - 1, 64);
+                const double S = __shfl(v, lane - nr, 64), N = __shfl(v, lane + nr, 64);
+                const double gs = divc(ae * E + aw * W + a_ns * S + a_ns * N - sv, a_c, inv_a_c);
+                const double nw = om1 * v + omega * gs;
+                if (interior && par == (s & 1)) v = nw;
+            }
+            if (in) psi[lane] = v;
+        }
+        __syncthreads();
+        return;
+    }
+    if (tot <= 64) {
+        // tiny level (9x9): one wave does every colour pass; LDS accesses of a single wave execute in order, so
+        // a wave-local fence replaces the 16-wave workgroup barrier of each pass
         if (threadIdx.x < 64) {
             for (int s = 0; s < 2 * n_sweeps; ++s) {
                 const int parity = s & 1;
@@ -532,11 +554,45 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                         psi[c] = om1 * psi[c] + omega * gs;
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // LDS stores of this pass visible to the next (same wave)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
             }
         }
         __syncthreads();
+        return;
+    }
+    // thread -> point mapping is the same in every pass: hoist the integer division out of the pass loop
+    constexpr int MAXIT = 4;  // 65x65 with 1024 threads needs 2
+    int cbase[MAXIT], flag[MAXIT], kcol[MAXIT];
+#pragma unroll
+    for (int j = 0; j < MAXIT; ++j) {
+        const int t = threadIdx.x + j * blockDim.x;
+        cbase[j] = -1;
+        flag[j] = 0;
+        kcol[j] = 0;
+        if (t < tot) {
+            const int iz = 1 + t / hw, k = t - (iz - 1) * hw;
+            cbase[j] = iz * nr + 1 + 2 * k;
+            flag[j] = (iz + 1) & 1;
+            kcol[j] = 1 + 2 * k;
+        }
+    }
+    if (tot <= MAXIT * (int)blockDim.x) {
+        for (int s = 0; s < 2 * n_sweeps; ++s) {
+            const int parity = s & 1;
+#pragma unroll
+            for (int j = 0; j < MAXIT; ++j) {
+                if (cbase[j] >= 0) {
+                    const int off = flag[j] ^ parity, ir = kcol[j] + off;
+                    if (ir <= nr - 2) {
+                        const int c = cbase[j] + off;
+                        double gs = divc(a_e[ir] * psi[c + 1] + a_w[ir] * psi[c - 1] + a_ns * psi[c - nr] + a_ns * psi[c + nr] - rhs[c], a_c, inv_a_c);
+                        psi[c] = om1 * psi[c] + omega * gs;
+                    }
+                }
+            }
+            __syncthreads();
+        }
         return;
     }
     for (int s = 0; s < 2 * n_sweeps; ++s) {
@@ -564,11 +620,18 @@ __device__ __forceinline__ double cv_resid(const double* psi, const double* rhs,
     double lpsi = d2r - divc(d1r, rs[ir], rs[nr + ir]) + d2z;
     return lpsi - rhs[c];
 }
+#ifdef CV_STAMPS
+__device__ unsigned long long g_cv_stamps[64];
+#define CV_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cv_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CV_STAMP(i)
+#endif
 __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, CoarseV V, double omega, double om1, int pre,
                                                         int post, const int* active) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
     if (active && !active[b]) return;
+    CV_STAMP(0);
     // stage the coefficient tables of every level and the top-level rhs
     for (int l = 0; l < V.n; ++l) {
         double* tab = lds + V.off_tab[l];
@@ -591,11 +654,13 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
         }
     }
     __syncthreads();
+    CV_STAMP(1);
     for (int l = 0; l < V.n - 1; ++l) {
         double* psi = lds + V.off_psi[l];
         const double* rhs = lds + V.off_rhs[l];
         const double* tab = lds + V.off_tab[l];
         cv_smooth(psi, rhs, tab, V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], omega, om1, pre);
+        CV_STAMP(2 + 2 * l);
         // coarse rhs = restrict_full_weight(-(L*psi - rhs)); coarse e = 0
         double* rc = lds + V.off_rhs[l + 1];
         double* pc = lds + V.off_psi[l + 1];
@@ -618,10 +683,12 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
             pc[i] = 0.0;
         }
         __syncthreads();
+        CV_STAMP(3 + 2 * l);
     }
     {
         const int l = V.n - 1;  // base case: 50 sweeps (multigrid_solve.py:293)
         cv_smooth(lds + V.off_psi[l], lds + V.off_rhs[l], lds + V.off_tab[l], V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], omega, om1, 50);
+        CV_STAMP(20);
     }
     for (int l = V.n - 2; l >= 0; --l) {
         double* psi = lds + V.off_psi[l];
@@ -632,7 +699,9 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
             psi[i] = psi[i] + prolong_at(pc, nrc, nzc, nrc, nzf, nrf, iz, ir);
         }
         __syncthreads();
+        CV_STAMP(21 + 2 * l);
         cv_smooth(psi, lds + V.off_rhs[l], lds + V.off_tab[l], nzf, nrf, V.a_ns[l], V.a_c[l], V.inv_a_c[l], omega, om1, post);
+        CV_STAMP(22 + 2 * l);
     }
     {
         double* g = eF.at(b);
@@ -643,6 +712,7 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
             g[(long)iz * V.ld0 + ir] = psi[i];
         }
     }
+    CV_STAMP(40);
 }
 
 // ADD: psi += P e (multigrid_solve.py:329-330) else fine = P c; grid (ceil(nr_f/64), ceil(nz_f/4), B)

@@ -1352,6 +1352,12 @@ int scpn_gs_compute_b_field(scpn_gs* g, int member, double* b_r, double* b_z) {
     int local = 0, gi = locate(g, member, &local);
     return S_compute_b_field(g->kids[gi], local, b_r, b_z);
 }
+#ifdef CV_STAMPS
+int scpn_debug_cv_stamps(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cv_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -2;
+}
+#endif
 int scpn_gs_num_groups(scpn_gs* g) { return g ? (int)g->kids.size() : 0; }
 int scpn_gs_fill_psi(scpn_gs* g, double value) {
     if (!g) return fail(SCPN_E_ARG, "null handle");
