@@ -378,13 +378,70 @@ __device__ __forceinline__ double prolong_at(const double* c, int ld_c, int nz_c
 // (out-of-place: neighbouring tiles read the halo from `in`).  Results are bit-identical to the
 // one-pass-per-launch kernel because a colour pass only reads the other colour.
 // Inactive members are passed through (out = in).  grid (tiles_r, tiles_z, B), dynamic LDS = TILE_LZ KiB.
+struct Prof {
+    int hmode;
+    double ped_p[4], ped_ff[4];
+};
+__device__ __forceinline__ double mtanh1(double x, const double* p) {  // core/fusion_kernel.py:376-390
+    double y = (p[0] - x) / p[1];
+    y = fmin(fmax(y, -20.0), 20.0);
+    double pedestal = (0.5 * p[2]) * (1.0 + tanh(y));
+    double core = 0.0;
+    if (x < p[0]) {
+        double q = x / p[0];
+        core = fmax(0.0, 1.0 - q * q);
+    }
+    return pedestal + p[3] * core;
+}
+__device__ __forceinline__ double j_raw_at(double psi, double R, double inv_mu0R, double psi_axis,
+                                           double denom, double inv_denom, const Prof& pf) {
+    // core/fusion_kernel.py:419-434
+    double pn = divc(psi - psi_axis, denom, inv_denom);
+    double p = 0.0, ff = 0.0;
+    if (pn >= 0.0 && pn < 1.0) {
+        if (pf.hmode) { p = mtanh1(pn, pf.ped_p); ff = mtanh1(pn, pf.ped_ff); }
+        else { p = 1.0 - pn; ff = p; }
+    }
+    double j_p = R * p;
+    double j_f = inv_mu0R * ff;
+    return 0.5 * j_p + 0.5 * j_f;
+}
+// Source generation fused into the pre-smoother (replaces k_jsum_final + k_source): every workgroup finishes the
+// J_raw reduction with the reduction tree of k_jsum_final, so all of them (and the unfused path) get the same scale.
+struct SrcGen {
+    const double* r_axis;
+    const double* inv_mu0R;
+    const double* neg_mu0R;
+    const double* part;  // J_raw partial sums [B][nblk] written by k_jsum
+    Member* st;
+    int nblk;
+    double dr, dz;
+    Prof pf;
+};
+#ifdef CV_STAMPS
+__device__ unsigned long long g_cv_stamps[64];
+__device__ unsigned long long g_tile_stamps[64];
+#define CV_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cv_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TILE_STAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && threadIdx.x == 0) g_tile_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CV_STAMP(i)
+#define TILE_STAMP(i)
+#endif
+#ifndef TILE_NW
+#define TILE_NW 8  // waves per tile workgroup
+#endif
+#ifndef TILE_WPE
+#define TILE_WPE 1
+#endif
 constexpr int TILE_LZ = 78;
 // PROLONG: the tile is loaded as in + P(coarse) (bilinear prolongation of the coarse-grid correction,
 // multigrid_solve.py:329-330) -- the separate prolong-add pass over the fine grid disappears.
-template <int S, bool PROLONG>
-__global__ void __launch_bounds__(512) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
-                                                     const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c) {
-    constexpr int LZ = TILE_LZ, H = 2 * S, NROWS = (LZ + 7) / 8;
+// SRCGEN: the source is not loaded but evaluated from the incoming psi (update_plasma_source_nonlinear,
+// core/fusion_kernel.py:419-440 and newton_solver.py:513) and written out for the later consumers.
+template <int S, bool PROLONG, bool SRCGEN>
+__global__ void __launch_bounds__(64 * TILE_NW, TILE_WPE) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
+                                                     const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, SrcGen sg) {
+    constexpr int LZ = TILE_LZ, H = 2 * S, NW = TILE_NW, NROWS = (LZ + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* A0 = lds;            // colour 0: (iz + ir) even
     double* A1 = lds + LZ * 64;  // colour 1
@@ -399,7 +456,7 @@ __global__ void __launch_bounds__(512) k_smooth_tile(Fld outF, Fld inF, Fld srcF
     if (pass) {
 #pragma unroll
         for (int i = 0; i < NROWS; ++i) {
-            int lz = w + 8 * i, gz = z0 + lz;
+            int lz = w + NW * i, gz = z0 + lz;
             if (lz >= H && lz < LZ - H && gz < nz) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
@@ -410,7 +467,26 @@ __global__ void __launch_bounds__(512) k_smooth_tile(Fld outF, Fld inF, Fld srcF
         }
         return;
     }
+    TILE_STAMP(0);
     const double* src = srcF.at(b);
+    double g_pa = 0.0, g_den = 1.0, g_iden = 1.0, g_sc = 0.0;
+    if (SRCGEN) {
+        __shared__ double shj[4];
+        double sj = 0.0;
+        if (threadIdx.x < 256)
+            for (int i = threadIdx.x; i < sg.nblk; i += 256) sj += sg.part[(long)b * sg.nblk + i];
+        sj = wave_sum(sj);
+        if (lane == 0 && w < 4) shj[w] = sj;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tot += shj[i];
+        const double ic = (tot * sg.dr) * sg.dz;  // core/fusion_kernel.py:436
+        const Member& m = sg.st[b];
+        g_pa = m.psi_axis; g_den = m.denom; g_iden = m.inv_denom;
+        g_sc = fabs(ic) > 1e-9 ? m.i_target / ic : 0.0;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sg.st[b].i_current = ic; sg.st[b].jscale = g_sc; }
+    }
     double ae0 = 0.0, ae1 = 0.0, aw0 = 0.0, aw1 = 0.0;
     if (c0 >= 1 && c0 <= nr - 2) { ae0 = L.a_e[c0]; aw0 = L.a_w[c0]; }
     if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { ae1 = L.a_e[c0 + 1]; aw1 = L.a_w[c0 + 1]; }
@@ -423,7 +499,7 @@ __global__ void __launch_bounds__(512) k_smooth_tile(Fld outF, Fld inF, Fld srcF
     const bool vec_ok = c0 >= 0 && c0 + 1 < nr;
 #pragma unroll
     for (int i = 0; i < NROWS; ++i) {
-        int lz = w + 8 * i;
+        int lz = w + NW * i;
         sC0[i] = 0.0;
         sC1[i] = 0.0;
         if (lz < LZ) {
@@ -433,11 +509,11 @@ __global__ void __launch_bounds__(512) k_smooth_tile(Fld outF, Fld inF, Fld srcF
                 long o = (long)gz * ld + c0;
                 if (vec_ok) {
                     double2 v = *reinterpret_cast<const double2*>(in + o);
-                    double2 sv = *reinterpret_cast<const double2*>(src + o);
-                    vx = v.x; vy = v.y; sx = sv.x; sy = sv.y;
+                    vx = v.x; vy = v.y;
+                    if (!SRCGEN) { double2 sv = *reinterpret_cast<const double2*>(src + o); sx = sv.x; sy = sv.y; }
                 } else {
-                    if (c0 >= 0 && c0 < nr) { vx = in[o]; sx = src[o]; }
-                    if (c0 + 1 >= 0 && c0 + 1 < nr) { vy = in[o + 1]; sy = src[o + 1]; }
+                    if (c0 >= 0 && c0 < nr) { vx = in[o]; if (!SRCGEN) sx = src[o]; }
+                    if (c0 + 1 >= 0 && c0 + 1 < nr) { vy = in[o + 1]; if (!SRCGEN) sy = src[o + 1]; }
                 }
             }
             if (PROLONG && gz >= 0 && gz < nz) {
@@ -450,7 +526,30 @@ __global__ void __launch_bounds__(512) k_smooth_tile(Fld outF, Fld inF, Fld srcF
             else { A0[lz * 64 + lane] = vx; A1[lz * 64 + lane] = vy; sC0[i] = sx; sC1[i] = sy; }
         }
     }
+    if (SRCGEN) {
+        // second pass over the wave's rows (psi read back from this lane's own LDS slots), one row at a time so the
+        // J_phi evaluation does not inflate the register footprint of the load phase
+        const bool ok0 = c0 >= 0 && c0 < nr, ok1 = c0 + 1 >= 0 && c0 + 1 < nr;
+        const double R0 = ok0 ? sg.r_axis[c0] : 1.0, R1 = ok1 ? sg.r_axis[c0 + 1] : 1.0;
+        const double im0 = ok0 ? sg.inv_mu0R[c0] : 0.0, im1 = ok1 ? sg.inv_mu0R[c0 + 1] : 0.0;
+        const double nm0 = ok0 ? sg.neg_mu0R[c0] : 0.0, nm1 = ok1 ? sg.neg_mu0R[c0 + 1] : 0.0;
+#pragma unroll
+        for (int i = 0; i < NROWS; ++i) {
+            const int lz = w + NW * i, gz = z0 + lz;
+            if (lz < LZ && gz >= 0 && gz < nz) {
+                const double vx = e0 ? A1[lz * 64 + lane] : A0[lz * 64 + lane];  // even column
+                const double vy = e0 ? A0[lz * 64 + lane] : A1[lz * 64 + lane];  // odd column
+                double sx = 0.0, sy = 0.0;
+                if (ok0) { const double jr = j_raw_at(vx, R0, im0, g_pa, g_den, g_iden, sg.pf); sx = nm0 * (g_sc != 0.0 ? jr * g_sc : 0.0); }
+                if (ok1) { const double jr = j_raw_at(vy, R1, im1, g_pa, g_den, g_iden, sg.pf); sy = nm1 * (g_sc != 0.0 ? jr * g_sc : 0.0); }
+                if (e0) { sC1[i] = sx; sC0[i] = sy; }
+                else { sC0[i] = sx; sC1[i] = sy; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     __syncthreads();
+    TILE_STAMP(1);
 #pragma unroll 1
     for (int hs = 0; hs < 2 * S; ++hs) {
         const int c = hs & 1;
@@ -463,7 +562,7 @@ __global__ void __launch_bounds__(512) k_smooth_tile(Fld outF, Fld inF, Fld srcF
         // rows still needed for the final window shrink by one per pass: [hs+1, LZ-2-hs]
 #pragma unroll
         for (int i = 0; i < NROWS; ++i) {
-            const int lz = w + 8 * i, gz = z0 + lz;
+            const int lz = w + NW * i, gz = z0 + lz;
             if (lz >= hs + 1 && lz <= LZ - 2 - hs && gz >= 1 && gz <= nz - 2) {  // wave-uniform
                 const double W = oth[lz * 64 + lane - 1 + pr], E = oth[lz * 64 + lane + pr];
                 const double Sv = oth[(lz - 1) * 64 + lane], N = oth[(lz + 1) * 64 + lane];
@@ -475,10 +574,11 @@ __global__ void __launch_bounds__(512) k_smooth_tile(Fld outF, Fld inF, Fld srcF
             }
         }
         __syncthreads();
+        TILE_STAMP(2 + hs);
     }
 #pragma unroll
     for (int i = 0; i < NROWS; ++i) {
-        const int lz = w + 8 * i, gz = z0 + lz;
+        const int lz = w + NW * i, gz = z0 + lz;
         if (lz >= H && lz < LZ - H && gz < nz) {
             double vx, vy;
             if (e0) { vx = A1[lz * 64 + lane]; vy = A0[lz * 64 + lane]; }
@@ -491,8 +591,15 @@ __global__ void __launch_bounds__(512) k_smooth_tile(Fld outF, Fld inF, Fld srcF
                 if (col >= H && col < 128 - H && c0 < nr) out[o] = vx;
                 if (col + 1 >= H && col + 1 < 128 - H && c0 + 1 < nr) out[o + 1] = vy;
             }
+            if (SRCGEN) {  // publish the generated source of the window for defect / post-smooth / residual norms
+                double* so = srcF.at(b);
+                const double sx = e0 ? sC1[i] : sC0[i], sy = e0 ? sC0[i] : sC1[i];
+                if (col >= H && col < 128 - H && c0 < nr) so[o] = sx;
+                if (col + 1 >= H && col + 1 < 128 - H && c0 + 1 < nr) so[o + 1] = sy;
+            }
         }
     }
+    TILE_STAMP(10);
 }
 
 // ---------------------------------------------------------------- whole coarse V-cycle in LDS
@@ -620,12 +727,6 @@ __device__ __forceinline__ double cv_resid(const double* psi, const double* rhs,
     double lpsi = d2r - divc(d1r, rs[ir], rs[nr + ir]) + d2z;
     return lpsi - rhs[c];
 }
-#ifdef CV_STAMPS
-__device__ unsigned long long g_cv_stamps[64];
-#define CV_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cv_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define CV_STAMP(i)
-#endif
 __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, CoarseV V, double omega, double om1, int pre,
                                                         int post, const int* active) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -867,34 +968,6 @@ __global__ void __launch_bounds__(256) k_topology_final(Fld psiF, Member* st, co
 }
 
 // ---------------------------------------------------------------- Picard: source (a9)
-struct Prof {
-    int hmode;
-    double ped_p[4], ped_ff[4];
-};
-__device__ __forceinline__ double mtanh1(double x, const double* p) {  // core/fusion_kernel.py:376-390
-    double y = (p[0] - x) / p[1];
-    y = fmin(fmax(y, -20.0), 20.0);
-    double pedestal = (0.5 * p[2]) * (1.0 + tanh(y));
-    double core = 0.0;
-    if (x < p[0]) {
-        double q = x / p[0];
-        core = fmax(0.0, 1.0 - q * q);
-    }
-    return pedestal + p[3] * core;
-}
-__device__ __forceinline__ double j_raw_at(double psi, double R, double inv_mu0R, double psi_axis,
-                                           double denom, double inv_denom, const Prof& pf) {
-    // core/fusion_kernel.py:419-434
-    double pn = divc(psi - psi_axis, denom, inv_denom);
-    double p = 0.0, ff = 0.0;
-    if (pn >= 0.0 && pn < 1.0) {
-        if (pf.hmode) { p = mtanh1(pn, pf.ped_p); ff = mtanh1(pn, pf.ped_ff); }
-        else { p = 1.0 - pn; ff = p; }
-    }
-    double j_p = R * p;
-    double j_f = inv_mu0R * ff;
-    return 0.5 * j_p + 0.5 * j_f;
-}
 // partial sums of J_raw; grid (nblk, B)
 __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz, int nr, int ld,
                                               const double* r_axis, const double* inv_mu0R, Prof pf,

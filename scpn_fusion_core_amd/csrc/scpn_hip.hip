@@ -132,7 +132,7 @@ struct Solver {
     DBuf<Member> d_st;
     DBuf<MgMember> d_mg;
     DBuf<int> d_cur, d_nxt, d_best, d_prev, d_active, d_nactive, d_pbad;
-    DBuf<double> d_part1, d_part2, d_part3;  // reduction partials [B][nblk]
+    DBuf<double> d_part1, d_part2, d_part3, d_jpart;  // reduction partials [B][nblk]
     DBuf<TopoPart> d_topo;
     DBuf<double> d_scal;
     int* h_nactive = nullptr;  // pinned
@@ -303,30 +303,33 @@ struct ProlongSrc {  // coarse-grid correction to add on load (nullptr base: non
     Fld c{nullptr, nullptr, 0, 0};
     int nz_c = 0, nr_c = 0, ld_c = 0;
 };
-template <int S, bool PROLONG>
-static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps) {
+template <int S, bool PROLONG, bool SRCGEN>
+static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
+                        const SrcGen* sg) {
     static bool attr_done = false;
     const size_t lds = (size_t)TILE_LZ * 128 * sizeof(double);
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_tile<S, PROLONG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_tile<S, PROLONG, SRCGEN>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     dim3 g(cdiv(L.nr, 128 - 4 * S), cdiv(L.nz, TILE_LZ - 4 * S), h->B);
-    hipLaunchKernelGGL((k_smooth_tile<S, PROLONG>), g, dim3(512), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, ps.c, ps.nz_c,
-                       ps.nr_c, ps.ld_c);
+    hipLaunchKernelGGL((k_smooth_tile<S, PROLONG, SRCGEN>), g, dim3(64 * TILE_NW), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active,
+                       ps.c, ps.nz_c, ps.nr_c, ps.ld_c, sg ? *sg : SrcGen{});
 }
 template <int S>
-static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps) {
-    if (ps.c.base) launch_tile<S, true>(h, L, out, in, src, omega, active, ps);
-    else launch_tile<S, false>(h, L, out, in, src, omega, active, ps);
+static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
+                          const SrcGen* sg) {
+    if (sg) launch_tile<S, false, true>(h, L, out, in, src, omega, active, ps, sg);
+    else if (ps.c.base) launch_tile<S, true, false>(h, L, out, in, src, omega, active, ps, nullptr);
+    else launch_tile<S, false, false>(h, L, out, in, src, omega, active, ps, nullptr);
 }
 
 // n_sweeps red-black SOR sweeps of (in, src).  Returns the field that holds the result: `in` itself for the
 // in-place kernels, or `in`/`alt` alternately for the out-of-place LDS-tiled kernel (`alt` must not alias `in`).
 static std::string lname(const char* kind, int lvl) { return std::string(kind) + "_L" + std::to_string(lvl); }
 static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omega, int n_sweeps, const int* active,
-                  bool clip = false, int lvl = 0, const ProlongSrc* prolong = nullptr) {
+                  bool clip = false, int lvl = 0, const ProlongSrc* prolong = nullptr, const SrcGen* srcgen = nullptr) {
     if (n_sweeps <= 0 || L.nz < 3 || L.nr < 3) return in;
     const double om1 = 1.0 - omega;
     if (!clip && (long)L.nz * L.nr <= SMALL_MAX) {
@@ -339,12 +342,14 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
         Fld a = in, b = alt;
         int left = n_sweeps;
         ProlongSrc pso = prolong ? *prolong : ProlongSrc{};  // only the first launch adds the coarse correction
+        const SrcGen* sgo = srcgen;                          // ... and only the first launch generates the source
         while (left > 0) {
             const int S = std::min(3, left);
-            if (S == 3) launch_tile_p<3>(h, L, b, a, src, omega, active, pso);
-            else if (S == 2) launch_tile_p<2>(h, L, b, a, src, omega, active, pso);
-            else launch_tile_p<1>(h, L, b, a, src, omega, active, pso);
+            if (S == 3) launch_tile_p<3>(h, L, b, a, src, omega, active, pso, sgo);
+            else if (S == 2) launch_tile_p<2>(h, L, b, a, src, omega, active, pso, sgo);
+            else launch_tile_p<1>(h, L, b, a, src, omega, active, pso, sgo);
             pso = ProlongSrc{};
+            sgo = nullptr;
             std::swap(a, b);
             left -= S;
         }
@@ -363,8 +368,13 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
 
 // One V-cycle (core/multigrid_solve.py:252-335) of (in0, src0) on level 0.  in0 is left untouched; the improved
 // estimate is produced in bufA or bufB (returned).  `active` (may be null) freezes members.
+static bool vcycle_can_srcgen(Solver* h, int pre, int min_grid) {
+    Hier& H = get_hier(h, min_grid);
+    const Lvl& L0 = H.lv[0]->dev;
+    return h->use_fused && H.lv.size() > 1 && pre > 0 && (long)L0.nz * L0.nr > SMALL_MAX;
+}
 static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega, int pre, int post, int min_grid,
-                  const int* active) {
+                  const int* active, const SrcGen* srcgen = nullptr) {
     Hier& H = get_hier(h, min_grid);
     auto& lv = H.lv;
     const int k = (int)lv.size() - 1;
@@ -378,7 +388,7 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
         const int n0 = (k == 0) ? 50 : pre;  // base case: 50 sweeps (multigrid_solve.py:292-293)
         const bool tile0 = fused && (long)L0.nz * L0.nr > SMALL_MAX && n0 > 0;
         if (tile0) {
-            Fld r = smooth(h, L0, in0, bufA, src0, omega, std::min(3, n0), active);  // in0 -> bufA
+            Fld r = smooth(h, L0, in0, bufA, src0, omega, std::min(3, n0), active, false, 0, nullptr, srcgen);  // in0 -> bufA
             if (n0 > 3) r = smooth(h, L0, bufA, bufB, src0, omega, n0 - 3, active);
             cur[0] = r;
         } else {
@@ -492,6 +502,7 @@ static void ensure_picard_bufs(Solver* h) {
     h->d_topo.alloc((size_t)h->B * h->nblk());
     h->d_part3.alloc((size_t)h->B * h->nblk());
     h->d_pbad.alloc((size_t)h->B * h->nblk());
+    h->d_jpart.alloc((size_t)h->B * h->nblk());
     h->picard_bufs = true;
 }
 
@@ -721,18 +732,28 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             hipLaunchKernelGGL(k_topology_final, dim3(B), dim3(256), 0, st, curF, h->d_st.p, (const TopoPart*)h->d_topo.p, ntopo, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_z.p);
         }
+        // source generation inside the pre-smoother is implemented and bit-exact, but its 160-VGPR footprint drops the
+        // tile kernel to one workgroup per CU and it measured slower (61.8 vs 48.9 us per launch): opt-in only
+        static const bool srcgen_env = [] { const char* e = std::getenv("SCPN_HIP_SRCGEN"); return e && e[0] == '1'; }();
+        const bool gen = srcgen_env && !p->external_profile_mode && p->method == 0 && vcycle_can_srcgen(h, 3, 5);
+        SrcGen sg{};
         if (!p->external_profile_mode) {
-            ProfScope ps(h, "source", 3);
+            ProfScope ps(h, "source", gen ? 1 : 3);
             hipLaunchKernelGGL(k_jsum, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
-                               (const double*)h->d_inv_mu0R.p, pf, h->d_part1.p, nblk1);
-            hipLaunchKernelGGL(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_part1.p, nblk1, h->dr, h->dz);
-            hipLaunchKernelGGL(k_source, g2, BLK2D, 0, st, srcF, jF, 0, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
-                               (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblk1);
+            if (gen) {  // scale + source are evaluated inside the pre-smoother's tile load
+                sg.r_axis = h->d_r.p; sg.inv_mu0R = h->d_inv_mu0R.p; sg.neg_mu0R = h->d_neg_mu0R.p; sg.part = h->d_jpart.p;
+                sg.st = h->d_st.p; sg.nblk = nblk1; sg.dr = h->dr; sg.dz = h->dz; sg.pf = pf;
+            } else {
+                hipLaunchKernelGGL(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblk1, h->dr, h->dz);
+                hipLaunchKernelGGL(k_source, g2, BLK2D, 0, st, srcF, jF, 0, curF, (const Member*)h->d_st.p, nz, nr, ld,
+                                   (const double*)h->d_r.p, (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
+            }
         }
         // _elliptic_solve (iterative_solver.py:361-380)
         Fld newF = WF;
         if (p->method == 0) {
-            newF = vcycle(h, curF, WF, W2F, srcF, p->sor_omega, 3, 3, 5, act);
+            newF = vcycle(h, curF, WF, W2F, srcF, p->sor_omega, 3, 3, 5, act, gen ? &sg : nullptr);
         } else if (p->method == 1) {
             hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, WF, curF, nz, nr, ld);
             hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, src2F, srcF, nz, nr, ld);
@@ -1353,6 +1374,10 @@ int scpn_gs_compute_b_field(scpn_gs* g, int member, double* b_r, double* b_z) {
     return S_compute_b_field(g->kids[gi], local, b_r, b_z);
 }
 #ifdef CV_STAMPS
+int scpn_debug_tile_stamps(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -2;
+}
 int scpn_debug_cv_stamps(unsigned long long* out) {
     (void)hipDeviceSynchronize();
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cv_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -2;
