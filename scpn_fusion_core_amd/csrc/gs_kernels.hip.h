@@ -439,7 +439,7 @@ constexpr int TILE_LZ = 78;
 // SRCGEN: the source is not loaded but evaluated from the incoming psi (update_plasma_source_nonlinear,
 // core/fusion_kernel.py:419-440 and newton_solver.py:513) and written out for the later consumers.
 template <int S, bool PROLONG, bool SRCGEN>
-__global__ void __launch_bounds__(64 * TILE_NW, TILE_WPE) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
+__global__ void __launch_bounds__(64 * TILE_NW, (PROLONG ? 4 : TILE_WPE)) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
                                                      const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, SrcGen sg) {
     constexpr int LZ = TILE_LZ, H = 2 * S, NW = TILE_NW, NROWS = (LZ + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -496,35 +496,72 @@ __global__ void __launch_bounds__(64 * TILE_NW, TILE_WPE) k_smooth_tile(Fld outF
     const int e0 = w & 1;  // element index of colour 0
     const double aeC0 = e0 ? ae1 : ae0, awC0 = e0 ? aw1 : aw0, aeC1 = e0 ? ae0 : ae1, awC1 = e0 ? aw0 : aw1;
     double sC0[NROWS], sC1[NROWS];
-    const bool vec_ok = c0 >= 0 && c0 + 1 < nr;
+    // Load phase: every row's 16-B loads are issued unconditionally from CLAMPED addresses (row clamped into the domain,
+    // column pair clamped into the row pitch -- ld >= nr + 1 for odd nr, so the pair (nr-1, nr) reads pitch padding) and
+    // out-of-domain values are zeroed by selects afterwards.  Without the per-row bounds branches the compiler keeps all
+    // NROWS row loads in flight instead of draining vmcnt after each row.
+    const int cc = min(max(c0, 0), ld - 2);  // even, 16-B aligned
+    const bool okx = c0 >= 0 && c0 < nr, oky = c0 + 1 >= 0 && c0 + 1 < nr;
+    // PROLONG: the four coarse values around the lane's column pair are loaded the same way (clamped, unconditional);
+    // rows are processed in groups of LG so that psi + src + coarse loads of a group fit the register budget
+    constexpr int LG = PROLONG ? (NROWS + 3) / 4 : NROWS;
+    const double* ccp = PROLONG ? coarseF.at(b) : nullptr;
+    const int jc = max(c0, 0) >> 1;
+    const int jcc = PROLONG ? min(jc, nr_c - 1) : 0, jcc1 = PROLONG ? min(jc + 1, nr_c - 1) : 0;
+    const int h_end = PROLONG ? min(2 * (nr_c - 1), nr - 1) : 0, v_end = PROLONG ? min(2 * (nz_c - 1), nz - 1) : 0;
 #pragma unroll
-    for (int i = 0; i < NROWS; ++i) {
-        int lz = w + NW * i;
-        sC0[i] = 0.0;
-        sC1[i] = 0.0;
-        if (lz < LZ) {
-            int gz = z0 + lz;
-            double vx = 0.0, vy = 0.0, sx = 0.0, sy = 0.0;
-            if (gz >= 0 && gz < nz) {
-                long o = (long)gz * ld + c0;
-                if (vec_ok) {
-                    double2 v = *reinterpret_cast<const double2*>(in + o);
-                    vx = v.x; vy = v.y;
-                    if (!SRCGEN) { double2 sv = *reinterpret_cast<const double2*>(src + o); sx = sv.x; sy = sv.y; }
-                } else {
-                    if (c0 >= 0 && c0 < nr) { vx = in[o]; if (!SRCGEN) sx = src[o]; }
-                    if (c0 + 1 >= 0 && c0 + 1 < nr) { vy = in[o + 1]; if (!SRCGEN) sy = src[o + 1]; }
-                }
+    for (int g0 = 0; g0 < NROWS; g0 += LG) {
+        double2 pv[LG], sv2[LG];
+        double ca0[LG], ca1[LG], cb0[LG], cb1[LG];
+#pragma unroll
+        for (int j = 0; j < LG; ++j) {
+            const int i = g0 + j, lz = w + NW * i;
+            const int gzc = min(max(z0 + min(lz, LZ - 1), 0), nz - 1);
+            const long o = (long)gzc * ld + cc;
+            pv[j] = *reinterpret_cast<const double2*>(in + o);
+            if (!SRCGEN) sv2[j] = *reinterpret_cast<const double2*>(src + o);
+            else sv2[j] = double2{0.0, 0.0};
+            if (PROLONG) {
+                const int ic = gzc >> 1, icc = min(ic, nz_c - 1), icc1 = (gzc & 1) ? min(ic + 1, nz_c - 1) : icc;
+                ca0[j] = ccp[(long)icc * ld_c + jcc];
+                ca1[j] = ccp[(long)icc * ld_c + jcc1];
+                cb0[j] = ccp[(long)icc1 * ld_c + jcc];
+                cb1[j] = ccp[(long)icc1 * ld_c + jcc1];
             }
-            if (PROLONG && gz >= 0 && gz < nz) {
-                const double* cc = coarseF.at(b);
-                if (c0 >= 0 && c0 < nr) vx = vx + prolong_at(cc, ld_c, nz_c, nr_c, nz, nr, gz, c0);
-                if (c0 + 1 >= 0 && c0 + 1 < nr) vy = vy + prolong_at(cc, ld_c, nz_c, nr_c, nz, nr, gz, c0 + 1);
-            }
-            // even column has colour (gz & 1) == (lz & 1) == e0 ? 1 : 0 since z0, c0 are even
-            if (e0) { A1[lz * 64 + lane] = vx; A0[lz * 64 + lane] = vy; sC1[i] = sx; sC0[i] = sy; }
-            else { A0[lz * 64 + lane] = vx; A1[lz * 64 + lane] = vy; sC0[i] = sx; sC1[i] = sy; }
         }
+#pragma unroll
+        for (int j = 0; j < LG; ++j) {
+            const int i = g0 + j;
+            if (i >= NROWS) continue;
+            const int lz = w + NW * i, gz = z0 + lz;
+            sC0[i] = 0.0;
+            sC1[i] = 0.0;
+            if (lz < LZ) {
+                const bool rowok = gz >= 0 && gz < nz;
+                double vx = (rowok && okx) ? pv[j].x : 0.0, vy = (rowok && oky) ? pv[j].y : 0.0;
+                const double sx = (rowok && okx) ? sv2[j].x : 0.0, sy = (rowok && oky) ? sv2[j].y : 0.0;
+                if (PROLONG && rowok) {
+                    // bilinear prolongation, core/multigrid_solve.py:117-143 (same expressions as prolong_at)
+                    double px, py;
+                    if (!(gz & 1)) {
+                        px = ca0[j];
+                        py = (c0 + 1 >= h_end) ? 0.0 : 0.5 * (ca0[j] + ca1[j]);
+                    } else if (gz >= v_end) {
+                        px = 0.0;
+                        py = 0.0;
+                    } else {
+                        px = 0.5 * (ca0[j] + cb0[j]);
+                        py = (c0 + 1 >= h_end) ? 0.0 : 0.25 * (ca0[j] + cb0[j] + ca1[j] + cb1[j]);
+                    }
+                    if (okx) vx = vx + px;
+                    if (oky) vy = vy + py;
+                }
+                // even column has colour (gz & 1) == (lz & 1) == e0 ? 1 : 0 since z0, c0 are even
+                if (e0) { A1[lz * 64 + lane] = vx; A0[lz * 64 + lane] = vy; sC1[i] = sx; sC0[i] = sy; }
+                else { A0[lz * 64 + lane] = vx; A1[lz * 64 + lane] = vy; sC0[i] = sx; sC1[i] = sy; }
+            }
+        }
+        if (PROLONG) __builtin_amdgcn_sched_barrier(0);  // keep the next group's loads behind this group's LDS writes
     }
     if (SRCGEN) {
         // second pass over the wave's rows (psi read back from this lane's own LDS slots), one row at a time so the
