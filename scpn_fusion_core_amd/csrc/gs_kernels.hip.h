@@ -428,20 +428,33 @@ __device__ unsigned long long g_tile_stamps[64];
 #define TILE_STAMP(i)
 #endif
 #ifndef TILE_NW
-#define TILE_NW 8  // waves per tile workgroup
+#define TILE_NW 16  // waves per tile workgroup (16: ~75 VGPRs, leaves register headroom for the fused defect stage)
 #endif
 #ifndef TILE_WPE
 #define TILE_WPE 1
+#endif
+#ifndef TILE_WPE_P
+#define TILE_WPE_P (TILE_NW <= 8 ? 4 : 1)  // the prolongation variant needs the 128-VGPR cap only with 8-wave tiles
 #endif
 constexpr int TILE_LZ = 78;
 // PROLONG: the tile is loaded as in + P(coarse) (bilinear prolongation of the coarse-grid correction,
 // multigrid_solve.py:329-330) -- the separate prolong-add pass over the fine grid disappears.
 // SRCGEN: the source is not loaded but evaluated from the incoming psi (update_plasma_source_nonlinear,
 // core/fusion_kernel.py:419-440 and newton_solver.py:513) and written out for the later consumers.
-template <int S, bool PROLONG, bool SRCGEN>
-__global__ void __launch_bounds__(64 * TILE_NW, (PROLONG ? 4 : TILE_WPE)) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
-                                                     const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, SrcGen sg) {
-    constexpr int LZ = TILE_LZ, H = 2 * S, NW = TILE_NW, NROWS = (LZ + NW - 1) / NW;
+// DEFECT: after the sweeps the tile also produces the coarse-grid right-hand side restrict_full_weight(-(L*psi - src))
+// (core/multigrid_solve.py:303-306) and zeroes the coarse correction: the halo grows by 2 (defect ring + restriction
+// stencil) and the separate defect/restrict pass over the fine grid disappears.  (coarseF = coarse rhs, coarse2F = coarse e.)
+struct DefectDst {
+    Fld e{nullptr, nullptr, 0, 0};
+    double dr2 = 1, dz2 = 1, two_dr = 1, inv_dr2 = 1, inv_dz2 = 1, inv_two_dr = 1;
+    const double* r_safe = nullptr;
+    const double* r_inv = nullptr;
+};
+template <int S, bool PROLONG, bool SRCGEN, bool DEFECT>
+__global__ void __launch_bounds__(64 * TILE_NW, (PROLONG ? TILE_WPE_P : TILE_WPE)) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
+                                                     const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, SrcGen sg,
+                                                     DefectDst dd) {
+    constexpr int LZ = TILE_LZ, H = 2 * S + (DEFECT ? 2 : 0), NW = TILE_NW, NROWS = (LZ + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* A0 = lds;            // colour 0: (iz + ir) even
     double* A1 = lds + LZ * 64;  // colour 1
@@ -634,6 +647,64 @@ __global__ void __launch_bounds__(64 * TILE_NW, (PROLONG ? 4 : TILE_WPE)) k_smoo
                 if (col >= H && col < 128 - H && c0 < nr) so[o] = sx;
                 if (col + 1 >= H && col + 1 < 128 - H && c0 + 1 < nr) so[o + 1] = sy;
             }
+        }
+    }
+    if (DEFECT) {
+        // (1) defect d = -(L*psi - src) of this wave's rows, both colours, into the source registers
+        double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0;  // r_safe / its reciprocal of the lane's even / odd column
+        if (c0 >= 1 && c0 <= nr - 2) { rs0 = dd.r_safe[c0]; ri0 = dd.r_inv[c0]; }
+        if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { rs1 = dd.r_safe[c0 + 1]; ri1 = dd.r_inv[c0 + 1]; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double* mine = c ? A1 : A0;
+            const double* oth = c ? A0 : A1;
+            const int pr = (c + w) & 1;
+            const int col = 2 * lane + pr, gc = r0 + col;
+            const bool colok = col >= 1 && col <= 126 && gc >= 1 && gc <= nr - 2;
+            const double rs = pr ? rs1 : rs0, ri = pr ? ri1 : ri0;
+#pragma unroll
+            for (int i = 0; i < NROWS; ++i) {
+                const int lz = w + NW * i, gz = z0 + lz;
+                double d = -0.0;
+                if (lz >= H - 1 && lz <= LZ - H && gz >= 1 && gz <= nz - 2) {  // wave-uniform
+                    const double W = oth[lz * 64 + lane - 1 + pr], E = oth[lz * 64 + lane + pr];
+                    const double Sv = oth[(lz - 1) * 64 + lane], N = oth[(lz + 1) * 64 + lane];
+                    const double C = mine[lz * 64 + lane];
+                    const double sv = c ? sC1[i] : sC0[i];
+                    const double d2r = divc(E - 2.0 * C + W, dd.dr2, dd.inv_dr2);
+                    const double d1r = divc(E - W, dd.two_dr, dd.inv_two_dr);
+                    const double d2z = divc(N - 2.0 * C + Sv, dd.dz2, dd.inv_dz2);
+                    const double lpsi = d2r - divc(d1r, rs, ri) + d2z;
+                    if (colok) d = -(lpsi - sv);
+                }
+                if (c) sC1[i] = d; else sC0[i] = d;
+            }
+        }
+        __syncthreads();  // every wave is done reading psi from the planes
+        // (2) the planes now hold the defect
+#pragma unroll
+        for (int i = 0; i < NROWS; ++i) {
+            const int lz = w + NW * i;
+            if (lz < LZ) { A0[lz * 64 + lane] = sC0[i]; A1[lz * 64 + lane] = sC1[i]; }
+        }
+        __syncthreads();
+        // (3) full-weighting restriction of the window's even/even points; coarse ring = injected -0.0
+        constexpr int CZ = (LZ - 2 * H) / 2, CR = (128 - 2 * H) / 2;
+        double* rc = coarseF.at(b);
+        double* ec = dd.e.at(b);
+        for (int t = threadIdx.x; t < CZ * CR; t += 64 * NW) {
+            const int cz = t / CR, cr = t - cz * CR;
+            const int lz = H + 2 * cz, col = H + 2 * cr;
+            const int ic = (z0 + lz) >> 1, jc = (r0 + col) >> 1;
+            if (ic >= nz_c || jc >= nr_c) continue;
+            double v = -0.0;
+            if (ic >= 1 && ic <= nz_c - 2 && jc >= 1 && jc <= nr_c - 2) {
+                auto dget = [&](int z, int x) { return (((z + x) & 1) ? A1 : A0)[z * 64 + (x >> 1)]; };
+                v = fw9(dget(lz, col), dget(lz - 1, col), dget(lz + 1, col), dget(lz, col - 1), dget(lz, col + 1), dget(lz - 1, col - 1),
+                        dget(lz - 1, col + 1), dget(lz + 1, col - 1), dget(lz + 1, col + 1));
+            }
+            rc[(long)ic * ld_c + jc] = v;
+            ec[(long)ic * ld_c + jc] = 0.0;
         }
     }
     TILE_STAMP(10);
@@ -1005,27 +1076,36 @@ __global__ void __launch_bounds__(256) k_topology_final(Fld psiF, Member* st, co
 }
 
 // ---------------------------------------------------------------- Picard: source (a9)
-// partial sums of J_raw; grid (nblk, B)
+// partial sums of J_raw.  Each thread owns a column pair (16-B loads) of 4 rows: block = 64 pairs x 4 row-lanes,
+// 16 rows per block.  grid (ceil(nr/128), ceil(nz/16), B); partial index = blockIdx.y * gridDim.x + blockIdx.x
+constexpr int JS_ROWS = 16;
 __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz, int nr, int ld,
                                               const double* r_axis, const double* inv_mu0R, Prof pf,
                                               double* part, int nblk) {
     __shared__ double sh[4];
-    int b = blockIdx.y;
+    int b = blockIdx.z;
     if (!st[b].active) return;
     const double* psi = psiF.at(b);
     const double pa = st[b].psi_axis, den = st[b].denom, iden = st[b].inv_denom;
-    const long n = (long)nz * nr;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + tx) * 2;
     double s = 0.0;
+    if (c0 < nr) {
+        const bool two = c0 + 1 < nr;
+        const double R0 = r_axis[c0], R1 = two ? r_axis[c0 + 1] : 1.0;
+        const double m0 = inv_mu0R[c0], m1 = two ? inv_mu0R[c0 + 1] : 0.0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
-        if (q < n) {
-            int iz = (int)(q / nr), ir = (int)(q - (long)iz * nr);
-            s += j_raw_at(psi[(long)iz * ld + ir], r_axis[ir], inv_mu0R[ir], pa, den, iden, pf);
+        for (int k = 0; k < JS_ROWS / 4; ++k) {
+            const int iz = blockIdx.y * JS_ROWS + ty + 4 * k;
+            if (iz < nz) {
+                const double2 v = *reinterpret_cast<const double2*>(psi + (long)iz * ld + c0);
+                s += j_raw_at(v.x, R0, m0, pa, den, iden, pf);
+                if (two) s += j_raw_at(v.y, R1, m1, pa, den, iden, pf);
+            }
         }
     }
     double bs = block_sum<256>(s, sh);
-    if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = bs;
+    if (threadIdx.x == 0) part[(long)b * nblk + (long)blockIdx.y * gridDim.x + blockIdx.x] = bs;
 }
 __global__ void __launch_bounds__(256) k_jsum_final(Member* st, const double* part, int nblk, double dr,
                                                     double dz) {
@@ -1041,20 +1121,41 @@ __global__ void __launch_bounds__(256) k_jsum_final(Member* st, const double* pa
         st[b].jscale = fabs(ic) > 1e-9 ? st[b].i_target / ic : 0.0;
     }
 }
-// Source = (-mu0*R) * (J_raw * scale)  (core/fusion_kernel.py:440, newton_solver.py:513);
-// optionally stores J_phi.  grid (ceil(nr/64), ceil(nz/4), B)
-__global__ void k_source(Fld srcF, Fld jF, int write_j, Fld psiF, const Member* st, int nz, int nr, int ld,
-                         const double* r_axis, const double* inv_mu0R, const double* neg_mu0R, Prof pf) {
+// Source = (-mu0*R) * (J_raw * scale)  (core/fusion_kernel.py:440, newton_solver.py:513); optionally stores J_phi.
+// Column pair per thread (16-B loads / stores); grid (ceil(nr/128), ceil(nz/16), B), 256 threads
+__global__ void __launch_bounds__(256) k_source(Fld srcF, Fld jF, int write_j, Fld psiF, const Member* st, int nz, int nr, int ld,
+                                                const double* r_axis, const double* inv_mu0R, const double* neg_mu0R, Prof pf) {
     int b = blockIdx.z;
     if (!st[b].active) return;
-    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
-    if (ir >= nr || iz >= nz) return;
-    long c = (long)iz * ld + ir;
-    double jr = j_raw_at(psiF.at(b)[c], r_axis[ir], inv_mu0R[ir], st[b].psi_axis, st[b].denom, st[b].inv_denom, pf);
-    double sc = st[b].jscale;
-    double j = sc != 0.0 ? jr * sc : 0.0;
-    srcF.at(b)[c] = neg_mu0R[ir] * j;
-    if (write_j) jF.at(b)[c] = j;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + tx) * 2;
+    if (c0 >= nr) return;
+    const bool two = c0 + 1 < nr;
+    const double pa = st[b].psi_axis, den = st[b].denom, iden = st[b].inv_denom, sc = st[b].jscale;
+    const double R0 = r_axis[c0], R1 = two ? r_axis[c0 + 1] : 1.0;
+    const double m0 = inv_mu0R[c0], m1 = two ? inv_mu0R[c0 + 1] : 0.0;
+    const double n0 = neg_mu0R[c0], n1 = two ? neg_mu0R[c0 + 1] : 0.0;
+    const double* psi = psiF.at(b);
+    double* so = srcF.at(b);
+    double* jo = jF.at(b);
+#pragma unroll
+    for (int k = 0; k < JS_ROWS / 4; ++k) {
+        const int iz = blockIdx.y * JS_ROWS + ty + 4 * k;
+        if (iz >= nz) continue;
+        const long c = (long)iz * ld + c0;
+        const double2 v = *reinterpret_cast<const double2*>(psi + c);
+        const double jr0 = j_raw_at(v.x, R0, m0, pa, den, iden, pf);
+        const double j0 = sc != 0.0 ? jr0 * sc : 0.0;
+        if (two) {
+            const double jr1 = j_raw_at(v.y, R1, m1, pa, den, iden, pf);
+            const double j1 = sc != 0.0 ? jr1 * sc : 0.0;
+            *reinterpret_cast<double2*>(so + c) = double2{n0 * j0, n1 * j1};
+            if (write_j) *reinterpret_cast<double2*>(jo + c) = double2{j0, j1};
+        } else {
+            so[c] = n0 * j0;
+            if (write_j) jo[c] = j0;
+        }
+    }
 }
 // Source from a stored J_phi (seed / external profile mode)
 __global__ void k_source_from_j(Fld srcF, Fld jF, int nz, int nr, int ld, const double* neg_mu0R,

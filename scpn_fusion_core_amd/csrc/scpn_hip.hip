@@ -303,33 +303,48 @@ struct ProlongSrc {  // coarse-grid correction to add on load (nullptr base: non
     Fld c{nullptr, nullptr, 0, 0};
     int nz_c = 0, nr_c = 0, ld_c = 0;
 };
-template <int S, bool PROLONG, bool SRCGEN>
+struct DefectOut {  // coarse rhs / coarse correction produced by the fused defect + restriction (nullptr base: none)
+    Fld rhs{nullptr, nullptr, 0, 0}, e{nullptr, nullptr, 0, 0};
+    int nz_c = 0, nr_c = 0, ld_c = 0;
+};
+template <int S, bool PROLONG, bool SRCGEN, bool DEFECT>
 static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                        const SrcGen* sg) {
+                        const SrcGen* sg, const DefectOut* dfo) {
     static bool attr_done = false;
     const size_t lds = (size_t)TILE_LZ * 128 * sizeof(double);
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_tile<S, PROLONG, SRCGEN>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_tile<S, PROLONG, SRCGEN, DEFECT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    dim3 g(cdiv(L.nr, 128 - 4 * S), cdiv(L.nz, TILE_LZ - 4 * S), h->B);
-    hipLaunchKernelGGL((k_smooth_tile<S, PROLONG, SRCGEN>), g, dim3(64 * TILE_NW), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active,
-                       ps.c, ps.nz_c, ps.nr_c, ps.ld_c, sg ? *sg : SrcGen{});
+    constexpr int H = 2 * S + (DEFECT ? 2 : 0);
+    dim3 g(cdiv(L.nr, 128 - 2 * H), cdiv(L.nz, TILE_LZ - 2 * H), h->B);
+    DefectDst dd;
+    Fld cF = ps.c;
+    int nz_c = ps.nz_c, nr_c = ps.nr_c, ld_c = ps.ld_c;
+    if (DEFECT) {
+        dd.e = dfo->e; dd.dr2 = L.dr2; dd.dz2 = L.dz2; dd.two_dr = L.two_dr; dd.inv_dr2 = L.inv_dr2; dd.inv_dz2 = L.inv_dz2;
+        dd.inv_two_dr = L.inv_two_dr; dd.r_safe = L.r_safe; dd.r_inv = L.r_inv;
+        cF = dfo->rhs; nz_c = dfo->nz_c; nr_c = dfo->nr_c; ld_c = dfo->ld_c;
+    }
+    hipLaunchKernelGGL((k_smooth_tile<S, PROLONG, SRCGEN, DEFECT>), g, dim3(64 * TILE_NW), lds, h->stream, out, in, src, L, omega, 1.0 - omega,
+                       active, cF, nz_c, nr_c, ld_c, sg ? *sg : SrcGen{}, dd);
 }
 template <int S>
 static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                          const SrcGen* sg) {
-    if (sg) launch_tile<S, false, true>(h, L, out, in, src, omega, active, ps, sg);
-    else if (ps.c.base) launch_tile<S, true, false>(h, L, out, in, src, omega, active, ps, nullptr);
-    else launch_tile<S, false, false>(h, L, out, in, src, omega, active, ps, nullptr);
+                          const SrcGen* sg, const DefectOut* dfo) {
+    if (dfo) launch_tile<S, false, false, true>(h, L, out, in, src, omega, active, ps, nullptr, dfo);
+    else if (sg) launch_tile<S, false, true, false>(h, L, out, in, src, omega, active, ps, sg, nullptr);
+    else if (ps.c.base) launch_tile<S, true, false, false>(h, L, out, in, src, omega, active, ps, nullptr, nullptr);
+    else launch_tile<S, false, false, false>(h, L, out, in, src, omega, active, ps, nullptr, nullptr);
 }
 
 // n_sweeps red-black SOR sweeps of (in, src).  Returns the field that holds the result: `in` itself for the
 // in-place kernels, or `in`/`alt` alternately for the out-of-place LDS-tiled kernel (`alt` must not alias `in`).
 static std::string lname(const char* kind, int lvl) { return std::string(kind) + "_L" + std::to_string(lvl); }
 static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omega, int n_sweeps, const int* active,
-                  bool clip = false, int lvl = 0, const ProlongSrc* prolong = nullptr, const SrcGen* srcgen = nullptr) {
+                  bool clip = false, int lvl = 0, const ProlongSrc* prolong = nullptr, const SrcGen* srcgen = nullptr,
+                  const DefectOut* defect = nullptr) {
     if (n_sweeps <= 0 || L.nz < 3 || L.nr < 3) return in;
     const double om1 = 1.0 - omega;
     if (!clip && (long)L.nz * L.nr <= SMALL_MAX) {
@@ -345,9 +360,11 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
         const SrcGen* sgo = srcgen;                          // ... and only the first launch generates the source
         while (left > 0) {
             const int S = std::min(3, left);
-            if (S == 3) launch_tile_p<3>(h, L, b, a, src, omega, active, pso, sgo);
-            else if (S == 2) launch_tile_p<2>(h, L, b, a, src, omega, active, pso, sgo);
-            else launch_tile_p<1>(h, L, b, a, src, omega, active, pso, sgo);
+            // the LAST launch of the sequence also produces the coarse rhs (it cannot be combined with source generation)
+            const DefectOut* dfo = (defect && left - S <= 0 && !sgo) ? defect : nullptr;
+            if (S == 3) launch_tile_p<3>(h, L, b, a, src, omega, active, pso, sgo, dfo);
+            else if (S == 2) launch_tile_p<2>(h, L, b, a, src, omega, active, pso, sgo, dfo);
+            else launch_tile_p<1>(h, L, b, a, src, omega, active, pso, sgo, dfo);
             pso = ProlongSrc{};
             sgo = nullptr;
             std::swap(a, b);
@@ -382,15 +399,40 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
     const bool fused = h->use_fused;
     auto lvf = [&](DBuf<double>& d, int l) { return Fld{d.p, nullptr, lv[l]->stride, B}; };
     std::vector<Fld> cur(k + 1);
+    const int lc = (fused && H.lc >= 1) ? H.lc : k + 1;  // levels >= lc run inside k_vcycle_coarse
+    auto rhs_of = [&](int l) { return l == 0 ? src0 : lvf(lv[l]->rhs, l); };
+    auto other_of = [&](int l, Fld f) {
+        if (l == 0) return f.base == bufA.base && f.slot == bufA.slot ? bufB : bufA;
+        return f.base == lv[l]->psi.p ? lvf(lv[l]->psi2, l) : lvf(lv[l]->psi, l);
+    };
+    // the pre-smoother of a tiled level can also emit the coarse rhs (fused defect + restriction)
+    static const int defect_min_level = [] { const char* e = std::getenv("SCPN_HIP_DEFECT_MINLVL"); return e ? std::atoi(e) : 0; }();
+    auto defect_fusable = [&](int l) {
+        return fused && !srcgen && pre > 0 && l < k && l >= defect_min_level && (long)lv[l]->dev.nz * lv[l]->dev.nr > SMALL_MAX;
+    };
+    auto defect_out = [&](int l) {
+        DefectOut d;
+        d.rhs = lvf(lv[l + 1]->rhs, l + 1); d.e = lvf(lv[l + 1]->psi, l + 1);
+        d.nz_c = lv[l + 1]->dev.nz; d.nr_c = lv[l + 1]->dev.nr; d.ld_c = lv[l + 1]->dev.ld;
+        return d;
+    };
     // level 0: first smoothing pass reads in0 and writes a work buffer
+    bool defect_done0 = false;
     {
         const Lvl& L0 = lv[0]->dev;
         const int n0 = (k == 0) ? 50 : pre;  // base case: 50 sweeps (multigrid_solve.py:292-293)
         const bool tile0 = fused && (long)L0.nz * L0.nr > SMALL_MAX && n0 > 0;
         if (tile0) {
-            Fld r = smooth(h, L0, in0, bufA, src0, omega, std::min(3, n0), active, false, 0, nullptr, srcgen);  // in0 -> bufA
-            if (n0 > 3) r = smooth(h, L0, bufA, bufB, src0, omega, n0 - 3, active);
-            cur[0] = r;
+            DefectOut d0;
+            const bool df = k > 0 && defect_fusable(0);
+            if (df) d0 = defect_out(0);
+            if (n0 <= 3) {
+                cur[0] = smooth(h, L0, in0, bufA, src0, omega, n0, active, false, 0, nullptr, srcgen, df ? &d0 : nullptr);  // in0 -> bufA
+            } else {
+                Fld r = smooth(h, L0, in0, bufA, src0, omega, 3, active, false, 0, nullptr, srcgen);
+                cur[0] = smooth(h, L0, r, bufB, src0, omega, n0 - 3, active, false, 0, nullptr, nullptr, df ? &d0 : nullptr);
+            }
+            defect_done0 = df;
         } else {
             ProfScope ps(h, "copy", 1);
             hipLaunchKernelGGL(k_copy, grid2d(L0.nr, L0.nz, B), BLK2D, 0, h->stream, bufA, in0, L0.nz, L0.nr, L0.ld, (const int*)nullptr);
@@ -399,17 +441,20 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
         }
         if (k == 0) return cur[0];
     }
-    const int lc = (fused && H.lc >= 1) ? H.lc : k + 1;  // levels >= lc run inside k_vcycle_coarse
-    auto rhs_of = [&](int l) { return l == 0 ? src0 : lvf(lv[l]->rhs, l); };
-    auto other_of = [&](int l, Fld f) {
-        if (l == 0) return f.base == bufA.base && f.slot == bufA.slot ? bufB : bufA;
-        return f.base == lv[l]->psi.p ? lvf(lv[l]->psi2, l) : lvf(lv[l]->psi, l);
-    };
     for (int l = 0; l < k && l < lc; ++l) {
-        if (l > 0) cur[l] = smooth(h, lv[l]->dev, cur[l], other_of(l, cur[l]), rhs_of(l), omega, pre, active, false, l);
+        bool done = (l == 0) ? defect_done0 : false;
+        if (l > 0) {
+            const bool df = defect_fusable(l);
+            DefectOut dl;
+            if (df) dl = defect_out(l);
+            cur[l] = smooth(h, lv[l]->dev, cur[l], other_of(l, cur[l]), rhs_of(l), omega, pre, active, false, l, nullptr, nullptr,
+                            df ? &dl : nullptr);
+            done = df;
+        }
+        cur[l + 1] = lvf(lv[l + 1]->psi, l + 1);
+        if (done) continue;
         ProfScope ps(h, lname("defect_restrict", l).c_str(), 1);
         const Lvl& Lc = lv[l + 1]->dev;
-        cur[l + 1] = lvf(lv[l + 1]->psi, l + 1);
         hipLaunchKernelGGL(k_defect_restrict, grid2d(Lc.nr, Lc.nz, B), BLK2D, 0, h->stream, rhs_of(l + 1), cur[l + 1], cur[l], rhs_of(l),
                            lv[l]->dev, Lc, active);
     }
@@ -636,6 +681,8 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     Fld jF = h->plain(h->jphi.p);
     dim3 g2 = grid2d(nr, nz, B);
     dim3 gring(cdiv(2L * (nz + nr), 256), B);
+    dim3 gjs(cdiv(nr, 128), cdiv(nz, JS_ROWS), B);  // column-pair kernels (k_jsum, k_source)
+    const int nblkj = (int)(gjs.x * gjs.y);
 
     // ---- _prepare_initial_flux (iterative_solver.py:412-451)
     bool need_vac = !p->has_boundary_flux && !p->preserve_initial_state;
@@ -739,14 +786,14 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         SrcGen sg{};
         if (!p->external_profile_mode) {
             ProfScope ps(h, "source", gen ? 1 : 3);
-            hipLaunchKernelGGL(k_jsum, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
-                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblk1);
+            hipLaunchKernelGGL(k_jsum, gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj);
             if (gen) {  // scale + source are evaluated inside the pre-smoother's tile load
                 sg.r_axis = h->d_r.p; sg.inv_mu0R = h->d_inv_mu0R.p; sg.neg_mu0R = h->d_neg_mu0R.p; sg.part = h->d_jpart.p;
-                sg.st = h->d_st.p; sg.nblk = nblk1; sg.dr = h->dr; sg.dz = h->dz; sg.pf = pf;
+                sg.st = h->d_st.p; sg.nblk = nblkj; sg.dr = h->dr; sg.dz = h->dz; sg.pf = pf;
             } else {
-                hipLaunchKernelGGL(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblk1, h->dr, h->dz);
-                hipLaunchKernelGGL(k_source, g2, BLK2D, 0, st, srcF, jF, 0, curF, (const Member*)h->d_st.p, nz, nr, ld,
+                hipLaunchKernelGGL(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
+                hipLaunchKernelGGL(k_source, gjs, dim3(256), 0, st, srcF, jF, 0, curF, (const Member*)h->d_st.p, nz, nr, ld,
                                    (const double*)h->d_r.p, (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
             }
         }
@@ -834,7 +881,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             DBuf<Member> d_tmp;
             d_tmp.alloc(B);
             HIP_TRY(hipMemcpyAsync(d_tmp.p, tmp.data(), sizeof(Member) * B, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_source, g2, BLK2D, 0, st, src2F, jF, 1, prevF, (const Member*)d_tmp.p, nz, nr, ld, (const double*)h->d_r.p,
+            hipLaunchKernelGGL(k_source, gjs, dim3(256), 0, st, src2F, jF, 1, prevF, (const Member*)d_tmp.p, nz, nr, ld, (const double*)h->d_r.p,
                                (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
             HIP_TRY(hipStreamSynchronize(st));
         }
