@@ -444,17 +444,39 @@ constexpr int TILE_LZ = 78;
 // DEFECT: after the sweeps the tile also produces the coarse-grid right-hand side restrict_full_weight(-(L*psi - src))
 // (core/multigrid_solve.py:303-306) and zeroes the coarse correction: the halo grows by 2 (defect ring + restriction
 // stencil) and the separate defect/restrict pass over the fine grid disappears.  (coarseF = coarse rhs, coarse2F = coarse e.)
+struct TopoPart {
+    double maxv;
+    long maxi;
+    double minb;
+    long mini;
+    double minpsi;
+    long pad;
+};
+// BLEND: the post-smoother of the Picard iteration also performs the tail of the iteration on its tile
+//   nxt = (1-alpha)*cur + alpha*psi_new (ring from bc), partial sum |psi_new-cur|, non-finite flag,
+//   partial max|r| / sum r^2 of r = L*nxt - src, topology partials of nxt for the next iteration
+// (the work of k_blend_fused) so psi_new never goes to HBM and cur / src are read once.
+struct BlendArgs {
+    Fld cur{nullptr, nullptr, 0, 0}, bc{nullptr, nullptr, 0, 0};
+    double alpha = 0, om_alpha = 0, dr = 1, dz = 1;
+    int n_mask_rows = 0, nblk = 0;
+    double* psum = nullptr;
+    int* pbad = nullptr;
+    double* rmax = nullptr;
+    double* rsum = nullptr;
+    TopoPart* topo = nullptr;
+};
 struct DefectDst {
     Fld e{nullptr, nullptr, 0, 0};
     double dr2 = 1, dz2 = 1, two_dr = 1, inv_dr2 = 1, inv_dz2 = 1, inv_two_dr = 1;
     const double* r_safe = nullptr;
     const double* r_inv = nullptr;
 };
-template <int S, bool PROLONG, bool SRCGEN, bool DEFECT>
+template <int S, bool PROLONG, bool SRCGEN, bool DEFECT, bool BLEND>
 __global__ void __launch_bounds__(64 * TILE_NW, (PROLONG ? TILE_WPE_P : TILE_WPE)) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
                                                      const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, SrcGen sg,
-                                                     DefectDst dd) {
-    constexpr int LZ = TILE_LZ, H = 2 * S + (DEFECT ? 2 : 0), NW = TILE_NW, NROWS = (LZ + NW - 1) / NW;
+                                                     DefectDst dd, BlendArgs ba) {
+    constexpr int LZ = TILE_LZ, H = 2 * S + ((DEFECT || BLEND) ? 2 : 0), NW = TILE_NW, NROWS = (LZ + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* A0 = lds;            // colour 0: (iz + ir) even
     double* A1 = lds + LZ * 64;  // colour 1
@@ -626,6 +648,7 @@ __global__ void __launch_bounds__(64 * TILE_NW, (PROLONG ? TILE_WPE_P : TILE_WPE
         __syncthreads();
         TILE_STAMP(2 + hs);
     }
+    if (!BLEND)
 #pragma unroll
     for (int i = 0; i < NROWS; ++i) {
         const int lz = w + NW * i, gz = z0 + lz;
@@ -705,6 +728,155 @@ __global__ void __launch_bounds__(64 * TILE_NW, (PROLONG ? TILE_WPE_P : TILE_WPE
             }
             rc[(long)ic * ld_c + jc] = v;
             ec[(long)ic * ld_c + jc] = 0.0;
+        }
+    }
+    if (BLEND) {
+        double* red = lds + 2 * LZ * 64;  // reduction scratch behind the colour planes (part of the dynamic LDS)
+        const double* cur = ba.cur.at(b);
+        const double* bc = ba.bc.at(b);
+        double dsum = 0.0, minpsi = INFINITY, rmx = 0.0, rs2 = 0.0;
+        int bad = 0;
+        VI mx{0.0, -1}, mn{0.0, -1};
+        // (1) blend: cur rows loaded like the tile (clamped, all in flight); psi_new from this lane's plane slots
+        double2 cv[NROWS];
+#pragma unroll
+        for (int i = 0; i < NROWS; ++i) {
+            const int lz = w + NW * i;
+            const int gzc = min(max(z0 + min(lz, LZ - 1), 0), nz - 1);
+            cv[i] = *reinterpret_cast<const double2*>(cur + (long)gzc * ld + cc);
+        }
+#pragma unroll
+        for (int i = 0; i < NROWS; ++i) {
+            const int lz = w + NW * i, gz = z0 + lz;
+            if (lz >= H - 1 && lz <= LZ - H && gz >= 0 && gz < nz) {  // wave-uniform
+                double* px = (e0 ? A1 : A0) + lz * 64 + lane;  // even column
+                double* py = (e0 ? A0 : A1) + lz * 64 + lane;  // odd column
+                const bool rowring = gz == 0 || gz == nz - 1;
+                const bool rowown = lz >= H && lz < LZ - H;
+                double vx = 0.0, vy = 0.0;
+                const int col = 2 * lane;
+                if (okx) {
+                    const bool ring = rowring || c0 == 0 || c0 == nr - 1;
+                    const double pn = ring ? bc[(long)gz * ld + c0] : *px;
+                    const double pc = cv[i].x;
+                    vx = ba.om_alpha * pc + ba.alpha * pn;
+                    if (rowown && col >= H && col < 128 - H) {
+                        if (!finite_d(pn)) bad = 1;
+                        dsum += fabs(pn - pc);
+                        const long q = (long)gz * nr + c0;
+                        if (vx == vx) mx = vi_max(mx, VI{vx, q});
+                        if (finite_d(vx)) minpsi = fmin(minpsi, vx);
+                    }
+                }
+                if (oky) {
+                    const bool ring = rowring || c0 + 1 == 0 || c0 + 1 == nr - 1;
+                    const double pn = ring ? bc[(long)gz * ld + c0 + 1] : *py;
+                    const double pc = cv[i].y;
+                    vy = ba.om_alpha * pc + ba.alpha * pn;
+                    if (rowown && col + 1 >= H && col + 1 < 128 - H) {
+                        if (!finite_d(pn)) bad = 1;
+                        dsum += fabs(pn - pc);
+                        const long q = (long)gz * nr + c0 + 1;
+                        if (vy == vy) mx = vi_max(mx, VI{vy, q});
+                        if (finite_d(vy)) minpsi = fmin(minpsi, vy);
+                    }
+                }
+                *px = vx;
+                *py = vy;
+                if (rowown) {
+                    const long o = (long)gz * ld + c0;
+                    if (col >= H && col + 1 < 128 - H && c0 + 1 < nr) {
+                        *reinterpret_cast<double2*>(out + o) = double2{vx, vy};
+                    } else {
+                        if (col >= H && col < 128 - H && okx) out[o] = vx;
+                        if (col + 1 >= H && col + 1 < 128 - H && oky) out[o + 1] = vy;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // the planes now hold nxt on [H-1, LZ-H] x all columns
+        // (2) residual norms and (divertor rows) |grad psi| of the owned points, one colour at a time
+        double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0;
+        if (c0 >= 1 && c0 <= nr - 2) { rs0 = dd.r_safe[c0]; ri0 = dd.r_inv[c0]; }
+        if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { rs1 = dd.r_safe[c0 + 1]; ri1 = dd.r_inv[c0 + 1]; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double* mine = c ? A1 : A0;
+            const double* oth = c ? A0 : A1;
+            const int pr = (c + w) & 1;
+            const int col = 2 * lane + pr, gc = r0 + col;
+            const bool colown = col >= H && col < 128 - H && gc >= 0 && gc < nr;
+            const bool colint = colown && gc >= 1 && gc <= nr - 2;
+            const double rs = pr ? rs1 : rs0, ri = pr ? ri1 : ri0;
+#pragma unroll
+            for (int i = 0; i < NROWS; ++i) {
+                const int lz = w + NW * i, gz = z0 + lz;
+                if (lz >= H && lz < LZ - H && gz >= 0 && gz < nz) {  // wave-uniform
+                    const double W = oth[lz * 64 + lane - 1 + pr], E = oth[lz * 64 + lane + pr];
+                    const double Sv = oth[(lz - 1) * 64 + lane], N = oth[(lz + 1) * 64 + lane];
+                    const double C = mine[lz * 64 + lane];
+                    if (colint && gz >= 1 && gz <= nz - 2) {
+                        const double sv = c ? sC1[i] : sC0[i];
+                        const double d2r = divc(E - 2.0 * C + W, dd.dr2, dd.inv_dr2);
+                        const double d1r = divc(E - W, dd.two_dr, dd.inv_two_dr);
+                        const double d2z = divc(N - 2.0 * C + Sv, dd.dz2, dd.inv_dz2);
+                        const double lpsi = d2r - divc(d1r, rs, ri) + d2z;
+                        const double r = sanitize1(lpsi - sv);
+                        rmx = fmax(rmx, fabs(r));
+                        rs2 += r * r;
+                    }
+                    if (colown && gz < ba.n_mask_rows) {  // np.gradient + hypot (fusion_kernel.py:276-288)
+                        const double ps = nan_to_num300(C);
+                        double gzv, grv;
+                        if (gz == 0) gzv = (nan_to_num300(N) - ps) / ba.dz;
+                        else if (gz == nz - 1) gzv = (ps - nan_to_num300(Sv)) / ba.dz;
+                        else gzv = (nan_to_num300(N) - nan_to_num300(Sv)) / (2.0 * ba.dz);
+                        if (gc == 0) grv = (nan_to_num300(E) - ps) / ba.dr;
+                        else if (gc == nr - 1) grv = (ps - nan_to_num300(W)) / ba.dr;
+                        else grv = (nan_to_num300(E) - nan_to_num300(W)) / (2.0 * ba.dr);
+                        const double bm = hypot(grv, gzv);
+                        if (finite_d(bm)) mn = vi_min(mn, VI{bm, (long)gz * nr + gc});
+                    }
+                }
+            }
+        }
+        // (3) workgroup reductions (fixed order: lanes by shuffle tree, then waves 0..NW-1) -> per-tile partials
+        dsum = wave_sum(dsum);
+        rs2 = wave_sum(rs2);
+        rmx = wave_max(rmx);
+        minpsi = -wave_max(-minpsi);
+        mx = wave_vi<true>(mx);
+        mn = wave_vi<false>(mn);
+        bad = __any(bad) ? 1 : 0;
+        double* r_dsum = red;
+        double* r_rs2 = red + NW;
+        double* r_rmx = red + 2 * NW;
+        double* r_minp = red + 3 * NW;
+        VI* r_mx = reinterpret_cast<VI*>(red + 4 * NW);
+        VI* r_mn = r_mx + NW;
+        int* r_bad = reinterpret_cast<int*>(r_mn + NW);
+        if (lane == 0) { r_dsum[w] = dsum; r_rs2[w] = rs2; r_rmx[w] = rmx; r_minp[w] = minpsi; r_mx[w] = mx; r_mn[w] = mn; r_bad[w] = bad; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0, c2 = 0.0, m1 = 0.0, mp = INFINITY;
+            VI vmx = r_mx[0], vmn = r_mn[0];
+            int bd = 0;
+            for (int i = 0; i < NW; ++i) {
+                a += r_dsum[i];
+                c2 += r_rs2[i];
+                m1 = fmax(m1, r_rmx[i]);
+                mp = fmin(mp, r_minp[i]);
+                bd |= r_bad[i];
+                if (i) { vmx = vi_max(vmx, r_mx[i]); vmn = vi_min(vmn, r_mn[i]); }
+            }
+            const long o = (long)b * ba.nblk + (long)blockIdx.y * gridDim.x + blockIdx.x;
+            ba.psum[o] = a;
+            ba.pbad[o] = bd;
+            ba.rmax[o] = m1;
+            ba.rsum[o] = c2;
+            TopoPart tp;
+            tp.maxv = vmx.v; tp.maxi = vmx.i; tp.minb = vmn.v; tp.mini = vmn.i; tp.minpsi = mp; tp.pad = 0;
+            ba.topo[o] = tp;
         }
     }
     TILE_STAMP(10);
@@ -981,14 +1153,6 @@ __global__ void k_sanitize(Fld dst, Fld src, int nz, int nr, int ld) {
 }
 
 // ---------------------------------------------------------------- Picard: topology (a8)
-struct TopoPart {
-    double maxv;
-    long maxi;
-    double minb;
-    long mini;
-    double minpsi;
-    long pad;
-};
 // argmax psi, argmin |grad psi| inside the divertor rows [0, n_mask_rows), min finite psi.
 // np.gradient semantics (2nd-order centred inside, 1st-order one-sided on the array edges),
 // core/fusion_kernel.py:276-288, 342-355.  grid (nblk, B), 256 threads x 4 points.

@@ -307,36 +307,48 @@ struct DefectOut {  // coarse rhs / coarse correction produced by the fused defe
     Fld rhs{nullptr, nullptr, 0, 0}, e{nullptr, nullptr, 0, 0};
     int nz_c = 0, nr_c = 0, ld_c = 0;
 };
-template <int S, bool PROLONG, bool SRCGEN, bool DEFECT>
+template <int S, bool PROLONG, bool SRCGEN, bool DEFECT, bool BLEND>
 static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                        const SrcGen* sg, const DefectOut* dfo) {
+                        const SrcGen* sg, const DefectOut* dfo, const BlendArgs* bl = nullptr) {
     static bool attr_done = false;
-    const size_t lds = (size_t)TILE_LZ * 128 * sizeof(double);
+    const size_t lds = (size_t)TILE_LZ * 128 * sizeof(double) + (BLEND ? 2048 : 0);  // + reduction scratch of the blend stage
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_tile<S, PROLONG, SRCGEN, DEFECT>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_tile<S, PROLONG, SRCGEN, DEFECT, BLEND>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    constexpr int H = 2 * S + (DEFECT ? 2 : 0);
+    constexpr int H = 2 * S + ((DEFECT || BLEND) ? 2 : 0);
     dim3 g(cdiv(L.nr, 128 - 2 * H), cdiv(L.nz, TILE_LZ - 2 * H), h->B);
     DefectDst dd;
     Fld cF = ps.c;
     int nz_c = ps.nz_c, nr_c = ps.nr_c, ld_c = ps.ld_c;
-    if (DEFECT) {
-        dd.e = dfo->e; dd.dr2 = L.dr2; dd.dz2 = L.dz2; dd.two_dr = L.two_dr; dd.inv_dr2 = L.inv_dr2; dd.inv_dz2 = L.inv_dz2;
+    if (DEFECT || BLEND) {  // residual constants of this level
+        dd.dr2 = L.dr2; dd.dz2 = L.dz2; dd.two_dr = L.two_dr; dd.inv_dr2 = L.inv_dr2; dd.inv_dz2 = L.inv_dz2;
         dd.inv_two_dr = L.inv_two_dr; dd.r_safe = L.r_safe; dd.r_inv = L.r_inv;
+    }
+    if (DEFECT) {
+        dd.e = dfo->e;
         cF = dfo->rhs; nz_c = dfo->nz_c; nr_c = dfo->nr_c; ld_c = dfo->ld_c;
     }
-    hipLaunchKernelGGL((k_smooth_tile<S, PROLONG, SRCGEN, DEFECT>), g, dim3(64 * TILE_NW), lds, h->stream, out, in, src, L, omega, 1.0 - omega,
-                       active, cF, nz_c, nr_c, ld_c, sg ? *sg : SrcGen{}, dd);
+    BlendArgs ba = bl ? *bl : BlendArgs{};
+    if (BLEND && (int)(g.x * g.y) != ba.nblk) throw std::runtime_error("blend partial layout mismatch");
+    hipLaunchKernelGGL((k_smooth_tile<S, PROLONG, SRCGEN, DEFECT, BLEND>), g, dim3(64 * TILE_NW), lds, h->stream, out, in, src, L, omega,
+                       1.0 - omega, active, cF, nz_c, nr_c, ld_c, sg ? *sg : SrcGen{}, dd, ba);
 }
 template <int S>
 static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                          const SrcGen* sg, const DefectOut* dfo) {
-    if (dfo) launch_tile<S, false, false, true>(h, L, out, in, src, omega, active, ps, nullptr, dfo);
-    else if (sg) launch_tile<S, false, true, false>(h, L, out, in, src, omega, active, ps, sg, nullptr);
-    else if (ps.c.base) launch_tile<S, true, false, false>(h, L, out, in, src, omega, active, ps, nullptr, nullptr);
-    else launch_tile<S, false, false, false>(h, L, out, in, src, omega, active, ps, nullptr, nullptr);
+                          const SrcGen* sg, const DefectOut* dfo, const BlendArgs* bl) {
+    if (bl && ps.c.base) launch_tile<S, true, false, false, true>(h, L, out, in, src, omega, active, ps, nullptr, nullptr, bl);
+    else if (bl) launch_tile<S, false, false, false, true>(h, L, out, in, src, omega, active, ps, nullptr, nullptr, bl);
+    else if (dfo) launch_tile<S, false, false, true, false>(h, L, out, in, src, omega, active, ps, nullptr, dfo);
+    else if (sg) launch_tile<S, false, true, false, false>(h, L, out, in, src, omega, active, ps, sg, nullptr);
+    else if (ps.c.base) launch_tile<S, true, false, false, false>(h, L, out, in, src, omega, active, ps, nullptr, nullptr);
+    else launch_tile<S, false, false, false, false>(h, L, out, in, src, omega, active, ps, nullptr, nullptr);
+}
+// tiles per member of the blend-fused post-smoother (its partial arrays are indexed by tile)
+static int blend_tiles(const Lvl& L, int post) {
+    const int S = ((post - 1) % 3) + 1, H = 2 * S + 2;
+    return cdiv(L.nr, 128 - 2 * H) * cdiv(L.nz, TILE_LZ - 2 * H);
 }
 
 // n_sweeps red-black SOR sweeps of (in, src).  Returns the field that holds the result: `in` itself for the
@@ -344,7 +356,7 @@ static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
 static std::string lname(const char* kind, int lvl) { return std::string(kind) + "_L" + std::to_string(lvl); }
 static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omega, int n_sweeps, const int* active,
                   bool clip = false, int lvl = 0, const ProlongSrc* prolong = nullptr, const SrcGen* srcgen = nullptr,
-                  const DefectOut* defect = nullptr) {
+                  const DefectOut* defect = nullptr, const BlendArgs* blend = nullptr, Fld blend_out = Fld{nullptr, nullptr, 0, 0}) {
     if (n_sweeps <= 0 || L.nz < 3 || L.nr < 3) return in;
     const double om1 = 1.0 - omega;
     if (!clip && (long)L.nz * L.nr <= SMALL_MAX) {
@@ -362,9 +374,13 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
             const int S = std::min(3, left);
             // the LAST launch of the sequence also produces the coarse rhs (it cannot be combined with source generation)
             const DefectOut* dfo = (defect && left - S <= 0 && !sgo) ? defect : nullptr;
-            if (S == 3) launch_tile_p<3>(h, L, b, a, src, omega, active, pso, sgo, dfo);
-            else if (S == 2) launch_tile_p<2>(h, L, b, a, src, omega, active, pso, sgo, dfo);
-            else launch_tile_p<1>(h, L, b, a, src, omega, active, pso, sgo, dfo);
+            const bool last = left - S <= 0;
+            const BlendArgs* bl = (blend && last) ? blend : nullptr;  // the last launch writes the blended iterate
+            Fld dst = bl ? blend_out : b;
+            if (S == 3) launch_tile_p<3>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
+            else if (S == 2) launch_tile_p<2>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
+            else launch_tile_p<1>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
+            if (bl) return dst;
             pso = ProlongSrc{};
             sgo = nullptr;
             std::swap(a, b);
@@ -390,8 +406,14 @@ static bool vcycle_can_srcgen(Solver* h, int pre, int min_grid) {
     const Lvl& L0 = H.lv[0]->dev;
     return h->use_fused && H.lv.size() > 1 && pre > 0 && (long)L0.nz * L0.nr > SMALL_MAX;
 }
+static bool vcycle_can_blend(Solver* h, int post, int min_grid) {
+    Hier& H = get_hier(h, min_grid);
+    const Lvl& L0 = H.lv[0]->dev;
+    return h->use_fused && H.lv.size() > 1 && post > 0 && (long)L0.nz * L0.nr > SMALL_MAX;
+}
 static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega, int pre, int post, int min_grid,
-                  const int* active, const SrcGen* srcgen = nullptr) {
+                  const int* active, const SrcGen* srcgen = nullptr, const BlendArgs* blend = nullptr,
+                  Fld blend_out = Fld{nullptr, nullptr, 0, 0}) {
     Hier& H = get_hier(h, min_grid);
     auto& lv = H.lv;
     const int k = (int)lv.size() - 1;
@@ -479,7 +501,8 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
         if (tile_post) {  // prolongation fused into the post-smoother's tile load
             ProlongSrc pso;
             pso.c = cur[l + 1]; pso.nz_c = Lc.nz; pso.nr_c = Lc.nr; pso.ld_c = Lc.ld;
-            cur[l] = smooth(h, Lf, cur[l], other_of(l, cur[l]), rhs_of(l), omega, post, active, false, l, &pso);
+            cur[l] = smooth(h, Lf, cur[l], other_of(l, cur[l]), rhs_of(l), omega, post, active, false, l, &pso, nullptr, nullptr,
+                            l == 0 ? blend : nullptr, blend_out);
         } else {
             {
                 ProfScope ps(h, lname("prolong_add", l).c_str(), 1);
@@ -767,10 +790,11 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     const int check_every = std::max(1, p->check_every);
     const double om_alpha = 1.0 - p->alpha;
     const int* act = h->d_active.p;
+    int topo_count = nblk2;
     auto iteration = [&](bool first) {
         {
             ProfScope ps(h, "topology", first || !h->use_fused ? 2 : 1);
-            int ntopo = nblk2;
+            int ntopo = topo_count;  // partial count produced by the previous iteration's fused tail
             if (first || !h->use_fused) {  // later iterations get their partials from the fused blend kernel
                 ntopo = nblk1;
                 hipLaunchKernelGGL(k_topology, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, h->dr, h->dz,
@@ -799,8 +823,20 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         }
         // _elliptic_solve (iterative_solver.py:361-380)
         Fld newF = WF;
+        // blend + norms + topology inside the post-smoother is implemented and bit-identical to k_blend_fused, but at one
+        // 16-wave workgroup per CU its extra compute is not hidden (160.8 vs 172.3 eq/s measured): opt-in (SCPN_HIP_BLENDFUSE=1)
+        static const bool blend_env = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1'; }();
+        const bool blend_in_tile = blend_env && p->method == 0 && vcycle_can_blend(h, 3, 5);
+        int nb_d = nblk1, nb_r = nblk_r;
         if (p->method == 0) {
-            newF = vcycle(h, curF, WF, W2F, srcF, p->sor_omega, 3, 3, 5, act, gen ? &sg : nullptr);
+            BlendArgs ba;
+            if (blend_in_tile) {  // the post-smoother's last launch blends, writes nxt and produces all partials
+                ba.cur = curF; ba.bc = bcF; ba.alpha = p->alpha; ba.om_alpha = om_alpha; ba.dr = h->dr; ba.dz = h->dz;
+                ba.n_mask_rows = n_mask_rows; ba.nblk = blend_tiles(L0, 3);
+                ba.psum = h->d_part1.p; ba.pbad = h->d_pbad.p; ba.rmax = h->d_part2.p; ba.rsum = h->d_part3.p; ba.topo = h->d_topo.p;
+                nb_d = nb_r = ba.nblk;
+            }
+            newF = vcycle(h, curF, WF, W2F, srcF, p->sor_omega, 3, 3, 5, act, gen ? &sg : nullptr, blend_in_tile ? &ba : nullptr, nxtF);
         } else if (p->method == 1) {
             hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, WF, curF, nz, nr, ld);
             hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, src2F, srcF, nz, nr, ld);
@@ -808,8 +844,9 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         } else {
             hipLaunchKernelGGL(k_jacobi, g2, BLK2D, 0, st, WF, curF, srcF, L0, act);
         }
-        int nb_d = nblk1, nb_r = nblk_r;
-        if (h->use_fused) {
+        if (blend_in_tile) {
+            // nothing to do: blend, norms and next-iteration topology partials came out of the post-smoother
+        } else if (h->use_fused) {
             ProfScope ps(h, "blend_fused", 1);
             nb_d = nb_r = nblk2;
             hipLaunchKernelGGL(k_blend_fused, dim3(cdiv(nr, BT_R), cdiv(nz, BT_Z), B), dim3(256), 0, st, nxtF, curF, newF, bcF, srcF,
@@ -821,6 +858,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
                                om_alpha, h->d_part1.p, h->d_pbad.p, nblk1);
             hipLaunchKernelGGL(k_resid_norms, dim3(nblk_r, B), dim3(256), 0, st, nxtF, srcF, L0, h->d_part2.p, h->d_part3.p, nblk_r, act);
         }
+        topo_count = nb_d;
         PicardCtl ctl;
         ctl.tol = p->tol; ctl.gs_tol = p->gs_tol; ctl.require_gs = p->require_gs_residual; ctl.max_iter = max_iter;
         ctl.iter = 0; ctl.pad = 0; ctl.n_total = (long)nz * nr; ctl.n_interior = (long)(nz - 2) * (nr - 2);
