@@ -125,7 +125,7 @@ typedef struct scpn_picard_params {
     double z_min_cfg;    /* cfg["dimensions"]["Z_min"]  (X-point mask, core/fusion_kernel.py:279) */
     double r_center;     /* (R_min + R_max)/2 of the config (seed, iterative_solver.py:400) */
     double mu0;          /* physics.vacuum_permeability */
-    int method;          /* 0 multigrid (one V-cycle / iteration), 1 sor, 2 jacobi */
+    int method;          /* 0 multigrid (one V-cycle / iteration), 1 sor, 2 jacobi, 3 anderson (sor + Anderson mixing) */
     double sor_omega;    /* solver.sor_omega */
     double alpha;        /* solver.relaxation_factor */
     double tol;          /* solver.convergence_threshold */
@@ -141,6 +141,7 @@ typedef struct scpn_picard_params {
     int check_every;     /* host polls the device convergence word every this many iterations (>=1) */
     int fail_on_diverge;
     int skip_seed;       /* 1: do not run _seed_plasma (not a reference behaviour; benchmarking aid) */
+    int anderson_m;      /* solver.anderson_depth (default 5, at most 5) */
 } scpn_picard_params;
 
 typedef struct scpn_picard_result {

@@ -556,6 +556,59 @@ double orc_update_source(const double *psi, const double *r_axis, int nz, int nr
     return i_current;
 }
 
+/* core/fusion_kernel_iterative_solver.py:248-314 _anderson_step.  hist arrays hold `len` fields (oldest first).
+ * Gram products are plain left-to-right sums (NumPy delegates dF.T @ dF to BLAS; order differs, tolerance parity). */
+static void anderson_step(double **psi_hist, double **res_hist, int len, int m, long n, double *mixed) {
+    int mk = m < len ? m : len;
+    double **P = psi_hist + (len - mk), **F = res_hist + (len - mk);
+    if (mk < 2) { memcpy(mixed, psi_hist[len - 1], sizeof(double) * (size_t)n); return; }
+    int q = mk - 1;
+    double G[16][16], v[16], gamma[16], alpha[16];
+    for (int a = 0; a < q; ++a) {
+        for (int b2 = 0; b2 < q; ++b2) {
+            double acc = 0.0;
+            for (long i = 0; i < n; ++i) acc += (F[a + 1][i] - F[a][i]) * (F[b2 + 1][i] - F[b2][i]);
+            G[a][b2] = acc + (a == b2 ? 1e-10 : 0.0);
+        }
+        double acc = 0.0;
+        for (long i = 0; i < n; ++i) acc += (F[a + 1][i] - F[a][i]) * F[mk - 1][i];
+        v[a] = acc;
+    }
+    /* np.linalg.solve: LU with partial pivoting */
+    int singular = 0;
+    for (int c = 0; c < q; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < q; ++r) if (fabs(G[r][c]) > fabs(G[piv][c])) piv = r;
+        if (G[piv][c] == 0.0) { singular = 1; break; }
+        if (piv != c) { for (int k = 0; k < q; ++k) { double t = G[c][k]; G[c][k] = G[piv][k]; G[piv][k] = t; } double t = v[c]; v[c] = v[piv]; v[piv] = t; }
+        for (int r = c + 1; r < q; ++r) {
+            double f = G[r][c] / G[c][c];
+            for (int k = c; k < q; ++k) G[r][k] -= f * G[c][k];
+            v[r] -= f * v[c];
+        }
+    }
+    if (singular) { memcpy(mixed, psi_hist[len - 1], sizeof(double) * (size_t)n); return; }
+    for (int r = q - 1; r >= 0; --r) {
+        double acc = v[r];
+        for (int k = r + 1; k < q; ++k) acc -= G[r][k] * gamma[k];
+        gamma[r] = acc / G[r][r];
+    }
+    double gsum = 0.0;
+    for (int a = 0; a < q; ++a) gsum += gamma[a];
+    for (int a = 0; a < mk; ++a) alpha[a] = 0.0;
+    alpha[mk - 1] = 1.0 - gsum;
+    for (int a = 0; a < q; ++a) alpha[a] -= gamma[a];
+    double asum = 0.0;
+    for (int a = 0; a < mk; ++a) asum += alpha[a];
+    if (fabs(asum) < 1e-12) { memcpy(mixed, psi_hist[len - 1], sizeof(double) * (size_t)n); return; }
+    for (int a = 0; a < mk; ++a) alpha[a] /= asum;
+    for (long i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int a = 0; a < mk; ++a) acc += alpha[a] * P[a][i];
+        mixed[i] = acc;
+    }
+}
+
 int orc_picard_solve(const orc_picard_params *p, double *psi, const double *boundary_flux,
                      double *j_phi, orc_picard_result *res, double *trace, int max_iter_budget) {
     int nz = p->nz, nr = p->nr;
@@ -619,6 +672,8 @@ int orc_picard_solve(const orc_picard_params *p, double *psi, const double *boun
 
     int max_iter = p->max_iter;
     if (max_iter_budget >= 0 && max_iter_budget < max_iter) max_iter = max_iter_budget;
+    double *and_psi[64], *and_res[64];
+    int and_len = 0;
     for (int k = 0; k < max_iter; ++k) {
         final_iter = k;
         ran = 1;
@@ -658,6 +713,25 @@ int orc_picard_solve(const orc_picard_params *p, double *psi, const double *boun
         for (long i = 0; i < n; ++i) tmp[i] = fabs(psi_new[i] - psi[i]);
         double diff = orc_np_sum(tmp, n) / (double)n;
         for (long i = 0; i < n; ++i) psi[i] = (1.0 - p->alpha) * psi[i] + p->alpha * psi_new[i];
+        if (p->method == 3) { /* Anderson acceleration, core/fusion_kernel_newton_solver.py:540-550 */
+            double *ph = dalloc(n), *rh = dalloc(n);
+            memcpy(ph, psi, sizeof(double) * (size_t)n);
+            for (long i = 0; i < n; ++i) rh[i] = psi_new[i] - psi[i];
+            and_psi[and_len] = ph;
+            and_res[and_len] = rh;
+            and_len += 1;
+            if (and_len >= 3 && k % 3 == 0) {
+                anderson_step(and_psi, and_res, and_len, p->anderson_m, n, tmp);
+                apply_bc(tmp, bc, nz, nr);
+                memcpy(psi, tmp, sizeof(double) * (size_t)n);
+            }
+            if (and_len > p->anderson_m + 2) {
+                free(and_psi[0]);
+                free(and_res[0]);
+                for (int j = 1; j < and_len; ++j) { and_psi[j - 1] = and_psi[j]; and_res[j - 1] = and_res[j]; }
+                and_len -= 1;
+            }
+        }
         double gs = orc_gs_residual_rms(psi, source, rr, nz, nr, dr, dz);
         gs_last = gs;
         if (gs < gs_best) gs_best = gs;
@@ -673,6 +747,7 @@ int orc_picard_solve(const orc_picard_params *p, double *psi, const double *boun
         int gsc = (!p->require_gs_residual) || (gs < p->gs_tol);
         if (upd && gsc) { converged = 1; break; }
     }
+    for (int j = 0; j < and_len; ++j) { free(and_psi[j]); free(and_res[j]); }
     res->converged = converged;
     res->iterations = ran ? final_iter + 1 : 1;
     res->residual = diff_best;

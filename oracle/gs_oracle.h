@@ -115,7 +115,7 @@ typedef struct orc_picard_params {
     double r_min, r_max, z_min, z_max; /* cfg["dimensions"] */
     double mu0;                        /* physics.vacuum_permeability */
     double i_target;                   /* physics.plasma_current_target */
-    int method;                        /* 0 multigrid, 1 sor, 2 jacobi */
+    int method;                        /* 0 multigrid, 1 sor, 2 jacobi, 3 anderson (sor + Anderson mixing) */
     double sor_omega;                  /* solver.sor_omega (default 1.6) */
     double alpha;                      /* solver.relaxation_factor (default 0.1) */
     double tol;                        /* solver.convergence_threshold */
@@ -129,6 +129,7 @@ typedef struct orc_picard_params {
     int external_profile_mode; /* skip source update, keep seeded J */
     int n_coils;               /* cfg["coils"] used for calculate_vacuum_field */
     const double *coil_r, *coil_z, *coil_i;
+    int anderson_m; /* solver.anderson_depth (default 5) */
 } orc_picard_params;
 
 typedef struct orc_picard_result {

@@ -33,6 +33,7 @@ class PicardParams(C.Structure):
         ("preserve_initial_state", _i), ("has_boundary_flux", _i), ("external_profile_mode", _i),
         ("n_coils", _i),
         ("coil_r", C.POINTER(_d)), ("coil_z", C.POINTER(_d)), ("coil_i", C.POINTER(_d)),
+        ("anderson_m", _i),
     ]
 
 
@@ -253,7 +254,7 @@ def update_source(psi, r_axis, dr, dz, psi_axis, psi_bnd, mu0, i_target, hmode=F
     return j, i_cur
 
 
-_METHODS = {"multigrid": 0, "sor": 1, "jacobi": 2}
+_METHODS = {"multigrid": 0, "sor": 1, "jacobi": 2, "anderson": 3}
 
 
 def make_params(cfg: dict, *, preserve=False, has_bc=False, external_profile_mode=False):
@@ -284,6 +285,7 @@ def make_params(cfg: dict, *, preserve=False, has_bc=False, external_profile_mod
     p.external_profile_mode = int(external_profile_mode)
     coils = cfg.get("coils", [])
     p.n_coils = len(coils)
+    p.anderson_m = int(sol.get("anderson_depth", 5))
     keep = [np.array([c[k] for c in coils], dtype=np.float64) for k in ("r", "z", "current")]
     p.coil_r, p.coil_z, p.coil_i = [a.ctypes.data_as(C.POINTER(_d)) for a in keep]
     p._keep = keep  # keep the arrays alive

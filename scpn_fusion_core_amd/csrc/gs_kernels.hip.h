@@ -1487,6 +1487,127 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
     }
 }
 
+// ---------------------------------------------------------------- Anderson mixing (a10, method "anderson")
+// core/fusion_kernel_newton_solver.py:540-550 and core/fusion_kernel_iterative_solver.py:248-314
+constexpr int AND_MAX = 8;  // max mixing depth m
+struct AndFields {
+    const double* f[AND_MAX];  // base pointers of the last mk history fields (oldest first), member stride = stride
+    long stride;
+    int mk;
+};
+// psi_hist <- blended psi; res_hist <- Psi_new - psi (Psi_new carries the Dirichlet ring of bc)
+__global__ void k_and_push(double* psi_h, double* res_h, long hstride, Fld nxtF, Fld newF, Fld bcF, int nz, int nr, int ld,
+                           const int* active) {
+    int b = blockIdx.z;
+    if (active && !active[b]) return;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    long c = (long)iz * ld + ir;
+    bool ring = iz == 0 || iz == nz - 1 || ir == 0 || ir == nr - 1;
+    double pn = ring ? bcF.at(b)[c] : newF.at(b)[c];
+    double p = nxtF.at(b)[c];
+    psi_h[(long)b * hstride + c] = p;
+    res_h[(long)b * hstride + c] = pn - p;
+}
+// partial sums of G[a][b] = sum dF_a dF_b and v[a] = sum dF_a F_last, dF_a = F_{a+1} - F_a; part[b][blk][20]
+__global__ void __launch_bounds__(256) k_and_gram(AndFields F, int nz, int nr, int ld, double* part, int nblk, const int* active) {
+    __shared__ double sh[4];
+    int b = blockIdx.y;
+    if (active && !active[b]) return;
+    const int q = F.mk - 1;
+    double acc[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) acc[i] = 0.0;
+    const long n = (long)nz * nr;
+    for (int k = 0; k < 4; ++k) {
+        long p = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (p < n) {
+            int iz = (int)(p / nr), ir = (int)(p - (long)iz * nr);
+            long c = (long)b * F.stride + (long)iz * ld + ir;
+            double fv[AND_MAX], d[AND_MAX];
+#pragma unroll
+            for (int j = 0; j < AND_MAX; ++j) fv[j] = j < F.mk ? F.f[j][c] : 0.0;
+#pragma unroll
+            for (int j = 0; j < AND_MAX - 1; ++j) d[j] = fv[j + 1] - fv[j];
+            const double last = fv[F.mk - 1];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2)
+                    if (a < q && c2 < q) acc[a * 4 + c2] += d[a] * d[c2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (a < q) acc[16 + a] += d[a] * last;
+        }
+    }
+    for (int i = 0; i < 20; ++i) {
+        double r = block_sum<256>(acc[i], sh);
+        if (threadIdx.x == 0) part[((long)b * nblk + blockIdx.x) * 20 + i] = r;
+    }
+}
+// one thread per member: finish the sums, regularise, solve (LU, partial pivoting), mixing weights alpha[mk] (or fallback)
+__global__ void k_and_final(const double* part, int nblk, int mk, double* alpha_out, int* fallback, int B, const int* active) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (active && !active[b]) return;
+    const int q = mk - 1;
+    double G[4][4], v[4], gamma[4], alpha[AND_MAX];
+    for (int a = 0; a < 4; ++a) { v[a] = 0.0; gamma[a] = 0.0; for (int c = 0; c < 4; ++c) G[a][c] = 0.0; }
+    for (int i = 0; i < nblk; ++i) {
+        const double* p = part + ((long)b * nblk + i) * 20;
+        for (int a = 0; a < q; ++a) { for (int c = 0; c < q; ++c) G[a][c] += p[a * 4 + c]; v[a] += p[16 + a]; }
+    }
+    for (int a = 0; a < q; ++a) G[a][a] += 1e-10;
+    bool sing = false;
+    for (int c = 0; c < q && !sing; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < q; ++r) if (fabs(G[r][c]) > fabs(G[piv][c])) piv = r;
+        if (G[piv][c] == 0.0 || !(G[piv][c] == G[piv][c])) { sing = true; break; }
+        if (piv != c) { for (int k = 0; k < q; ++k) { double t = G[c][k]; G[c][k] = G[piv][k]; G[piv][k] = t; } double t = v[c]; v[c] = v[piv]; v[piv] = t; }
+        for (int r = c + 1; r < q; ++r) {
+            double f = G[r][c] / G[c][c];
+            for (int k = c; k < q; ++k) G[r][k] -= f * G[c][k];
+            v[r] -= f * v[c];
+        }
+    }
+    int fb = sing ? 1 : 0;
+    if (!sing) {
+        for (int r = q - 1; r >= 0; --r) {
+            double acc = v[r];
+            for (int k = r + 1; k < q; ++k) acc -= G[r][k] * gamma[k];
+            gamma[r] = acc / G[r][r];
+        }
+        double gsum = 0.0;
+        for (int a = 0; a < q; ++a) gsum += gamma[a];
+        for (int a = 0; a < mk; ++a) alpha[a] = 0.0;
+        alpha[mk - 1] = 1.0 - gsum;
+        for (int a = 0; a < q; ++a) alpha[a] -= gamma[a];
+        double asum = 0.0;
+        for (int a = 0; a < mk; ++a) asum += alpha[a];
+        if (fabs(asum) < 1e-12 || !(asum == asum)) fb = 1;
+        else for (int a = 0; a < mk; ++a) alpha_out[(long)b * AND_MAX + a] = alpha[a] / asum;
+    }
+    fallback[b] = fb;
+}
+// psi <- sum alpha_j psi_hist_j (or the latest iterate on fallback), Dirichlet ring from bc
+__global__ void k_and_mix(Fld nxtF, AndFields P, const double* alpha, const int* fallback, Fld bcF, int nz, int nr, int ld,
+                          const int* active) {
+    int b = blockIdx.z;
+    if (active && !active[b]) return;
+    int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    long c = (long)iz * ld + ir;
+    bool ring = iz == 0 || iz == nz - 1 || ir == 0 || ir == nr - 1;
+    double v;
+    if (ring) v = bcF.at(b)[c];
+    else if (fallback[b]) v = P.f[P.mk - 1][(long)b * P.stride + c];
+    else {
+        v = 0.0;
+        for (int j = 0; j < P.mk; ++j) v += alpha[(long)b * AND_MAX + j] * P.f[j][(long)b * P.stride + c];
+    }
+    nxtF.at(b)[c] = v;
+}
+
 struct PicardCtl {
     double tol, gs_tol;
     int require_gs, max_iter, iter, pad;

@@ -126,7 +126,8 @@ struct Solver {
     bool use_fused = true;  // SCPN_HIP_FUSED=0 selects the one-pass-per-launch kernels (A/B testing)
     // fields (B members each)
     DBuf<double> psi_slots;  // 3 ping-pong slots
-    DBuf<double> W, W2, src, src2, bc, jphi, ext, old, dense;
+    DBuf<double> W, W2, src, src2, bc, jphi, ext, old, dense, and_psi, and_res, and_part, and_alpha;
+    DBuf<int> and_fb;
     bool picard_bufs = false;
     DBuf<double> d_r, d_z, d_inv_mu0R, d_neg_mu0R, d_seed;
     DBuf<Member> d_st;
@@ -791,11 +792,20 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     const double om_alpha = 1.0 - p->alpha;
     const int* act = h->d_active.p;
     int topo_count = nblk2;
+    int and_start = 0, and_len = 0, iter_k = 0;  // Anderson history ring (uniform across members: lock-step iterations)
+    if (p->method == 3) {
+        const size_t hs = (size_t)h->stride * B, cap = (size_t)p->anderson_m + 3;
+        h->and_psi.alloc(hs * cap);
+        h->and_res.alloc(hs * cap);
+        h->and_part.alloc((size_t)B * nblk1 * 20);
+        h->and_alpha.alloc((size_t)B * AND_MAX);
+        h->and_fb.alloc(B);
+    }
     auto iteration = [&](bool first) {
         {
-            ProfScope ps(h, "topology", first || !h->use_fused ? 2 : 1);
+            ProfScope ps(h, "topology", first || !h->use_fused || p->method == 3 ? 2 : 1);
             int ntopo = topo_count;  // partial count produced by the previous iteration's fused tail
-            if (first || !h->use_fused) {  // later iterations get their partials from the fused blend kernel
+            if (first || !h->use_fused || p->method == 3) {  // later iterations get their partials from the fused blend kernel
                 ntopo = nblk1;
                 hipLaunchKernelGGL(k_topology, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, h->dr, h->dz,
                                    n_mask_rows, h->d_topo.p, nblk1);
@@ -837,7 +847,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
                 nb_d = nb_r = ba.nblk;
             }
             newF = vcycle(h, curF, WF, W2F, srcF, p->sor_omega, 3, 3, 5, act, gen ? &sg : nullptr, blend_in_tile ? &ba : nullptr, nxtF);
-        } else if (p->method == 1) {
+        } else if (p->method == 1 || p->method == 3) {
             hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, WF, curF, nz, nr, ld);
             hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, src2F, srcF, nz, nr, ld);
             smooth(h, L0, WF, Fld{nullptr, nullptr, 0, 0}, src2F, p->sor_omega, 1, act, true);
@@ -846,7 +856,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         }
         if (blend_in_tile) {
             // nothing to do: blend, norms and next-iteration topology partials came out of the post-smoother
-        } else if (h->use_fused) {
+        } else if (h->use_fused && p->method != 3) {
             ProfScope ps(h, "blend_fused", 1);
             nb_d = nb_r = nblk2;
             hipLaunchKernelGGL(k_blend_fused, dim3(cdiv(nr, BT_R), cdiv(nz, BT_Z), B), dim3(256), 0, st, nxtF, curF, newF, bcF, srcF,
@@ -856,6 +866,34 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             ProfScope ps(h, "blend_norms", 2);
             hipLaunchKernelGGL(k_blend, dim3(nblk1, B), dim3(256), 0, st, nxtF, curF, newF, bcF, (const Member*)h->d_st.p, nz, nr, ld, p->alpha,
                                om_alpha, h->d_part1.p, h->d_pbad.p, nblk1);
+            if (p->method == 3) {  // Anderson acceleration (newton_solver.py:540-550)
+                const int cap = p->anderson_m + 3;
+                const long hs = h->stride * (long)B;
+                const int slot = (and_start + and_len) % cap;
+                hipLaunchKernelGGL(k_and_push, g2, BLK2D, 0, st, h->and_psi.p + slot * hs, h->and_res.p + slot * hs, h->stride, nxtF, newF, bcF,
+                                   nz, nr, ld, act);
+                and_len += 1;
+                if (and_len >= 3 && iter_k % 3 == 0) {
+                    const int mk = std::min(p->anderson_m, and_len);
+                    if (mk >= 2) {
+                        AndFields F{}, P{};
+                        F.mk = P.mk = mk; F.stride = P.stride = h->stride;
+                        for (int j = 0; j < mk; ++j) {
+                            const int sl = (and_start + and_len - mk + j) % cap;
+                            F.f[j] = h->and_res.p + sl * hs;
+                            P.f[j] = h->and_psi.p + sl * hs;
+                        }
+                        hipLaunchKernelGGL(k_and_gram, dim3(nblk1, B), dim3(256), 0, st, F, nz, nr, ld, h->and_part.p, nblk1, act);
+                        hipLaunchKernelGGL(k_and_final, dim3(cdiv(B, 64)), dim3(64), 0, st, (const double*)h->and_part.p, nblk1, mk, h->and_alpha.p,
+                                           h->and_fb.p, B, act);
+                        hipLaunchKernelGGL(k_and_mix, g2, BLK2D, 0, st, nxtF, P, (const double*)h->and_alpha.p, (const int*)h->and_fb.p, bcF, nz, nr,
+                                           ld, act);
+                    } else {  // mk < 2: the latest iterate with the boundary re-applied
+                        hipLaunchKernelGGL(k_apply_bc, gring, dim3(256), 0, st, nxtF, bcF, nz, nr, ld, act);
+                    }
+                }
+                if (and_len > p->anderson_m + 2) { and_start = (and_start + 1) % cap; and_len -= 1; }
+            }
             hipLaunchKernelGGL(k_resid_norms, dim3(nblk_r, B), dim3(256), 0, st, nxtF, srcF, L0, h->d_part2.p, h->d_part3.p, nblk_r, act);
         }
         topo_count = nb_d;
@@ -880,6 +918,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     hipGraphExec_t gexec = nullptr;
     int k = 0;
     if (n_act > 0 && max_iter > 0) {
+        iter_k = 0;
         iteration(true);
         ++k;
         if (k % check_every == 0 || k >= max_iter) {
@@ -888,13 +927,14 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             n_act = h->h_nactive[0];
         }
     }
-    if (graph_env && !h->prof_on && n_act > 0 && k < max_iter) {
+    if (graph_env && p->method != 3 && !h->prof_on && n_act > 0 && k < max_iter) {
         HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         iteration(false);
         HIP_TRY(hipStreamEndCapture(st, &graph));
         HIP_TRY(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
     }
     while (n_act > 0 && k < max_iter) {
+        iter_k = k;
         if (gexec) HIP_TRY(hipGraphLaunch(gexec, st));
         else iteration(false);
         ++k;
@@ -1118,7 +1158,8 @@ static int S_set_seed(Solver* h, const double* seed) {
 static int S_picard_solve(Solver* h, const scpn_picard_params* p, scpn_picard_result* results, double* hist_diff, double* hist_gs,
                          double* trace) {
     if (!h || !p) return fail(SCPN_E_ARG, "null handle / params");
-    if (p->method < 0 || p->method > 2) return fail(SCPN_E_ARG, "method must be 0 (multigrid), 1 (sor) or 2 (jacobi)");
+    if (p->method < 0 || p->method > 3) return fail(SCPN_E_ARG, "method must be 0 (multigrid), 1 (sor), 2 (jacobi) or 3 (anderson)");
+    if (p->method == 3 && (p->anderson_m < 1 || p->anderson_m > 5)) return fail(SCPN_E_ARG, "anderson_depth must be in [1, 5]");
     if (p->method != 2 && !omega_ok(p->sor_omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
     if (p->require_gs_residual && !(p->gs_tol > 0.0)) return fail(SCPN_E_ARG, "solver.gs_residual_threshold must be > 0");
     if (h->nz < 3 || h->nr < 3) return fail(SCPN_E_ARG, "grid must be at least 3x3");

@@ -18,7 +18,7 @@ import numpy as np
 from . import _lib
 from ._lib import PicardParams, PicardResult, as_f64, check, ptr
 
-_METHODS = {"multigrid": 0, "sor": 1, "jacobi": 2}
+_METHODS = {"multigrid": 0, "sor": 1, "jacobi": 2, "anderson": 3}
 _PED_DEFAULT = {"ped_top": 0.92, "ped_width": 0.05, "ped_height": 1.0, "core_alpha": 0.3}  # core/fusion_kernel.py:181-192
 
 
@@ -28,7 +28,7 @@ def picard_params_from_cfg(cfg: dict, *, preserve_initial_state=False, has_bound
     dims, phys, sol = cfg["dimensions"], cfg["physics"], cfg.get("solver", {})
     method = sol.get("solver_method", "multigrid")
     if method not in _METHODS:
-        raise NotImplementedError(f"solver_method={method!r} is not on the HIP path (multigrid, sor, jacobi are)")
+        raise NotImplementedError(f"solver_method={method!r} is not on the HIP path (multigrid, sor, anderson, jacobi are)")
     p = PicardParams()
     p.z_min_cfg = dims["Z_min"]
     p.r_center = (dims["R_min"] + dims["R_max"]) / 2.0
@@ -56,6 +56,7 @@ def picard_params_from_cfg(cfg: dict, *, preserve_initial_state=False, has_bound
     p.check_every = int(check_every)
     p.fail_on_diverge = int(bool(sol.get("fail_on_diverge", False)))
     p.skip_seed = 0
+    p.anderson_m = int(sol.get("anderson_depth", 5))
     return p
 
 

@@ -170,7 +170,7 @@ class FusionKernel:
         """core/fusion_kernel_newton_solver.py:390-615 (Picard methods multigrid / sor / jacobi)."""
         t0 = time.time()
         method = self.cfg["solver"].get("solver_method", "multigrid")
-        if method in ("newton", "rust_multigrid", "anderson"):
+        if method in ("newton", "rust_multigrid"):
             raise NotImplementedError(f"solver_method={method!r} is not on the HIP path yet (SURVEY.md section 8 row f1)")
         if boundary_flux is not None:
             bf = np.asarray(boundary_flux, dtype=np.float64)

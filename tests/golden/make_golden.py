@@ -235,6 +235,29 @@ def gen_picard():
     save("picard.npz", **out)
 
 
+# ── Anderson-accelerated Picard  core/fusion_kernel_newton_solver.py:540-550, iterative_solver.py:248-314 ──
+def gen_anderson():
+    out, cfgs = {}, {}
+    cases = {
+        "iter33_anderson": iter_cfg(33, method="anderson", omega=1.6, tol=1e-6, max_iter=150),
+        "iter65_anderson_m3": iter_cfg(65, method="anderson", omega=1.3, tol=1e-5, max_iter=100),
+    }
+    cases["iter65_anderson_m3"]["solver"]["anderson_depth"] = 3
+    for name, cfg in cases.items():
+        k = make_kernel(cfg)
+        res, rec = traced_solve(k)
+        cfgs[name] = cfg
+        out[f"{name}_psi"] = res["psi"]
+        out[f"{name}_axis_bnd"] = rec
+        out[f"{name}_diff"] = np.array(res["residual_history"])
+        out[f"{name}_gs"] = np.array(res["gs_residual_history"])
+        out[f"{name}_stats"] = np.array([float(res["converged"]), res["iterations"], res["residual"], res["gs_residual"],
+                                         res["gs_residual_best"]])
+        print(name, res["iterations"], res["converged"], res["residual"])
+    out["_configs"] = np.array(json.dumps(cfgs))
+    save("anderson.npz", **out)
+
+
 # ── (j,k) unit pieces: axis / x-point / source / jacobi / sor ────────────────
 def gen_pieces():
     out = {}
@@ -338,6 +361,6 @@ def gen_fastsolver():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["smooth", "operators", "mgsolve", "polyglot", "picard", "pieces", "green",
-                             "free_boundary", "fastsolver"]
+                             "free_boundary", "fastsolver", "anderson"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -339,6 +339,26 @@ def test_external_profile_mode_matches_reference_semantics(hip, orc):
     assert np.abs(jphi - ref["j_phi"]).max() <= 1e-12 * np.abs(ref["j_phi"]).max()
 
 
+def test_anderson_picard_golden(hip, golden, orc):
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    g = golden("anderson.npz")
+    cfgs = configs_from(g)
+    cfg = cfgs["iter65_anderson_m3"]
+    with EnsembleSolver(cfg, batch=2) as es:
+        res = es.solve_equilibrium(history=True, check_every=4)
+        psi = es.get_psi()
+    assert res[0]["iterations"] == int(g["iter65_anderson_m3_stats"][1]) and not res[0]["converged"]
+    np.testing.assert_allclose(res[0]["residual_history"], g["iter65_anderson_m3_diff"], rtol=1e-6, atol=1e-11)
+    assert np.abs(psi[0] - g["iter65_anderson_m3_psi"]).max() <= 1e-8 * np.abs(g["iter65_anderson_m3_psi"]).max()
+    assert np.array_equal(psi[0], psi[1])
+    # depth 5: ill-conditioned mixing (see tests/test_oracle_golden.py) -- the first iterations agree
+    with EnsembleSolver(cfgs["iter33_anderson"], batch=1) as es:
+        r5 = es.solve_equilibrium(history=True)[0]
+    np.testing.assert_allclose(r5["residual_history"][:9], g["iter33_anderson_diff"][:9], rtol=1e-6)
+    assert r5["iterations"] == 150
+
+
 @pytest.mark.parametrize("name", ["iter33", "d3d33", "iter65"])
 def test_free_boundary_golden(hip, golden, name):
     from scpn_fusion_core_amd.ensemble import EnsembleSolver

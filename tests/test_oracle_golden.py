@@ -206,3 +206,17 @@ def test_fastsolver_restatement_matches_compiled_reference(golden):
         s = orc.RefFastSolver(nr, nz, *ext)
         assert np.array_equal(s.run_step(j, 50), g["run50_a"])
         s.close()
+
+
+def test_anderson_picard(golden):
+    """Anderson-accelerated lane.  With depth 3 the oracle reproduces the reference to rounding; with depth 5 the
+    (1e-10-regularised) Gram system is so ill-conditioned that BLAS-vs-loop summation order is amplified after a few
+    mixing steps -- the reference itself does not converge there -- so only the first iterations are comparable."""
+    g = golden("anderson.npz")
+    cfgs = configs_from(g)
+    out = orc.picard_solve(cfgs["iter65_anderson_m3"], trace=True)
+    assert out["iterations"] == int(g["iter65_anderson_m3_stats"][1]) and not out["converged"]
+    np.testing.assert_allclose(out["trace"][:, 4], g["iter65_anderson_m3_diff"], rtol=1e-7, atol=1e-12)
+    assert np.abs(out["psi"] - g["iter65_anderson_m3_psi"]).max() <= 1e-9 * np.abs(g["iter65_anderson_m3_psi"]).max()
+    out5 = orc.picard_solve(cfgs["iter33_anderson"], trace=True)
+    np.testing.assert_allclose(out5["trace"][:9, 4], g["iter33_anderson_diff"][:9], rtol=1e-6)
