@@ -1618,7 +1618,8 @@ struct PicardCtl {
 __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* psum, const int* pbad,
                                                       const double* rmax, const double* rsum, int nblk,
                                                       int nblk_r, PicardCtl ctl, double* hist_diff,
-                                                      double* hist_gs, double* trace, int* n_active) {
+                                                      double* hist_gs, double* trace, int* n_active, int* f_cur, int* f_nxt,
+                                                      int* f_best, int* f_prev, int* f_active) {
     __shared__ double sh[4];
     __shared__ int shbad;
     int b = blockIdx.x;
@@ -1649,6 +1650,7 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
             m.diverged = 1;
             m.active = 0;
             atomicSub(n_active, 1);
+            f_cur[b] = m.cur; f_nxt[b] = m.nxt; f_best[b] = m.best; f_prev[b] = m.prev; f_active[b] = 0;
             return;
         }
         double diff = tot / (double)ctl.n_total;
@@ -1675,6 +1677,8 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
         bool gsc = (!ctl.require_gs) || (gs < ctl.gs_tol);
         if (upd && gsc) { m.converged = 1; m.active = 0; atomicSub(n_active, 1); }
         else if (it + 1 >= ctl.max_iter) { m.active = 0; atomicSub(n_active, 1); }
+        // publish the slot indices / activity the field kernels index (was a separate k_publish_slots launch)
+        f_cur[b] = m.cur; f_nxt[b] = m.nxt; f_best[b] = m.best; f_prev[b] = m.prev; f_active[b] = m.active;
     }
 }
 // copies the per-member slot indices into flat int arrays the kernels index (cur/nxt/best/prev/active)
@@ -1790,10 +1794,14 @@ __device__ __forceinline__ double green_si(double r_src, double z_src, double r_
 // ring_only: evaluate only the Dirichlet ring (the only part the free-boundary loop consumes)
 __global__ void k_coil_flux(Fld outF, int nz, int nr, int ld, const double* r_axis, const double* z_axis,
                             int n_coils, const double* coil_r, const double* coil_z, const double* coil_i,
-                            const double* coil_turns, double mu0, int mode) {
+                            const double* coil_turns, double mu0, int mode, int ring_only = 0) {
     int b = blockIdx.z;
     int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
     if (ir >= nr || iz >= nz) return;
+    if (ring_only && !(iz == 0 || iz == nz - 1 || ir == 0 || ir == nr - 1)) {  // only the Dirichlet ring is consumed
+        outF.at(b)[(long)iz * ld + ir] = 0.0;
+        return;
+    }
     double R = r_axis[ir], Z = z_axis[iz];
     double acc = 0.0;
     for (int c = 0; c < n_coils; ++c) {

@@ -901,12 +901,10 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         ctl.tol = p->tol; ctl.gs_tol = p->gs_tol; ctl.require_gs = p->require_gs_residual; ctl.max_iter = max_iter;
         ctl.iter = 0; ctl.pad = 0; ctl.n_total = (long)nz * nr; ctl.n_interior = (long)(nz - 2) * (nr - 2);
         {
-            ProfScope ps(h, "picard_final", 2);
+            ProfScope ps(h, "picard_final", 1);
             hipLaunchKernelGGL(k_picard_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_part1.p, (const int*)h->d_pbad.p,
                                (const double*)h->d_part2.p, (const double*)h->d_part3.p, nb_d, nb_r, ctl, d_hist_diff.p, d_hist_gs.p,
-                               d_trace.p, h->d_nactive.p);
-            hipLaunchKernelGGL(k_publish_slots, dim3(cdiv(B, 64)), dim3(64), 0, st, (const Member*)h->d_st.p, h->d_cur.p, h->d_nxt.p,
-                               h->d_best.p, h->d_prev.p, h->d_active.p, B);
+                               d_trace.p, h->d_nactive.p, h->d_cur.p, h->d_nxt.p, h->d_best.p, h->d_prev.p, h->d_active.p);
         }
     };
     // iteration 0 runs eagerly (it needs the stand-alone topology kernel and performs all one-time kernel attribute
@@ -1197,8 +1195,9 @@ static int S_free_boundary_solve(Solver* h, const scpn_picard_params* p, int n_c
     Fld extF = h->plain(h->ext.p), bcF = h->plain(h->bc.p), oldF = h->plain(h->old.p);
     {
         ProfScope ps(h, "coil_flux", 1);
+        // only the Dirichlet ring of psi_ext is consumed (free_boundary.py:652-655 and the Picard boundary map)
         hipLaunchKernelGGL(k_coil_flux, g2, BLK2D, 0, st, extF, nz, nr, ld, h->d_r.p, h->d_z.p, n_coils, h->d_fb_r.p, h->d_fb_z.p,
-                           h->d_fb_i.p, coil_turns ? (const double*)h->d_fb_t.p : (const double*)nullptr, 0.0, 1);
+                           h->d_fb_i.p, coil_turns ? (const double*)h->d_fb_t.p : (const double*)nullptr, 0.0, 1, 1);
     }
     hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, bcF, extF, nz, nr, ld, (const int*)nullptr);
     scpn_picard_params q = *p;
