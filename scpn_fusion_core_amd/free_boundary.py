@@ -116,19 +116,109 @@ def interp_psi(kernel: Any, R_pt: float, Z_pt: float) -> float:
                  + t_r * t_z * P[iz + 1, ir + 1])
 
 
+def resolve_shape_target_flux(kernel: Any, coils: CoilSet) -> np.ndarray:
+    """core/fusion_kernel_free_boundary.py:583-605: explicit target values, or the isoflux mean of bilinear psi samples."""
+    if coils.target_flux_points is None:
+        raise ValueError("CoilSet.target_flux_points must be set for shape optimisation.")
+    obs = np.asarray(coils.target_flux_points, dtype=np.float64)
+    n_pts = int(obs.shape[0])
+    if obs.ndim != 2 or obs.shape[1] != 2 or n_pts == 0:
+        raise ValueError("target_flux_points must have shape (n_points, 2) with n_points > 0.")
+    if coils.target_flux_values is not None:
+        target = np.asarray(coils.target_flux_values, dtype=np.float64).reshape(-1)
+        if target.shape[0] != n_pts:
+            raise ValueError("target_flux_values must have the same length as target_flux_points.")
+        if not np.all(np.isfinite(target)):
+            raise ValueError("target_flux_values must contain finite values only.")
+        return target
+    samples = np.array([float(interp_psi(kernel, R_t, Z_t)) for R_t, Z_t in obs], dtype=np.float64)
+    return np.full(n_pts, float(np.mean(samples)), dtype=np.float64)
+
+
+def optimize_coil_currents(kernel: Any, coils: CoilSet, target_flux, tikhonov_alpha: float = 1e-4) -> np.ndarray:
+    """Bounded Tikhonov least squares for the coil currents (core/fusion_kernel_free_boundary.py:491-559).  The response
+    matrix comes from the device Green's-function kernel; the (n_pts + n_coils) x n_coils ``lsq_linear`` stays on the host."""
+    from scipy.optimize import lsq_linear
+
+    if coils.target_flux_points is None:
+        raise ValueError("CoilSet.target_flux_points must be set for optimisation.")
+    if len(coils.positions) == 0:
+        raise ValueError("CoilSet.positions must contain at least one coil.")
+    if len(coils.currents) != len(coils.positions):
+        raise ValueError("CoilSet.currents length must match number of coil positions.")
+    if not np.isfinite(tikhonov_alpha) or tikhonov_alpha < 0.0:
+        raise ValueError("tikhonov_alpha must be finite and non-negative.")
+    obs = np.asarray(coils.target_flux_points, dtype=np.float64)
+    if obs.ndim != 2 or obs.shape[1] != 2 or obs.shape[0] == 0:
+        raise ValueError("target_flux_points must have shape (n_points, 2) with n_points > 0.")
+    target = np.asarray(target_flux, dtype=np.float64).reshape(-1)
+    if target.shape[0] != obs.shape[0]:
+        raise ValueError("target_flux must have the same length as target_flux_points.")
+    if not np.all(np.isfinite(target)):
+        raise ValueError("target_flux must contain finite values only.")
+    M = build_mutual_inductance_matrix(kernel, coils, obs)
+    if not np.all(np.isfinite(M)):
+        raise ValueError("Mutual inductance matrix contains non-finite entries.")
+    n_coils = M.shape[0]
+    A = np.vstack([M.T, np.sqrt(tikhonov_alpha) * np.eye(n_coils)])
+    rhs = np.concatenate([target, np.zeros(n_coils)])
+    if coils.current_limits is not None:
+        limits = np.asarray(coils.current_limits, dtype=np.float64).reshape(-1)
+        if limits.shape[0] != n_coils:
+            raise ValueError("current_limits must have one entry per coil.")
+        lb, ub = -np.abs(limits), np.abs(limits)
+    else:
+        lb, ub = -np.inf * np.ones(n_coils), np.inf * np.ones(n_coils)
+    result = lsq_linear(A, rhs, bounds=(lb, ub), method="trf")
+    if not bool(getattr(result, "success", False)) or not np.all(np.isfinite(result.x)):
+        return np.clip(np.asarray(coils.currents, dtype=np.float64).copy(), lb, ub)
+    return np.asarray(result.x, dtype=np.float64)
+
+
 def solve_free_boundary(kernel: Any, coils: CoilSet, max_outer_iter: int = 20, tol: float = 1e-4,
-                        optimize_shape: bool = False, **_unused) -> dict[str, Any]:
-    """core/fusion_kernel_free_boundary.py:623-739 for ``optimize_shape=False`` (the whole outer loop
-    runs on the device).  ``optimize_shape=True`` (host ``lsq_linear`` between device solves) is
-    SURVEY.md section 8 row f3 and not wired yet."""
+                        optimize_shape: bool = False, tikhonov_alpha: float = 1e-4, **_unused) -> dict[str, Any]:
+    """core/fusion_kernel_free_boundary.py:623-739.  ``optimize_shape=False``: the whole outer loop runs on the device.
+    ``optimize_shape=True``: each outer iteration is a device Picard solve followed by the host-side bounded
+    least-squares update of the coil currents (the reference's structure)."""
     if max_outer_iter < 1:
         raise ValueError("max_outer_iter must be >= 1.")
     if not np.isfinite(tol) or tol < 0.0:
         raise ValueError("tol must be finite and >= 0.")
-    if optimize_shape and coils.target_flux_points is not None:
-        raise NotImplementedError("optimize_shape=True is not on the HIP path yet")
-    return kernel._solve_free_boundary_device(coils, max_outer_iter, tol)
+    if not (optimize_shape and coils.target_flux_points is not None):
+        return kernel._solve_free_boundary_device(coils, max_outer_iter, tol)
+    psi_ext = compute_external_flux(kernel, coils)
+    diff, outer, shape_optimization = float("inf"), 0, None
+    for outer in range(max_outer_iter):
+        kernel.Psi[0, :], kernel.Psi[-1, :] = psi_ext[0, :], psi_ext[-1, :]
+        kernel.Psi[:, 0], kernel.Psi[:, -1] = psi_ext[:, 0], psi_ext[:, -1]
+        psi_old = kernel.Psi.copy()
+        kernel.solve_equilibrium(preserve_initial_state=True, boundary_flux=psi_ext)
+        target_psi = resolve_shape_target_flux(kernel, coils)
+        response = build_mutual_inductance_matrix(kernel, coils, coils.target_flux_points)
+        new_currents = np.asarray(optimize_coil_currents(kernel, coils, target_psi, tikhonov_alpha=tikhonov_alpha),
+                                  dtype=np.float64).reshape(-1)
+        if new_currents.shape != (len(coils.positions),):
+            raise ValueError("optimised coil current vector length must match coil count.")
+        if not np.all(np.isfinite(new_currents)):
+            raise ValueError("optimised coil currents must contain finite values only.")
+        achieved = response.T @ new_currents
+        residual = achieved - target_psi
+        flux_rmse = float(np.sqrt(np.mean(residual**2)))
+        shape_optimization = {
+            "solver_mode": "free_boundary_solver_shape_current_optimization",
+            "target_point_count": int(target_psi.shape[0]), "coil_count": int(len(coils.positions)),
+            "flux_rmse": flux_rmse, "flux_relative_rmse": float(flux_rmse / max(float(np.sqrt(np.mean(target_psi**2))), 1.0)),
+            "max_abs_flux_residual": float(np.max(np.abs(residual))), "target_flux": target_psi.copy(), "achieved_flux": achieved,
+        }
+        coils.currents = new_currents
+        psi_ext = compute_external_flux(kernel, coils)
+        diff = float(np.max(np.abs(kernel.Psi - psi_old)))
+        if diff < tol:
+            break
+    return {"outer_iterations": outer + 1, "final_diff": diff, "coil_currents": coils.currents.copy(),
+            "shape_optimization": shape_optimization}
 
 
 __all__ = ["CoilSet", "coil_flux_grid", "green_points", "green_function", "compute_external_flux",
-           "build_mutual_inductance_matrix", "interp_psi", "solve_free_boundary"]
+           "build_mutual_inductance_matrix", "interp_psi", "resolve_shape_target_flux", "optimize_coil_currents",
+           "solve_free_boundary"]

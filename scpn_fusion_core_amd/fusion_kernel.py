@@ -215,8 +215,12 @@ class FusionKernel:
                 "picard_iterations": r["picard_iterations"], "converged": r["converged"], "shape_optimization": None}
 
     def solve_free_boundary(self, coils: _fb.CoilSet, max_outer_iter: int = 20, tol: float = 1e-4,
-                            optimize_shape: bool = False, **kw) -> dict[str, Any]:
-        return _fb.solve_free_boundary(self, coils, max_outer_iter=max_outer_iter, tol=tol, optimize_shape=optimize_shape, **kw)
+                            optimize_shape: bool = False, tikhonov_alpha: float = 1e-4, **kw) -> dict[str, Any]:
+        return _fb.solve_free_boundary(self, coils, max_outer_iter=max_outer_iter, tol=tol, optimize_shape=optimize_shape,
+                                       tikhonov_alpha=tikhonov_alpha, **kw)
+
+    def optimize_coil_currents(self, coils: _fb.CoilSet, target_flux, tikhonov_alpha: float = 1e-4):
+        return _fb.optimize_coil_currents(self, coils, target_flux, tikhonov_alpha=tikhonov_alpha)
 
     # -- post-processing (core/fusion_kernel.py:450-467) ---------------------------------------------
     def compute_b_field(self) -> None:

@@ -336,6 +336,31 @@ def gen_free_boundary():
     save("free_boundary.npz", **out)
 
 
+# ── shape optimisation  core/fusion_kernel_free_boundary.py:491-559,583-605,664-705 ─
+def gen_shape():
+    out = {}
+    cfg = iter_cfg(33, tol=1e-6, max_iter=400)
+    # SI-consistent units so the coil flux matters: mu0 = 4*pi*1e-7, currents in ampere-turns
+    cfg["physics"]["vacuum_permeability"] = 4e-7 * np.pi
+    cfg["physics"]["plasma_current_target"] = 15.0e6
+    for c in cfg["coils"]:
+        c["current"] = c["current"] * 1.0e6
+    k = make_kernel(cfg)
+    th = np.linspace(0.0, 2.0 * np.pi, 8, endpoint=False)
+    pts = np.column_stack([6.2 + 1.6 * np.cos(th), 2.6 * np.sin(th)])
+    coils = CoilSet(positions=[(c["r"], c["z"]) for c in cfg["coils"]],
+                    currents=np.array([c["current"] for c in cfg["coils"]], dtype=float), turns=[1] * len(cfg["coils"]),
+                    current_limits=np.full(len(cfg["coils"]), 5.0e7), target_flux_points=pts)
+    r = k.solve_free_boundary(coils, max_outer_iter=4, tol=1e-6, optimize_shape=True)
+    out["psi"] = k.Psi
+    out["points"] = pts
+    out["currents"] = r["coil_currents"]
+    out["stats"] = np.array([r["outer_iterations"], r["final_diff"], r["shape_optimization"]["flux_rmse"]])
+    out["_configs"] = np.array(json.dumps({"shape33": cfg}))
+    print("shape", r["outer_iterations"], r["final_diff"], r["coil_currents"])
+    save("shape.npz", **out)
+
+
 # ── (g) compiled hpc/solver.cpp through oracle/_ref  hpc/solver.cpp:200-335 ──
 def gen_fastsolver():
     sys.path.insert(0, str(OUT.parents[1]))
@@ -361,6 +386,6 @@ def gen_fastsolver():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["smooth", "operators", "mgsolve", "polyglot", "picard", "pieces", "green",
-                             "free_boundary", "fastsolver", "anderson"]
+                             "free_boundary", "fastsolver", "anderson", "shape"]
     for w in which:
         globals()[f"gen_{w}"]()

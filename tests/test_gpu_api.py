@@ -95,6 +95,25 @@ def test_fusion_kernel_free_boundary_and_zero_current(golden):
     k0.close()
 
 
+def test_shape_optimisation_outer_loop_golden(golden):
+    """solve_free_boundary(optimize_shape=True): device Picard + host bounded least squares per outer iteration
+    (core/fusion_kernel_free_boundary.py:664-705)."""
+    from scpn_fusion_core_amd.free_boundary import CoilSet
+    from scpn_fusion_core_amd.fusion_kernel import FusionKernel
+
+    g = golden("shape.npz")
+    cfg = configs_from(g)["shape33"]
+    k = FusionKernel(cfg)
+    coils = CoilSet(positions=[(c["r"], c["z"]) for c in cfg["coils"]], currents=np.array([c["current"] for c in cfg["coils"]]),
+                    turns=[1] * len(cfg["coils"]), current_limits=np.full(len(cfg["coils"]), 5.0e7), target_flux_points=g["points"])
+    out = k.solve_free_boundary(coils, max_outer_iter=4, tol=1e-6, optimize_shape=True)
+    assert out["outer_iterations"] == int(g["stats"][0])
+    np.testing.assert_allclose(out["coil_currents"], g["currents"], rtol=1e-6, atol=1e-9)
+    assert np.abs(k.Psi - g["psi"]).max() <= 1e-8 * np.abs(g["psi"]).max()
+    assert out["shape_optimization"]["flux_rmse"] == pytest.approx(float(g["stats"][2]), rel=1e-5, abs=1e-14)
+    k.close()
+
+
 def test_fail_on_diverge_and_revert(orc):
     from scpn_fusion_core_amd.fusion_kernel import FusionKernel
 
