@@ -361,6 +361,26 @@ def gen_shape():
     save("shape.npz", **out)
 
 
+# ── GEQDSK  core/eqdsk.py:128-196,349-541; data file validation/reference_data/diiid/diiid_lmode_1MA.geqdsk ──
+def gen_eqdsk():
+    from scpn_fusion.core.eqdsk import read_geqdsk
+
+    src = REF / "validation" / "reference_data" / "diiid" / "diiid_lmode_1MA.geqdsk"
+    eq = read_geqdsk(src)
+    cfg = eq.to_config("diiid_lmode_1MA")
+    cfg["solver"].update(solver_method="sor", sor_omega=1.6, max_iterations=400, convergence_threshold=1e-4, relaxation_factor=0.1)
+    k = make_kernel({key: val for key, val in cfg.items()})
+    res = k.solve_equilibrium()
+    out = {"scalars": np.array([eq.nw, eq.nh, eq.rdim, eq.zdim, eq.rcentr, eq.rleft, eq.zmid, eq.rmaxis, eq.zmaxis, eq.simag, eq.sibry,
+                                eq.bcentr, eq.current]),
+           "fpol": eq.fpol, "pres": eq.pres, "ffprime": eq.ffprime, "pprime": eq.pprime, "qpsi": eq.qpsi, "psirz": eq.psirz,
+           "rbdry": eq.rbdry, "zbdry": eq.zbdry, "rlim": eq.rlim, "zlim": eq.zlim,
+           "solve_psi": res["psi"], "solve_stats": np.array([float(res["converged"]), res["iterations"], res["residual"]]),
+           "_configs": np.array(json.dumps({"diiid_lmode_1MA": cfg}))}
+    print("eqdsk", eq.nw, eq.nh, eq.current, res["iterations"], res["converged"], res["residual"])
+    save("eqdsk.npz", **out)
+
+
 # ── (g) compiled hpc/solver.cpp through oracle/_ref  hpc/solver.cpp:200-335 ──
 def gen_fastsolver():
     sys.path.insert(0, str(OUT.parents[1]))
@@ -386,6 +406,6 @@ def gen_fastsolver():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["smooth", "operators", "mgsolve", "polyglot", "picard", "pieces", "green",
-                             "free_boundary", "fastsolver", "anderson", "shape"]
+                             "free_boundary", "fastsolver", "anderson", "shape", "eqdsk"]
     for w in which:
         globals()[f"gen_{w}"]()
