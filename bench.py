@@ -65,7 +65,7 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SCPN_BENCH_FORCE_DIST") == "1":  # (the override exercises the RCCL path on one rank)
         import torch
         import torch.distributed as dist  # rendezvous + RCCL gather only; the solver itself is torch-free
 

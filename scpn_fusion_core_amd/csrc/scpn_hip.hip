@@ -341,6 +341,7 @@ static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
                           const SrcGen* sg, const DefectOut* dfo, const BlendArgs* bl) {
     if (bl && ps.c.base) launch_tile<S, true, false, false, true>(h, L, out, in, src, omega, active, ps, nullptr, nullptr, bl);
     else if (bl) launch_tile<S, false, false, false, true>(h, L, out, in, src, omega, active, ps, nullptr, nullptr, bl);
+    else if (dfo && sg) launch_tile<S, false, true, true, false>(h, L, out, in, src, omega, active, ps, sg, dfo);
     else if (dfo) launch_tile<S, false, false, true, false>(h, L, out, in, src, omega, active, ps, nullptr, dfo);
     else if (sg) launch_tile<S, false, true, false, false>(h, L, out, in, src, omega, active, ps, sg, nullptr);
     else if (ps.c.base) launch_tile<S, true, false, false, false>(h, L, out, in, src, omega, active, ps, nullptr, nullptr);
@@ -374,7 +375,7 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
         while (left > 0) {
             const int S = std::min(3, left);
             // the LAST launch of the sequence also produces the coarse rhs (it cannot be combined with source generation)
-            const DefectOut* dfo = (defect && left - S <= 0 && !sgo) ? defect : nullptr;
+            const DefectOut* dfo = (defect && left - S <= 0) ? defect : nullptr;
             const bool last = left - S <= 0;
             const BlendArgs* bl = (blend && last) ? blend : nullptr;  // the last launch writes the blended iterate
             Fld dst = bl ? blend_out : b;
@@ -431,7 +432,7 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
     // the pre-smoother of a tiled level can also emit the coarse rhs (fused defect + restriction)
     static const int defect_min_level = [] { const char* e = std::getenv("SCPN_HIP_DEFECT_MINLVL"); return e ? std::atoi(e) : 0; }();
     auto defect_fusable = [&](int l) {
-        return fused && !srcgen && pre > 0 && l < k && l >= defect_min_level && (long)lv[l]->dev.nz * lv[l]->dev.nr > SMALL_MAX;
+        return fused && pre > 0 && l < k && l >= defect_min_level && (long)lv[l]->dev.nz * lv[l]->dev.nr > SMALL_MAX;
     };
     auto defect_out = [&](int l) {
         DefectOut d;
