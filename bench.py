@@ -135,26 +135,39 @@ def main() -> int:
         es.profile(False)
         dom = max(fam, key=lambda k: fam[k]["ms"]) if fam else None
         if dom:
-            # algorithmic bytes per launch (DESIGN.md "Kernels"): one colour pass reads the 4 neighbours
-            # (the other colour: N/2 values), own old value, source and writes the colour: 16 B per grid
-            # point per launch (= SURVEY 8d "two-pass colour kernels: 32 B/pt/sweep"), x B members.
-            # the LDS-tiled kernel does 3 sweeps per launch with compulsory traffic read psi + read src + write psi
-            per_pt = 24.0 if dom.startswith("smooth_tile") else 16.0
+            # ALGORITHMIC bytes per launch = SURVEY 8(d) per-point figures x what one launch processes:
+            #   RB-SOR sweep 24 B/pt, residual 24, full-weight restriction 10, prolong-add 18, blend+norms 40, one colour pass 16.
+            #   smooth_tile_*_pre  = 3 sweeps + residual + restriction        -> 3*24 + 24 + 10 = 106 B/pt
+            #   smooth_tile_*_post = prolong-add + 3 sweeps                   -> 18 + 3*24      =  90 B/pt
+            # "fused_compulsory" = the bytes the FUSED kernel itself must move once (psi, src in; psi (+coarse rhs/e) out).
+            if dom.endswith("_pre"):
+                per_pt, fused_pt = 106.0, 28.0
+            elif dom.endswith("_post"):
+                per_pt, fused_pt = 90.0, 26.0
+            elif dom.startswith("smooth_tile"):
+                per_pt, fused_pt = 72.0, 24.0
+            elif dom.startswith("blend_fused"):
+                per_pt, fused_pt = 40.0, 32.0
+            else:
+                per_pt, fused_pt = 16.0, 16.0
+            members = B / es.num_groups  # one launch covers one group's members
             avg_s = fam[dom]["ms"] * 1e-3 / fam[dom]["launches"]
-            alg_bytes = per_pt * n_pts * B / es.num_groups  # one launch covers one group's members
+            alg_bytes = per_pt * n_pts * members
             ach = alg_bytes / avg_s / 1e9
             traffic = None  # HBM bytes per launch from the committed PMC passes (same kernel, same grid)
             try:
                 pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
                 if pmc.get("grid") == args.grid and dom in pmc["hbm_bytes_per_member_launch"]:
-                    traffic = round(pmc["hbm_bytes_per_member_launch"][dom] * B / es.num_groups)
+                    traffic = round(pmc["hbm_bytes_per_member_launch"][dom] * members)
             except (OSError, ValueError, KeyError):
                 pass
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "groups": es.num_groups,
-                        "members_per_launch": B // es.num_groups, "isolated_kernel_timing": True,
-                        "avg_launch_us": round(avg_s * 1e6, 2), "alg_bytes_per_launch": alg_bytes,
-                        "families_ms": fam}
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "alg_bytes_per_point": per_pt, "alg_bytes_per_launch": alg_bytes,
+                        "fused_compulsory_bytes_per_point": fused_pt,
+                        "achieved_fused_compulsory": round(fused_pt * n_pts * members / avg_s / 1e9, 1),
+                        "avg_launch_us": round(avg_s * 1e6, 2), "groups": es.num_groups, "members_per_launch": int(members),
+                        "isolated_kernel_timing": True, "families_ms": fam}
 
     # ---- CPU baseline: the C oracle (port of the reference algorithm), one full free-boundary solve of
     #      member 0 on one host core

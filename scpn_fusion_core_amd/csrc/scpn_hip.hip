@@ -367,7 +367,9 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
         return in;
     }
     if (!clip && h->use_fused && alt.base != nullptr) {
-        ProfScope ps(h, lname("smooth_tile", lvl).c_str(), (n_sweeps + 2) / 3);
+        // family name: level + role (pre = ... + fused defect/restriction, post = fused prolongation + ...)
+        const std::string fam = lname("smooth_tile", lvl) + (defect ? "_pre" : (prolong ? "_post" : ""));
+        ProfScope ps(h, fam.c_str(), (n_sweeps + 2) / 3);
         Fld a = in, b = alt;
         int left = n_sweeps;
         ProlongSrc pso = prolong ? *prolong : ProlongSrc{};  // only the first launch adds the coarse correction
