@@ -184,6 +184,47 @@ int scpn_gs_set_seed(scpn_gs *h, const double *seed_j);
 int scpn_gs_picard_solve(scpn_gs *h, const scpn_picard_params *p, scpn_picard_result *results,
                          double *residual_history, double *gs_history, double *trace);
 
+/* ---- Newton-Kantorovich + GMRES ------------------------------------------------
+ * core/fusion_kernel_newton_solver.py:104-372 _newton_solve_dispatch on all members:
+ * Picard warm-up (min(15, max_iter/2) SOR-step iterations), then Newton steps, each solving
+ * (L - diag) delta = -r with restarted GMRES exactly as scipy.sparse.linalg.gmres (SciPy 1.15.3) runs
+ * for core/fusion_kernel_solver_runtime.py:206-315 (restart 50, maxiter 100, atol 1e-8, rtol 1e-6;
+ * preconditioner none | diagonal; "ilu" is not available on the device), psi += 0.5*delta or the
+ * Armijo backtracking line search (:246-294).  p->method is ignored (the warm-up is the SOR branch). */
+typedef struct scpn_newton_opts {
+    int precond;            /* 0 none, 1 diagonal (solver.gmres_preconditioner) */
+    int line_search;        /* solver.newton_line_search */
+    double line_search_c;   /* solver.newton_line_search_c (1e-4) */
+    int max_backtracks;     /* solver.newton_line_search_max_backtracks (6) */
+    int warmup_steps;       /* < 0: min(15, max_iter/2) as the reference */
+    double newton_alpha;    /* 0.5 */
+    int gmres_restart;      /* 50 (at most 50) */
+    int gmres_maxiter;      /* 100 restart cycles */
+    double gmres_atol;      /* 1e-8 */
+    double gmres_rtol;      /* 1e-6 */
+    int poll_every;         /* host polls the device "inner loop finished" word every this many columns (>=1) */
+    int reserved;
+} scpn_newton_opts;
+
+typedef struct scpn_newton_result {
+    int converged;
+    int iterations;
+    int diverged;
+    int n_hist;               /* entries of residual_history */
+    int n_gs_hist;            /* entries of gs_residual_history */
+    int ls_attempts, ls_accepts, ls_rejects;
+    int gmres_nonconverged, gmres_breakdown, gmres_last_info;
+    int reserved;
+    long gmres_inner;         /* total GMRES inner iterations (operator applications) */
+    double residual;          /* residual_history[-1], +inf when empty */
+    double gs_residual;       /* gs_residual_history[-1] */
+    double gs_residual_best;
+} scpn_newton_result;
+
+/* histories (may be NULL): [batch][max_iter + 2], entry counts in the results */
+int scpn_gs_newton_solve(scpn_gs *h, const scpn_picard_params *p, const scpn_newton_opts *o,
+                         scpn_newton_result *results, double *residual_history, double *gs_history);
+
 /* core/fusion_kernel_free_boundary.py:623-739 with optimize_shape=False: coil arrays [batch][n];
  * outer_iterations[batch], final_diff[batch], picard_iters [batch][max_outer] (may be NULL) */
 int scpn_gs_free_boundary_solve(scpn_gs *h, const scpn_picard_params *p, int n_coils,

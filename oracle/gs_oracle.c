@@ -897,3 +897,437 @@ double orc_fastsolver_sweeps(double *psi, const double *j, int nr, int nz, doubl
     if (performed) *performed = done;
     return last;
 }
+
+/* =====================================================================================
+ * Newton-Kantorovich + GMRES  
+ * ===================================================================================== */
+
+void orc_dlartg(double f, double g, double *c, double *s, double *r) {
+    /* LAPACK 3.11 SRC/la_lartg.f90 (real double) */
+    const double safmin = 2.2250738585072014e-308, safmax = 1.0 / safmin;
+    const double rtmin = sqrt(safmin), rtmax = sqrt(safmax / 2.0);
+    double f1 = fabs(f), g1 = fabs(g);
+    if (g == 0.0) { *c = 1.0; *s = 0.0; *r = f; }
+    else if (f == 0.0) { *c = 0.0; *s = copysign(1.0, g); *r = g1; }
+    else if (f1 > rtmin && f1 < rtmax && g1 > rtmin && g1 < rtmax) {
+        double d = sqrt(f * f + g * g);
+        *c = f1 / d;
+        *r = copysign(d, f);
+        *s = g / *r;
+    } else {
+        double u = fmin(safmax, fmax(safmin, fmax(f1, g1)));
+        double fs = f / u, gs = g / u;
+        double d = sqrt(fs * fs + gs * gs);
+        *c = fabs(fs) / d;
+        *r = copysign(d, f);
+        *s = gs / *r;
+        *r = *r * u;
+    }
+}
+
+/* BLAS-like dot: 32 interleaved partial sums (the reference's OpenBLAS kernel order is not
+ * specified; parity on this path is to tolerance) */
+static double dotn(const double *a, const double *b, long n) {
+    double acc[32] = {0};
+    long i = 0;
+    for (; i + 32 <= n; i += 32)
+        for (int j = 0; j < 32; ++j) acc[j] += a[i + j] * b[i + j];
+    for (int j = 0; i < n; ++i, ++j) acc[j] += a[i] * b[i];
+    for (int w = 16; w >= 1; w >>= 1)
+        for (int j = 0; j < w; ++j) acc[j] += acc[j + w];
+    return acc[0];
+}
+static double nrm2n(const double *a, long n) { return sqrt(dotn(a, a, n)); }
+
+/* matvec of core/fusion_kernel_newton_solver.py:217-222: (L v - diag_term*v) on the interior */
+static void newton_matvec(const double *v_flat, const double *diag_term, const double *r_grid, int nz, int nr,
+                          double dr, double dz, double *v2d, double *lv, const double *zero, double *out) {
+    int ni = nr - 2;
+    memset(v2d, 0, sizeof(double) * (size_t)nz * nr);
+    for (int iz = 1; iz < nz - 1; ++iz)
+        memcpy(v2d + IDX(iz, 1), v_flat + (long)(iz - 1) * ni, sizeof(double) * (size_t)ni);
+    orc_mg_residual(v2d, zero, r_grid, nz, nr, dr, dz, lv); /* apply_gs_operator: same stencil, zero source */
+    for (int iz = 1; iz < nz - 1; ++iz)
+        for (int ir = 1; ir < nr - 1; ++ir)
+            out[(long)(iz - 1) * ni + (ir - 1)] = lv[IDX(iz, ir)] - diag_term[IDX(iz, ir)] * v2d[IDX(iz, ir)];
+}
+
+int orc_gmres_gs(const double *diag_term, const double *r_grid, int nz, int nr, double dr, double dz,
+                 const double *rhs, const double *inv_diag, int restart, int maxiter, double atol_in,
+                 double rtol, double *x, long *inner_out) {
+    long n = (long)(nz - 2) * (nr - 2), ng = (long)nz * nr;
+    double *v2d = dalloc(ng), *lv = dalloc(ng), *zero = dalloc(ng);
+    double *r = dalloc(n), *w = dalloc(n), *av = dalloc(n);
+    memset(x, 0, sizeof(double) * (size_t)n);
+    long inner = 0;
+    if (inner_out) *inner_out = 0;
+    double bnrm2 = nrm2n(rhs, n);
+    double atol = fmax(atol_in, rtol * bnrm2);
+    if (bnrm2 == 0.0) { free(v2d); free(lv); free(zero); free(r); free(w); free(av); return 0; }
+    const double eps = 2.220446049250313e-16;
+    if (restart > n) restart = (int)n;
+    double Mb;
+    if (inv_diag) { for (long i = 0; i < n; ++i) w[i] = inv_diag[i] * rhs[i]; Mb = nrm2n(w, n); }
+    else Mb = bnrm2;
+    double ptol_max_factor = 1.0;
+    double ptol = Mb * fmin(ptol_max_factor, atol / bnrm2);
+    double presid = 0.0, rnorm = 0.0;
+    double *v = dalloc((long)(restart + 1) * n);
+    double *h = dalloc((long)restart * (restart + 1));
+    double *giv = dalloc(2L * restart), *S = dalloc(restart + 1), *y = dalloc(restart + 1);
+#define H(c, k) h[(long)(c) * (restart + 1) + (k)]
+    int info = maxiter, done = 0;
+    for (int it = 0; it < maxiter && !done; ++it) {
+        if (it == 0) {
+            memcpy(r, rhs, sizeof(double) * (size_t)n); /* x0 = 0 -> r = b.copy() */
+            if (nrm2n(r, n) < atol) { info = 0; rnorm = 0.0; done = 2; break; }
+        }
+        if (inv_diag) for (long i = 0; i < n; ++i) v[i] = inv_diag[i] * r[i];
+        else memcpy(v, r, sizeof(double) * (size_t)n);
+        double tmp = nrm2n(v, n);
+        double inv = 1.0 / tmp;
+        for (long i = 0; i < n; ++i) v[i] *= inv;
+        for (int i = 0; i <= restart; ++i) S[i] = 0.0;
+        S[0] = tmp;
+        int breakdown = 0, col = 0;
+        for (col = 0; col < restart; ++col) {
+            newton_matvec(v + (long)col * n, diag_term, r_grid, nz, nr, dr, dz, v2d, lv, zero, av);
+            if (inv_diag) for (long i = 0; i < n; ++i) w[i] = inv_diag[i] * av[i];
+            else memcpy(w, av, sizeof(double) * (size_t)n);
+            double h0 = nrm2n(w, n);
+            for (int k = 0; k <= col; ++k) {
+                const double *vk = v + (long)k * n;
+                double t = dotn(vk, w, n);
+                H(col, k) = t;
+                for (long i = 0; i < n; ++i) w[i] -= t * vk[i];
+            }
+            double h1 = nrm2n(w, n);
+            H(col, col + 1) = h1;
+            double *vn = v + (long)(col + 1) * n;
+            memcpy(vn, w, sizeof(double) * (size_t)n);
+            if (h1 <= eps * h0) { H(col, col + 1) = 0.0; breakdown = 1; }
+            else { double ih = 1.0 / h1; for (long i = 0; i < n; ++i) vn[i] *= ih; }
+            for (int k = 0; k < col; ++k) {
+                double c = giv[2 * k], s = giv[2 * k + 1];
+                double n0 = H(col, k), n1 = H(col, k + 1);
+                H(col, k) = c * n0 + s * n1;
+                H(col, k + 1) = -s * n0 + c * n1;
+            }
+            double c, s, mag;
+            orc_dlartg(H(col, col), H(col, col + 1), &c, &s, &mag);
+            giv[2 * col] = c; giv[2 * col + 1] = s;
+            H(col, col) = mag; H(col, col + 1) = 0.0;
+            double t2 = -s * S[col];
+            S[col] = c * S[col];
+            S[col + 1] = t2;
+            presid = fabs(t2);
+            inner += 1;
+            if (presid <= ptol || breakdown) break;
+        }
+        if (col == restart) col = restart - 1; /* python's loop variable after exhaustion */
+        if (H(col, col) == 0.0) S[col] = 0.0;
+        for (int k = 0; k <= col; ++k) y[k] = S[k];
+        for (int k = col; k > 0; --k)
+            if (y[k] != 0.0) {
+                y[k] /= H(k, k);
+                double t = y[k];
+                for (int j = 0; j < k; ++j) y[j] -= t * H(k, j);
+            }
+        if (y[0] != 0.0) y[0] /= H(0, 0);
+        for (long i = 0; i < n; ++i) { /* x += y @ v[:col+1] */
+            double acc = 0.0;
+            for (int k = 0; k <= col; ++k) acc += y[k] * v[(long)k * n + i];
+            x[i] += acc;
+        }
+        newton_matvec(x, diag_term, r_grid, nz, nr, dr, dz, v2d, lv, zero, av);
+        for (long i = 0; i < n; ++i) r[i] = rhs[i] - av[i];
+        rnorm = nrm2n(r, n);
+        if (rnorm <= atol) break;
+        else if (breakdown) break;
+        else if (presid <= ptol) ptol_max_factor = fmax(eps, 0.25 * ptol_max_factor);
+        else ptol_max_factor = fmin(1.0, 1.5 * ptol_max_factor);
+        ptol = presid * fmin(ptol_max_factor, atol / rnorm);
+    }
+#undef H
+    if (done != 2) info = (rnorm <= atol) ? 0 : maxiter;
+    if (inner_out) *inner_out = inner;
+    free(v2d); free(lv); free(zero); free(r); free(w); free(av); free(v); free(h); free(giv); free(S); free(y);
+    return info;
+}
+
+void orc_profile_jacobian(const double *psi, const double *j_phi, const double *r_axis, int nz, int nr,
+                          double dr, double dz, double psi_axis_in, double psi_bnd_in, double i_target,
+                          int external_profile_mode, double *dj) {
+    long n = (long)nz * nr;
+    double psi_axis = isfinite(psi_axis_in) ? psi_axis_in : 0.0;
+    double psi_bnd = psi_bnd_in;
+    if (isnan(psi_bnd) || (isinf(psi_bnd) && psi_bnd > 0)) psi_bnd = psi_axis + 1e-9;
+    else if (isinf(psi_bnd)) psi_bnd = psi_axis - 1e-9;
+    double denom = psi_bnd - psi_axis;
+    if (!isfinite(denom)) denom = 1e-9;
+    if (fabs(denom) < 1e-9) denom = denom >= 0.0 ? 1e-9 : -1e-9;
+    double *tmp = dalloc(n);
+    unsigned char *mask = (unsigned char *)calloc((size_t)n, 1);
+    for (int iz = 0; iz < nz; ++iz)
+        for (int ir = 0; ir < nr; ++ir) {
+            double ps = psi[IDX(iz, ir)];
+            if (isnan(ps)) ps = psi_axis;
+            else if (isinf(ps)) ps = ps > 0 ? psi_axis + 1e9 : psi_axis - 1e9;
+            double rr = r_axis[ir];
+            if (isnan(rr)) rr = 0.0; else if (isinf(rr)) rr = rr > 0 ? 1e6 : 0.0;
+            rr = fmin(fmax(rr, 0.0), 1e6);
+            double pn = (ps - psi_axis) / denom;
+            int m = (pn >= 0) && (pn < 1.0);
+            mask[IDX(iz, ir)] = (unsigned char)m;
+            tmp[IDX(iz, ir)] = m ? (1 - pn) * rr : 0.0;
+        }
+    if (external_profile_mode) {
+        double scale = fmax(fabs(denom), 1e-9);
+        for (long i = 0; i < n; ++i) {
+            double ja = j_phi[i];
+            if (isnan(ja)) ja = 0.0; else if (isinf(ja)) ja = 1e12;
+            ja = fabs(ja);
+            double d = mask[i] ? -ja / scale : 0.0;
+            if (isnan(d)) d = 0.0; else if (isinf(d)) d = d > 0 ? 0.0 : -1e12;
+            dj[i] = d;
+        }
+        free(tmp); free(mask);
+        return;
+    }
+    double it = isfinite(i_target) ? i_target : 0.0;
+    double s = orc_np_sum(tmp, n) * dr * dz;
+    if (!isfinite(s)) s = 0.0;
+    double c = it / fmax(fabs(s), 1e-9);
+    for (int iz = 0; iz < nz; ++iz)
+        for (int ir = 0; ir < nr; ++ir) {
+            double rr = r_axis[ir];
+            if (isnan(rr)) rr = 0.0; else if (isinf(rr)) rr = rr > 0 ? 1e6 : 0.0;
+            rr = fmin(fmax(rr, 0.0), 1e6);
+            double d = mask[IDX(iz, ir)] ? (-c * rr) / denom : 0.0;
+            if (isnan(d)) d = 0.0; else if (isinf(d)) d = d > 0 ? 1e12 : -1e12;
+            dj[IDX(iz, ir)] = d;
+        }
+    free(tmp); free(mask);
+}
+
+/* sqrt(sum(r[1:-1,1:-1]**2)) and sqrt(mean(...)) of core/fusion_kernel_newton_solver.py:199-200 */
+static void interior_norms(const double *r, int nz, int nr, double *sum_norm, double *rms) {
+    long ni = (long)(nz - 2) * (nr - 2);
+    double *sq = dalloc(ni);
+    for (int iz = 1; iz < nz - 1; ++iz)
+        for (int ir = 1; ir < nr - 1; ++ir) {
+            double v = r[IDX(iz, ir)];
+            sq[(long)(iz - 1) * (nr - 2) + (ir - 1)] = v * v;
+        }
+    double s = orc_np_sum(sq, ni);
+    free(sq);
+    if (sum_norm) *sum_norm = sqrt(s);
+    if (rms) *rms = sqrt(s / (double)ni);
+}
+
+typedef struct {
+    const orc_picard_params *p;
+    const double *r_axis, *z_axis, *rr;
+    double dr, dz;
+} nctx;
+
+/* axis + X-point + 0.1 heuristic + source update (when not external_profile_mode) */
+static void newton_topology_source(const nctx *c, const double *psi, double *j_phi, double *psi_axis, double *psi_bnd) {
+    const orc_picard_params *p = c->p;
+    int aiz, air;
+    long xidx;
+    orc_find_axis(psi, p->nz, p->nr, &aiz, &air, psi_axis);
+    orc_find_x_point(psi, c->z_axis, p->nz, p->nr, c->dr, c->dz, p->z_min, &xidx, psi_bnd);
+    if (fabs(*psi_axis - *psi_bnd) < 0.1) *psi_bnd = *psi_axis * 0.1;
+    if (!p->external_profile_mode)
+        orc_update_source(psi, c->r_axis, p->nz, p->nr, c->dr, c->dz, *psi_axis, *psi_bnd, p->mu0, p->i_target,
+                          p->hmode, p->ped_p, p->ped_ff, j_phi);
+}
+
+int orc_newton_solve(const orc_picard_params *p, const orc_newton_opts *o, double *psi,
+                     const double *boundary_flux, double *j_phi, orc_newton_result *res, double *hist,
+                     double *gs_hist) {
+    int nz = p->nz, nr = p->nr;
+    long n = (long)nz * nr, ni = (long)(nz - 2) * (nr - 2);
+    memset(res, 0, sizeof(*res));
+    double *r_axis = dalloc(nr), *z_axis = dalloc(nz), *rr = dalloc(n);
+    orc_linspace(p->r_min, p->r_max, nr, r_axis);
+    orc_linspace(p->z_min, p->z_max, nz, z_axis);
+    double dr = r_axis[1] - r_axis[0], dz = z_axis[1] - z_axis[0];
+    meshgrid_r(r_axis, nz, nr, rr);
+    nctx cx = {p, r_axis, z_axis, rr, dr, dz};
+
+    double *bc = dalloc(n);
+    if (p->has_boundary_flux && boundary_flux) memcpy(bc, boundary_flux, sizeof(double) * (size_t)n);
+    else if (p->preserve_initial_state) memcpy(bc, psi, sizeof(double) * (size_t)n);
+    else orc_vacuum_field(r_axis, z_axis, nz, nr, p->n_coils, p->coil_r, p->coil_z, p->coil_i, p->mu0, bc);
+    if (p->preserve_initial_state) apply_bc(psi, bc, nz, nr);
+    else memcpy(psi, bc, sizeof(double) * (size_t)n);
+
+    double *source = dalloc(n), *psi_new = dalloc(n), *tmp = dalloc(n), *rk = dalloc(n), *dj = dalloc(n),
+           *diag = dalloc(n), *rhs = dalloc(ni), *delta = dalloc(ni), *invd = dalloc(ni), *psi_prev = dalloc(n),
+           *src_trial = dalloc(n);
+    int nh = 0, ngh = 0;
+    double last_hist = INFINITY, gs_best = INFINITY, gs_last = INFINITY;
+    int converged = 0, final_iter = 0, have_source = 0;
+    int max_iter = p->max_iter;
+    int warmup = max_iter / 2 < 15 ? max_iter / 2 : 15;
+#define PUSH_H(v) do { last_hist = (v); if (hist) hist[nh] = (v); nh++; } while (0)
+#define PUSH_G(v) do { gs_last = (v); if (gs_hist) gs_hist[ngh] = (v); ngh++; if ((v) < gs_best) gs_best = (v); } while (0)
+#define MAKE_SOURCE(dst) do { for (int iz = 0; iz < nz; ++iz) for (int ir = 0; ir < nr; ++ir) \
+        (dst)[IDX(iz, ir)] = ((-p->mu0) * r_axis[ir]) * j_phi[IDX(iz, ir)]; } while (0)
+
+    /* _seed_plasma */
+    if (fabs(p->i_target) < 1e-12) {
+        memset(j_phi, 0, sizeof(double) * (size_t)n);
+    } else {
+        double r_center = (p->r_min + p->r_max) / 2.0;
+        for (int iz = 0; iz < nz; ++iz)
+            for (int ir = 0; ir < nr; ++ir) {
+                double a = r_axis[ir] - r_center;
+                j_phi[IDX(iz, ir)] = exp(-(a * a + z_axis[iz] * z_axis[iz]) / 2.0);
+            }
+        double i_seed = (orc_np_sum(j_phi, n) * dr) * dz;
+        if (i_seed > 0) {
+            double s = p->i_target / i_seed;
+            for (long i = 0; i < n; ++i) j_phi[i] *= s;
+        }
+        MAKE_SOURCE(source);
+        for (int s = 0; s < 50; ++s) {
+            orc_jacobi_step(psi, source, rr, nz, nr, dr, dz, tmp);
+            memcpy(psi, tmp, sizeof(double) * (size_t)n);
+        }
+    }
+
+    /* Phase A: Picard warm-up (the "newton" method string falls to the SOR branch of _elliptic_solve) */
+    for (int k = 0; k < warmup; ++k) {
+        final_iter = k;
+        double psi_axis, psi_bnd;
+        newton_topology_source(&cx, psi, j_phi, &psi_axis, &psi_bnd);
+        MAKE_SOURCE(source);
+        have_source = 1;
+        orc_sor_step(psi, source, rr, nz, nr, dr, dz, p->sor_omega, psi_new);
+        apply_bc(psi_new, bc, nz, nr);
+        int bad = 0;
+        for (long i = 0; i < n; ++i) if (!isfinite(psi_new[i])) { bad = 1; break; }
+        if (bad) { res->diverged = 1; break; }
+        for (long i = 0; i < n; ++i) tmp[i] = fabs(psi_new[i] - psi[i]);
+        double diff = orc_np_sum(tmp, n) / (double)n;
+        PUSH_H(diff);
+        for (long i = 0; i < n; ++i) psi[i] = (1.0 - p->alpha) * psi[i] + p->alpha * psi_new[i];
+        apply_bc(psi, bc, nz, nr);
+        double gs = orc_gs_residual_rms(psi, source, rr, nz, nr, dr, dz);
+        PUSH_G(gs);
+        if (diff < p->tol && ((!p->require_gs_residual) || gs < p->gs_tol)) { converged = 1; break; }
+    }
+
+    /* Phase B: Newton */
+    if (!converged) {
+        for (int k = warmup; k < max_iter; ++k) {
+            final_iter = k;
+            double psi_axis, psi_bnd;
+            newton_topology_source(&cx, psi, j_phi, &psi_axis, &psi_bnd);
+            MAKE_SOURCE(source);
+            have_source = 1;
+            orc_mg_residual(psi, source, rr, nz, nr, dr, dz, rk);
+            double res_norm, gs;
+            interior_norms(rk, nz, nr, &res_norm, &gs);
+            if (!o->line_search) PUSH_H(res_norm);
+            PUSH_G(gs);
+            if (res_norm < p->tol && ((!p->require_gs_residual) || gs < p->gs_tol)) {
+                if (o->line_search) PUSH_H(res_norm);
+                converged = 1;
+                break;
+            }
+            orc_profile_jacobian(psi, j_phi, r_axis, nz, nr, dr, dz, psi_axis, psi_bnd, p->i_target,
+                                 p->external_profile_mode, dj);
+            for (int iz = 0; iz < nz; ++iz)
+                for (int ir = 0; ir < nr; ++ir) diag[IDX(iz, ir)] = ((-p->mu0) * r_axis[ir]) * dj[IDX(iz, ir)];
+            for (int iz = 1; iz < nz - 1; ++iz)
+                for (int ir = 1; ir < nr - 1; ++ir) rhs[(long)(iz - 1) * (nr - 2) + (ir - 1)] = -rk[IDX(iz, ir)];
+            const double *pre = NULL;
+            if (o->precond == 1) {
+                double dl = -2.0 / (dr * dr) - 2.0 / (dz * dz);
+                for (int iz = 1; iz < nz - 1; ++iz)
+                    for (int ir = 1; ir < nr - 1; ++ir) {
+                        double dj_ = dl - diag[IDX(iz, ir)];
+                        double sd = fabs(dj_) > 1e-12 ? dj_ : (dj_ >= 0.0 ? 1e-12 : -1e-12);
+                        invd[(long)(iz - 1) * (nr - 2) + (ir - 1)] = 1.0 / sd;
+                    }
+                pre = invd;
+            }
+            long inner = 0;
+            int info = orc_gmres_gs(diag, rr, nz, nr, dr, dz, rhs, pre, 50, 100, 1e-8, 1e-6, delta, &inner);
+            res->gmres_matvecs += inner;
+            res->gmres_last_info = info;
+            if (info > 0) res->gmres_nonconverged += 1;
+            else if (info < 0) res->gmres_breakdown += 1;
+
+            if (o->line_search) {
+                memcpy(psi_prev, psi, sizeof(double) * (size_t)n);
+                double alpha = 0.5;
+                int accepted = 0;
+                memcpy(src_trial, source, sizeof(double) * (size_t)n);
+                for (int b = 0; b < o->max_backtracks; ++b) {
+                    res->ls_attempts += 1;
+                    memcpy(psi, psi_prev, sizeof(double) * (size_t)n);
+                    for (int iz = 1; iz < nz - 1; ++iz)
+                        for (int ir = 1; ir < nr - 1; ++ir)
+                            psi[IDX(iz, ir)] = psi_prev[IDX(iz, ir)] + alpha * delta[(long)(iz - 1) * (nr - 2) + (ir - 1)];
+                    apply_bc(psi, bc, nz, nr);
+                    if (!p->external_profile_mode) {
+                        double ta, tb;
+                        newton_topology_source(&cx, psi, j_phi, &ta, &tb);
+                        MAKE_SOURCE(src_trial);
+                    }
+                    orc_mg_residual(psi, src_trial, rr, nz, nr, dr, dz, tmp);
+                    double tn;
+                    interior_norms(tmp, nz, nr, &tn, NULL);
+                    if (tn <= (1.0 - o->line_search_c * alpha) * res_norm) { accepted = 1; res->ls_accepts += 1; break; }
+                    res->ls_rejects += 1;
+                    alpha *= 0.5;
+                }
+                if (!accepted) {
+                    for (int iz = 1; iz < nz - 1; ++iz)
+                        for (int ir = 1; ir < nr - 1; ++ir)
+                            psi[IDX(iz, ir)] = psi_prev[IDX(iz, ir)] + alpha * delta[(long)(iz - 1) * (nr - 2) + (ir - 1)];
+                    for (int ir = 0; ir < nr; ++ir) { psi[IDX(0, ir)] = psi_prev[IDX(0, ir)]; psi[IDX(nz - 1, ir)] = psi_prev[IDX(nz - 1, ir)]; }
+                    for (int iz = 0; iz < nz; ++iz) { psi[IDX(iz, 0)] = psi_prev[IDX(iz, 0)]; psi[IDX(iz, nr - 1)] = psi_prev[IDX(iz, nr - 1)]; }
+                    apply_bc(psi, bc, nz, nr);
+                    if (!p->external_profile_mode) {
+                        double ta, tb;
+                        newton_topology_source(&cx, psi, j_phi, &ta, &tb);
+                    }
+                    /* Source stays the pre-step one (reference: only J_phi is refreshed here) */
+                } else {
+                    memcpy(source, src_trial, sizeof(double) * (size_t)n);
+                }
+                orc_mg_residual(psi, source, rr, nz, nr, dr, dz, tmp);
+                double pn;
+                interior_norms(tmp, nz, nr, &pn, NULL);
+                PUSH_H(pn);
+            } else {
+                for (int iz = 1; iz < nz - 1; ++iz)
+                    for (int ir = 1; ir < nr - 1; ++ir)
+                        psi[IDX(iz, ir)] += 0.5 * delta[(long)(iz - 1) * (nr - 2) + (ir - 1)];
+                apply_bc(psi, bc, nz, nr);
+            }
+            int bad = 0;
+            for (long i = 0; i < n; ++i) if (!isfinite(psi[i])) { bad = 1; break; }
+            if (bad) { res->diverged = 1; break; }
+        }
+    }
+#undef PUSH_H
+#undef PUSH_G
+#undef MAKE_SOURCE
+    res->converged = converged;
+    res->iterations = final_iter + 1;
+    res->residual = last_hist;
+    res->gs_residual = have_source ? gs_last : INFINITY;
+    res->gs_residual_best = have_source ? gs_best : INFINITY;
+    res->n_hist = nh;
+    res->n_gs_hist = ngh;
+    free(r_axis); free(z_axis); free(rr); free(bc); free(source); free(psi_new); free(tmp); free(rk); free(dj);
+    free(diag); free(rhs); free(delta); free(invd); free(psi_prev); free(src_trial);
+    return 0;
+}

@@ -169,6 +169,53 @@ double orc_fastsolver_sweeps(double *psi_state, const double *j, int nr, int nz,
                              double r_max, double z_min, double z_max, double boundary_value,
                              double omega, int iterations, double tol, int *performed);
 
+/* ---- Newton-Kantorovich + GMRES ---------------------------------------------
+ * core/fusion_kernel_newton_solver.py:104-372 _newton_solve_dispatch; helpers
+ * core/fusion_kernel_solver_runtime.py:25-68 (residual / operator), :71-136 (profile Jacobian),
+ * :206-315 (linear solve).  The linear solve is scipy.sparse.linalg.gmres -- third-party,
+ * SciPy 1.15.3 (scipy/sparse/linalg/_isolve/iterative.py, pure-Python restarted GMRES with
+ * modified Gram-Schmidt + Givens rotations from LAPACK dlartg, LAPACK 3.11 la_lartg.f90 as
+ * bundled by the OpenBLAS 0.3.28 wheel) -- restated here from its published algorithm with
+ * restart=50, maxiter=100, atol=1e-8, rtol=1e-6.  Dot products / norms go through BLAS in the
+ * reference, so parity is to floating-point tolerance, not bit-exact.  The "ilu" preconditioner
+ * (SuperLU spilu) is not restated. */
+typedef struct orc_newton_opts {
+    int precond;        /* 0 none, 1 diagonal (solver.gmres_preconditioner) */
+    int line_search;    /* solver.newton_line_search */
+    double line_search_c;
+    int max_backtracks;
+} orc_newton_opts;
+
+typedef struct orc_newton_result {
+    int converged, iterations, diverged;
+    double residual;          /* residual_history[-1] (inf when empty) */
+    double gs_residual, gs_residual_best;
+    int ls_attempts, ls_accepts, ls_rejects;
+    int gmres_nonconverged, gmres_breakdown, gmres_last_info;
+    int n_hist, n_gs_hist;    /* entries written to the history buffers */
+    long gmres_matvecs;       /* total inner GMRES iterations (telemetry for the bench) */
+} orc_newton_result;
+
+/* LAPACK 3.11 dlartg (plane rotation), exposed for the pin test against scipy.linalg.lapack.dlartg */
+void orc_dlartg(double f, double g, double *c, double *s, double *r);
+
+/* restarted GMRES exactly as SciPy 1.15.3 runs it for the Newton step.  op: y = L*x - diag*x on the
+ * interior of an (nz, nr) grid (vectors have (nz-2)*(nr-2) entries, row-major).  inv_diag may be
+ * NULL (no preconditioner).  returns info (0 or maxiter); *inner_out = inner iterations done */
+int orc_gmres_gs(const double *diag_term, const double *r_grid, int nz, int nr, double dr, double dz,
+                 const double *rhs, const double *inv_diag, int restart, int maxiter, double atol,
+                 double rtol, double *x_out, long *inner_out);
+
+/* core/fusion_kernel_solver_runtime.py:71-136 compute_profile_jacobian (dJ/dpsi field) */
+void orc_profile_jacobian(const double *psi, const double *j_phi, const double *r_axis, int nz, int nr,
+                          double dr, double dz, double psi_axis, double psi_bnd, double i_target,
+                          int external_profile_mode, double *dj_dpsi);
+
+/* _newton_solve_dispatch.  hist / gs_hist: caller buffers of >= 2*max_iter+2 doubles (may be NULL) */
+int orc_newton_solve(const orc_picard_params *p, const orc_newton_opts *o, double *psi,
+                     const double *boundary_flux, double *j_phi, orc_newton_result *res, double *hist,
+                     double *gs_hist);
+
 #ifdef __cplusplus
 }
 #endif

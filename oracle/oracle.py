@@ -95,6 +95,11 @@ def lib() -> C.CDLL:
         L.orc_gs_solve_np.argtypes = [_d, _d, _d, _d, _i, _i, _d, _d, _i, _i, _d, _d, _d, _dp]
         L.orc_fastsolver_sweeps.restype = _d
         L.orc_fastsolver_sweeps.argtypes = [_dp, _dp, _i, _i, _d, _d, _d, _d, _d, _d, _i, _d, C.POINTER(_i)]
+        L.orc_dlartg.argtypes = [_d, _d, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]
+        L.orc_gmres_gs.argtypes = [_dp, _dp, _i, _i, _d, _d, _dp, C.c_void_p, _i, _i, _d, _d, _dp, C.POINTER(C.c_long)]
+        L.orc_profile_jacobian.argtypes = [_dp, _dp, _dp, _i, _i, _d, _d, _d, _d, _d, _i, _dp]
+        L.orc_newton_solve.argtypes = [C.POINTER(PicardParams), C.POINTER(NewtonOpts), _dp, C.c_void_p, _dp,
+                                       C.POINTER(NewtonResult), C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -254,7 +259,7 @@ def update_source(psi, r_axis, dr, dz, psi_axis, psi_bnd, mu0, i_target, hmode=F
     return j, i_cur
 
 
-_METHODS = {"multigrid": 0, "sor": 1, "jacobi": 2, "anderson": 3}
+_METHODS = {"multigrid": 0, "sor": 1, "jacobi": 2, "anderson": 3, "newton": 4}
 
 
 def make_params(cfg: dict, *, preserve=False, has_bc=False, external_profile_mode=False):
@@ -311,6 +316,86 @@ def picard_solve(cfg, psi0=None, boundary_flux=None, *, preserve=False, external
     if trace:
         out["trace"] = tr[: res.iterations]
     return out
+
+
+class NewtonOpts(C.Structure):
+    _fields_ = [("precond", _i), ("line_search", _i), ("line_search_c", _d), ("max_backtracks", _i)]
+
+
+class NewtonResult(C.Structure):
+    _fields_ = [
+        ("converged", _i), ("iterations", _i), ("diverged", _i),
+        ("residual", _d), ("gs_residual", _d), ("gs_residual_best", _d),
+        ("ls_attempts", _i), ("ls_accepts", _i), ("ls_rejects", _i),
+        ("gmres_nonconverged", _i), ("gmres_breakdown", _i), ("gmres_last_info", _i),
+        ("n_hist", _i), ("n_gs_hist", _i), ("gmres_matvecs", C.c_long),
+    ]
+
+
+def newton_opts_from_cfg(cfg: dict) -> NewtonOpts:
+    """core/fusion_kernel_newton_runtime.py:75-150 parse_newton_dispatch_config (the GMRES / line-search keys)."""
+    sol = cfg["solver"]
+    mode = str(sol.get("gmres_preconditioner", "none")).strip().lower()
+    if mode in ("", "auto", "default", "legacy"):
+        mode = "none"
+    if mode == "none" and bool(sol.get("gmres_diagonal_preconditioner", False)):
+        mode = "diagonal"
+    if mode not in ("none", "diagonal"):
+        raise ValueError("oracle restates gmres_preconditioner none|diagonal only")
+    o = NewtonOpts()
+    o.precond = 1 if mode == "diagonal" else 0
+    o.line_search = int(bool(sol.get("newton_line_search", False)))
+    o.line_search_c = float(sol.get("newton_line_search_c", 1e-4))
+    o.max_backtracks = int(sol.get("newton_line_search_max_backtracks", 6))
+    return o
+
+
+def dlartg(f, g):
+    c, s, r = _d(), _d(), _d()
+    lib().orc_dlartg(float(f), float(g), C.byref(c), C.byref(s), C.byref(r))
+    return c.value, s.value, r.value
+
+
+def profile_jacobian(psi, j_phi, r_axis, dr, dz, psi_axis, psi_bnd, i_target, external_profile_mode=False):
+    psi = _c(psi)
+    out = np.zeros_like(psi)
+    lib().orc_profile_jacobian(psi, _c(j_phi), _c(r_axis), psi.shape[0], psi.shape[1], dr, dz, psi_axis, psi_bnd,
+                               i_target, int(external_profile_mode), out)
+    return out
+
+
+def gmres_gs(diag_term, r_grid, dr, dz, rhs, inv_diag=None, restart=50, maxiter=100, atol=1e-8, rtol=1e-6):
+    diag_term = _c(diag_term)
+    nz, nr = diag_term.shape
+    x = np.zeros((nz - 2) * (nr - 2))
+    inner = C.c_long()
+    info = lib().orc_gmres_gs(diag_term, _c(r_grid), nz, nr, dr, dz, _c(rhs).ravel(),
+                              None if inv_diag is None else _c(inv_diag).ravel().ctypes.data, restart, maxiter, atol, rtol,
+                              x, C.byref(inner))
+    return x, info, inner.value
+
+
+def newton_solve(cfg, psi0=None, boundary_flux=None, *, preserve=False, external_profile_mode=False):
+    p = make_params(cfg, preserve=preserve, has_bc=boundary_flux is not None,
+                    external_profile_mode=external_profile_mode)
+    o = newton_opts_from_cfg(cfg)
+    nz, nr = p.nz, p.nr
+    psi = np.zeros((nz, nr)) if psi0 is None else _c(psi0).copy()
+    j = np.zeros((nz, nr))
+    res = NewtonResult()
+    hist = np.full(2 * p.max_iter + 2, np.nan)
+    gsh = np.full(2 * p.max_iter + 2, np.nan)
+    bf = None if boundary_flux is None else _c(boundary_flux)
+    lib().orc_newton_solve(C.byref(p), C.byref(o), psi, None if bf is None else bf.ctypes.data, j, C.byref(res),
+                           hist.ctypes.data, gsh.ctypes.data)
+    return {"psi": psi, "j_phi": j, "converged": bool(res.converged), "iterations": res.iterations,
+            "diverged": bool(res.diverged), "residual": res.residual, "gs_residual": res.gs_residual,
+            "gs_residual_best": res.gs_residual_best, "residual_history": hist[: res.n_hist].copy(),
+            "gs_residual_history": gsh[: res.n_gs_hist].copy(), "newton_line_search": bool(o.line_search),
+            "newton_line_search_attempts": res.ls_attempts, "newton_line_search_accepts": res.ls_accepts,
+            "newton_line_search_rejects": res.ls_rejects, "gmres_nonconverged_count": res.gmres_nonconverged,
+            "gmres_breakdown_count": res.gmres_breakdown, "gmres_last_info": res.gmres_last_info,
+            "gmres_matvecs": res.gmres_matvecs, "solver_method": "newton"}
 
 
 def free_boundary_solve(cfg, coils_r, coils_z, coils_i, turns, *, psi0=None, max_outer=20, tol=1e-4):

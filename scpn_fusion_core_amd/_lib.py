@@ -51,6 +51,23 @@ class PicardResult(C.Structure):
     ]
 
 
+class NewtonOpts(C.Structure):
+    _fields_ = [
+        ("precond", _i), ("line_search", _i), ("line_search_c", _d), ("max_backtracks", _i), ("warmup_steps", _i),
+        ("newton_alpha", _d), ("gmres_restart", _i), ("gmres_maxiter", _i), ("gmres_atol", _d), ("gmres_rtol", _d),
+        ("poll_every", _i), ("reserved", _i),
+    ]
+
+
+class NewtonResult(C.Structure):
+    _fields_ = [
+        ("converged", _i), ("iterations", _i), ("diverged", _i), ("n_hist", _i), ("n_gs_hist", _i),
+        ("ls_attempts", _i), ("ls_accepts", _i), ("ls_rejects", _i),
+        ("gmres_nonconverged", _i), ("gmres_breakdown", _i), ("gmres_last_info", _i), ("reserved", _i),
+        ("gmres_inner", C.c_long), ("residual", _d), ("gs_residual", _d), ("gs_residual_best", _d),
+    ]
+
+
 # symbol -> (restype, argtypes); the single source of truth also checked by tests/test_abi_symbols.py
 SIGNATURES = {
     # legacy libscpn_solver ABI
@@ -95,6 +112,7 @@ SIGNATURES = {
     "scpn_gs_set_vacuum_coils": (_i, [_vp, _i, _vp, _vp, _vp]),
     "scpn_gs_set_seed": (_i, [_vp, _vp]),
     "scpn_gs_picard_solve": (_i, [_vp, C.POINTER(PicardParams), C.POINTER(PicardResult), _vp, _vp, _vp]),
+    "scpn_gs_newton_solve": (_i, [_vp, C.POINTER(PicardParams), C.POINTER(NewtonOpts), C.POINTER(NewtonResult), _vp, _vp]),
     "scpn_gs_free_boundary_solve": (_i, [_vp, C.POINTER(PicardParams), _i, _vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp,
                                          C.POINTER(PicardResult)]),
     "scpn_gs_rb_sor": (_i, [_vp, _d, _i]),
@@ -112,7 +130,7 @@ SIGNATURES = {
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile csrc/scpn_hip.hip for gfx950 into the in-tree libscpn_hip.so (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / "scpn_hip.hip", CSRC / "gs_kernels.hip.h", PKG_DIR.parent / "include" / "scpn_hip.h"]
+    srcs = [CSRC / "scpn_hip.hip", CSRC / "gs_kernels.hip.h", CSRC / "newton_kernels.hip.h", PKG_DIR.parent / "include" / "scpn_hip.h"]
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

@@ -1332,8 +1332,9 @@ __global__ void k_source_from_j(Fld srcF, Fld jF, int nz, int nr, int ld, const 
     srcF.at(b)[c] = neg_mu0R[ir] * jF.at(b)[c];
 }
 // J_phi = seed * (I_target / I_seed) per member (iterative_solver.py:404-406)
-__global__ void k_seed_j(Fld jF, const double* seed, const Member* st, double i_seed, int nz, int nr, int ld) {
+__global__ void k_seed_j(Fld jF, const double* seed, const Member* st, double i_seed, int nz, int nr, int ld, const int* active) {
     int b = blockIdx.z;
+    if (active && !active[b]) return;
     int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
     if (ir >= nr || iz >= nz) return;
     double s = seed[(long)iz * nr + ir];
@@ -1644,9 +1645,11 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
         Member& m = st[b];
         const int it = m.iterations;  // iteration index lives on the device: kernel arguments stay constant (HIP graph replay)
         m.iterations = it + 1;
-        if (shbad) {  // diverged: revert to best, stop (newton_solver.py:518-532)
-            m.prev = m.cur;
-            m.cur = m.best;
+        if (shbad) {  // diverged: revert to best, stop (newton_solver.py:518-532); the Newton warm-up keeps Psi (:163-166)
+            if (!ctl.pad) {
+                m.prev = m.cur;
+                m.cur = m.best;
+            }
             m.diverged = 1;
             m.active = 0;
             atomicSub(n_active, 1);

@@ -1,0 +1,623 @@
+// newton_kernels.hip.h -- device side of the Newton-Kantorovich + GMRES equilibrium solve.
+//
+// Reference: core/fusion_kernel_newton_solver.py:104-372 (_newton_solve_dispatch),
+// core/fusion_kernel_solver_runtime.py:25-136 (residual / operator / profile Jacobian), :206-315 (linear
+// solve = scipy.sparse.linalg.gmres, SciPy 1.15.3: restarted GMRES, modified Gram-Schmidt, Givens rotations
+// from LAPACK dlartg).  Everything is batched over ensemble members; each member carries its own GMRES state
+// (Hessenberg column, rotations, tolerances, activity flags) in HBM and all members advance in lock-step,
+// finished members being masked out.
+//
+// Layout: Krylov vectors are stored on the padded (nz, ld) grid of the solver with a ZERO ring and ZERO pad
+// columns, so a vector of the reference's interior space (nz-2)*(nr-2) is the same numbers plus zeros: dots
+// and norms run flat over the member stride (16-B loads), the operator is the plain 5-point stencil.
+// Reductions: every block writes a partial, the last block to finish (agent-scope atomic counter) adds the
+// partials in index order and runs the scalar tail (Gram-Schmidt coefficient, rotation, tolerance control),
+// so one MGS step is one launch and results do not depend on block scheduling.
+#pragma once
+
+namespace gs {
+
+constexpr int GM_R = 50;  // restart length used by the reference (fusion_kernel_solver_runtime.py:297-300)
+
+struct GmState {
+    double bnrm2, atol, ptol, ptol_max_factor, presid, rnorm, h0, tmp, Mb;
+    double S[GM_R + 1], y[GM_R + 1], giv[GM_R * 2], h[GM_R * (GM_R + 1)];
+    int inner_on, solve_on, breakdown, info, col_final, inner_total, cycles, restart;
+    unsigned counter;
+    int pad;
+};
+
+// per-member Newton state
+struct NtMember {
+    double res_norm, gs, gs_best, last_hist;
+    double jac_c, jac_denom;     // profile-Jacobian scalars (fusion_kernel_solver_runtime.py:119-131)
+    double ls_alpha, ls_res0;    // line search
+    int on;                      // still iterating in phase B
+    int converged, diverged, iterations;
+    int n_hist, n_gs_hist;
+    int ls_on, ls_accepted, ls_attempts, ls_accepts, ls_rejects;
+    int gm_nonconv, gm_breakdown, gm_last_info;
+    long gm_inner;
+    unsigned counter;
+    int bad;
+};
+
+struct NtCtl {
+    double tol, gs_tol;
+    int require_gs, line_search, hist_cap, pad;
+    long n_interior;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool last_block(unsigned* counter, unsigned nblocks) {
+    __shared__ int is_last;
+    __threadfence();  // publish this block's partial
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == nblocks - 1);
+    }
+    __syncthreads();
+    if (is_last) __threadfence();  // acquire the other blocks' partials
+    return is_last != 0;
+}
+__device__ __forceinline__ double ld_partial(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// sum of `n` partials in index order by the 256 threads of the (last) block; valid in thread 0
+__device__ __forceinline__ double sum_partials(const double* part, int n, double* sh) {
+    double s = 0.0;
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int i = t; i < n; i += 256) s += ld_partial(part + i);
+    // block_sum<256> uses threadIdx.x only; flatten
+    s = wave_sum(s);
+    if ((t & 63) == 0) sh[t >> 6] = s;
+    __syncthreads();
+    double r = 0.0;
+    if (t == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_sum_flat(double v, double* sh) {
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    v = wave_sum(v);
+    if ((t & 63) == 0) sh[t >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (t == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return r;
+}
+
+// LAPACK 3.11 la_lartg.f90 (double): plane rotation with r = sign(f)*hypot(f,g)
+__device__ __forceinline__ void dlartg(double f, double g, double& c, double& s, double& r) {
+    const double safmin = 2.2250738585072014e-308, safmax = 1.0 / safmin;
+    const double rtmin = 1.4916681462400413e-154;  // sqrt(safmin)
+    const double rtmax = 4.7403759540545887e+153;  // sqrt(safmax/2)
+    double f1 = fabs(f), g1 = fabs(g);
+    if (g == 0.0) { c = 1.0; s = 0.0; r = f; }
+    else if (f == 0.0) { c = 0.0; s = copysign(1.0, g); r = g1; }
+    else if (f1 > rtmin && f1 < rtmax && g1 > rtmin && g1 < rtmax) {
+        double d = sqrt(f * f + g * g);
+        c = f1 / d;
+        r = copysign(d, f);
+        s = g / r;
+    } else {
+        double u = fmin(safmax, fmax(safmin, fmax(f1, g1)));
+        double fs = f / u, gs_ = g / u;
+        double d = sqrt(fs * fs + gs_ * gs_);
+        c = fabs(fs) / d;
+        r = copysign(d, f);
+        s = gs_ / r;
+        r = r * u;
+    }
+}
+
+// L*v at an interior point (fusion_kernel_solver_runtime.py:54-68 apply_gs_operator); same arithmetic as resid_at
+__device__ __forceinline__ double lop_at(const double* v, const Lvl& L, int iz, int ir) {
+    long c = (long)iz * L.ld + ir;
+    double p = v[c], e = v[c + 1], w = v[c - 1], n = v[c + L.ld], s = v[c - L.ld];
+    double d2r = divc(e - 2.0 * p + w, L.dr2, L.inv_dr2);
+    double d1r = divc(e - w, L.two_dr, L.inv_two_dr);
+    double d2z = divc(n - 2.0 * p + s, L.dz2, L.inv_dz2);
+    return d2r - divc(d1r, L.r_safe[ir], L.r_inv[ir]) + d2z;
+}
+
+// ------------------------------------------------------------------------------------------------ Newton level
+// r_k = L psi - Source on the interior (zero ring) + sum r^2.  2-D grid (ceil(nr/64), ceil(nz/4), B), block 64x4.
+// mode 0: Newton residual of the iteration (history, convergence test, newton_solver.py:197-214)
+// mode 1: line-search trial norm (accept test :267-274)      mode 2: post-step norm of the line search (:292-294)
+__global__ void __launch_bounds__(256) k_nt_resid(Fld outF, Fld psiF, Fld srcF, Lvl L, Member* st, NtMember* nt, NtCtl ctl, int mode,
+                                                  double ls_c, double* hist, double* gs_hist, double* part, int* f_active,
+                                                  int* n_on) {
+    __shared__ double sh[4];
+    const int b = blockIdx.z;
+    if (mode == 1 ? !nt[b].ls_on : !nt[b].on) return;
+    const int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    double v = 0.0;
+    const bool in = ir < L.nr && iz < L.nz;
+    if (in && iz > 0 && iz < L.nz - 1 && ir > 0 && ir < L.nr - 1) v = resid_at(psiF.at(b), srcF.at(b), L, iz, ir);
+    if (in && outF.base) outF.at(b)[(long)iz * L.ld + ir] = v;
+    const int nblk = gridDim.x * gridDim.y;
+    double bs = block_sum_flat(v * v, sh);
+    double* mypart = part + (long)b * nblk;
+    if (threadIdx.x == 0 && threadIdx.y == 0) mypart[blockIdx.y * gridDim.x + blockIdx.x] = bs;
+    if (!last_block(&nt[b].counter, nblk)) return;
+    double tot = sum_partials(mypart, nblk, sh);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        NtMember& m = nt[b];
+        m.counter = 0;
+        const double nrm = sqrt(tot);
+        if (mode == 0) {
+            const double gsr = sqrt(tot / (double)ctl.n_interior);
+            m.res_norm = nrm;
+            m.gs = gsr;
+            if (!ctl.line_search) { if (m.n_hist < ctl.hist_cap) hist[(long)b * ctl.hist_cap + m.n_hist] = nrm; m.n_hist++; m.last_hist = nrm; }
+            if (m.n_gs_hist < ctl.hist_cap) gs_hist[(long)b * ctl.hist_cap + m.n_gs_hist] = gsr;
+            m.n_gs_hist++;
+            if (gsr < m.gs_best) m.gs_best = gsr;
+            const bool upd = nrm < ctl.tol;
+            const bool gsc = (!ctl.require_gs) || (gsr < ctl.gs_tol);
+            if (upd && gsc) {
+                if (ctl.line_search) { if (m.n_hist < ctl.hist_cap) hist[(long)b * ctl.hist_cap + m.n_hist] = nrm; m.n_hist++; m.last_hist = nrm; }
+                m.converged = 1;
+                m.on = 0;
+                st[b].active = 0;
+                st[b].converged = 1;
+                f_active[b] = 0;
+                atomicSub(n_on, 1);
+            }
+        } else if (mode == 1) {
+            m.ls_attempts++;
+            if (nrm <= (1.0 - ls_c * m.ls_alpha) * m.res_norm) { m.ls_accepted = 1; m.ls_accepts++; m.ls_on = 0; }
+            else { m.ls_rejects++; m.ls_alpha *= 0.5; }
+        } else {
+            if (m.n_hist < ctl.hist_cap) hist[(long)b * ctl.hist_cap + m.n_hist] = nrm;
+            m.n_hist++;
+            m.last_hist = nrm;
+        }
+    }
+}
+
+// s = sum(mask * (1 - psi_N) * R)  (fusion_kernel_solver_runtime.py:124); flat over nz*nr, grid (nblk, B)
+__global__ void __launch_bounds__(256) k_nt_jac_sum(Fld psiF, const Member* st, NtMember* nt, int nz, int nr, int ld, const double* r_axis,
+                                                    double dr, double dz, double* part, int nblk) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y;
+    if (!nt[b].on) return;
+    const double* psi = psiF.at(b);
+    double pa = st[b].psi_axis, pb = st[b].psi_bnd;
+    if (!finite_d(pa)) pa = 0.0;
+    if (pb != pb || pb > 1.79e308) pb = pa + 1e-9; else if (pb < -1.79e308) pb = pa - 1e-9;
+    double denom = pb - pa;
+    if (!finite_d(denom)) denom = 1e-9;
+    if (fabs(denom) < 1e-9) denom = denom >= 0.0 ? 1e-9 : -1e-9;
+    const long n = (long)nz * nr;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (q < n) {
+            int iz = (int)(q / nr), ir = (int)(q - (long)iz * nr);
+            double p = psi[(long)iz * ld + ir];
+            if (p != p) p = pa; else if (p > 1.79e308) p = pa + 1e9; else if (p < -1.79e308) p = pa - 1e9;
+            double R = fmin(fmax(r_axis[ir], 0.0), 1e6);
+            double pn = (p - pa) / denom;
+            if (pn >= 0 && pn < 1.0) s += (1 - pn) * R;
+        }
+    }
+    double bs = block_sum<256>(s, sh);
+    double* mypart = part + (long)b * nblk;
+    if (threadIdx.x == 0) mypart[blockIdx.x] = bs;
+    if (!last_block(&nt[b].counter, nblk)) return;
+    double tot = sum_partials(mypart, nblk, sh);
+    if (threadIdx.x == 0) {
+        NtMember& m = nt[b];
+        m.counter = 0;
+        double sv = tot * dr * dz;
+        if (!finite_d(sv)) sv = 0.0;
+        double it = st[b].i_target;
+        if (!finite_d(it)) it = 0.0;
+        m.jac_c = it / fmax(fabs(sv), 1e-9);
+        m.jac_denom = denom;
+    }
+}
+// diag_term = (-mu0 R) * dJ/dpsi (newton_solver.py:215) and, for the diagonal preconditioner,
+// inv_diag = 1 / safe(-2/dR^2 - 2/dZ^2 - diag_term) (fusion_kernel_solver_runtime.py:222-232); ring / pads stay 0
+__global__ void k_nt_jac_diag(Fld dF, Fld ivdF, Fld psiF, Fld jF, const Member* st, const NtMember* nt, int nz, int nr, int ld,
+                              const double* r_axis, const double* neg_mu0R, int external_mode, int precond, double diag_lap) {
+    const int b = blockIdx.z;
+    if (!nt[b].on) return;
+    const int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir < 1 || iz < 1 || ir >= nr - 1 || iz >= nz - 1) return;
+    const long c = (long)iz * ld + ir;
+    double pa = st[b].psi_axis;
+    if (!finite_d(pa)) pa = 0.0;
+    const double denom = nt[b].jac_denom;
+    double p = psiF.at(b)[c];
+    if (p != p) p = pa; else if (p > 1.79e308) p = pa + 1e9; else if (p < -1.79e308) p = pa - 1e9;
+    const double R = fmin(fmax(r_axis[ir], 0.0), 1e6);
+    const double pn = (p - pa) / denom;
+    const bool mask = pn >= 0 && pn < 1.0;
+    double dj = 0.0;
+    if (mask) {
+        if (external_mode) {
+            double ja = jF.at(b)[c];
+            if (ja != ja) ja = 0.0; else if (!finite_d(ja)) ja = 1e12;
+            dj = -fabs(ja) / fmax(fabs(denom), 1e-9);
+            if (dj != dj) dj = 0.0; else if (dj > 1.79e308) dj = 0.0; else if (dj < -1.79e308) dj = -1e12;
+        } else {
+            dj = (-nt[b].jac_c * R) / denom;
+            if (dj != dj) dj = 0.0; else if (dj > 1.79e308) dj = 1e12; else if (dj < -1.79e308) dj = -1e12;
+        }
+    }
+    const double d = neg_mu0R[ir] * dj;
+    dF.at(b)[c] = d;
+    if (precond) {
+        const double dja = diag_lap - d;
+        const double sd = fabs(dja) > 1e-12 ? dja : (dja >= 0.0 ? 1e-12 : -1e-12);
+        ivdF.at(b)[c] = 1.0 / sd;
+    }
+}
+
+// psi_trial = base + alpha * delta on the interior, ring from bc (newton_solver.py:253-256 / :296-297); detects NaN/Inf.
+// which: 0 fixed step (members nt.on, alpha = fixed_alpha, base == psi in place)
+//        1 line-search trial (members nt.ls_on, alpha = nt.ls_alpha)   2 rejected-all fallback (members on && !accepted)
+__global__ void __launch_bounds__(256) k_nt_step(Fld psiF, Fld baseF, Fld dxF, Fld bcF, Member* st, NtMember* nt, int nz, int nr, int ld,
+                                                 int which, double fixed_alpha, int* part_bad, int* f_active, int* n_on, int check) {
+    __shared__ int shbad;
+    const int b = blockIdx.z;
+    const NtMember& m0 = nt[b];
+    const bool go = which == 0 ? m0.on : (which == 1 ? m0.ls_on : (m0.on && !m0.ls_accepted));
+    if (!go) return;
+    if (threadIdx.x == 0 && threadIdx.y == 0) shbad = 0;
+    __syncthreads();
+    const int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    const double alpha = which == 0 ? fixed_alpha : m0.ls_alpha;
+    if (ir < nr && iz < nz) {
+        const long c = (long)iz * ld + ir;
+        double v;
+        if (iz == 0 || iz == nz - 1 || ir == 0 || ir == nr - 1) v = bcF.at(b)[c];
+        else v = baseF.at(b)[c] + alpha * dxF.at(b)[c];
+        psiF.at(b)[c] = v;
+        if (!finite_d(v)) atomicOr(&shbad, 1);
+    }
+    if (!check) return;
+    __syncthreads();
+    const int nblk = gridDim.x * gridDim.y;
+    int* mypart = part_bad + (long)b * nblk;
+    if (threadIdx.x == 0 && threadIdx.y == 0) mypart[blockIdx.y * gridDim.x + blockIdx.x] = shbad;
+    if (!last_block(&nt[b].counter, nblk)) return;
+    int bad = 0;
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    for (int i = t; i < nblk; i += 256) bad |= __hip_atomic_load(mypart + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bad) atomicOr(&shbad, 2);
+    __syncthreads();
+    if (t == 0) {
+        NtMember& m = nt[b];
+        m.counter = 0;
+        if (shbad & 2) {  // newton_solver.py:301-306: stop iterating, keep the state
+            m.diverged = 1;
+            m.on = 0;
+            st[b].active = 0;
+            st[b].diverged = 1;
+            f_active[b] = 0;
+            atomicSub(n_on, 1);
+        }
+    }
+}
+// line-search bookkeeping; one thread per member
+// op 0: start of a Newton step (ls_on = on, alpha = newton_alpha, accepted = 0)
+// op 1: Member.active := ls_on          op 2: Member.active := on && !accepted        op 3: Member.active := on
+// op 4: iteration counter (iterations = k + 1 for members still on)
+__global__ void k_nt_flags(Member* st, NtMember* nt, int* f_active, int B, int op, double alpha0, int k) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    NtMember& m = nt[b];
+    if (op == 0) { m.ls_on = m.on; m.ls_alpha = alpha0; m.ls_accepted = 0; return; }
+    if (op == 4) { if (m.on) m.iterations = k + 1; return; }
+    int a = op == 1 ? m.ls_on : (op == 2 ? (m.on && !m.ls_accepted) : m.on);
+    st[b].active = a;
+    f_active[b] = a;
+}
+// masked field copy keyed on NtMember flags: which 0 -> members on, 1 -> members on && accepted
+__global__ void k_nt_copy(Fld dst, Fld src, const NtMember* nt, int which, int nz, int nr, int ld) {
+    const int b = blockIdx.z;
+    if (!(which == 0 ? nt[b].on : (nt[b].on && nt[b].ls_accepted))) return;
+    const int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    const long c = (long)iz * ld + ir;
+    dst.at(b)[c] = src.at(b)[c];
+}
+
+// ------------------------------------------------------------------------------------------------ GMRES
+// b = -r_k, x = 0, r = b; ||b|| and the tolerances (scipy _isolve/iterative.py gmres prologue).  flat grid (nbf, B)
+__global__ void __launch_bounds__(256) k_gm_init(double* rhs, double* x, double* r, const double* rk, long stride, GmState* gm,
+                                                 const NtMember* nt, double atol_in, double rtol, int restart, int precond, double* part,
+                                                 int nbf) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y;
+    if (!nt[b].on) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { gm[b].solve_on = 0; gm[b].inner_on = 0; }
+        return;
+    }
+    const long off = (long)b * stride;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        long i = ((long)blockIdx.x * 512 + k * 256 + threadIdx.x) * 2;
+        if (i < stride) {
+            double2 v = *reinterpret_cast<const double2*>(rk + off + i);
+            double2 nb{-v.x, -v.y};
+            *reinterpret_cast<double2*>(rhs + off + i) = nb;
+            *reinterpret_cast<double2*>(r + off + i) = nb;
+            *reinterpret_cast<double2*>(x + off + i) = double2{0.0, 0.0};
+            s += nb.x * nb.x;
+            s += nb.y * nb.y;
+        }
+    }
+    double bs = block_sum<256>(s, sh);
+    double* mypart = part + (long)b * nbf;
+    if (threadIdx.x == 0) mypart[blockIdx.x] = bs;
+    if (!last_block(&gm[b].counter, nbf)) return;
+    double tot = sum_partials(mypart, nbf, sh);
+    if (threadIdx.x == 0) {
+        GmState& g = gm[b];
+        g.counter = 0;
+        g.bnrm2 = sqrt(tot);
+        g.atol = fmax(atol_in, rtol * g.bnrm2);
+        g.ptol_max_factor = 1.0;
+        g.presid = 0.0;
+        g.rnorm = g.bnrm2;
+        g.restart = restart;
+        g.inner_total = 0;
+        g.cycles = 0;
+        g.breakdown = 0;
+        g.inner_on = 0;
+        g.col_final = 0;
+        if (g.bnrm2 == 0.0 || g.bnrm2 < g.atol) { g.solve_on = 0; g.info = 0; }  // x = 0 is the answer
+        else { g.solve_on = 1; g.info = -1; }
+        g.Mb = g.bnrm2;
+        if (!precond) g.ptol = g.Mb * fmin(1.0, g.atol / g.bnrm2);
+    }
+}
+// v0 = M^-1 r (start of a restart cycle) or, with `only_norm`, Mb = ||M^-1 b|| for the first ptol.  flat grid (nbf, B)
+__global__ void __launch_bounds__(256) k_gm_start(double* v0, const double* r, const double* ivd, long stride, GmState* gm, int precond,
+                                                  int only_norm, double* part, int nbf) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y;
+    if (!gm[b].solve_on) return;
+    const long off = (long)b * stride;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        long i = ((long)blockIdx.x * 512 + k * 256 + threadIdx.x) * 2;
+        if (i < stride) {
+            double2 v = *reinterpret_cast<const double2*>(r + off + i);
+            if (precond) {
+                double2 d = *reinterpret_cast<const double2*>(ivd + off + i);
+                v.x = d.x * v.x;
+                v.y = d.y * v.y;
+            }
+            if (!only_norm) *reinterpret_cast<double2*>(v0 + off + i) = v;
+            s += v.x * v.x;
+            s += v.y * v.y;
+        }
+    }
+    double bs = block_sum<256>(s, sh);
+    double* mypart = part + (long)b * nbf;
+    if (threadIdx.x == 0) mypart[blockIdx.x] = bs;
+    if (!last_block(&gm[b].counter, nbf)) return;
+    double tot = sum_partials(mypart, nbf, sh);
+    if (threadIdx.x == 0) {
+        GmState& g = gm[b];
+        g.counter = 0;
+        if (only_norm) {
+            g.Mb = sqrt(tot);
+            g.ptol = g.Mb * fmin(1.0, g.atol / g.bnrm2);
+        } else {
+            g.tmp = sqrt(tot);
+            for (int i = 0; i <= GM_R; ++i) g.S[i] = 0.0;
+            g.S[0] = g.tmp;
+            g.breakdown = 0;
+            g.inner_on = 1;
+            g.col_final = 0;
+        }
+    }
+}
+// v *= 1/tmp (v0 normalisation) -- which 0; v_next = w * (1/h1) unless breakdown -- which 1.  flat grid (nbf, B)
+__global__ void __launch_bounds__(256) k_gm_scale(double* dst, const double* src, long stride, const GmState* gm, int which, int col) {
+    const int b = blockIdx.y;
+    const GmState& g = gm[b];
+    double f;
+    if (which == 0) {
+        if (!g.solve_on || !g.inner_on) return;
+        f = 1.0 / g.tmp;
+    } else {
+        // written for the members that executed column `col` (still inner_on, or finished exactly at this column)
+        if (!g.solve_on || !(g.inner_on || g.col_final == col)) return;
+        const double h1 = g.h0;  // h1 is parked in h0 by the column tail
+        f = g.breakdown ? 1.0 : 1.0 / h1;
+    }
+    const long off = (long)b * stride;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        long i = ((long)blockIdx.x * 512 + k * 256 + threadIdx.x) * 2;
+        if (i < stride) {
+            double2 v = *reinterpret_cast<const double2*>(src + off + i);
+            if (f != 1.0 || which == 0) { v.x *= f; v.y *= f; }
+            *reinterpret_cast<double2*>(dst + off + i) = v;
+        }
+    }
+}
+// w = M^-1 (L v - D v) on the interior + ||w||^2 (h0).  2-D grid, block 64x4.
+// resid_mode: out = b - (L x - D x) instead (end-of-cycle residual), tail = restart / tolerance control
+__global__ void __launch_bounds__(256) k_gm_matvec(double* out, const double* vin, const double* dterm, const double* ivd,
+                                                   const double* rhs, long stride, Lvl L, GmState* gm, NtMember* nt, int precond,
+                                                   int resid_mode, int maxiter, double* part, int* n_solve) {
+    __shared__ double sh[4];
+    const int b = blockIdx.z;
+    if (!gm[b].solve_on) return;
+    if (!resid_mode && !gm[b].inner_on) return;
+    const long off = (long)b * stride;
+    const int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    double v = 0.0;
+    if (iz > 0 && iz < L.nz - 1 && ir > 0 && ir < L.nr - 1) {
+        const long c = (long)iz * L.ld + ir;
+        const double* x = vin + off;
+        double av = lop_at(x, L, iz, ir) - dterm[off + c] * x[c];
+        if (resid_mode) v = rhs[off + c] - av;
+        else v = precond ? ivd[off + c] * av : av;
+        out[off + c] = v;
+    }
+    const int nblk = gridDim.x * gridDim.y;
+    double bs = block_sum_flat(v * v, sh);
+    double* mypart = part + (long)b * nblk;
+    if (threadIdx.x == 0 && threadIdx.y == 0) mypart[blockIdx.y * gridDim.x + blockIdx.x] = bs;
+    if (!last_block(&gm[b].counter, nblk)) return;
+    double tot = sum_partials(mypart, nblk, sh);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        GmState& g = gm[b];
+        g.counter = 0;
+        if (!resid_mode) { g.h0 = sqrt(tot); return; }
+        // end of a restart cycle (scipy gmres: rnorm test, breakdown bail-out, inner tolerance adaptation)
+        const double eps = 2.220446049250313e-16;
+        g.rnorm = sqrt(tot);
+        g.cycles += 1;
+        bool stop = false;
+        if (g.rnorm <= g.atol) stop = true;
+        else if (g.breakdown) stop = true;
+        else if (g.presid <= g.ptol) g.ptol_max_factor = fmax(eps, 0.25 * g.ptol_max_factor);
+        else g.ptol_max_factor = fmin(1.0, 1.5 * g.ptol_max_factor);
+        if (!stop) g.ptol = g.presid * fmin(g.ptol_max_factor, g.atol / g.rnorm);
+        if (stop || g.cycles >= maxiter) {
+            g.solve_on = 0;
+            g.info = (g.rnorm <= g.atol) ? 0 : maxiter;
+            NtMember& m = nt[b];
+            m.gm_last_info = g.info;
+            if (g.info > 0) m.gm_nonconv += 1;
+            m.gm_inner += g.inner_total;
+            atomicSub(n_solve, 1);
+        }
+    }
+}
+// one modified Gram-Schmidt step of column `col` (scipy gmres: "for k in range(col+1): tmp = dot(v[k], w); w -= tmp*v[k]"):
+//   k > 0 : w -= h[col][k-1] * v[k-1]           (the previous step's update, fused in)
+//   k<=col: h[col][k] = <v[k], w>
+//   k==col+1 (tail): w -= h[col][col]*v[col]; h1 = ||w||; rotations, residual estimate, inner-loop exit, and -- when the
+//            inner loop ends -- the triangular solve for y.
+// V: base of the Krylov basis, vector j of member b at V + (j*B + b)*stride.  flat grid (nbf, B)
+__global__ void __launch_bounds__(256) k_gm_mgs(double* w, const double* V, long stride, int B, GmState* gm, int col, int k, double* part,
+                                                int nbf, int* n_inner) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y;
+    if (!gm[b].solve_on || !gm[b].inner_on) return;
+    GmState& g = gm[b];
+    const long off = (long)b * stride;
+    const bool tail = k == col + 1;
+    const double hprev = k > 0 ? g.h[col * (GM_R + 1) + (k - 1)] : 0.0;
+    const double* vp = k > 0 ? V + ((long)(k - 1) * B + b) * stride : nullptr;
+    const double* vk = tail ? nullptr : V + ((long)k * B + b) * stride;
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        long i = ((long)blockIdx.x * 512 + q * 256 + threadIdx.x) * 2;
+        if (i < stride) {
+            double2 wv = *reinterpret_cast<const double2*>(w + off + i);
+            if (k > 0) {
+                double2 p = *reinterpret_cast<const double2*>(vp + i);
+                wv.x -= hprev * p.x;
+                wv.y -= hprev * p.y;
+                *reinterpret_cast<double2*>(w + off + i) = wv;
+            }
+            if (tail) { s += wv.x * wv.x; s += wv.y * wv.y; }
+            else {
+                double2 c = *reinterpret_cast<const double2*>(vk + i);
+                s += c.x * wv.x;
+                s += c.y * wv.y;
+            }
+        }
+    }
+    double bs = block_sum<256>(s, sh);
+    double* mypart = part + (long)b * nbf;
+    if (threadIdx.x == 0) mypart[blockIdx.x] = bs;
+    if (!last_block(&g.counter, nbf)) return;
+    double tot = sum_partials(mypart, nbf, sh);
+    if (threadIdx.x != 0) return;
+    g.counter = 0;
+    double* hc = g.h + col * (GM_R + 1);
+    if (!tail) { hc[k] = tot; return; }
+    // ---- column tail
+    const double eps = 2.220446049250313e-16;
+    const double h1 = sqrt(tot);
+    hc[col + 1] = h1;
+    g.breakdown = 0;
+    if (h1 <= eps * g.h0) { hc[col + 1] = 0.0; g.breakdown = 1; }
+    g.h0 = h1;  // parked for k_gm_scale
+    for (int j = 0; j < col; ++j) {
+        const double c = g.giv[2 * j], s_ = g.giv[2 * j + 1];
+        const double n0 = hc[j], n1 = hc[j + 1];
+        hc[j] = c * n0 + s_ * n1;
+        hc[j + 1] = -s_ * n0 + c * n1;
+    }
+    double c, s_, mag;
+    dlartg(hc[col], hc[col + 1], c, s_, mag);
+    g.giv[2 * col] = c;
+    g.giv[2 * col + 1] = s_;
+    hc[col] = mag;
+    hc[col + 1] = 0.0;
+    const double t2 = -s_ * g.S[col];
+    g.S[col] = c * g.S[col];
+    g.S[col + 1] = t2;
+    g.presid = fabs(t2);
+    g.inner_total += 1;
+    g.col_final = col;
+    if (g.presid <= g.ptol || g.breakdown || col == g.restart - 1) {
+        g.inner_on = 0;
+        atomicSub(n_inner, 1);
+        // y = trsv(h[:col+1,:col+1].T, S[:col+1]) with the pseudo-solve of singular cases
+        if (g.h[col * (GM_R + 1) + col] == 0.0) g.S[col] = 0.0;
+        for (int j = 0; j <= col; ++j) g.y[j] = g.S[j];
+        for (int j = col; j > 0; --j)
+            if (g.y[j] != 0.0) {
+                g.y[j] /= g.h[j * (GM_R + 1) + j];
+                const double t = g.y[j];
+                for (int i = 0; i < j; ++i) g.y[i] -= t * g.h[j * (GM_R + 1) + i];
+            }
+        if (g.y[0] != 0.0) g.y[0] /= g.h[0];
+    }
+}
+// x += y @ v[:col_final+1]  (sequential in k per element).  flat grid (nbf, B)
+__global__ void __launch_bounds__(256) k_gm_update_x(double* x, const double* V, long stride, int B, const GmState* gm) {
+    const int b = blockIdx.y;
+    const GmState& g = gm[b];
+    if (!g.solve_on) return;
+    const long off = (long)b * stride;
+    const int nk = g.col_final + 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        long i = ((long)blockIdx.x * 512 + q * 256 + threadIdx.x) * 2;
+        if (i < stride) {
+            double ax = 0.0, ay = 0.0;
+            for (int k = 0; k < nk; ++k) {
+                const double2 v = *reinterpret_cast<const double2*>(V + ((long)k * B + b) * stride + i);
+                ax += g.y[k] * v.x;
+                ay += g.y[k] * v.y;
+            }
+            double2 xv = *reinterpret_cast<double2*>(x + off + i);
+            xv.x += ax;
+            xv.y += ay;
+            *reinterpret_cast<double2*>(x + off + i) = xv;
+        }
+    }
+}
+// number of members with solve_on / inner_on (start of a cycle: host polls these)
+__global__ void k_gm_count(const GmState* gm, int B, int* n_solve, int* n_inner) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int s = 0, i = 0;
+        for (int b = 0; b < B; ++b) { s += gm[b].solve_on ? 1 : 0; i += (gm[b].solve_on && gm[b].inner_on) ? 1 : 0; }
+        *n_solve = s;
+        *n_inner = i;
+    }
+}
+
+}  // namespace gs

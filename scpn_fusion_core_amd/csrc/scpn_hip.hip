@@ -18,6 +18,7 @@
 
 #include "../../include/scpn_hip.h"
 #include "gs_kernels.hip.h"
+#include "newton_kernels.hip.h"
 
 using namespace gs;
 
@@ -128,6 +129,12 @@ struct Solver {
     DBuf<double> psi_slots;  // 3 ping-pong slots
     DBuf<double> W, W2, src, src2, bc, jphi, ext, old, dense, and_psi, and_res, and_part, and_alpha;
     DBuf<int> and_fb;
+    // Newton / GMRES workspace (allocated on first use)
+    DBuf<double> nt_ws, nt_V, nt_part;
+    DBuf<GmState> nt_gm;
+    DBuf<NtMember> nt_st;
+    DBuf<int> nt_pbad, nt_cnt;
+    int nt_V_vecs = 0;
     bool picard_bufs = false;
     DBuf<double> d_r, d_z, d_inv_mu0R, d_neg_mu0R, d_seed;
     DBuf<Member> d_st;
@@ -687,7 +694,8 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         m.x_idx = -1;
         bool masked_out = member_mask && !(*member_mask)[b];
         // zero-current short-circuit (newton_solver.py:448-465)
-        if (!masked_out && std::fabs(m.i_target) < 1e-12 && !p->preserve_initial_state) zero_current[b] = 1;
+        // (the Newton dispatch, method 4 = its Picard warm-up, has no such short-circuit: newton_solver.py:435-439)
+        if (!masked_out && p->method != 4 && std::fabs(m.i_target) < 1e-12 && !p->preserve_initial_state) zero_current[b] = 1;
         m.active = (!masked_out && !zero_current[b] && max_iter > 0) ? 1 : 0;
         if (zero_current[b]) m.converged = 1;
         n_act += m.active;
@@ -745,7 +753,9 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, bestF, curF, nz, nr, ld, (const int*)h->d_active.p);
 
     // ---- _seed_plasma (iterative_solver.py:384-410)
-    if (!p->skip_seed && n_act > 0) {
+    int n_part = 0;
+    for (int b = 0; b < B; ++b) n_part += part[b];
+    if (!p->skip_seed && n_part > 0) {
         if (!h->seed_user) {
             h->seed_host.assign((size_t)nz * nr, 0.0);
             for (int iz = 0; iz < nz; ++iz)
@@ -758,10 +768,11 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         double i_seed = (np_sum(h->seed_host.data(), (long)nz * nr) * h->dr) * h->dz;
         h->d_seed.alloc((size_t)nz * nr);
         HIP_TRY(hipMemcpyAsync(h->d_seed.p, h->seed_host.data(), sizeof(double) * nz * nr, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_seed_j, g2, BLK2D, 0, st, jF, (const double*)h->d_seed.p, (const Member*)h->d_st.p, i_seed, nz, nr, ld);
+        hipLaunchKernelGGL(k_seed_j, g2, BLK2D, 0, st, jF, (const double*)h->d_seed.p, (const Member*)h->d_st.p, i_seed, nz, nr, ld,
+                           (const int*)d_part.p);
         // members with |I_target| < 1e-12 keep psi untouched (their J is zero)
         std::vector<int> seed_act(B);
-        for (int b = 0; b < B; ++b) seed_act[b] = ms[b].active && std::fabs(ms[b].i_target) >= 1e-12;
+        for (int b = 0; b < B; ++b) seed_act[b] = part[b] && std::fabs(ms[b].i_target) >= 1e-12;
         DBuf<int> d_sa;
         d_sa.alloc(B);
         HIP_TRY(hipMemcpyAsync(d_sa.p, seed_act.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
@@ -850,7 +861,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
                 nb_d = nb_r = ba.nblk;
             }
             newF = vcycle(h, curF, WF, W2F, srcF, p->sor_omega, 3, 3, 5, act, gen ? &sg : nullptr, blend_in_tile ? &ba : nullptr, nxtF);
-        } else if (p->method == 1 || p->method == 3) {
+        } else if (p->method == 1 || p->method == 3 || p->method == 4) {  // "sor", "anderson" and any other method string (iterative_solver.py:376-378)
             hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, WF, curF, nz, nr, ld);
             hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, src2F, srcF, nz, nr, ld);
             smooth(h, L0, WF, Fld{nullptr, nullptr, 0, 0}, src2F, p->sor_omega, 1, act, true);
@@ -902,7 +913,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         topo_count = nb_d;
         PicardCtl ctl;
         ctl.tol = p->tol; ctl.gs_tol = p->gs_tol; ctl.require_gs = p->require_gs_residual; ctl.max_iter = max_iter;
-        ctl.iter = 0; ctl.pad = 0; ctl.n_total = (long)nz * nr; ctl.n_interior = (long)(nz - 2) * (nr - 2);
+        ctl.iter = 0; ctl.pad = (p->method == 4) ? 1 : 0; /* pad = keep the state on divergence (Newton warm-up) */ ctl.n_total = (long)nz * nr; ctl.n_interior = (long)(nz - 2) * (nr - 2);
         {
             ProfScope ps(h, "picard_final", 1);
             hipLaunchKernelGGL(k_picard_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_part1.p, (const int*)h->d_pbad.p,
@@ -991,6 +1002,252 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     if (hist_diff) HIP_TRY(hipMemcpy(hist_diff, d_hist_diff.p, sizeof(double) * B * max_iter, hipMemcpyDeviceToHost));
     if (hist_gs) HIP_TRY(hipMemcpy(hist_gs, d_hist_gs.p, sizeof(double) * B * max_iter, hipMemcpyDeviceToHost));
     if (trace) HIP_TRY(hipMemcpy(trace, d_trace.p, sizeof(double) * B * max_iter * 6, hipMemcpyDeviceToHost));
+}
+
+// ------------------------------------------------------------------------------------------ Newton-Kantorovich + GMRES
+// core/fusion_kernel_newton_solver.py:104-372.  Phase A = picard_solve_impl in warm-up mode (method 4); phase B below.
+static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn_newton_opts* o, scpn_newton_result* results,
+                              double* hist_out, double* gs_hist_out) {
+    const int B = h->B, nz = h->nz, nr = h->nr, ld = h->ld;
+    const long stride = h->stride;
+    const int max_iter = std::max(p->max_iter, 0);
+    const int warmup = o->warmup_steps >= 0 ? std::min(o->warmup_steps, max_iter) : std::min(15, max_iter / 2);
+    const int cap = max_iter + 2;
+    hipStream_t st = h->stream;
+
+    // ---- phase A: Picard warm-up
+    scpn_picard_params pa = *p;
+    pa.method = 4;
+    pa.max_iter = warmup;
+    pa.skip_seed = 0;
+    std::vector<scpn_picard_result> ra(B);
+    std::vector<double> hd((size_t)B * std::max(warmup, 1), 0.0), hg((size_t)B * std::max(warmup, 1), 0.0);
+    picard_solve_impl(h, &pa, ra.data(), warmup > 0 ? hd.data() : nullptr, warmup > 0 ? hg.data() : nullptr, nullptr, nullptr);
+
+    // ---- workspace
+    const long n = stride * B;
+    const int restart = std::max(1, std::min({o->gmres_restart > 0 ? o->gmres_restart : GM_R, GM_R, (nz - 2) * (nr - 2)}));
+    enum { RK = 0, RHS, RES, WV, XV, DG, IVD, SRT, PRV, NBUF };
+    if (!h->nt_ws.p) {
+        h->nt_ws.alloc((size_t)n * NBUF);
+        HIP_TRY(hipMemsetAsync(h->nt_ws.p, 0, sizeof(double) * n * NBUF, st));
+        h->nt_gm.alloc(B);
+        h->nt_st.alloc(B);
+        HIP_TRY(hipMemsetAsync(h->nt_gm.p, 0, sizeof(GmState) * B, st));
+        const int nbmax = std::max(cdiv(stride, 1024), (int)(cdiv(nr, 64) * cdiv(nz, 4)));
+        h->nt_part.alloc((size_t)B * nbmax);
+        h->nt_pbad.alloc((size_t)B * nbmax);
+        h->nt_cnt.alloc(4);
+    }
+    if (h->nt_V_vecs < restart) {
+        h->nt_V.alloc((size_t)n * restart);
+        HIP_TRY(hipMemsetAsync(h->nt_V.p, 0, sizeof(double) * n * restart, st));
+        h->nt_V_vecs = restart;
+    }
+    auto buf = [&](int i) { return h->nt_ws.p + (long)i * n; };
+    Fld rkF = h->plain(buf(RK)), dxF = h->plain(buf(XV)), dgF = h->plain(buf(DG)), ivF = h->plain(buf(IVD)), srtF = h->plain(buf(SRT)),
+        prvF = h->plain(buf(PRV));
+    Fld curF = h->slot_fld(h->d_cur.p), srcF = h->plain(h->src.p), src2F = h->plain(h->src2.p), bcF = h->plain(h->bc.p),
+        jF = h->plain(h->jphi.p);
+    auto& lv = get_hierarchy(h, 5);
+    const Lvl& L0 = lv[0]->dev;
+    const dim3 g2 = grid2d(nr, nz, B);
+    const int nb2 = (int)(g2.x * g2.y);
+    const int nbf = cdiv(stride, 1024);
+    const dim3 gflat(nbf, B);
+    const int nblk1 = h->nblk1();
+    const dim3 gjs(cdiv(nr, 128), cdiv(nz, JS_ROWS), B);
+    const int nblkj = (int)(gjs.x * gjs.y);
+    Prof pf;
+    pf.hmode = p->hmode;
+    for (int i = 0; i < 4; ++i) { pf.ped_p[i] = p->ped_p[i]; pf.ped_ff[i] = p->ped_ff[i]; }
+    int n_mask_rows = 0;
+    for (int iz = 0; iz < nz; ++iz) if ((p->z_min_cfg * 0.5) > h->z_axis[iz]) n_mask_rows = iz + 1;
+
+    // ---- per-member Newton state from the warm-up results
+    std::vector<NtMember> nm(B);
+    DBuf<double> d_hist, d_gs;
+    d_hist.alloc((size_t)B * cap);
+    d_gs.alloc((size_t)B * cap);
+    std::vector<double> hh((size_t)B * cap, 0.0), hgs((size_t)B * cap, 0.0);
+    int n_on = 0;
+    for (int b = 0; b < B; ++b) {
+        NtMember& m = nm[b];
+        std::memset(&m, 0, sizeof(m));
+        const int its = warmup > 0 ? ra[b].iterations : 0;
+        const int pushed = std::max(0, its - (ra[b].diverged ? 1 : 0));
+        for (int i = 0; i < pushed; ++i) { hh[(size_t)b * cap + i] = hd[(size_t)b * warmup + i]; hgs[(size_t)b * cap + i] = hg[(size_t)b * warmup + i]; }
+        m.n_hist = m.n_gs_hist = pushed;
+        m.last_hist = pushed > 0 ? hh[(size_t)b * cap + pushed - 1] : INFINITY;
+        m.gs = pushed > 0 ? hgs[(size_t)b * cap + pushed - 1] : INFINITY;
+        m.gs_best = pushed > 0 ? ra[b].gs_residual_best : INFINITY;
+        m.converged = ra[b].converged;
+        m.iterations = warmup > 0 ? ra[b].iterations : 1;
+        m.on = (!m.converged && warmup < max_iter) ? 1 : 0;
+        n_on += m.on;
+    }
+    HIP_TRY(hipMemcpyAsync(h->nt_st.p, nm.data(), sizeof(NtMember) * B, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_hist.p, hh.data(), sizeof(double) * B * cap, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_gs.p, hgs.data(), sizeof(double) * B * cap, hipMemcpyHostToDevice, st));
+    int* d_non = h->nt_cnt.p;          // members still iterating (phase B)
+    int* d_nsolve = h->nt_cnt.p + 1;   // members whose GMRES is still running
+    int* d_ninner = h->nt_cnt.p + 2;   // members inside the current inner loop
+    int hcnt[4] = {n_on, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(d_non, hcnt, sizeof(int) * 4, hipMemcpyHostToDevice, st));
+    auto flags = [&](int op, int k = 0) {
+        hipLaunchKernelGGL(k_nt_flags, dim3(cdiv(B, 64)), dim3(64), 0, st, h->d_st.p, h->nt_st.p, h->d_active.p, B, op, o->newton_alpha, k);
+    };
+    flags(3);
+    if (p->external_profile_mode)
+        hipLaunchKernelGGL(k_source_from_j, g2, BLK2D, 0, st, srcF, jF, nz, nr, ld, (const double*)h->d_neg_mu0R.p, (const int*)h->d_active.p);
+
+    NtCtl ctl;
+    ctl.tol = p->tol; ctl.gs_tol = p->gs_tol; ctl.require_gs = p->require_gs_residual; ctl.line_search = o->line_search;
+    ctl.hist_cap = cap; ctl.pad = 0; ctl.n_interior = (long)(nz - 2) * (nr - 2);
+    const double diag_lap = -2.0 / std::pow(h->dr, 2.0) - 2.0 / std::pow(h->dz, 2.0);
+
+    // axis / X-point / (source) on the psi in `cur` for the members whose Member.active is set
+    auto topo_source = [&](Fld dstSrc) {
+        {
+            ProfScope ps(h, "topology", 2);
+            hipLaunchKernelGGL(k_topology, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, h->dr, h->dz,
+                               n_mask_rows, h->d_topo.p, nblk1);
+            hipLaunchKernelGGL(k_topology_final, dim3(B), dim3(256), 0, st, curF, h->d_st.p, (const TopoPart*)h->d_topo.p, nblk1, nr, ld,
+                               (const double*)h->d_r.p, (const double*)h->d_z.p);
+        }
+        if (!p->external_profile_mode) {
+            ProfScope ps(h, "source", 3);
+            hipLaunchKernelGGL(k_jsum, gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj);
+            hipLaunchKernelGGL(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
+            hipLaunchKernelGGL(k_source, gjs, dim3(256), 0, st, dstSrc, jF, 1, curF, (const Member*)h->d_st.p, nz, nr, ld,
+                               (const double*)h->d_r.p, (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
+        }
+    };
+    auto resid = [&](Fld outF, Fld sF, int mode) {
+        ProfScope ps(h, "newton_resid", 1);
+        hipLaunchKernelGGL(k_nt_resid, g2, BLK2D, 0, st, outF, curF, sF, L0, h->d_st.p, h->nt_st.p, ctl, mode, o->line_search_c, d_hist.p,
+                           d_gs.p, h->nt_part.p, h->d_active.p, d_non);
+    };
+    auto poll = [&](int* dptr) {
+        HIP_TRY(hipMemcpyAsync(h->h_nactive, dptr, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return h->h_nactive[0];
+    };
+    // restarted GMRES on (L - diag) x = -r_k for the members that are `on` (scipy gmres, see newton_kernels.hip.h)
+    auto gmres = [&]() {
+        const int precond = o->precond ? 1 : 0;
+        const int maxit = o->gmres_maxiter > 0 ? o->gmres_maxiter : 100;
+        const int pe = std::max(1, o->poll_every);
+        double* V = h->nt_V.p;
+        {
+            ProfScope ps(h, "gmres_init", 1);
+            hipLaunchKernelGGL(k_gm_init, gflat, dim3(256), 0, st, buf(RHS), buf(XV), buf(RES), (const double*)buf(RK), stride, h->nt_gm.p,
+                               (const NtMember*)h->nt_st.p, o->gmres_atol, o->gmres_rtol, restart, precond, h->nt_part.p, nbf);
+            if (precond)
+                hipLaunchKernelGGL(k_gm_start, gflat, dim3(256), 0, st, (double*)nullptr, (const double*)buf(RHS), (const double*)buf(IVD), stride,
+                                   h->nt_gm.p, 1, 1, h->nt_part.p, nbf);
+        }
+        for (int cyc = 0; cyc < maxit; ++cyc) {
+            hipLaunchKernelGGL(k_gm_start, gflat, dim3(256), 0, st, V, (const double*)buf(RES), (const double*)buf(IVD), stride, h->nt_gm.p, precond,
+                               0, h->nt_part.p, nbf);
+            hipLaunchKernelGGL(k_gm_count, dim3(1), dim3(64), 0, st, (const GmState*)h->nt_gm.p, B, d_nsolve, d_ninner);
+            if (poll(d_nsolve) == 0) break;
+            hipLaunchKernelGGL(k_gm_scale, gflat, dim3(256), 0, st, V, (const double*)V, stride, (const GmState*)h->nt_gm.p, 0, 0);
+            for (int col = 0; col < restart; ++col) {
+                {
+                    ProfScope ps(h, "gmres_matvec", 1);
+                    hipLaunchKernelGGL(k_gm_matvec, g2, BLK2D, 0, st, buf(WV), (const double*)(V + (long)col * n), (const double*)buf(DG),
+                                       (const double*)buf(IVD), (const double*)buf(RHS), stride, L0, h->nt_gm.p, h->nt_st.p, precond, 0, maxit,
+                                       h->nt_part.p, d_nsolve);
+                }
+                {
+                    ProfScope ps(h, "gmres_mgs", col + 2);
+                    for (int k = 0; k <= col + 1; ++k)
+                        hipLaunchKernelGGL(k_gm_mgs, gflat, dim3(256), 0, st, buf(WV), (const double*)V, stride, B, h->nt_gm.p, col, k, h->nt_part.p,
+                                           nbf, d_ninner);
+                }
+                if (col + 1 < restart)
+                    hipLaunchKernelGGL(k_gm_scale, gflat, dim3(256), 0, st, V + (long)(col + 1) * n, (const double*)buf(WV), stride,
+                                       (const GmState*)h->nt_gm.p, 1, col);
+                if ((col + 1) % pe == 0 && col + 1 < restart && poll(d_ninner) == 0) break;
+            }
+            {
+                ProfScope ps(h, "gmres_update", 2);
+                hipLaunchKernelGGL(k_gm_update_x, gflat, dim3(256), 0, st, buf(XV), (const double*)V, stride, B, (const GmState*)h->nt_gm.p);
+                hipLaunchKernelGGL(k_gm_matvec, g2, BLK2D, 0, st, buf(RES), (const double*)buf(XV), (const double*)buf(DG), (const double*)buf(IVD),
+                                   (const double*)buf(RHS), stride, L0, h->nt_gm.p, h->nt_st.p, precond, 1, maxit, h->nt_part.p, d_nsolve);
+            }
+        }
+    };
+
+    // ---- phase B: Newton iterations (newton_solver.py:183-306)
+    for (int k = warmup; k < max_iter && n_on > 0; ++k) {
+        flags(4, k);
+        topo_source(srcF);
+        resid(rkF, srcF, 0);
+        n_on = poll(d_non);
+        if (n_on == 0) break;
+        {
+            ProfScope ps(h, "newton_jacobian", 2);
+            if (!p->external_profile_mode)
+                hipLaunchKernelGGL(k_nt_jac_sum, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, h->nt_st.p, nz, nr, ld,
+                                   (const double*)h->d_r.p, h->dr, h->dz, h->nt_part.p, nblk1);
+            else  // the secant-like diagonal needs only the denominator: same kernel, sum unused
+                hipLaunchKernelGGL(k_nt_jac_sum, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, h->nt_st.p, nz, nr, ld,
+                                   (const double*)h->d_r.p, h->dr, h->dz, h->nt_part.p, nblk1);
+            hipLaunchKernelGGL(k_nt_jac_diag, g2, BLK2D, 0, st, dgF, ivF, curF, jF, (const Member*)h->d_st.p, (const NtMember*)h->nt_st.p, nz, nr, ld,
+                               (const double*)h->d_r.p, (const double*)h->d_neg_mu0R.p, p->external_profile_mode, o->precond ? 1 : 0, diag_lap);
+        }
+        gmres();
+        if (!o->line_search) {
+            hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, curF, dxF, bcF, h->d_st.p, h->nt_st.p, nz, nr, ld, 0, o->newton_alpha,
+                               h->nt_pbad.p, h->d_active.p, d_non, 1);
+        } else {
+            hipLaunchKernelGGL(k_nt_copy, g2, BLK2D, 0, st, prvF, curF, (const NtMember*)h->nt_st.p, 0, nz, nr, ld);
+            hipLaunchKernelGGL(k_nt_copy, g2, BLK2D, 0, st, srtF, srcF, (const NtMember*)h->nt_st.p, 0, nz, nr, ld);
+            flags(0);
+            for (int bt = 0; bt < o->max_backtracks; ++bt) {
+                hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, prvF, dxF, bcF, h->d_st.p, h->nt_st.p, nz, nr, ld, 1, 0.0, h->nt_pbad.p,
+                                   h->d_active.p, d_non, 0);
+                if (!p->external_profile_mode) { flags(1); topo_source(srtF); }
+                resid(Fld{nullptr, nullptr, 0, 0}, srtF, 1);
+            }
+            // every backtrack rejected: minimum step, J_phi refreshed, Source kept (:277-291)
+            hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, prvF, dxF, bcF, h->d_st.p, h->nt_st.p, nz, nr, ld, 2, 0.0, h->nt_pbad.p,
+                               h->d_active.p, d_non, 0);
+            if (!p->external_profile_mode) { flags(2); topo_source(src2F); }
+            hipLaunchKernelGGL(k_nt_copy, g2, BLK2D, 0, st, srcF, srtF, (const NtMember*)h->nt_st.p, 1, nz, nr, ld);
+            flags(3);
+            resid(Fld{nullptr, nullptr, 0, 0}, srcF, 2);
+            hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, curF, dxF, bcF, h->d_st.p, h->nt_st.p, nz, nr, ld, 0, 0.0, h->nt_pbad.p,
+                               h->d_active.p, d_non, 1);  // alpha 0: NaN / Inf check of the accepted state only
+        }
+        n_on = poll(d_non);
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+
+    // ---- results
+    HIP_TRY(hipMemcpy(nm.data(), h->nt_st.p, sizeof(NtMember) * B, hipMemcpyDeviceToHost));
+    if (hist_out) HIP_TRY(hipMemcpy(hist_out, d_hist.p, sizeof(double) * B * cap, hipMemcpyDeviceToHost));
+    if (gs_hist_out) HIP_TRY(hipMemcpy(gs_hist_out, d_gs.p, sizeof(double) * B * cap, hipMemcpyDeviceToHost));
+    if (results)
+        for (int b = 0; b < B; ++b) {
+            const NtMember& m = nm[b];
+            scpn_newton_result& r = results[b];
+            std::memset(&r, 0, sizeof(r));
+            r.converged = m.converged;
+            r.iterations = m.iterations;
+            r.diverged = m.diverged || ra[b].diverged;
+            r.n_hist = std::min(m.n_hist, cap);
+            r.n_gs_hist = std::min(m.n_gs_hist, cap);
+            r.ls_attempts = m.ls_attempts; r.ls_accepts = m.ls_accepts; r.ls_rejects = m.ls_rejects;
+            r.gmres_nonconverged = m.gm_nonconv; r.gmres_breakdown = m.gm_breakdown; r.gmres_last_info = m.gm_last_info;
+            r.gmres_inner = m.gm_inner;
+            r.residual = m.n_hist > 0 ? m.last_hist : INFINITY;
+            r.gs_residual = m.n_gs_hist > 0 ? m.gs : INFINITY;
+            r.gs_residual_best = m.n_gs_hist > 0 ? m.gs_best : INFINITY;
+        }
 }
 
 // ------------------------------------------------------------------------------------------ legacy FastSolver handle
@@ -1169,6 +1426,25 @@ static int S_picard_solve(Solver* h, const scpn_picard_params* p, scpn_picard_re
     if (p->fail_on_diverge && results)
         for (int b = 0; b < h->B; ++b)
             if (results[b].diverged) return fail(SCPN_E_DIVERGED, "Equilibrium solver diverged");
+    API_END
+}
+
+static int S_newton_solve(Solver* h, const scpn_picard_params* p, const scpn_newton_opts* o, scpn_newton_result* results, double* hist,
+                          double* gs_hist) {
+    if (!h || !p || !o) return fail(SCPN_E_ARG, "null handle / params");
+    if (!omega_ok(p->sor_omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
+    if (p->require_gs_residual && !(p->gs_tol > 0.0)) return fail(SCPN_E_ARG, "solver.gs_residual_threshold must be > 0");
+    if (o->precond < 0 || o->precond > 1) return fail(SCPN_E_ARG, "solver.gmres_preconditioner must be none or diagonal on the device");
+    if (o->line_search && (!(o->line_search_c > 0.0) || !(o->line_search_c < 1.0)))
+        return fail(SCPN_E_ARG, "solver.newton_line_search_c must be finite and in (0, 1)");
+    if (o->line_search && o->max_backtracks <= 0) return fail(SCPN_E_ARG, "solver.newton_line_search_max_backtracks must be >= 1");
+    if (o->gmres_restart > GM_R) return fail(SCPN_E_ARG, "gmres_restart must be <= 50");
+    if (h->nz < 3 || h->nr < 3) return fail(SCPN_E_ARG, "grid must be at least 3x3");
+    API_BEGIN
+    newton_solve_impl(h, p, o, results, hist, gs_hist);
+    if (p->fail_on_diverge && results)
+        for (int b = 0; b < h->B; ++b)
+            if (results[b].diverged) return fail(SCPN_E_DIVERGED, "Newton solver diverged");
     API_END
 }
 
@@ -1473,6 +1749,15 @@ int scpn_gs_picard_solve(scpn_gs* g, const scpn_picard_params* p, scpn_picard_re
         const size_t o = (size_t)g->off[gi];
         return S_picard_solve(k, p, results ? results + o : nullptr, hist_diff ? hist_diff + o * mi : nullptr,
                               hist_gs ? hist_gs + o * mi : nullptr, trace ? trace + o * mi * 6 : nullptr);
+    });
+}
+int scpn_gs_newton_solve(scpn_gs* g, const scpn_picard_params* p, const scpn_newton_opts* o, scpn_newton_result* results, double* hist,
+                         double* gs_hist) {
+    if (!g || !p || !o) return fail(SCPN_E_ARG, "null handle / params");
+    const size_t cap = (size_t)std::max(p->max_iter, 0) + 2;
+    return run_groups(g, [&](int gi, Solver* k) {
+        const size_t of = (size_t)g->off[gi];
+        return S_newton_solve(k, p, o, results ? results + of : nullptr, hist ? hist + of * cap : nullptr, gs_hist ? gs_hist + of * cap : nullptr);
     });
 }
 int scpn_gs_free_boundary_solve(scpn_gs* g, const scpn_picard_params* p, int n_coils, const double* coil_r, const double* coil_z,

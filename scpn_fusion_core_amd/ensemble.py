@@ -16,9 +16,9 @@ from typing import Any, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import PicardParams, PicardResult, as_f64, check, ptr
+from ._lib import NewtonOpts, NewtonResult, PicardParams, PicardResult, as_f64, check, ptr
 
-_METHODS = {"multigrid": 0, "sor": 1, "jacobi": 2, "anderson": 3}
+_METHODS = {"multigrid": 0, "sor": 1, "jacobi": 2, "anderson": 3, "newton": 1}  # newton: its warm-up is the SOR branch
 _PED_DEFAULT = {"ped_top": 0.92, "ped_width": 0.05, "ped_height": 1.0, "core_alpha": 0.3}  # core/fusion_kernel.py:181-192
 
 
@@ -58,6 +58,44 @@ def picard_params_from_cfg(cfg: dict, *, preserve_initial_state=False, has_bound
     p.skip_seed = 0
     p.anderson_m = int(sol.get("anderson_depth", 5))
     return p
+
+
+def newton_opts_from_cfg(cfg: dict, *, poll_every: int = 10) -> NewtonOpts:
+    """core/fusion_kernel_newton_runtime.py:75-150 parse_newton_dispatch_config (line-search / GMRES keys)."""
+    sol = cfg["solver"]
+    c = float(sol.get("newton_line_search_c", 1e-4))
+    if (not np.isfinite(c)) or c <= 0.0 or c >= 1.0:
+        raise ValueError("solver.newton_line_search_c must be finite and in (0, 1)")
+    mb = int(sol.get("newton_line_search_max_backtracks", 6))
+    if mb <= 0:
+        raise ValueError("solver.newton_line_search_max_backtracks must be >= 1")
+    mode = str(sol.get("gmres_preconditioner", "none")).strip().lower()
+    if mode in {"", "auto", "default", "legacy"}:
+        mode = "none"
+    if mode == "none" and bool(sol.get("gmres_diagonal_preconditioner", False)):
+        mode = "diagonal"
+    if mode not in {"none", "diagonal", "ilu"}:
+        raise ValueError("solver.gmres_preconditioner must be one of {'none', 'diagonal', 'ilu'}")
+    if mode == "ilu":
+        raise NotImplementedError("gmres_preconditioner='ilu' (SuperLU spilu) is not on the HIP path; use 'none' or 'diagonal'")
+    drop, fill = float(sol.get("gmres_ilu_drop_tol", 1e-4)), float(sol.get("gmres_ilu_fill_factor", 8.0))
+    if (not np.isfinite(drop)) or drop <= 0.0:
+        raise ValueError("solver.gmres_ilu_drop_tol must be finite and > 0")
+    if (not np.isfinite(fill)) or fill < 1.0:
+        raise ValueError("solver.gmres_ilu_fill_factor must be finite and >= 1")
+    budget = sol.get("gmres_nonconverged_budget")
+    if budget is not None and (isinstance(budget, bool) or int(budget) < 0):
+        raise ValueError("solver.gmres_nonconverged_budget must be an int >= 0")
+    o = NewtonOpts()
+    o.precond = 1 if mode == "diagonal" else 0
+    o.line_search = int(bool(sol.get("newton_line_search", False)))
+    o.line_search_c = c
+    o.max_backtracks = mb
+    o.warmup_steps = -1
+    o.newton_alpha = 0.5
+    o.gmres_restart, o.gmres_maxiter, o.gmres_atol, o.gmres_rtol = 50, 100, 1e-8, 1e-6
+    o.poll_every = int(poll_every)
+    return o
 
 
 def _result_dict(r: PicardResult) -> dict[str, Any]:
@@ -185,7 +223,10 @@ class EnsembleSolver:
     # -- solves ---------------------------------------------------------------------------------
     def solve_equilibrium(self, preserve_initial_state=False, boundary_flux=None, *, history=False, trace=False,
                           check_every=8) -> list[dict[str, Any]]:
-        """Picard solve of every member (core/fusion_kernel_newton_solver.py:390-615)."""
+        """Picard solve of every member (core/fusion_kernel_newton_solver.py:390-615); ``solver_method="newton"`` dispatches
+        to :meth:`solve_newton` as the reference does (:435-439)."""
+        if self.cfg.get("solver", {}).get("solver_method", "multigrid") == "newton":
+            return self.solve_newton(preserve_initial_state=preserve_initial_state, boundary_flux=boundary_flux)
         if boundary_flux is not None:
             bf = as_f64(boundary_flux)
             if bf.shape == (self.NZ, self.NR):
@@ -212,6 +253,47 @@ class EnsembleSolver:
             if trace:
                 d["trace"] = tr[b, :n].copy()
             out.append(d)
+        return out
+
+    def solve_newton(self, preserve_initial_state=False, boundary_flux=None, *, poll_every=10) -> list[dict[str, Any]]:
+        """Newton-Kantorovich + GMRES solve of every member (core/fusion_kernel_newton_solver.py:104-372).
+
+        Result dicts carry the reference's keys (``residual_history``, ``gs_residual_history``, ``newton_line_search*``,
+        ``gmres_*``, ``solver_method="newton"``).  The GMRES non-convergence budget / fail-on-breakdown policy of
+        ``GmresTelemetry`` (core/fusion_kernel_newton_runtime.py:44-72) is applied to the returned counters.
+        """
+        if boundary_flux is not None:
+            bf = as_f64(boundary_flux)
+            if bf.shape == (self.NZ, self.NR):
+                bf = np.broadcast_to(bf, (self.batch, self.NZ, self.NR))
+            if bf.shape != (self.batch, self.NZ, self.NR):
+                raise ValueError(f"boundary_flux shape {bf.shape} must match Psi shape {(self.NZ, self.NR)}")
+            self.set_boundary_flux(np.ascontiguousarray(bf))
+        p = picard_params_from_cfg({**self.cfg, "solver": {**self.cfg["solver"], "solver_method": "newton"}},
+                                   preserve_initial_state=preserve_initial_state, has_boundary_flux=boundary_flux is not None,
+                                   external_profile_mode=self.external_profile_mode)
+        o = newton_opts_from_cfg(self.cfg, poll_every=poll_every)
+        res = (NewtonResult * self.batch)()
+        cap = max(int(p.max_iter), 0) + 2
+        hd, hg = np.zeros((self.batch, cap)), np.zeros((self.batch, cap))
+        check(self._L.scpn_gs_newton_solve(self._h, C.byref(p), C.byref(o), res, ptr(hd), ptr(hg)))
+        sol = self.cfg["solver"]
+        budget = sol.get("gmres_nonconverged_budget")
+        out = []
+        for b in range(self.batch):
+            r = res[b]
+            if budget is not None and r.gmres_nonconverged > int(budget):
+                raise RuntimeError(f"GMRES non-convergence budget exceeded: {r.gmres_nonconverged}>{int(budget)} "
+                                   f"(last info={r.gmres_last_info}, member={b})")
+            out.append({"converged": bool(r.converged), "iterations": int(r.iterations), "diverged": bool(r.diverged),
+                        "residual": r.residual, "residual_history": hd[b, : r.n_hist].tolist(), "gs_residual": r.gs_residual,
+                        "gs_residual_best": r.gs_residual_best, "gs_residual_history": hg[b, : r.n_gs_hist].tolist(),
+                        "newton_line_search": bool(o.line_search), "newton_line_search_attempts": int(r.ls_attempts),
+                        "newton_line_search_accepts": int(r.ls_accepts), "newton_line_search_rejects": int(r.ls_rejects),
+                        "gmres_nonconverged_count": int(r.gmres_nonconverged), "gmres_breakdown_count": int(r.gmres_breakdown),
+                        "gmres_last_info": int(r.gmres_last_info), "gmres_inner_iterations": int(r.gmres_inner),
+                        "gmres_fail_on_breakdown": bool(sol.get("gmres_fail_on_breakdown", True)),
+                        "gmres_nonconverged_budget": None if budget is None else int(budget), "solver_method": "newton"})
         return out
 
     def solve_free_boundary(self, coil_r=None, coil_z=None, coil_currents=None, turns=None, *, max_outer_iter=20, tol=1e-4,

@@ -170,8 +170,10 @@ class FusionKernel:
         """core/fusion_kernel_newton_solver.py:390-615 (Picard methods multigrid / sor / jacobi)."""
         t0 = time.time()
         method = self.cfg["solver"].get("solver_method", "multigrid")
-        if method in ("newton", "rust_multigrid"):
-            raise NotImplementedError(f"solver_method={method!r} is not on the HIP path yet (SURVEY.md section 8 row f1)")
+        if method == "rust_multigrid":
+            raise NotImplementedError("solver_method='rust_multigrid' delegates to the Rust crate; not on the HIP path")
+        if method == "newton":
+            return self._newton_solve_dispatch(preserve_initial_state, boundary_flux)
         if boundary_flux is not None:
             bf = np.asarray(boundary_flux, dtype=np.float64)
             if bf.shape != self.Psi.shape:
@@ -201,6 +203,28 @@ class FusionKernel:
             "wall_time_s": time.time() - t0,
             "solver_method": method,
         }
+
+    def _newton_solve_dispatch(self, preserve_initial_state: bool = False, boundary_flux=None) -> dict[str, Any]:
+        """core/fusion_kernel_newton_solver.py:104-372 on the device (Picard warm-up + Newton/GMRES)."""
+        t0 = time.time()
+        if boundary_flux is not None:
+            bf = np.asarray(boundary_flux, dtype=np.float64)
+            if bf.shape != self.Psi.shape:
+                raise ValueError(f"boundary_flux shape {bf.shape} must match Psi shape {self.Psi.shape}")
+        es = self._solver()
+        if preserve_initial_state:
+            es.set_psi(np.ascontiguousarray(self.Psi, dtype=np.float64), 0)
+        if self.external_profile_mode:
+            es.set_jphi(np.ascontiguousarray(self.J_phi, dtype=np.float64), 0)
+        res = es.solve_newton(preserve_initial_state=preserve_initial_state, boundary_flux=boundary_flux)[0]
+        if res["diverged"] and self.cfg["solver"].get("fail_on_diverge", False):
+            raise RuntimeError(f"Newton solver diverged at iter={res['iterations'] - 1}")
+        self.Psi = es.get_psi(0)
+        self.J_phi = es.get_jphi(0)
+        self.compute_b_field()
+        res.pop("diverged", None)
+        res.pop("gmres_inner_iterations", None)
+        return {"psi": self.Psi, **res, "wall_time_s": time.time() - t0}
 
     def _solve_free_boundary_device(self, coils: _fb.CoilSet, max_outer_iter: int, tol: float) -> dict[str, Any]:
         es = self._solver()

@@ -404,8 +404,115 @@ def gen_fastsolver():
     save("fastsolver.npz", **out)
 
 
+# ── (f1) Newton-Kantorovich + GMRES  core/fusion_kernel_newton_solver.py:104-372 ──
+def gen_newton():
+    """Full Newton dispatch runs (residual histories, psi) + unit vectors for the profile Jacobian,
+    one scipy GMRES solve on the Newton operator, and LAPACK dlartg samples."""
+    from scipy.linalg.lapack import dlartg
+    from scipy.sparse.linalg import LinearOperator, gmres
+
+    from scpn_fusion.core.fusion_kernel_solver_runtime import apply_gs_operator, compute_profile_jacobian
+
+    out, cfgs = {}, {}
+    mock = {  # tests/test_newton_equilibrium.py:21-38 MOCK_CONFIG
+        "reactor_name": "Newton-Test", "grid_resolution": [20, 20],
+        "dimensions": {"R_min": 4.0, "R_max": 8.0, "Z_min": -4.0, "Z_max": 4.0},
+        "physics": {"plasma_current_target": 15.0, "vacuum_permeability": 1.0},
+        "coils": [{"name": "PF1", "r": 3.0, "z": 7.6, "current": 8.0}, {"name": "PF2", "r": 8.2, "z": 6.7, "current": -1.32},
+                  {"name": "CS", "r": 1.7, "z": 0.0, "current": 0.15}],
+        "solver": {"max_iterations": 60, "convergence_threshold": 1e-3, "relaxation_factor": 0.1, "solver_method": "newton"},
+    }
+
+    def variant(**solver):
+        c = json.loads(json.dumps(mock))
+        c["solver"].update(solver)
+        return c
+
+    hm = variant()
+    hm["physics"]["profiles"] = {"mode": "h-mode",
+                                 "p_prime": {"ped_top": 0.92, "ped_width": 0.05, "ped_height": 1.0, "core_alpha": 0.3},
+                                 "ff_prime": {"ped_top": 0.92, "ped_width": 0.05, "ped_height": 1.0, "core_alpha": 0.3}}
+    it33 = iter_cfg(33, method="newton", omega=1.6, tol=1e-6, max_iter=40, alpha=0.1)
+    it65 = iter_cfg(65, method="newton", omega=1.6, tol=1e-6, max_iter=30, alpha=0.1)
+    it65d = iter_cfg(65, method="newton", omega=1.6, tol=1e-6, max_iter=30, alpha=0.1)
+    it65d["solver"]["gmres_preconditioner"] = "diagonal"
+    cases = {
+        "mock20": variant(),
+        "mock20_diag": variant(gmres_preconditioner="diagonal"),
+        "mock20_ls": variant(newton_line_search=True, newton_line_search_c=1e-4, newton_line_search_max_backtracks=8),
+        "mock20_hmode": hm,
+        "mock20_gsreq": variant(require_gs_residual=True, gs_residual_threshold=1e-4, max_iterations=40),
+        "iter33": it33,
+        "iter65": it65,
+        "iter65_diag": it65d,
+    }
+    for name, cfg in cases.items():
+        k = make_kernel(cfg)
+        res = k.solve_equilibrium()
+        cfgs[name] = cfg
+        out[f"{name}_psi"] = res["psi"]
+        out[f"{name}_jphi"] = k.J_phi
+        out[f"{name}_hist"] = np.array(res["residual_history"])
+        out[f"{name}_gs"] = np.array(res["gs_residual_history"])
+        out[f"{name}_stats"] = np.array([float(res["converged"]), res["iterations"], res["residual"], res["gs_residual"],
+                                         res["gs_residual_best"], res["newton_line_search_attempts"],
+                                         res["newton_line_search_accepts"], res["newton_line_search_rejects"],
+                                         res["gmres_nonconverged_count"], res["gmres_breakdown_count"], res["gmres_last_info"]])
+        print(name, res["iterations"], res["converged"], res["residual"], res["gmres_nonconverged_count"])
+    out["_configs"] = np.array(json.dumps(cfgs))
+
+    # unit: profile Jacobian + one GMRES solve on a mid-solve state (33^2 Picard-converged psi)
+    k = make_kernel(iter_cfg(33, tol=1e-4, max_iter=200))
+    k.solve_equilibrium()
+    _, _, pa = k._find_magnetic_axis()
+    _, pb = k.find_x_point(k.Psi)
+    mu0 = k.cfg["physics"]["vacuum_permeability"]
+    dj = compute_profile_jacobian(k, pa, pb, mu0)
+    k.external_profile_mode = True
+    dj_ext = compute_profile_jacobian(k, pa, pb, mu0)
+    k.external_profile_mode = False
+    out["jac_psi"], out["jac_jphi"], out["jac_axis_bnd"] = k.Psi.copy(), k.J_phi.copy(), np.array([pa, pb])
+    out["jac_dj"], out["jac_dj_ext"] = dj, dj_ext
+    out["jac_itarget"] = np.array(k.cfg["physics"]["plasma_current_target"])
+    diag_term = -mu0 * k.RR * dj
+    NZ, NR = k.Psi.shape
+    n_int = (NZ - 2) * (NR - 2)
+
+    def matvec(v):
+        v2 = np.zeros((NZ, NR))
+        v2[1:-1, 1:-1] = v.reshape(NZ - 2, NR - 2)
+        lv = apply_gs_operator(k, v2)
+        lv[1:-1, 1:-1] -= diag_term[1:-1, 1:-1] * v2[1:-1, 1:-1]
+        return lv[1:-1, 1:-1].ravel()
+
+    rng = np.random.default_rng(7)
+    rhs = rng.normal(size=n_int)
+    J = LinearOperator((n_int, n_int), matvec=matvec, dtype=np.float64)
+    resn = []
+    x, info = gmres(J, rhs, maxiter=100, restart=50, atol=1e-8, rtol=1e-6, callback=resn.append, callback_type="pr_norm")
+    dl = -2.0 / k.dR**2 - 2.0 / k.dZ**2
+    inv_diag = 1.0 / (dl - diag_term[1:-1, 1:-1]).ravel()
+    M = LinearOperator((n_int, n_int), matvec=lambda v: inv_diag * v, dtype=np.float64)
+    resn_d = []
+    xd, info_d = gmres(J, rhs, maxiter=100, restart=50, atol=1e-8, rtol=1e-6, M=M, callback=resn_d.append,
+                       callback_type="pr_norm")
+    x3, info3 = gmres(J, rhs, maxiter=3, restart=50, atol=1e-8, rtol=1e-6)
+    out["gm_diag_term"], out["gm_rhs"], out["gm_r"] = diag_term, rhs, k.RR.copy()
+    out["gm_drdz"] = np.array([k.dR, k.dZ])
+    out["gm_x"], out["gm_info"], out["gm_prnorm"] = x, np.array(info), np.array(resn)
+    out["gm_xd"], out["gm_info_d"], out["gm_prnorm_d"], out["gm_inv_diag"] = xd, np.array(info_d), np.array(resn_d), inv_diag
+    out["gm_x3"], out["gm_info3"] = x3, np.array(info3)
+    print("gmres", info, len(resn), "diag", info_d, len(resn_d), "3 cycles", info3)
+
+    fg = np.array([[3.0, 4.0], [-3.0, 4.0], [3.0, -4.0], [0.0, 2.0], [0.0, -2.0], [5.0, 0.0], [1e-200, 1e-180], [1e200, -1e190],
+                   [1e-320, 1.0], [-2.5, 1e-17], [0.3, 0.7]])
+    out["lartg_in"] = fg
+    out["lartg_out"] = np.array([dlartg(f, g) for f, g in fg])
+    save("newton.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["smooth", "operators", "mgsolve", "polyglot", "picard", "pieces", "green",
-                             "free_boundary", "fastsolver", "anderson", "shape", "eqdsk"]
+                             "free_boundary", "fastsolver", "anderson", "shape", "eqdsk", "newton"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -121,9 +121,24 @@ def test_config_contract_and_param_block():
     cfg["solver"]["solver_method"] = "sor"
     p = picard_params_from_cfg(cfg)
     assert p.hmode == 1 and p.ped_p[0] == 0.9 and p.ped_ff[0] == 0.92 and p.method == 1 and p.sor_omega == 1.0
-    cfg["solver"]["solver_method"] = "newton"
+    cfg["solver"]["solver_method"] = "rust_multigrid"
     with pytest.raises(NotImplementedError):
         picard_params_from_cfg(cfg)
+    from scpn_fusion_core_amd.ensemble import newton_opts_from_cfg
+
+    cfg["solver"].update(solver_method="newton", gmres_preconditioner="diagonal", newton_line_search=True,
+                         newton_line_search_max_backtracks=8)
+    o = newton_opts_from_cfg(cfg)
+    assert (o.precond, o.line_search, o.max_backtracks, o.gmres_restart, o.gmres_maxiter) == (1, 1, 8, 50, 100)
+    assert o.line_search_c == 1e-4 and o.newton_alpha == 0.5 and o.warmup_steps == -1
+    for bad in ({"gmres_preconditioner": "bogus"}, {"newton_line_search_c": 1.5}, {"newton_line_search_max_backtracks": 0},
+                {"gmres_nonconverged_budget": -1}, {"gmres_ilu_drop_tol": 0.0}):  # tests/test_newton_equilibrium.py:176-230
+        with pytest.raises(ValueError):
+            newton_opts_from_cfg({**cfg, "solver": {**cfg["solver"], **bad}})
+    with pytest.raises(NotImplementedError):
+        newton_opts_from_cfg({**cfg, "solver": {**cfg["solver"], "gmres_preconditioner": "ilu"}})
+    for k in ("gmres_preconditioner", "newton_line_search", "newton_line_search_max_backtracks"):
+        cfg["solver"].pop(k)
     cfg["solver"].update(solver_method="multigrid", require_gs_residual=True, gs_residual_threshold=0.0)
     with pytest.raises(ValueError):
         picard_params_from_cfg(cfg)
