@@ -10,9 +10,11 @@
 // Layout: Krylov vectors are stored on the padded (nz, ld) grid of the solver with a ZERO ring and ZERO pad
 // columns, so a vector of the reference's interior space (nz-2)*(nr-2) is the same numbers plus zeros: dots
 // and norms run flat over the member stride (16-B loads), the operator is the plain 5-point stencil.
-// Reductions: every block writes a partial, the last block to finish (agent-scope atomic counter) adds the
-// partials in index order and runs the scalar tail (Gram-Schmidt coefficient, rotation, tolerance control),
-// so one MGS step is one launch and results do not depend on block scheduling.
+// Reductions: every block writes a partial; the CONSUMER kernel (the next launch on the stream) has each of its blocks
+// add the partials in index order at its start, so a Gram-Schmidt step is one launch, no device-scope fence or atomic
+// is needed (on gfx950 an agent-scope release/acquire per block costs an L2 write-back + invalidate: measured 100x
+// slower), and results do not depend on block scheduling.  Scalar tails (rotations, tolerance control) run in
+// one-block-per-member kernels once per column / cycle.
 #pragma once
 
 namespace gs {
@@ -23,8 +25,7 @@ struct GmState {
     double bnrm2, atol, ptol, ptol_max_factor, presid, rnorm, h0, tmp, Mb;
     double S[GM_R + 1], y[GM_R + 1], giv[GM_R * 2], h[GM_R * (GM_R + 1)];
     int inner_on, solve_on, breakdown, info, col_final, inner_total, cycles, restart;
-    unsigned counter;
-    int pad;
+    int pad0, pad1;
 };
 
 // per-member Newton state
@@ -38,8 +39,7 @@ struct NtMember {
     int ls_on, ls_accepted, ls_attempts, ls_accepts, ls_rejects;
     int gm_nonconv, gm_breakdown, gm_last_info;
     long gm_inner;
-    unsigned counter;
-    int bad;
+    int pad0, pad1;
 };
 
 struct NtCtl {
@@ -49,33 +49,16 @@ struct NtCtl {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool last_block(unsigned* counter, unsigned nblocks) {
-    __shared__ int is_last;
-    __threadfence();  // publish this block's partial
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-        unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (t == nblocks - 1);
-    }
-    __syncthreads();
-    if (is_last) __threadfence();  // acquire the other blocks' partials
-    return is_last != 0;
-}
-__device__ __forceinline__ double ld_partial(const double* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// sum of `n` partials in index order by the 256 threads of the (last) block; valid in thread 0
+// sum of `n` partials in index order by the 256 threads of a block; the result is returned to EVERY thread
 __device__ __forceinline__ double sum_partials(const double* part, int n, double* sh) {
     double s = 0.0;
     const int t = threadIdx.y * blockDim.x + threadIdx.x;
-    for (int i = t; i < n; i += 256) s += ld_partial(part + i);
-    // block_sum<256> uses threadIdx.x only; flatten
+    for (int i = t; i < n; i += 256) s += part[i];
     s = wave_sum(s);
+    __syncthreads();
     if ((t & 63) == 0) sh[t >> 6] = s;
     __syncthreads();
-    double r = 0.0;
-    if (t == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-    __syncthreads();
-    return r;
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 __device__ __forceinline__ double block_sum_flat(double v, double* sh) {
     const int t = threadIdx.y * blockDim.x + threadIdx.x;
@@ -123,15 +106,12 @@ __device__ __forceinline__ double lop_at(const double* v, const Lvl& L, int iz, 
 }
 
 // ------------------------------------------------------------------------------------------------ Newton level
-// r_k = L psi - Source on the interior (zero ring) + sum r^2.  2-D grid (ceil(nr/64), ceil(nz/4), B), block 64x4.
-// mode 0: Newton residual of the iteration (history, convergence test, newton_solver.py:197-214)
-// mode 1: line-search trial norm (accept test :267-274)      mode 2: post-step norm of the line search (:292-294)
-__global__ void __launch_bounds__(256) k_nt_resid(Fld outF, Fld psiF, Fld srcF, Lvl L, Member* st, NtMember* nt, NtCtl ctl, int mode,
-                                                  double ls_c, double* hist, double* gs_hist, double* part, int* f_active,
-                                                  int* n_on) {
+// r_k = L psi - Source on the interior (zero ring) + per-block sum r^2.  2-D grid (ceil(nr/64), ceil(nz/4), B), block 64x4.
+// which 0: members nt.on            which 1: members nt.ls_on (line-search trial)
+__global__ void __launch_bounds__(256) k_nt_resid(Fld outF, Fld psiF, Fld srcF, Lvl L, const NtMember* nt, int which, double* part) {
     __shared__ double sh[4];
     const int b = blockIdx.z;
-    if (mode == 1 ? !nt[b].ls_on : !nt[b].on) return;
+    if (which == 1 ? !nt[b].ls_on : !nt[b].on) return;
     const int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
     double v = 0.0;
     const bool in = ir < L.nr && iz < L.nz;
@@ -139,58 +119,69 @@ __global__ void __launch_bounds__(256) k_nt_resid(Fld outF, Fld psiF, Fld srcF, 
     if (in && outF.base) outF.at(b)[(long)iz * L.ld + ir] = v;
     const int nblk = gridDim.x * gridDim.y;
     double bs = block_sum_flat(v * v, sh);
-    double* mypart = part + (long)b * nblk;
-    if (threadIdx.x == 0 && threadIdx.y == 0) mypart[blockIdx.y * gridDim.x + blockIdx.x] = bs;
-    if (!last_block(&nt[b].counter, nblk)) return;
-    double tot = sum_partials(mypart, nblk, sh);
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-        NtMember& m = nt[b];
-        m.counter = 0;
-        const double nrm = sqrt(tot);
-        if (mode == 0) {
-            const double gsr = sqrt(tot / (double)ctl.n_interior);
-            m.res_norm = nrm;
-            m.gs = gsr;
-            if (!ctl.line_search) { if (m.n_hist < ctl.hist_cap) hist[(long)b * ctl.hist_cap + m.n_hist] = nrm; m.n_hist++; m.last_hist = nrm; }
-            if (m.n_gs_hist < ctl.hist_cap) gs_hist[(long)b * ctl.hist_cap + m.n_gs_hist] = gsr;
-            m.n_gs_hist++;
-            if (gsr < m.gs_best) m.gs_best = gsr;
-            const bool upd = nrm < ctl.tol;
-            const bool gsc = (!ctl.require_gs) || (gsr < ctl.gs_tol);
-            if (upd && gsc) {
-                if (ctl.line_search) { if (m.n_hist < ctl.hist_cap) hist[(long)b * ctl.hist_cap + m.n_hist] = nrm; m.n_hist++; m.last_hist = nrm; }
-                m.converged = 1;
-                m.on = 0;
-                st[b].active = 0;
-                st[b].converged = 1;
-                f_active[b] = 0;
-                atomicSub(n_on, 1);
-            }
-        } else if (mode == 1) {
-            m.ls_attempts++;
-            if (nrm <= (1.0 - ls_c * m.ls_alpha) * m.res_norm) { m.ls_accepted = 1; m.ls_accepts++; m.ls_on = 0; }
-            else { m.ls_rejects++; m.ls_alpha *= 0.5; }
-        } else {
-            if (m.n_hist < ctl.hist_cap) hist[(long)b * ctl.hist_cap + m.n_hist] = nrm;
-            m.n_hist++;
-            m.last_hist = nrm;
+    if (threadIdx.x == 0 && threadIdx.y == 0) part[(long)b * nblk + blockIdx.y * gridDim.x + blockIdx.x] = bs;
+}
+// one block per member: finish the norm and act on it
+// mode 0: Newton residual of the iteration (history, convergence test, newton_solver.py:197-214)
+// mode 1: line-search trial norm (accept test :267-274)      mode 2: post-step norm of the line search (:292-294)
+__global__ void __launch_bounds__(256) k_nt_resid_final(Member* st, NtMember* nt, NtCtl ctl, int mode, double ls_c, double* hist,
+                                                        double* gs_hist, const double* part, int nblk, int* f_active, int* n_on) {
+    __shared__ double sh[4];
+    const int b = blockIdx.x;
+    if (mode == 1 ? !nt[b].ls_on : !nt[b].on) return;
+    const double tot = sum_partials(part + (long)b * nblk, nblk, sh);
+    if (threadIdx.x != 0) return;
+    NtMember& m = nt[b];
+    const double nrm = sqrt(tot);
+    if (mode == 0) {
+        const double gsr = sqrt(tot / (double)ctl.n_interior);
+        m.res_norm = nrm;
+        m.gs = gsr;
+        if (!ctl.line_search) { if (m.n_hist < ctl.hist_cap) hist[(long)b * ctl.hist_cap + m.n_hist] = nrm; m.n_hist++; m.last_hist = nrm; }
+        if (m.n_gs_hist < ctl.hist_cap) gs_hist[(long)b * ctl.hist_cap + m.n_gs_hist] = gsr;
+        m.n_gs_hist++;
+        if (gsr < m.gs_best) m.gs_best = gsr;
+        const bool upd = nrm < ctl.tol;
+        const bool gsc = (!ctl.require_gs) || (gsr < ctl.gs_tol);
+        if (upd && gsc) {
+            if (ctl.line_search) { if (m.n_hist < ctl.hist_cap) hist[(long)b * ctl.hist_cap + m.n_hist] = nrm; m.n_hist++; m.last_hist = nrm; }
+            m.converged = 1;
+            m.on = 0;
+            st[b].active = 0;
+            st[b].converged = 1;
+            f_active[b] = 0;
+            atomicSub(n_on, 1);
         }
+    } else if (mode == 1) {
+        m.ls_attempts++;
+        if (nrm <= (1.0 - ls_c * m.ls_alpha) * m.res_norm) { m.ls_accepted = 1; m.ls_accepts++; m.ls_on = 0; }
+        else { m.ls_rejects++; m.ls_alpha *= 0.5; }
+    } else {
+        if (m.n_hist < ctl.hist_cap) hist[(long)b * ctl.hist_cap + m.n_hist] = nrm;
+        m.n_hist++;
+        m.last_hist = nrm;
     }
 }
 
-// s = sum(mask * (1 - psi_N) * R)  (fusion_kernel_solver_runtime.py:124); flat over nz*nr, grid (nblk, B)
-__global__ void __launch_bounds__(256) k_nt_jac_sum(Fld psiF, const Member* st, NtMember* nt, int nz, int nr, int ld, const double* r_axis,
-                                                    double dr, double dz, double* part, int nblk) {
-    __shared__ double sh[4];
-    const int b = blockIdx.y;
-    if (!nt[b].on) return;
-    const double* psi = psiF.at(b);
-    double pa = st[b].psi_axis, pb = st[b].psi_bnd;
+__device__ __forceinline__ double jac_denom_of(const Member& m, double& pa_out) {
+    double pa = m.psi_axis, pb = m.psi_bnd;  // fusion_kernel_solver_runtime.py:75-86
     if (!finite_d(pa)) pa = 0.0;
     if (pb != pb || pb > 1.79e308) pb = pa + 1e-9; else if (pb < -1.79e308) pb = pa - 1e-9;
     double denom = pb - pa;
     if (!finite_d(denom)) denom = 1e-9;
     if (fabs(denom) < 1e-9) denom = denom >= 0.0 ? 1e-9 : -1e-9;
+    pa_out = pa;
+    return denom;
+}
+// partial sums of mask * (1 - psi_N) * R  (fusion_kernel_solver_runtime.py:124); flat over nz*nr, grid (nblk, B)
+__global__ void __launch_bounds__(256) k_nt_jac_sum(Fld psiF, const Member* st, const NtMember* nt, int nz, int nr, int ld,
+                                                    const double* r_axis, double* part, int nblk) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y;
+    if (!nt[b].on) return;
+    const double* psi = psiF.at(b);
+    double pa;
+    const double denom = jac_denom_of(st[b], pa);
     const long n = (long)nz * nr;
     double s = 0.0;
 #pragma unroll
@@ -206,33 +197,30 @@ __global__ void __launch_bounds__(256) k_nt_jac_sum(Fld psiF, const Member* st, 
         }
     }
     double bs = block_sum<256>(s, sh);
-    double* mypart = part + (long)b * nblk;
-    if (threadIdx.x == 0) mypart[blockIdx.x] = bs;
-    if (!last_block(&nt[b].counter, nblk)) return;
-    double tot = sum_partials(mypart, nblk, sh);
-    if (threadIdx.x == 0) {
-        NtMember& m = nt[b];
-        m.counter = 0;
-        double sv = tot * dr * dz;
+    if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = bs;
+}
+// diag_term = (-mu0 R) * dJ/dpsi (newton_solver.py:215) and, for the diagonal preconditioner,
+// inv_diag = 1 / safe(-2/dR^2 - 2/dZ^2 - diag_term) (fusion_kernel_solver_runtime.py:222-232); ring / pads stay 0.
+// Every block first finishes s = sum(...) * dR * dZ and c = I_target / max(|s|, 1e-9) from the partials (:124-128).
+__global__ void __launch_bounds__(256) k_nt_jac_diag(Fld dF, Fld ivdF, Fld psiF, Fld jF, const Member* st, const NtMember* nt, int nz,
+                                                     int nr, int ld, const double* r_axis, const double* neg_mu0R, int external_mode,
+                                                     int precond, double diag_lap, double dr, double dz, const double* part, int nblk) {
+    __shared__ double sh[4];
+    const int b = blockIdx.z;
+    if (!nt[b].on) return;
+    double jac_c = 0.0;
+    if (!external_mode) {
+        double sv = sum_partials(part + (long)b * nblk, nblk, sh) * dr * dz;
         if (!finite_d(sv)) sv = 0.0;
         double it = st[b].i_target;
         if (!finite_d(it)) it = 0.0;
-        m.jac_c = it / fmax(fabs(sv), 1e-9);
-        m.jac_denom = denom;
+        jac_c = it / fmax(fabs(sv), 1e-9);
     }
-}
-// diag_term = (-mu0 R) * dJ/dpsi (newton_solver.py:215) and, for the diagonal preconditioner,
-// inv_diag = 1 / safe(-2/dR^2 - 2/dZ^2 - diag_term) (fusion_kernel_solver_runtime.py:222-232); ring / pads stay 0
-__global__ void k_nt_jac_diag(Fld dF, Fld ivdF, Fld psiF, Fld jF, const Member* st, const NtMember* nt, int nz, int nr, int ld,
-                              const double* r_axis, const double* neg_mu0R, int external_mode, int precond, double diag_lap) {
-    const int b = blockIdx.z;
-    if (!nt[b].on) return;
     const int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
     if (ir < 1 || iz < 1 || ir >= nr - 1 || iz >= nz - 1) return;
     const long c = (long)iz * ld + ir;
-    double pa = st[b].psi_axis;
-    if (!finite_d(pa)) pa = 0.0;
-    const double denom = nt[b].jac_denom;
+    double pa;
+    const double denom = jac_denom_of(st[b], pa);
     double p = psiF.at(b)[c];
     if (p != p) p = pa; else if (p > 1.79e308) p = pa + 1e9; else if (p < -1.79e308) p = pa - 1e9;
     const double R = fmin(fmax(r_axis[ir], 0.0), 1e6);
@@ -246,7 +234,7 @@ __global__ void k_nt_jac_diag(Fld dF, Fld ivdF, Fld psiF, Fld jF, const Member* 
             dj = -fabs(ja) / fmax(fabs(denom), 1e-9);
             if (dj != dj) dj = 0.0; else if (dj > 1.79e308) dj = 0.0; else if (dj < -1.79e308) dj = -1e12;
         } else {
-            dj = (-nt[b].jac_c * R) / denom;
+            dj = (-jac_c * R) / denom;
             if (dj != dj) dj = 0.0; else if (dj > 1.79e308) dj = 1e12; else if (dj < -1.79e308) dj = -1e12;
         }
     }
@@ -259,11 +247,11 @@ __global__ void k_nt_jac_diag(Fld dF, Fld ivdF, Fld psiF, Fld jF, const Member* 
     }
 }
 
-// psi_trial = base + alpha * delta on the interior, ring from bc (newton_solver.py:253-256 / :296-297); detects NaN/Inf.
+// psi_trial = base + alpha * delta on the interior, ring from bc (newton_solver.py:253-256 / :296-297); per-block NaN/Inf flag.
 // which: 0 fixed step (members nt.on, alpha = fixed_alpha, base == psi in place)
 //        1 line-search trial (members nt.ls_on, alpha = nt.ls_alpha)   2 rejected-all fallback (members on && !accepted)
-__global__ void __launch_bounds__(256) k_nt_step(Fld psiF, Fld baseF, Fld dxF, Fld bcF, Member* st, NtMember* nt, int nz, int nr, int ld,
-                                                 int which, double fixed_alpha, int* part_bad, int* f_active, int* n_on, int check) {
+__global__ void __launch_bounds__(256) k_nt_step(Fld psiF, Fld baseF, Fld dxF, Fld bcF, const NtMember* nt, int nz, int nr, int ld,
+                                                 int which, double fixed_alpha, int* part_bad) {
     __shared__ int shbad;
     const int b = blockIdx.z;
     const NtMember& m0 = nt[b];
@@ -281,28 +269,29 @@ __global__ void __launch_bounds__(256) k_nt_step(Fld psiF, Fld baseF, Fld dxF, F
         psiF.at(b)[c] = v;
         if (!finite_d(v)) atomicOr(&shbad, 1);
     }
-    if (!check) return;
     __syncthreads();
-    const int nblk = gridDim.x * gridDim.y;
-    int* mypart = part_bad + (long)b * nblk;
-    if (threadIdx.x == 0 && threadIdx.y == 0) mypart[blockIdx.y * gridDim.x + blockIdx.x] = shbad;
-    if (!last_block(&nt[b].counter, nblk)) return;
+    if (part_bad && threadIdx.x == 0 && threadIdx.y == 0)
+        part_bad[(long)b * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] = shbad;
+}
+// NaN / Inf verdict of a Newton step (newton_solver.py:301-306): stop iterating, keep the state.  grid (B), 256 threads
+__global__ void __launch_bounds__(256) k_nt_step_final(Member* st, NtMember* nt, const int* part_bad, int nblk, int* f_active, int* n_on) {
+    __shared__ int shbad;
+    const int b = blockIdx.x;
+    if (!nt[b].on) return;
+    if (threadIdx.x == 0) shbad = 0;
+    __syncthreads();
     int bad = 0;
-    const int t = threadIdx.y * blockDim.x + threadIdx.x;
-    for (int i = t; i < nblk; i += 256) bad |= __hip_atomic_load(mypart + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (bad) atomicOr(&shbad, 2);
+    for (int i = threadIdx.x; i < nblk; i += 256) bad |= part_bad[(long)b * nblk + i];
+    if (bad) atomicOr(&shbad, 1);
     __syncthreads();
-    if (t == 0) {
+    if (threadIdx.x == 0 && shbad) {
         NtMember& m = nt[b];
-        m.counter = 0;
-        if (shbad & 2) {  // newton_solver.py:301-306: stop iterating, keep the state
-            m.diverged = 1;
-            m.on = 0;
-            st[b].active = 0;
-            st[b].diverged = 1;
-            f_active[b] = 0;
-            atomicSub(n_on, 1);
-        }
+        m.diverged = 1;
+        m.on = 0;
+        st[b].active = 0;
+        st[b].diverged = 1;
+        f_active[b] = 0;
+        atomicSub(n_on, 1);
     }
 }
 // line-search bookkeeping; one thread per member
@@ -330,10 +319,9 @@ __global__ void k_nt_copy(Fld dst, Fld src, const NtMember* nt, int which, int n
 }
 
 // ------------------------------------------------------------------------------------------------ GMRES
-// b = -r_k, x = 0, r = b; ||b|| and the tolerances (scipy _isolve/iterative.py gmres prologue).  flat grid (nbf, B)
+// b = -r_k, x = 0, r = b; per-block sum b^2 (scipy _isolve/iterative.py gmres prologue).  flat grid (nbf, B)
 __global__ void __launch_bounds__(256) k_gm_init(double* rhs, double* x, double* r, const double* rk, long stride, GmState* gm,
-                                                 const NtMember* nt, double atol_in, double rtol, int restart, int precond, double* part,
-                                                 int nbf) {
+                                                 const NtMember* nt, double* part, int nbf) {
     __shared__ double sh[4];
     const int b = blockIdx.y;
     if (!nt[b].on) {
@@ -356,13 +344,21 @@ __global__ void __launch_bounds__(256) k_gm_init(double* rhs, double* x, double*
         }
     }
     double bs = block_sum<256>(s, sh);
-    double* mypart = part + (long)b * nbf;
-    if (threadIdx.x == 0) mypart[blockIdx.x] = bs;
-    if (!last_block(&gm[b].counter, nbf)) return;
-    double tot = sum_partials(mypart, nbf, sh);
-    if (threadIdx.x == 0) {
-        GmState& g = gm[b];
-        g.counter = 0;
+    if (threadIdx.x == 0) part[(long)b * nbf + blockIdx.x] = bs;
+}
+// scalar tails of the GMRES driver; one block per member.
+// mode 0 (after k_gm_init): ||b||, atol, solve_on                      mode 1 (after k_gm_norm): Mb = ||M^-1 b||, first ptol
+// mode 2 (after the end-of-cycle residual): rnorm, restart / exit logic, inner-tolerance adaptation, telemetry
+__global__ void __launch_bounds__(256) k_gm_tail(GmState* gm, NtMember* nt, int mode, double atol_in, double rtol, int restart,
+                                                 int precond, int maxiter, const double* part, int nblk, int* n_solve) {
+    __shared__ double sh[4];
+    const int b = blockIdx.x;
+    if (mode == 0 ? !nt[b].on : !gm[b].solve_on) return;
+    const double tot = sum_partials(part + (long)b * nblk, nblk, sh);
+    if (threadIdx.x != 0) return;
+    GmState& g = gm[b];
+    const double eps = 2.220446049250313e-16;
+    if (mode == 0) {
         g.bnrm2 = sqrt(tot);
         g.atol = fmax(atol_in, rtol * g.bnrm2);
         g.ptol_max_factor = 1.0;
@@ -374,14 +370,35 @@ __global__ void __launch_bounds__(256) k_gm_init(double* rhs, double* x, double*
         g.breakdown = 0;
         g.inner_on = 0;
         g.col_final = 0;
-        if (g.bnrm2 == 0.0 || g.bnrm2 < g.atol) { g.solve_on = 0; g.info = 0; }  // x = 0 is the answer
+        if (g.bnrm2 == 0.0 || g.bnrm2 < g.atol) { g.solve_on = 0; g.info = 0; nt[b].gm_last_info = 0; }  // x = 0 is the answer
         else { g.solve_on = 1; g.info = -1; }
         g.Mb = g.bnrm2;
-        if (!precond) g.ptol = g.Mb * fmin(1.0, g.atol / g.bnrm2);
+        if (!precond && g.solve_on) g.ptol = g.Mb * fmin(1.0, g.atol / g.bnrm2);
+    } else if (mode == 1) {
+        g.Mb = sqrt(tot);
+        g.ptol = g.Mb * fmin(1.0, g.atol / g.bnrm2);
+    } else {
+        g.rnorm = sqrt(tot);
+        g.cycles += 1;
+        bool stop = false;
+        if (g.rnorm <= g.atol) stop = true;
+        else if (g.breakdown) stop = true;
+        else if (g.presid <= g.ptol) g.ptol_max_factor = fmax(eps, 0.25 * g.ptol_max_factor);
+        else g.ptol_max_factor = fmin(1.0, 1.5 * g.ptol_max_factor);
+        if (!stop) g.ptol = g.presid * fmin(g.ptol_max_factor, g.atol / g.rnorm);
+        if (stop || g.cycles >= maxiter) {
+            g.solve_on = 0;
+            g.info = (g.rnorm <= g.atol) ? 0 : maxiter;
+            NtMember& m = nt[b];
+            m.gm_last_info = g.info;
+            if (g.info > 0) m.gm_nonconv += 1;
+            m.gm_inner += g.inner_total;
+            atomicSub(n_solve, 1);
+        }
     }
 }
-// v0 = M^-1 r (start of a restart cycle) or, with `only_norm`, Mb = ||M^-1 b|| for the first ptol.  flat grid (nbf, B)
-__global__ void __launch_bounds__(256) k_gm_start(double* v0, const double* r, const double* ivd, long stride, GmState* gm, int precond,
+// v0 = M^-1 r (start of a restart cycle; only_norm: nothing stored, for Mb = ||M^-1 b||) + per-block sum of squares
+__global__ void __launch_bounds__(256) k_gm_start(double* v0, const double* r, const double* ivd, long stride, const GmState* gm, int precond,
                                                   int only_norm, double* part, int nbf) {
     __shared__ double sh[4];
     const int b = blockIdx.y;
@@ -404,39 +421,32 @@ __global__ void __launch_bounds__(256) k_gm_start(double* v0, const double* r, c
         }
     }
     double bs = block_sum<256>(s, sh);
-    double* mypart = part + (long)b * nbf;
-    if (threadIdx.x == 0) mypart[blockIdx.x] = bs;
-    if (!last_block(&gm[b].counter, nbf)) return;
-    double tot = sum_partials(mypart, nbf, sh);
-    if (threadIdx.x == 0) {
-        GmState& g = gm[b];
-        g.counter = 0;
-        if (only_norm) {
-            g.Mb = sqrt(tot);
-            g.ptol = g.Mb * fmin(1.0, g.atol / g.bnrm2);
-        } else {
-            g.tmp = sqrt(tot);
+    if (threadIdx.x == 0) part[(long)b * nbf + blockIdx.x] = bs;
+}
+// which 0: v0 *= 1/tmp with tmp = ||v0|| finished from k_gm_start's partials by every block; block 0 also resets the cycle state
+//          (S = tmp e_0, inner loop on).
+// which 1: v[col+1] = w * (1/h1) for the members still inside the inner loop (h1 parked in g.h0 by k_gm_col_tail).
+__global__ void __launch_bounds__(256) k_gm_scale(double* dst, const double* src, long stride, GmState* gm, int which, const double* part,
+                                                  int nbf) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y;
+    GmState& g = gm[b];
+    if (!g.solve_on) return;
+    double f;
+    if (which == 0) {
+        const double tmp = sqrt(sum_partials(part + (long)b * nbf, nbf, sh));
+        f = 1.0 / tmp;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            g.tmp = tmp;
             for (int i = 0; i <= GM_R; ++i) g.S[i] = 0.0;
-            g.S[0] = g.tmp;
+            g.S[0] = tmp;
             g.breakdown = 0;
             g.inner_on = 1;
             g.col_final = 0;
         }
-    }
-}
-// v *= 1/tmp (v0 normalisation) -- which 0; v_next = w * (1/h1) unless breakdown -- which 1.  flat grid (nbf, B)
-__global__ void __launch_bounds__(256) k_gm_scale(double* dst, const double* src, long stride, const GmState* gm, int which, int col) {
-    const int b = blockIdx.y;
-    const GmState& g = gm[b];
-    double f;
-    if (which == 0) {
-        if (!g.solve_on || !g.inner_on) return;
-        f = 1.0 / g.tmp;
     } else {
-        // written for the members that executed column `col` (still inner_on, or finished exactly at this column)
-        if (!g.solve_on || !(g.inner_on || g.col_final == col)) return;
-        const double h1 = g.h0;  // h1 is parked in h0 by the column tail
-        f = g.breakdown ? 1.0 : 1.0 / h1;
+        if (!g.inner_on) return;
+        f = 1.0 / g.h0;
     }
     const long off = (long)b * stride;
 #pragma unroll
@@ -444,16 +454,17 @@ __global__ void __launch_bounds__(256) k_gm_scale(double* dst, const double* src
         long i = ((long)blockIdx.x * 512 + k * 256 + threadIdx.x) * 2;
         if (i < stride) {
             double2 v = *reinterpret_cast<const double2*>(src + off + i);
-            if (f != 1.0 || which == 0) { v.x *= f; v.y *= f; }
+            v.x *= f;
+            v.y *= f;
             *reinterpret_cast<double2*>(dst + off + i) = v;
         }
     }
 }
-// w = M^-1 (L v - D v) on the interior + ||w||^2 (h0).  2-D grid, block 64x4.
-// resid_mode: out = b - (L x - D x) instead (end-of-cycle residual), tail = restart / tolerance control
+// w = M^-1 (L v - D v) on the interior + per-block ||w||^2.  2-D grid, block 64x4.
+// resid_mode: out = b - (L x - D x) instead (end-of-cycle residual; members solve_on)
 __global__ void __launch_bounds__(256) k_gm_matvec(double* out, const double* vin, const double* dterm, const double* ivd,
-                                                   const double* rhs, long stride, Lvl L, GmState* gm, NtMember* nt, int precond,
-                                                   int resid_mode, int maxiter, double* part, int* n_solve) {
+                                                   const double* rhs, long stride, Lvl L, const GmState* gm, int precond, int resid_mode,
+                                                   double* part) {
     __shared__ double sh[4];
     const int b = blockIdx.z;
     if (!gm[b].solve_on) return;
@@ -471,50 +482,30 @@ __global__ void __launch_bounds__(256) k_gm_matvec(double* out, const double* vi
     }
     const int nblk = gridDim.x * gridDim.y;
     double bs = block_sum_flat(v * v, sh);
-    double* mypart = part + (long)b * nblk;
-    if (threadIdx.x == 0 && threadIdx.y == 0) mypart[blockIdx.y * gridDim.x + blockIdx.x] = bs;
-    if (!last_block(&gm[b].counter, nblk)) return;
-    double tot = sum_partials(mypart, nblk, sh);
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-        GmState& g = gm[b];
-        g.counter = 0;
-        if (!resid_mode) { g.h0 = sqrt(tot); return; }
-        // end of a restart cycle (scipy gmres: rnorm test, breakdown bail-out, inner tolerance adaptation)
-        const double eps = 2.220446049250313e-16;
-        g.rnorm = sqrt(tot);
-        g.cycles += 1;
-        bool stop = false;
-        if (g.rnorm <= g.atol) stop = true;
-        else if (g.breakdown) stop = true;
-        else if (g.presid <= g.ptol) g.ptol_max_factor = fmax(eps, 0.25 * g.ptol_max_factor);
-        else g.ptol_max_factor = fmin(1.0, 1.5 * g.ptol_max_factor);
-        if (!stop) g.ptol = g.presid * fmin(g.ptol_max_factor, g.atol / g.rnorm);
-        if (stop || g.cycles >= maxiter) {
-            g.solve_on = 0;
-            g.info = (g.rnorm <= g.atol) ? 0 : maxiter;
-            NtMember& m = nt[b];
-            m.gm_last_info = g.info;
-            if (g.info > 0) m.gm_nonconv += 1;
-            m.gm_inner += g.inner_total;
-            atomicSub(n_solve, 1);
-        }
-    }
+    if (threadIdx.x == 0 && threadIdx.y == 0) part[(long)b * nblk + blockIdx.y * gridDim.x + blockIdx.x] = bs;
 }
 // one modified Gram-Schmidt step of column `col` (scipy gmres: "for k in range(col+1): tmp = dot(v[k], w); w -= tmp*v[k]"):
-//   k > 0 : w -= h[col][k-1] * v[k-1]           (the previous step's update, fused in)
-//   k<=col: h[col][k] = <v[k], w>
-//   k==col+1 (tail): w -= h[col][col]*v[col]; h1 = ||w||; rotations, residual estimate, inner-loop exit, and -- when the
-//            inner loop ends -- the triangular solve for y.
+//   every block first finishes the PREVIOUS launch's reduction from `part_in` (k == 0: h0 = ||w||, else h[col][k-1] = <v[k-1], w>),
+//   block 0 stores it in the member state;
+//   k > 0 : w -= h[col][k-1] * v[k-1]
+//   k<=col: partial <v[k], w>            k == col+1: partial ||w||^2 (h1)
 // V: base of the Krylov basis, vector j of member b at V + (j*B + b)*stride.  flat grid (nbf, B)
-__global__ void __launch_bounds__(256) k_gm_mgs(double* w, const double* V, long stride, int B, GmState* gm, int col, int k, double* part,
-                                                int nbf, int* n_inner) {
+__global__ void __launch_bounds__(256) k_gm_mgs(double* w, const double* V, long stride, int B, GmState* gm, int col, int k,
+                                                const double* part_in, int n_in, double* part_out, int nbf) {
     __shared__ double sh[4];
     const int b = blockIdx.y;
     if (!gm[b].solve_on || !gm[b].inner_on) return;
     GmState& g = gm[b];
+    const double prev = sum_partials(part_in + (long)b * n_in, n_in, sh);
+    double hprev = 0.0;
+    if (k == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) g.h0 = sqrt(prev);
+    } else {
+        hprev = prev;
+        if (blockIdx.x == 0 && threadIdx.x == 0) g.h[col * (GM_R + 1) + (k - 1)] = prev;
+    }
     const long off = (long)b * stride;
     const bool tail = k == col + 1;
-    const double hprev = k > 0 ? g.h[col * (GM_R + 1) + (k - 1)] : 0.0;
     const double* vp = k > 0 ? V + ((long)(k - 1) * B + b) * stride : nullptr;
     const double* vk = tail ? nullptr : V + ((long)k * B + b) * stride;
     double s = 0.0;
@@ -538,23 +529,30 @@ __global__ void __launch_bounds__(256) k_gm_mgs(double* w, const double* V, long
         }
     }
     double bs = block_sum<256>(s, sh);
-    double* mypart = part + (long)b * nbf;
-    if (threadIdx.x == 0) mypart[blockIdx.x] = bs;
-    if (!last_block(&g.counter, nbf)) return;
-    double tot = sum_partials(mypart, nbf, sh);
+    if (threadIdx.x == 0) part_out[(long)b * nbf + blockIdx.x] = bs;
+}
+// column tail, one block per member: h1 = ||w||, breakdown test, rotations, residual estimate, inner-loop exit and -- when the
+// inner loop ends -- the triangular solve for y.  The Hessenberg column / rotations are staged through LDS.
+__global__ void __launch_bounds__(256) k_gm_col_tail(GmState* gm, int col, const double* part, int nbf, int* n_inner) {
+    __shared__ double sh[4];
+    __shared__ double hc[GM_R + 1], gv[GM_R * 2];
+    const int b = blockIdx.x;
+    if (!gm[b].solve_on || !gm[b].inner_on) return;
+    GmState& g = gm[b];
+    const double tot = sum_partials(part + (long)b * nbf, nbf, sh);
+    for (int i = threadIdx.x; i <= col; i += 256) hc[i] = g.h[col * (GM_R + 1) + i];
+    for (int i = threadIdx.x; i < 2 * col; i += 256) gv[i] = g.giv[i];
+    __syncthreads();
     if (threadIdx.x != 0) return;
-    g.counter = 0;
-    double* hc = g.h + col * (GM_R + 1);
-    if (!tail) { hc[k] = tot; return; }
-    // ---- column tail
     const double eps = 2.220446049250313e-16;
     const double h1 = sqrt(tot);
     hc[col + 1] = h1;
-    g.breakdown = 0;
-    if (h1 <= eps * g.h0) { hc[col + 1] = 0.0; g.breakdown = 1; }
+    int breakdown = 0;
+    if (h1 <= eps * g.h0) { hc[col + 1] = 0.0; breakdown = 1; }
+    g.breakdown = breakdown;
     g.h0 = h1;  // parked for k_gm_scale
     for (int j = 0; j < col; ++j) {
-        const double c = g.giv[2 * j], s_ = g.giv[2 * j + 1];
+        const double c = gv[2 * j], s_ = gv[2 * j + 1];
         const double n0 = hc[j], n1 = hc[j + 1];
         hc[j] = c * n0 + s_ * n1;
         hc[j + 1] = -s_ * n0 + c * n1;
@@ -565,13 +563,14 @@ __global__ void __launch_bounds__(256) k_gm_mgs(double* w, const double* V, long
     g.giv[2 * col + 1] = s_;
     hc[col] = mag;
     hc[col + 1] = 0.0;
+    for (int j = 0; j <= col + 1; ++j) g.h[col * (GM_R + 1) + j] = hc[j];
     const double t2 = -s_ * g.S[col];
     g.S[col] = c * g.S[col];
     g.S[col + 1] = t2;
     g.presid = fabs(t2);
     g.inner_total += 1;
     g.col_final = col;
-    if (g.presid <= g.ptol || g.breakdown || col == g.restart - 1) {
+    if (g.presid <= g.ptol || breakdown || col == g.restart - 1) {
         g.inner_on = 0;
         atomicSub(n_inner, 1);
         // y = trsv(h[:col+1,:col+1].T, S[:col+1]) with the pseudo-solve of singular cases
@@ -610,13 +609,13 @@ __global__ void __launch_bounds__(256) k_gm_update_x(double* x, const double* V,
         }
     }
 }
-// number of members with solve_on / inner_on (start of a cycle: host polls these)
+// number of members whose solve is still running (start of a cycle: the host polls this; they all enter the inner loop)
 __global__ void k_gm_count(const GmState* gm, int B, int* n_solve, int* n_inner) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int s = 0, i = 0;
-        for (int b = 0; b < B; ++b) { s += gm[b].solve_on ? 1 : 0; i += (gm[b].solve_on && gm[b].inner_on) ? 1 : 0; }
+        int s = 0;
+        for (int b = 0; b < B; ++b) s += gm[b].solve_on ? 1 : 0;
         *n_solve = s;
-        *n_inner = i;
+        *n_inner = s;
     }
 }
 

@@ -1035,7 +1035,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         h->nt_st.alloc(B);
         HIP_TRY(hipMemsetAsync(h->nt_gm.p, 0, sizeof(GmState) * B, st));
         const int nbmax = std::max(cdiv(stride, 1024), (int)(cdiv(nr, 64) * cdiv(nz, 4)));
-        h->nt_part.alloc((size_t)B * nbmax);
+        h->nt_part.alloc((size_t)2 * B * nbmax);
         h->nt_pbad.alloc((size_t)B * nbmax);
         h->nt_cnt.alloc(4);
     }
@@ -1124,10 +1124,13 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
                                (const double*)h->d_r.p, (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
         }
     };
+    double* P0 = h->nt_part.p;                        // reduction partials, ping-pong halves
+    double* P1 = h->nt_part.p + (size_t)B * h->nt_part.n / (2 * (size_t)B);
     auto resid = [&](Fld outF, Fld sF, int mode) {
-        ProfScope ps(h, "newton_resid", 1);
-        hipLaunchKernelGGL(k_nt_resid, g2, BLK2D, 0, st, outF, curF, sF, L0, h->d_st.p, h->nt_st.p, ctl, mode, o->line_search_c, d_hist.p,
-                           d_gs.p, h->nt_part.p, h->d_active.p, d_non);
+        ProfScope ps(h, "newton_resid", 2);
+        hipLaunchKernelGGL(k_nt_resid, g2, BLK2D, 0, st, outF, curF, sF, L0, (const NtMember*)h->nt_st.p, mode == 1 ? 1 : 0, P0);
+        hipLaunchKernelGGL(k_nt_resid_final, dim3(B), dim3(256), 0, st, h->d_st.p, h->nt_st.p, ctl, mode, o->line_search_c, d_hist.p, d_gs.p,
+                           (const double*)P0, nb2, h->d_active.p, d_non);
     };
     auto poll = [&](int* dptr) {
         HIP_TRY(hipMemcpyAsync(h->h_nactive, dptr, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1140,45 +1143,57 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         const int maxit = o->gmres_maxiter > 0 ? o->gmres_maxiter : 100;
         const int pe = std::max(1, o->poll_every);
         double* V = h->nt_V.p;
+        auto tail = [&](int mode, const double* part, int nblk) {
+            hipLaunchKernelGGL(k_gm_tail, dim3(B), dim3(256), 0, st, h->nt_gm.p, h->nt_st.p, mode, o->gmres_atol, o->gmres_rtol, restart, precond,
+                               maxit, part, nblk, d_nsolve);
+        };
         {
-            ProfScope ps(h, "gmres_init", 1);
+            ProfScope ps(h, "gmres_init", precond ? 4 : 2);
             hipLaunchKernelGGL(k_gm_init, gflat, dim3(256), 0, st, buf(RHS), buf(XV), buf(RES), (const double*)buf(RK), stride, h->nt_gm.p,
-                               (const NtMember*)h->nt_st.p, o->gmres_atol, o->gmres_rtol, restart, precond, h->nt_part.p, nbf);
-            if (precond)
+                               (const NtMember*)h->nt_st.p, P0, nbf);
+            tail(0, P0, nbf);
+            if (precond) {
                 hipLaunchKernelGGL(k_gm_start, gflat, dim3(256), 0, st, (double*)nullptr, (const double*)buf(RHS), (const double*)buf(IVD), stride,
-                                   h->nt_gm.p, 1, 1, h->nt_part.p, nbf);
+                                   (const GmState*)h->nt_gm.p, 1, 1, P0, nbf);
+                tail(1, P0, nbf);
+            }
         }
         for (int cyc = 0; cyc < maxit; ++cyc) {
-            hipLaunchKernelGGL(k_gm_start, gflat, dim3(256), 0, st, V, (const double*)buf(RES), (const double*)buf(IVD), stride, h->nt_gm.p, precond,
-                               0, h->nt_part.p, nbf);
             hipLaunchKernelGGL(k_gm_count, dim3(1), dim3(64), 0, st, (const GmState*)h->nt_gm.p, B, d_nsolve, d_ninner);
             if (poll(d_nsolve) == 0) break;
-            hipLaunchKernelGGL(k_gm_scale, gflat, dim3(256), 0, st, V, (const double*)V, stride, (const GmState*)h->nt_gm.p, 0, 0);
+            hipLaunchKernelGGL(k_gm_start, gflat, dim3(256), 0, st, V, (const double*)buf(RES), (const double*)buf(IVD), stride,
+                               (const GmState*)h->nt_gm.p, precond, 0, P0, nbf);
+            hipLaunchKernelGGL(k_gm_scale, gflat, dim3(256), 0, st, V, (const double*)V, stride, h->nt_gm.p, 0, (const double*)P0, nbf);
             for (int col = 0; col < restart; ++col) {
                 {
                     ProfScope ps(h, "gmres_matvec", 1);
                     hipLaunchKernelGGL(k_gm_matvec, g2, BLK2D, 0, st, buf(WV), (const double*)(V + (long)col * n), (const double*)buf(DG),
-                                       (const double*)buf(IVD), (const double*)buf(RHS), stride, L0, h->nt_gm.p, h->nt_st.p, precond, 0, maxit,
-                                       h->nt_part.p, d_nsolve);
+                                       (const double*)buf(IVD), (const double*)buf(RHS), stride, L0, (const GmState*)h->nt_gm.p, precond, 0, P0);
                 }
                 {
-                    ProfScope ps(h, "gmres_mgs", col + 2);
-                    for (int k = 0; k <= col + 1; ++k)
-                        hipLaunchKernelGGL(k_gm_mgs, gflat, dim3(256), 0, st, buf(WV), (const double*)V, stride, B, h->nt_gm.p, col, k, h->nt_part.p,
-                                           nbf, d_ninner);
+                    ProfScope ps(h, "gmres_mgs", col + 3);
+                    for (int k = 0; k <= col + 1; ++k)  // launch k reads the partials of the previous launch, writes the other half
+                        hipLaunchKernelGGL(k_gm_mgs, gflat, dim3(256), 0, st, buf(WV), (const double*)V, stride, B, h->nt_gm.p, col, k,
+                                           (const double*)((k & 1) ? P1 : P0), k == 0 ? nb2 : nbf, (k & 1) ? P0 : P1, nbf);
+                    hipLaunchKernelGGL(k_gm_col_tail, dim3(B), dim3(256), 0, st, h->nt_gm.p, col, (const double*)(((col + 1) & 1) ? P0 : P1), nbf,
+                                       d_ninner);
                 }
                 if (col + 1 < restart)
-                    hipLaunchKernelGGL(k_gm_scale, gflat, dim3(256), 0, st, V + (long)(col + 1) * n, (const double*)buf(WV), stride,
-                                       (const GmState*)h->nt_gm.p, 1, col);
+                    hipLaunchKernelGGL(k_gm_scale, gflat, dim3(256), 0, st, V + (long)(col + 1) * n, (const double*)buf(WV), stride, h->nt_gm.p, 1,
+                                       (const double*)P0, nbf);
                 if ((col + 1) % pe == 0 && col + 1 < restart && poll(d_ninner) == 0) break;
             }
             {
-                ProfScope ps(h, "gmres_update", 2);
+                ProfScope ps(h, "gmres_update", 3);
                 hipLaunchKernelGGL(k_gm_update_x, gflat, dim3(256), 0, st, buf(XV), (const double*)V, stride, B, (const GmState*)h->nt_gm.p);
                 hipLaunchKernelGGL(k_gm_matvec, g2, BLK2D, 0, st, buf(RES), (const double*)buf(XV), (const double*)buf(DG), (const double*)buf(IVD),
-                                   (const double*)buf(RHS), stride, L0, h->nt_gm.p, h->nt_st.p, precond, 1, maxit, h->nt_part.p, d_nsolve);
+                                   (const double*)buf(RHS), stride, L0, (const GmState*)h->nt_gm.p, precond, 1, P0);
+                tail(2, P0, nb2);
             }
         }
+    };
+    auto step_check = [&]() {
+        hipLaunchKernelGGL(k_nt_step_final, dim3(B), dim3(256), 0, st, h->d_st.p, h->nt_st.p, (const int*)h->nt_pbad.p, nb2, h->d_active.p, d_non);
     };
 
     // ---- phase B: Newton iterations (newton_solver.py:183-306)
@@ -1191,37 +1206,35 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         {
             ProfScope ps(h, "newton_jacobian", 2);
             if (!p->external_profile_mode)
-                hipLaunchKernelGGL(k_nt_jac_sum, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, h->nt_st.p, nz, nr, ld,
-                                   (const double*)h->d_r.p, h->dr, h->dz, h->nt_part.p, nblk1);
-            else  // the secant-like diagonal needs only the denominator: same kernel, sum unused
-                hipLaunchKernelGGL(k_nt_jac_sum, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, h->nt_st.p, nz, nr, ld,
-                                   (const double*)h->d_r.p, h->dr, h->dz, h->nt_part.p, nblk1);
+                hipLaunchKernelGGL(k_nt_jac_sum, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, (const NtMember*)h->nt_st.p, nz, nr,
+                                   ld, (const double*)h->d_r.p, P0, nblk1);
             hipLaunchKernelGGL(k_nt_jac_diag, g2, BLK2D, 0, st, dgF, ivF, curF, jF, (const Member*)h->d_st.p, (const NtMember*)h->nt_st.p, nz, nr, ld,
-                               (const double*)h->d_r.p, (const double*)h->d_neg_mu0R.p, p->external_profile_mode, o->precond ? 1 : 0, diag_lap);
+                               (const double*)h->d_r.p, (const double*)h->d_neg_mu0R.p, p->external_profile_mode, o->precond ? 1 : 0, diag_lap,
+                               h->dr, h->dz, (const double*)P0, nblk1);
         }
         gmres();
         if (!o->line_search) {
-            hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, curF, dxF, bcF, h->d_st.p, h->nt_st.p, nz, nr, ld, 0, o->newton_alpha,
-                               h->nt_pbad.p, h->d_active.p, d_non, 1);
+            hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, curF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 0, o->newton_alpha,
+                               h->nt_pbad.p);
+            step_check();
         } else {
             hipLaunchKernelGGL(k_nt_copy, g2, BLK2D, 0, st, prvF, curF, (const NtMember*)h->nt_st.p, 0, nz, nr, ld);
             hipLaunchKernelGGL(k_nt_copy, g2, BLK2D, 0, st, srtF, srcF, (const NtMember*)h->nt_st.p, 0, nz, nr, ld);
             flags(0);
             for (int bt = 0; bt < o->max_backtracks; ++bt) {
-                hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, prvF, dxF, bcF, h->d_st.p, h->nt_st.p, nz, nr, ld, 1, 0.0, h->nt_pbad.p,
-                                   h->d_active.p, d_non, 0);
+                hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, prvF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 1, 0.0, (int*)nullptr);
                 if (!p->external_profile_mode) { flags(1); topo_source(srtF); }
                 resid(Fld{nullptr, nullptr, 0, 0}, srtF, 1);
             }
             // every backtrack rejected: minimum step, J_phi refreshed, Source kept (:277-291)
-            hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, prvF, dxF, bcF, h->d_st.p, h->nt_st.p, nz, nr, ld, 2, 0.0, h->nt_pbad.p,
-                               h->d_active.p, d_non, 0);
+            hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, prvF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 2, 0.0, (int*)nullptr);
             if (!p->external_profile_mode) { flags(2); topo_source(src2F); }
             hipLaunchKernelGGL(k_nt_copy, g2, BLK2D, 0, st, srcF, srtF, (const NtMember*)h->nt_st.p, 1, nz, nr, ld);
             flags(3);
             resid(Fld{nullptr, nullptr, 0, 0}, srcF, 2);
-            hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, curF, dxF, bcF, h->d_st.p, h->nt_st.p, nz, nr, ld, 0, 0.0, h->nt_pbad.p,
-                               h->d_active.p, d_non, 1);  // alpha 0: NaN / Inf check of the accepted state only
+            // NaN / Inf check of the accepted state (alpha 0 leaves psi as it is)
+            hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, curF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 0, 0.0, h->nt_pbad.p);
+            step_check();
         }
         n_on = poll(d_non);
     }
