@@ -110,6 +110,12 @@ int scpn_coil_flux(const double *r_axis, const double *z_axis, int nz, int nr, i
  * out[c*n_pts + p] = G(coil c -> point p); NaN where the reference raises ValueError */
 int scpn_green_points(int n_coils, const double *coil_r, const double *coil_z, int n_pts,
                       const double *pts_r, const double *pts_z, double *out);
+/* core/fusion_kernel_free_boundary.py:285-373 build_magnetic_probe_response_matrix: out[(n_flux+n_b)][n_coils];
+ * flux-loop rows turns*G, B-probe rows by central differences of the same kernel; b_dir[i] 0 = "R", 1 = "Z";
+ * coil_turns may be NULL (all 1) */
+int scpn_probe_response(int n_coils, const double *coil_r, const double *coil_z, const double *coil_turns,
+                        int n_flux, const double *flux_r, const double *flux_z, int n_b, const double *b_r,
+                        const double *b_z, const int *b_dir, double *out);
 /* core/jax_gs_solver.py:126-167 gs_solve_np (polyglot Picard + damped-Jacobi lane), batch=1 */
 int scpn_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int nr, int nz,
                      const double *r_axis, const double *z_axis, const double *psi_seed,
@@ -238,8 +244,11 @@ int scpn_gs_free_boundary_solve(scpn_gs *h, const scpn_picard_params *p, int n_c
 int scpn_gs_set_source(scpn_gs *h, int member, const double *source);
 int scpn_gs_rb_sor(scpn_gs *h, double omega, int n_sweeps);
 int scpn_gs_vcycle(scpn_gs *h, double omega, int pre_smooth, int post_smooth, int min_grid);
-/* post-solve products core/fusion_kernel.py:450-456 compute_b_field */
+/* post-solve products core/fusion_kernel.py:450-456 compute_b_field; member = -1: all members, [batch][nz][nr] */
 int scpn_gs_compute_b_field(scpn_gs *h, int member, double *b_r, double *b_z);
+/* core/fusion_kernel_free_boundary.py:156-159 sample_flux_at_points / :562-580 interp_psi of every member's psi at
+ * n_pts (R, Z) points; out [batch][n_pts] */
+int scpn_gs_sample_psi(scpn_gs *h, int n_pts, const double *pts_r, const double *pts_z, double *out);
 
 /* psi <- value on every member, on the device (ensemble re-runs without a host upload) */
 int scpn_gs_fill_psi(scpn_gs *h, double value);

@@ -1331,3 +1331,67 @@ int orc_newton_solve(const orc_picard_params *p, const orc_newton_opts *o, doubl
     free(diag); free(rhs); free(delta); free(invd); free(psi_prev); free(src_trial);
     return 0;
 }
+
+/* =====================================================================================
+ * f3: field products  
+ * ===================================================================================== */
+static int searchsorted_left(const double *a, int n, double x) {
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) / 2; if (a[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+double orc_interp_psi(const double *psi, const double *r_axis, const double *z_axis, int nz, int nr, double dr,
+                      double dz, double r_pt, double z_pt) {
+    int ir = searchsorted_left(r_axis, nr, r_pt) - 1, iz = searchsorted_left(z_axis, nz, z_pt) - 1;
+    if (ir < 0) ir = 0;
+    if (ir > nr - 2) ir = nr - 2;
+    if (iz < 0) iz = 0;
+    if (iz > nz - 2) iz = nz - 2;
+    double tr = (r_pt - r_axis[ir]) / dr, tz = (z_pt - z_axis[iz]) / dz;
+    tr = fmax(0.0, fmin(1.0, tr));
+    tz = fmax(0.0, fmin(1.0, tz));
+    double v = ((1 - tr) * (1 - tz)) * psi[IDX(iz, ir)];
+    v = v + (tr * (1 - tz)) * psi[IDX(iz, ir + 1)];
+    v = v + ((1 - tr) * tz) * psi[IDX(iz + 1, ir)];
+    v = v + (tr * tz) * psi[IDX(iz + 1, ir + 1)];
+    return v;
+}
+void orc_b_field(const double *psi, const double *r_axis, int nz, int nr, double dr, double dz, double *b_r,
+                 double *b_z) {
+    for (int iz = 0; iz < nz; ++iz)
+        for (int ir = 0; ir < nr; ++ir) {
+            double gz, gr;
+            if (iz == 0) gz = (psi[IDX(1, ir)] - psi[IDX(0, ir)]) / dz;
+            else if (iz == nz - 1) gz = (psi[IDX(nz - 1, ir)] - psi[IDX(nz - 2, ir)]) / dz;
+            else gz = (psi[IDX(iz + 1, ir)] - psi[IDX(iz - 1, ir)]) / (2.0 * dz);
+            if (ir == 0) gr = (psi[IDX(iz, 1)] - psi[IDX(iz, 0)]) / dr;
+            else if (ir == nr - 1) gr = (psi[IDX(iz, nr - 1)] - psi[IDX(iz, nr - 2)]) / dr;
+            else gr = (psi[IDX(iz, ir + 1)] - psi[IDX(iz, ir - 1)]) / (2.0 * dr);
+            double rs = fmax(r_axis[ir], 1e-6);
+            b_r[IDX(iz, ir)] = -(1.0 / rs) * gz;
+            b_z[IDX(iz, ir)] = (1.0 / rs) * gr;
+        }
+}
+void orc_probe_response(int n_coils, const double *coil_r, const double *coil_z, const double *coil_turns, int n_flux,
+                        const double *fr, const double *fz, int n_b, const double *br, const double *bz,
+                        const int *bdir, double *out) {
+    for (int c = 0; c < n_coils; ++c) {
+        double turns = coil_turns ? coil_turns[c] : 1.0, rc = coil_r[c], zc = coil_z[c];
+        for (int i = 0; i < n_flux; ++i) out[(long)i * n_coils + c] = turns * orc_green_function(rc, zc, fr[i], fz[i]);
+        for (int q = 0; q < n_b; ++q) {
+            double r_obs = br[q], z_obs = bz[q];
+            double eps_r = fmax(1.0e-5, 1.0e-5 * fabs(r_obs)), eps_z = fmax(1.0e-5, 1.0e-5 * (1.0 + fabs(z_obs)));
+            double r_safe = fmax(r_obs, eps_r), v;
+            if (bdir[q] == 0) {
+                double plus = turns * orc_green_function(rc, zc, r_safe, z_obs + eps_z);
+                double minus = turns * orc_green_function(rc, zc, r_safe, z_obs - eps_z);
+                v = -(plus - minus) / ((2.0 * eps_z) * r_safe);
+            } else {
+                double plus = turns * orc_green_function(rc, zc, r_safe + eps_r, z_obs);
+                double minus = turns * orc_green_function(rc, zc, r_safe - eps_r, z_obs);
+                v = (plus - minus) / ((2.0 * eps_r) * r_safe);
+            }
+            out[(long)(n_flux + q) * n_coils + c] = v;
+        }
+    }
+}

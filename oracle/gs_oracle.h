@@ -216,6 +216,19 @@ int orc_newton_solve(const orc_picard_params *p, const orc_newton_opts *o, doubl
                      const double *boundary_flux, double *j_phi, orc_newton_result *res, double *hist,
                      double *gs_hist);
 
+/* ---- field products ----------------------------------------------------------
+ * core/fusion_kernel_free_boundary.py:562-580 interp_psi (bilinear sample of psi) */
+double orc_interp_psi(const double *psi, const double *r_axis, const double *z_axis, int nz, int nr, double dr,
+                      double dz, double r_pt, double z_pt);
+/* core/fusion_kernel.py:450-456 compute_b_field (numpy.gradient, edge_order 1) */
+void orc_b_field(const double *psi, const double *r_axis, int nz, int nr, double dr, double dz, double *b_r,
+                 double *b_z);
+/* core/fusion_kernel_free_boundary.py:285-373 build_magnetic_probe_response_matrix; bdir 0 = "R", 1 = "Z";
+ * out [(n_flux+n_b)][n_coils] */
+void orc_probe_response(int n_coils, const double *coil_r, const double *coil_z, const double *coil_turns, int n_flux,
+                        const double *fr, const double *fz, int n_b, const double *br, const double *bz,
+                        const int *bdir, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,11 @@ def lib() -> C.CDLL:
         L.orc_gs_solve_np.argtypes = [_d, _d, _d, _d, _i, _i, _d, _d, _i, _i, _d, _d, _d, _dp]
         L.orc_fastsolver_sweeps.restype = _d
         L.orc_fastsolver_sweeps.argtypes = [_dp, _dp, _i, _i, _d, _d, _d, _d, _d, _d, _i, _d, C.POINTER(_i)]
+        L.orc_interp_psi.restype = _d
+        L.orc_interp_psi.argtypes = [_dp, _dp, _dp, _i, _i, _d, _d, _d, _d]
+        L.orc_b_field.argtypes = [_dp, _dp, _i, _i, _d, _d, _dp, _dp]
+        L.orc_probe_response.argtypes = [_i, _dp, _dp, C.c_void_p, _i, C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, _dp]
         L.orc_dlartg.argtypes = [_d, _d, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]
         L.orc_gmres_gs.argtypes = [_dp, _dp, _i, _i, _d, _d, _dp, C.c_void_p, _i, _i, _d, _d, _dp, C.POINTER(C.c_long)]
         L.orc_profile_jacobian.argtypes = [_dp, _dp, _dp, _i, _i, _d, _d, _d, _d, _d, _i, _dp]
@@ -396,6 +401,31 @@ def newton_solve(cfg, psi0=None, boundary_flux=None, *, preserve=False, external
             "newton_line_search_rejects": res.ls_rejects, "gmres_nonconverged_count": res.gmres_nonconverged,
             "gmres_breakdown_count": res.gmres_breakdown, "gmres_last_info": res.gmres_last_info,
             "gmres_matvecs": res.gmres_matvecs, "solver_method": "newton"}
+
+
+def interp_psi(psi, r_axis, z_axis, dr, dz, r_pt, z_pt):
+    psi = _c(psi)
+    return lib().orc_interp_psi(psi, _c(r_axis), _c(z_axis), psi.shape[0], psi.shape[1], dr, dz, float(r_pt), float(z_pt))
+
+
+def b_field(psi, r_axis, dr, dz):
+    psi = _c(psi)
+    br, bz = np.zeros_like(psi), np.zeros_like(psi)
+    lib().orc_b_field(psi, _c(r_axis), psi.shape[0], psi.shape[1], dr, dz, br, bz)
+    return br, bz
+
+
+def probe_response(coil_r, coil_z, turns, flux_points=None, b_points=None, b_dirs=None):
+    cr, cz = _c(coil_r), _c(coil_z)
+    ct = None if turns is None else _c(turns)
+    fp = np.zeros((0, 2)) if flux_points is None else _c(flux_points).reshape(-1, 2)
+    bp = np.zeros((0, 2)) if b_points is None else _c(b_points).reshape(-1, 2)
+    fr, fz, br, bz = (np.ascontiguousarray(a) for a in (fp[:, 0], fp[:, 1], bp[:, 0], bp[:, 1]))
+    bd = np.array([0 if str(d).upper() == "R" else 1 for d in (b_dirs or [])], dtype=np.int32)
+    out = np.zeros((len(fr) + len(br), len(cr)))
+    lib().orc_probe_response(len(cr), cr, cz, None if ct is None else ct.ctypes.data, len(fr), fr.ctypes.data, fz.ctypes.data,
+                             len(br), br.ctypes.data, bz.ctypes.data, bd.ctypes.data, out)
+    return out
 
 
 def free_boundary_solve(cfg, coils_r, coils_z, coils_i, turns, *, psi0=None, max_outer=20, tol=1e-4):

@@ -1960,10 +1960,16 @@ __global__ void k_fast_ctl(unsigned long long* delta_bits, double* last_delta, i
 }
 
 // compute_b_field, core/fusion_kernel.py:450-456
+// member >= 0: that member into br/bz (nz*nr); member < 0: every member b = blockIdx.z into br/bz + b*nz*nr
 __global__ void k_b_field(double* br, double* bz, Fld psiF, int member, int nz, int nr, int ld, double dr, double dz,
                           const double* r_axis) {
     int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
     if (ir >= nr || iz >= nz) return;
+    if (member < 0) {
+        member = blockIdx.z;
+        br += (long)member * nz * nr;
+        bz += (long)member * nz * nr;
+    }
     const double* psi = psiF.at(member);
     long c = (long)iz * ld + ir;
     double gz, gr;
@@ -1976,6 +1982,68 @@ __global__ void k_b_field(double* br, double* bz, Fld psiF, int member, int nz, 
     double rs = fmax(r_axis[ir], 1e-6);
     br[(long)iz * nr + ir] = -(1.0 / rs) * gz;
     bz[(long)iz * nr + ir] = (1.0 / rs) * gr;
+}
+
+
+// ---------------------------------------------------------------- f3: flux sampling and diagnostic response matrices
+// numpy.searchsorted(a, x) (side="left") on an ascending axis: first index i with a[i] >= x
+__device__ __forceinline__ int searchsorted_left(const double* a, int n, double x) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// interp_psi (core/fusion_kernel_free_boundary.py:562-580) at n_pts points for every member; out [B][n_pts]
+__global__ void k_sample_psi(double* out, Fld psiF, int nz, int nr, int ld, double dr, double dz, const double* r_axis,
+                             const double* z_axis, int n_pts, const double* pr, const double* pz) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (p >= n_pts) return;
+    const double R = pr[p], Z = pz[p];
+    int ir = searchsorted_left(r_axis, nr, R) - 1, iz = searchsorted_left(z_axis, nz, Z) - 1;
+    ir = max(0, min(ir, nr - 2));
+    iz = max(0, min(iz, nz - 2));
+    double tr = (R - r_axis[ir]) / dr, tz = (Z - z_axis[iz]) / dz;
+    tr = fmax(0.0, fmin(1.0, tr));
+    tz = fmax(0.0, fmin(1.0, tz));
+    const double* psi = psiF.at(b);
+    const long c = (long)iz * ld + ir;
+    double v = ((1 - tr) * (1 - tz)) * psi[c];
+    v = v + (tr * (1 - tz)) * psi[c + 1];
+    v = v + ((1 - tr) * tz) * psi[c + ld];
+    v = v + (tr * tz) * psi[c + ld + 1];
+    out[(long)b * n_pts + p] = v;
+}
+// build_magnetic_probe_response_matrix (core/fusion_kernel_free_boundary.py:285-373): out[row][coil]; rows 0..n_flux-1 are
+// flux loops (turns * G), rows n_flux.. are B probes by central differences of the same Green's function
+// (dir 0: B_R = -(dG/dZ)/R, dir 1: B_Z = (dG/dR)/R).  grid (ceil(rows/64), n_coils)
+__global__ void k_probe_response(double* out, int n_coils, const double* coil_r, const double* coil_z, const double* coil_turns,
+                                 int n_flux, const double* fr, const double* fz, int n_b, const double* br, const double* bz,
+                                 const int* bdir) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+    if (row >= n_flux + n_b) return;
+    const double rc = coil_r[c], zc = coil_z[c], turns = coil_turns ? coil_turns[c] : 1.0;
+    double v;
+    if (row < n_flux) {
+        v = turns * green_si(rc, zc, fr[row], fz[row]);
+    } else {
+        const int q = row - n_flux;
+        const double r_obs = br[q], z_obs = bz[q];
+        const double eps_r = fmax(1.0e-5, 1.0e-5 * fabs(r_obs));
+        const double eps_z = fmax(1.0e-5, 1.0e-5 * (1.0 + fabs(z_obs)));
+        const double r_safe = fmax(r_obs, eps_r);
+        if (bdir[q] == 0) {
+            const double plus = turns * green_si(rc, zc, r_safe, z_obs + eps_z);
+            const double minus = turns * green_si(rc, zc, r_safe, z_obs - eps_z);
+            v = -(plus - minus) / ((2.0 * eps_z) * r_safe);
+        } else {
+            const double plus = turns * green_si(rc, zc, r_safe + eps_r, z_obs);
+            const double minus = turns * green_si(rc, zc, r_safe - eps_r, z_obs);
+            v = (plus - minus) / ((2.0 * eps_r) * r_safe);
+        }
+    }
+    out[(long)row * n_coils + c] = v;
 }
 
 }  // namespace gs

@@ -1557,16 +1557,31 @@ static int S_vcycle(Solver* h, double omega, int pre, int post, int min_grid) {
     API_END
 }
 static int S_compute_b_field(Solver* h, int member, double* b_r, double* b_z) {
-    if (!h || member < 0 || member >= h->B || !b_r || !b_z) return fail(SCPN_E_ARG, "bad arguments");
+    if (!h || member < -1 || member >= h->B || !b_r || !b_z) return fail(SCPN_E_ARG, "bad arguments");
     API_BEGIN
-    size_t n = (size_t)h->nz * h->nr;
+    const int nb = member < 0 ? h->B : 1;
+    size_t n = (size_t)h->nz * h->nr * nb;
     DBuf<double> dbr, dbz;
     dbr.alloc(n);
     dbz.alloc(n);
-    hipLaunchKernelGGL(k_b_field, grid2d(h->nr, h->nz, 1), BLK2D, 0, h->stream, dbr.p, dbz.p, h->slot_fld(h->d_cur.p), member, h->nz, h->nr,
+    hipLaunchKernelGGL(k_b_field, grid2d(h->nr, h->nz, nb), BLK2D, 0, h->stream, dbr.p, dbz.p, h->slot_fld(h->d_cur.p), member, h->nz, h->nr,
                        h->ld, h->dr, h->dz, (const double*)h->d_r.p);
     HIP_TRY(hipMemcpyAsync(b_r, dbr.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(b_z, dbz.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    API_END
+}
+// interp_psi of every member at n_pts points (core/fusion_kernel_free_boundary.py:156-159, 562-580); out [B][n_pts]
+static int S_sample_psi(Solver* h, int n_pts, const double* pts_r, const double* pts_z, double* out) {
+    if (!h || n_pts < 1 || !pts_r || !pts_z || !out) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    DBuf<double> dr_, dz_, dout;
+    dr_.alloc(n_pts); dz_.alloc(n_pts); dout.alloc((size_t)n_pts * h->B);
+    HIP_TRY(hipMemcpyAsync(dr_.p, pts_r, sizeof(double) * n_pts, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dz_.p, pts_z, sizeof(double) * n_pts, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_sample_psi, dim3(cdiv(n_pts, 128), h->B), dim3(128), 0, h->stream, dout.p, h->slot_fld(h->d_cur.p), h->nz, h->nr, h->ld,
+                       h->dr, h->dz, (const double*)h->d_r.p, (const double*)h->d_z.p, n_pts, (const double*)dr_.p, (const double*)dz_.p);
+    HIP_TRY(hipMemcpyAsync(out, dout.p, sizeof(double) * n_pts * h->B, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     API_END
 }
@@ -1795,9 +1810,17 @@ int scpn_gs_vcycle(scpn_gs* g, double omega, int pre, int post, int min_grid) {
     return run_groups(g, [&](int, Solver* k) { return S_vcycle(k, omega, pre, post, min_grid); });
 }
 int scpn_gs_compute_b_field(scpn_gs* g, int member, double* b_r, double* b_z) {
-    if (!g || member < 0 || member >= g->B) return fail(SCPN_E_ARG, "bad arguments");
+    if (!g || member < -1 || member >= g->B) return fail(SCPN_E_ARG, "bad arguments");
+    if (member < 0) {
+        const size_t n = (size_t)g->nz * g->nr;
+        return each_group(g, [&](int gi, Solver* k) { return S_compute_b_field(k, -1, b_r + n * g->off[gi], b_z + n * g->off[gi]); });
+    }
     int local = 0, gi = locate(g, member, &local);
     return S_compute_b_field(g->kids[gi], local, b_r, b_z);
+}
+int scpn_gs_sample_psi(scpn_gs* g, int n_pts, const double* pts_r, const double* pts_z, double* out) {
+    if (!g) return fail(SCPN_E_ARG, "null handle");
+    return each_group(g, [&](int gi, Solver* k) { return S_sample_psi(k, n_pts, pts_r, pts_z, out ? out + (size_t)n_pts * g->off[gi] : nullptr); });
 }
 #ifdef CV_STAMPS
 int scpn_debug_tile_stamps(unsigned long long* out) {
@@ -2101,6 +2124,33 @@ int scpn_coil_flux(const double* r_axis, const double* z_axis, int nz, int nr, i
                        (const double*)dz_.p, n_coils, (const double*)cr.p, (const double*)cz.p, (const double*)ci.p,
                        coil_turns ? (const double*)ct.p : (const double*)nullptr, mu0, mode);
     HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * n * batch, hipMemcpyDeviceToHost));
+    API_END
+}
+int scpn_probe_response(int n_coils, const double* coil_r, const double* coil_z, const double* coil_turns, int n_flux, const double* flux_r,
+                        const double* flux_z, int n_b, const double* b_r, const double* b_z, const int* b_dir, double* out) {
+    if (n_coils < 1 || !coil_r || !coil_z || !out) return fail(SCPN_E_ARG, "CoilSet.positions must contain at least one coil.");
+    if (n_flux < 0 || n_b < 0 || n_flux + n_b < 1) return fail(SCPN_E_ARG, "At least one flux point or B probe point must be provided.");
+    if ((n_flux > 0 && (!flux_r || !flux_z)) || (n_b > 0 && (!b_r || !b_z || !b_dir))) return fail(SCPN_E_ARG, "null probe arrays");
+    for (int i = 0; i < n_b; ++i)
+        if (b_dir[i] != 0 && b_dir[i] != 1) return fail(SCPN_E_ARG, "b_probe_directions entries must be 'R' or 'Z'.");
+    API_BEGIN
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available");
+    HIP_TRY(hipSetDevice(g_device));
+    const int rows = n_flux + n_b;
+    DBuf<double> cr, cz, ct, fr, fz, br, bz, dout;
+    DBuf<int> bd;
+    auto up = [&](DBuf<double>& d, const double* src, int n) { d.alloc(std::max(n, 1)); if (n > 0) HIP_TRY(hipMemcpy(d.p, src, sizeof(double) * n, hipMemcpyHostToDevice)); };
+    up(cr, coil_r, n_coils); up(cz, coil_z, n_coils);
+    if (coil_turns) up(ct, coil_turns, n_coils);
+    up(fr, flux_r, n_flux); up(fz, flux_z, n_flux); up(br, b_r, n_b); up(bz, b_z, n_b);
+    bd.alloc(std::max(n_b, 1));
+    if (n_b > 0) HIP_TRY(hipMemcpy(bd.p, b_dir, sizeof(int) * n_b, hipMemcpyHostToDevice));
+    dout.alloc((size_t)rows * n_coils);
+    hipLaunchKernelGGL(k_probe_response, dim3(cdiv(rows, 64), n_coils), dim3(64), 0, 0, dout.p, n_coils, (const double*)cr.p, (const double*)cz.p,
+                       coil_turns ? (const double*)ct.p : (const double*)nullptr, n_flux, (const double*)fr.p, (const double*)fz.p, n_b,
+                       (const double*)br.p, (const double*)bz.p, (const int*)bd.p);
+    HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * rows * n_coils, hipMemcpyDeviceToHost));
     API_END
 }
 int scpn_green_points(int n_coils, const double* coil_r, const double* coil_z, int n_pts, const double* pts_r, const double* pts_z,

@@ -119,7 +119,8 @@ class EnsembleSolver:
         Per-member ``plasma_current_target``.
     """
 
-    def __init__(self, cfg: dict, batch: int = 1, coil_currents=None, current_targets=None, device: int | None = None):
+    def __init__(self, cfg: dict, batch: int = 1, coil_currents=None, current_targets=None, device: int | None = None,
+                 r_axis=None, z_axis=None):
         self._L = _lib.require_gpu()
         if device is not None:
             check(self._L.scpn_set_device(int(device)))
@@ -129,6 +130,10 @@ class EnsembleSolver:
         d = cfg["dimensions"]
         self.R = np.linspace(d["R_min"], d["R_max"], self.NR)  # core/fusion_kernel.py:165-168
         self.Z = np.linspace(d["Z_min"], d["Z_max"], self.NZ)
+        if r_axis is not None:  # caller-supplied axes (sampling a host array whose axes are already materialised)
+            self.R = np.ascontiguousarray(as_f64(r_axis).reshape(self.NR))
+        if z_axis is not None:
+            self.Z = np.ascontiguousarray(as_f64(z_axis).reshape(self.NZ))
         self.dR = float(self.R[1] - self.R[0])
         self.dZ = float(self.Z[1] - self.Z[0])
         h = C.c_void_p()
@@ -340,6 +345,25 @@ class EnsembleSolver:
 
     def vcycle(self, omega=1.0, pre_smooth=3, post_smooth=3, min_grid=5):
         check(self._L.scpn_gs_vcycle(self._h, float(omega), int(pre_smooth), int(post_smooth), int(min_grid)))
+
+    def sample_psi(self, points) -> np.ndarray:
+        """Bilinear psi samples of every member at ``points`` (n, 2) = (R, Z): ``sample_flux_at_points`` / ``interp_psi``
+        (core/fusion_kernel_free_boundary.py:156-159, 562-580) evaluated on the device; returns (batch, n)."""
+        pts = as_f64(points)
+        if pts.ndim != 2 or pts.shape[1] != 2 or pts.shape[0] < 1:
+            raise ValueError("points must have shape (n_points, 2) with n_points > 0.")
+        if not np.all(np.isfinite(pts)):
+            raise ValueError("points must contain finite values only.")
+        pr, pz = np.ascontiguousarray(pts[:, 0]), np.ascontiguousarray(pts[:, 1])
+        out = np.empty((self.batch, pts.shape[0]))
+        check(self._L.scpn_gs_sample_psi(self._h, pts.shape[0], pr, pz, out))
+        return out
+
+    def compute_b_field_all(self):
+        """(B_R, B_Z) of every member, each (batch, NZ, NR) (core/fusion_kernel.py:450-456)."""
+        br, bz = np.empty((self.batch, self.NZ, self.NR)), np.empty((self.batch, self.NZ, self.NR))
+        check(self._L.scpn_gs_compute_b_field(self._h, -1, br, bz))
+        return br, bz
 
     def compute_b_field(self, member=0):
         br, bz = np.empty((self.NZ, self.NR)), np.empty((self.NZ, self.NR))

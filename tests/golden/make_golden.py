@@ -404,6 +404,61 @@ def gen_fastsolver():
     save("fastsolver.npz", **out)
 
 
+# ── (f3) field products: psi sampling, B field, diagnostic response matrices, probe-based reconstruction ──
+def gen_products():
+    """core/fusion_kernel.py:450-456; core/fusion_kernel_free_boundary.py:137-159, 162-270, 285-488, 562-580."""
+    from scpn_fusion.core import fusion_kernel_free_boundary as fb
+
+    out = {}
+    cfg = iter_cfg(33, tol=1e-6, max_iter=300)
+    k = make_kernel(cfg)
+    k.solve_equilibrium()
+    out["psi"], out["b_r"], out["b_z"] = k.Psi.copy(), k.B_R.copy(), k.B_Z.copy()
+    rng = np.random.default_rng(5)
+    d = cfg["dimensions"]
+    pts = np.column_stack([rng.uniform(d["R_min"] - 0.3, d["R_max"] + 0.3, 40), rng.uniform(d["Z_min"] - 0.3, d["Z_max"] + 0.3, 40)])
+    pts[:6] = [[k.R[0], k.Z[0]], [k.R[-1], k.Z[-1]], [k.R[3], k.Z[7]], [k.R[3] + 1e-13, k.Z[7] - 1e-13], [d["R_min"] - 1.0, 0.0],
+               [6.2, d["Z_max"] + 2.0]]
+    out["sample_pts"] = pts
+    out["sample_psi"] = fb.sample_flux_at_points(k, pts)
+    pos = [(c["r"], c["z"]) for c in cfg["coils"]]
+    cur = np.array([c["current"] for c in cfg["coils"]], dtype=float) * 1e6
+    turns = [1, 2, 1, 3, 1][: len(pos)] + [1] * max(0, len(pos) - 5)
+    coils = CoilSet(positions=pos, currents=cur, turns=turns, current_limits=np.full(len(pos), 5.0e7))
+    th = np.linspace(0.0, 2.0 * np.pi, 12, endpoint=False)
+    flux_pts = np.column_stack([6.2 + 2.4 * np.cos(th), 3.8 * np.sin(th)])
+    b_pts = np.column_stack([6.2 + 2.6 * np.cos(th[::2] + 0.2), 4.0 * np.sin(th[::2] + 0.2)])
+    dirs = ["R", "Z", "R", "Z", "z", "r"]
+    resp = fb.build_magnetic_probe_response_matrix(k, coils, flux_points=flux_pts, b_probe_points=b_pts, b_probe_directions=dirs)
+    out["coil_pos"], out["coil_cur"], out["coil_turns"] = np.array(pos), cur, np.array(turns, dtype=float)
+    out["flux_pts"], out["b_pts"], out["b_dirs"] = flux_pts, b_pts, np.array([0 if x.upper() == "R" else 1 for x in dirs])
+    out["response"] = resp
+    out["mutual"] = fb.build_mutual_inductance_matrix(k, coils, flux_pts)
+    true_cur = cur * (1.0 + 0.2 * rng.uniform(-1, 1, cur.size))
+    meas = resp @ true_cur
+    sigma = np.concatenate([np.full(len(flux_pts), 1e-3), np.full(len(b_pts), 1e-4)])
+    rec = fb.reconstruct_coil_currents_from_magnetic_probes(
+        k, coils, flux_points=flux_pts, flux_measurements=meas[: len(flux_pts)], b_probe_points=b_pts, b_probe_directions=dirs,
+        b_probe_measurements=meas[len(flux_pts):], measurement_sigma=sigma, tikhonov_alpha=1e-12)
+    out["true_cur"], out["meas"], out["sigma"] = true_cur, meas, sigma
+    out["rec_currents"], out["rec_residual"] = rec["coil_currents"], rec["residual"]
+    out["rec_stats"] = np.array([rec["residual_rms"], rec["weighted_residual_rms"], rec["response_rank"], rec["response_condition"],
+                                 rec["active_bounds"]])
+    lim = np.column_stack([6.2 + 3.2 * np.cos(th), 5.0 * np.sin(th)])
+    bnd = np.column_stack([6.2 + 1.8 * np.cos(th), 3.0 * np.sin(th)])
+    target = rng.normal(size=len(bnd)) * 1e-2
+    diag = fb.reconstruct_boundary_flux_from_coils(k, coils, boundary_points=bnd, limiter_points=lim, axis_point=np.array([6.2, 0.0]),
+                                                   x_points=np.array([[5.0, -3.4], [5.0, 3.4]]), target_flux=target)
+    out["bnd_pts"], out["lim_pts"], out["bnd_target"] = bnd, lim, target
+    out["bnd_flux"], out["lim_flux"], out["x_flux"] = diag["reconstructed_flux"], diag["limiter_flux"], diag["x_point_flux"]
+    out["bnd_stats"] = np.array([diag["response_rank"], diag["min_limiter_distance_m"], diag["boundary_containment_fraction"],
+                                 diag["axis_flux"], diag["x_point_flux_span"], diag["x_point_pair_symmetry_abs_error"], diag["rmse"],
+                                 diag["max_abs_error"]])
+    out["_configs"] = np.array(json.dumps({"iter33": cfg}))
+    print("products", resp.shape, rec["coil_currents"], rec["active_bounds"], diag["rmse"])
+    save("products.npz", **out)
+
+
 # ── (f1) Newton-Kantorovich + GMRES  core/fusion_kernel_newton_solver.py:104-372 ──
 def gen_newton():
     """Full Newton dispatch runs (residual histories, psi) + unit vectors for the profile Jacobian,
@@ -513,6 +568,6 @@ def gen_newton():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["smooth", "operators", "mgsolve", "polyglot", "picard", "pieces", "green",
-                             "free_boundary", "fastsolver", "anderson", "shape", "eqdsk", "newton"]
+                             "free_boundary", "fastsolver", "anderson", "shape", "eqdsk", "newton", "products"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -273,3 +273,26 @@ def test_newton_solve(golden, name, n_cmp, rtol, cmp_psi):
         assert [out["newton_line_search_attempts"], out["newton_line_search_accepts"], out["newton_line_search_rejects"]] == \
             [int(v) for v in st[5:8]]
         assert out["gmres_nonconverged_count"] == int(st[8])
+
+
+# ── SURVEY 8 row f3: field products ───────────────────────────────────────────────────────────────────────
+def test_field_products(golden):
+    """interp_psi / compute_b_field / build_magnetic_probe_response_matrix restatements vs the reference
+    (tests/golden/make_golden.py gen_products): sampling and B are bit-exact, responses to 1e-12 (Cephes vs AGM)."""
+    g = golden("products.npz")
+    cfg = configs_from(g)["iter33"]
+    d = cfg["dimensions"]
+    r = np.linspace(d["R_min"], d["R_max"], 33)
+    z = np.linspace(d["Z_min"], d["Z_max"], 33)
+    dr, dz = r[1] - r[0], z[1] - z[0]
+    got = np.array([orc.interp_psi(g["psi"], r, z, dr, dz, a, b) for a, b in g["sample_pts"]])
+    assert np.array_equal(got, g["sample_psi"])
+    br, bz = orc.b_field(g["psi"], r, dr, dz)
+    assert np.array_equal(br, g["b_r"]) and np.array_equal(bz, g["b_z"])
+    dirs = ["R" if v == 0 else "Z" for v in g["b_dirs"]]
+    resp = orc.probe_response(g["coil_pos"][:, 0], g["coil_pos"][:, 1], g["coil_turns"], g["flux_pts"], g["b_pts"], dirs)
+    n_flux = len(g["flux_pts"])
+    np.testing.assert_allclose(resp[:n_flux], g["response"][:n_flux], rtol=1e-12)
+    # B-probe rows are central differences with eps 1e-5: the 1e-12 Green's-function agreement is amplified by ~1/eps
+    np.testing.assert_allclose(resp[n_flux:], g["response"][n_flux:], rtol=1e-6, atol=1e-7 * np.abs(g["response"][n_flux:]).max())
+    np.testing.assert_allclose(resp[:n_flux].T, g["mutual"], rtol=1e-12)
