@@ -23,6 +23,13 @@ MAX_GEQDSK_CONTOUR_POINTS = 100_000
 _FLOAT_RE = re.compile(r"[+-]?\d*\.?\d+(?:[eEdD][+-]?\d+)?")
 
 
+GEQDSK_SOURCE_CONVENTION_MODES = {"raw_canonical": "raw_canonical", "public_sparc_named_adapter": "public_sparc_named_adapter"}
+# public SPARC files whose ffprime / pprime are stored per-radian (core/eqdsk.py:44-53)
+GEQDSK_PUBLIC_SPARC_SOURCE_ADAPTERS = {"sparc_1305.eqdsk": "scaled_by_2pi", "sparc_1310.eqdsk": "scaled_by_2pi",
+                                       "sparc_1315.eqdsk": "scaled_by_2pi", "sparc_1349.eqdsk": "scaled_by_2pi"}
+GEQDSK_SOURCE_CONVENTION_ADAPTERS = {"scaled_by_2pi": 2.0 * np.pi}
+
+
 def _empty():
     return np.array([], dtype=np.float64)
 
@@ -53,6 +60,14 @@ class GEqdsk:
     zbdry: np.ndarray = field(default_factory=_empty)
     rlim: np.ndarray = field(default_factory=_empty)
     zlim: np.ndarray = field(default_factory=_empty)
+    source_convention: str = "raw_canonical"
+    source_convention_adapter: str = "none"
+    source_convention_adapter_pass: bool = True
+    source_convention_metadata: dict = field(default_factory=dict)
+
+    @property
+    def psi_norm(self) -> np.ndarray:
+        return np.linspace(0.0, 1.0, self.nw)
 
     @property
     def r(self) -> np.ndarray:
@@ -111,8 +126,31 @@ def _validate(eq: GEqdsk) -> None:
         raise ValueError(f"GEQDSK psirz must be a finite array of shape {(eq.nh, eq.nw)}.")
 
 
-def read_geqdsk(path) -> GEqdsk:
+def _apply_source_adapter(eq: GEqdsk, *, convention: str, source_file: Path, mode: str) -> GEqdsk:
+    """Documented source-convention adapter with provenance (core/eqdsk.py:295-346)."""
+    multiplier = GEQDSK_SOURCE_CONVENTION_ADAPTERS.get(convention)
+    if multiplier is None:
+        eq.source_convention, eq.source_convention_adapter, eq.source_convention_adapter_pass = "unsupported", convention, False
+        eq.source_convention_metadata = {"requested_mode": mode, "source_file": source_file.name, "adapter": convention,
+                                         "applied_scale": float("nan"), "provenance": "unsupported_named_adapter",
+                                         "error": "unsupported source convention adapter"}
+        return eq
+    eq.ffprime = np.round(multiplier * eq.ffprime, decimals=11)
+    eq.pprime = np.round(multiplier * eq.pprime, decimals=11)
+    eq.source_convention, eq.source_convention_adapter, eq.source_convention_adapter_pass = "canonical", convention, True
+    eq.source_convention_metadata = {"requested_mode": mode, "source_file": source_file.name, "adapter": convention,
+                                     "applied_scale": float(multiplier), "provenance": "public_sparc_named_adapter",
+                                     "public_case": source_file.name}
+    return eq
+
+
+def read_geqdsk(path, *, source_convention_mode: str = "raw_canonical") -> GEqdsk:
+    """core/eqdsk.py:349-539.  ``source_convention_mode="public_sparc_named_adapter"`` rescales ffprime / pprime of the
+    explicitly recognised public SPARC files by 2*pi and records the provenance; anything else stays raw."""
     path = Path(path)
+    if source_convention_mode not in GEQDSK_SOURCE_CONVENTION_MODES:
+        raise ValueError(f"Unsupported source_convention_mode: {source_convention_mode}. Expected one of: "
+                         + ", ".join(sorted(GEQDSK_SOURCE_CONVENTION_MODES)))
     if path.stat().st_size > MAX_GEQDSK_BYTES:
         raise ValueError("GEQDSK file too large")
     lines = path.read_text(encoding="utf-8").splitlines()
@@ -155,6 +193,16 @@ def read_geqdsk(path) -> GEqdsk:
         lm = take(2 * nl)
         eq.rlim, eq.zlim = lm[0::2].copy(), lm[1::2].copy()
     _validate(eq)
+    if source_convention_mode == "public_sparc_named_adapter":
+        adapter = GEQDSK_PUBLIC_SPARC_SOURCE_ADAPTERS.get(path.name.lower())
+        if adapter is None:
+            eq.source_convention_adapter, eq.source_convention_adapter_pass, eq.source_convention = "no_named_adapter", False, "raw_canonical"
+            eq.source_convention_metadata = {"requested_mode": source_convention_mode, "source_file": path.name,
+                                             "adapter": "no_named_adapter", "applied_scale": 1.0,
+                                             "provenance": "public_sparc_named_adapter_no_match",
+                                             "error": "no recognized public SPARC convention mapping"}
+        else:
+            eq = _apply_source_adapter(eq, convention=adapter, source_file=path, mode=source_convention_mode)
     return eq
 
 

@@ -377,7 +377,18 @@ def gen_eqdsk():
            "rbdry": eq.rbdry, "zbdry": eq.zbdry, "rlim": eq.rlim, "zlim": eq.zlim,
            "solve_psi": res["psi"], "solve_stats": np.array([float(res["converged"]), res["iterations"], res["residual"]]),
            "_configs": np.array(json.dumps({"diiid_lmode_1MA": cfg}))}
-    print("eqdsk", eq.nw, eq.nh, eq.current, res["iterations"], res["converged"], res["residual"])
+    sp = REF / "validation" / "reference_data" / "sparc" / "sparc_1305.eqdsk"  # public SPARC file (MIT, see sparc/LICENSE)
+    raw, ad = read_geqdsk(sp), read_geqdsk(sp, source_convention_mode="public_sparc_named_adapter")
+    none = read_geqdsk(src, source_convention_mode="public_sparc_named_adapter")
+    out.update(sparc_scalars=np.array([raw.nw, raw.nh, raw.rdim, raw.zdim, raw.rcentr, raw.rleft, raw.zmid, raw.rmaxis, raw.zmaxis,
+                                       raw.simag, raw.sibry, raw.bcentr, raw.current]),
+               sparc_psirz=raw.psirz, sparc_ffprime_raw=raw.ffprime, sparc_pprime_raw=raw.pprime, sparc_ffprime_adapted=ad.ffprime,
+               sparc_pprime_adapted=ad.pprime, sparc_rbdry=raw.rbdry, sparc_zlim=raw.zlim,
+               sparc_meta=np.array(json.dumps({"adapted": [ad.source_convention, ad.source_convention_adapter,
+                                                           ad.source_convention_adapter_pass, ad.source_convention_metadata],
+                                               "no_match": [none.source_convention, none.source_convention_adapter,
+                                                            none.source_convention_adapter_pass, none.source_convention_metadata]})))
+    print("eqdsk", eq.nw, eq.nh, eq.current, res["iterations"], res["converged"], res["residual"], "sparc", raw.nw, raw.nh)
     save("eqdsk.npz", **out)
 
 

@@ -73,3 +73,31 @@ def test_geqdsk_drives_the_solver(golden):
     assert res["residual"] == pytest.approx(resid, rel=1e-6)
     assert np.abs(k.Psi - g["solve_psi"]).max() <= 1e-10 * np.abs(g["solve_psi"]).max()
     k.close()
+
+
+def test_public_sparc_source_convention_adapter(golden):
+    """core/eqdsk.py:290-346, 513-537: the named-file adapter rescales ffprime / pprime of recognised public SPARC files
+    (fixture tests/golden/sparc/sparc_1305.eqdsk, MIT licence alongside) by 2*pi and records provenance; other files and
+    the default mode stay raw."""
+    import json
+
+    g = golden("eqdsk.npz")
+    f = ROOT / "tests" / "golden" / "sparc" / "sparc_1305.eqdsk"
+    raw = read_geqdsk(f)
+    got = [raw.nw, raw.nh, raw.rdim, raw.zdim, raw.rcentr, raw.rleft, raw.zmid, raw.rmaxis, raw.zmaxis, raw.simag, raw.sibry, raw.bcentr,
+           raw.current]
+    assert got == list(g["sparc_scalars"])
+    assert np.array_equal(raw.psirz, g["sparc_psirz"]) and np.array_equal(raw.ffprime, g["sparc_ffprime_raw"])
+    assert np.array_equal(raw.pprime, g["sparc_pprime_raw"]) and np.array_equal(raw.rbdry, g["sparc_rbdry"])
+    assert np.array_equal(raw.zlim, g["sparc_zlim"]) and raw.source_convention == "raw_canonical"
+    ad = read_geqdsk(f, source_convention_mode="public_sparc_named_adapter")
+    assert np.array_equal(ad.ffprime, g["sparc_ffprime_adapted"]) and np.array_equal(ad.pprime, g["sparc_pprime_adapted"])
+    meta = json.loads(str(g["sparc_meta"]))
+    assert [ad.source_convention, ad.source_convention_adapter, ad.source_convention_adapter_pass, ad.source_convention_metadata] == \
+        meta["adapted"]
+    none = read_geqdsk(FILE, source_convention_mode="public_sparc_named_adapter")
+    assert [none.source_convention, none.source_convention_adapter, none.source_convention_adapter_pass,
+            none.source_convention_metadata] == meta["no_match"]
+    with pytest.raises(ValueError):
+        read_geqdsk(f, source_convention_mode="bogus")
+    assert np.array_equal(raw.psi_norm, np.linspace(0.0, 1.0, raw.nw))
