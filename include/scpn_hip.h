@@ -116,6 +116,16 @@ int scpn_green_points(int n_coils, const double *coil_r, const double *coil_z, i
 int scpn_probe_response(int n_coils, const double *coil_r, const double *coil_z, const double *coil_turns,
                         int n_flux, const double *flux_r, const double *flux_z, int n_b, const double *b_r,
                         const double *b_z, const int *b_dir, double *out);
+/* ---- transport coupling ----
+ * scipy.linalg.solve_banded((1, 1), ab, b) of `batch` independent tridiagonal systems, i.e. LAPACK dgtsv (partial pivoting,
+ * bit-identical operation order): dl/du [batch][n-1], d/b/x [batch][n]; info[batch] (0, or i>0: U(i,i) == 0) may be NULL */
+int scpn_tridiag_solve(int batch, int n, const double *dl, const double *d, const double *du, const double *b,
+                       double *x, int *info);
+/* core/current_diffusion.py:277-353 CurrentDiffusionSolver.step for `batch` profiles on one rho grid: psi [batch][n] in/out,
+ * te/ne/j_* [batch][n], j_ext may be NULL */
+int scpn_current_diffusion_step(int batch, int n, const double *rho, double *psi, double r0, double a, double b0,
+                                double dt, const double *te, const double *ne, double z_eff, const double *j_bs,
+                                const double *j_cd, const double *j_ext, int *info);
 /* core/jax_gs_solver.py:126-167 gs_solve_np (polyglot Picard + damped-Jacobi lane), batch=1 */
 int scpn_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int nr, int nz,
                      const double *r_axis, const double *z_axis, const double *psi_seed,
@@ -246,6 +256,12 @@ int scpn_gs_rb_sor(scpn_gs *h, double omega, int n_sweeps);
 int scpn_gs_vcycle(scpn_gs *h, double omega, int pre_smooth, int post_smooth, int min_grid);
 /* post-solve products core/fusion_kernel.py:450-456 compute_b_field; member = -1: all members, [batch][nz][nr] */
 int scpn_gs_compute_b_field(scpn_gs *h, int member, double *b_r, double *b_z);
+/* core/integrated_transport_solver_coupling.py:39-73 map_profiles_to_2d for every member: from the resident psi and the 1-D
+ * profiles rho[n_rho] (shared), pressure_1d = ne*(Ti+Te) and the bootstrap profile jbs_1d ([batch][n_rho]) to the device
+ * J_phi (read it with scpn_gs_get_jphi; a following Picard solve in external_profile_mode consumes it in place).
+ * z_min_cfg as in scpn_picard_params.  pressure_2d_out [batch][nz][nr] and i_current_out [batch] may be NULL */
+int scpn_gs_map_profiles(scpn_gs *h, double z_min_cfg, int n_rho, const double *rho, const double *pressure_1d,
+                         const double *jbs_1d, double *pressure_2d_out, double *i_current_out);
 /* core/fusion_kernel_free_boundary.py:156-159 sample_flux_at_points / :562-580 interp_psi of every member's psi at
  * n_pts (R, Z) points; out [batch][n_pts] */
 int scpn_gs_sample_psi(scpn_gs *h, int n_pts, const double *pts_r, const double *pts_z, double *out);

@@ -1395,3 +1395,197 @@ void orc_probe_response(int n_coils, const double *coil_r, const double *coil_z,
         }
     }
 }
+
+/* =====================================================================================
+ * f4: transport coupling  
+ * ===================================================================================== */
+/* numpy.interp (numpy/_core/src/multiarray/compiled_base.c arr_interp; third-party NumPy 2.2.6): xp ascending, left = fp[0],
+ * right = fp[m-1]; slope form with the non-finite fall-backs */
+void orc_np_interp(const double *x, long n, const double *xp, const double *fp, int m, double *out) {
+    for (long i = 0; i < n; ++i) {
+        double xv = x[i];
+        if (isnan(xv)) { out[i] = xv; continue; }
+        if (xv > xp[m - 1]) { out[i] = fp[m - 1]; continue; }
+        if (xv < xp[0]) { out[i] = fp[0]; continue; }
+        int lo = 0, hi = m; /* largest j with xp[j] <= xv */
+        while (hi - lo > 1) { int mid = (lo + hi) / 2; if (xp[mid] <= xv) lo = mid; else hi = mid; }
+        int j = lo;
+        if (j == m - 1) { out[i] = fp[j]; continue; }
+        if (xp[j] == xv) { out[i] = fp[j]; continue; }
+        double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+        double r = slope * (xv - xp[j]) + fp[j];
+        if (isnan(r)) {
+            r = slope * (xv - xp[j + 1]) + fp[j + 1];
+            if (isnan(r) && fp[j] == fp[j + 1]) r = fp[j];
+        }
+        out[i] = r;
+    }
+}
+
+/* core/integrated_transport_solver_coupling.py:39-73 map_profiles_to_2d.  pressure_1d = ne*(Ti+Te), jbs_1d = the bootstrap
+ * profile (both evaluated by the transport side).  Writes Pressure_2D and J_phi; returns I_current before renormalisation */
+double orc_map_profiles_to_2d(const double *psi, const double *r_axis, const double *z_axis, int nz, int nr, double dr,
+                              double dz, double z_min_cfg, double i_target, const double *rho, const double *pressure_1d,
+                              const double *jbs_1d, int n_rho, double *pressure_2d, double *j_phi) {
+    long n = (long)nz * nr;
+    int aiz, air;
+    double psi_axis, psi_x;
+    long xidx;
+    /* np.argmax(self.Psi) -- plain argmax, no |psi_axis| floor here */
+    long imax = 0;
+    for (long i = 1; i < n; ++i) if (psi[i] > psi[imax] || (isnan(psi[i]) && !isnan(psi[imax]))) imax = i;
+    (void)aiz; (void)air;
+    psi_axis = psi[imax];
+    orc_find_x_point(psi, z_axis, nz, nr, dr, dz, z_min_cfg, &xidx, &psi_x);
+    double psi_edge = psi_x;
+    if (fabs(psi_edge - psi_axis) < 1.0) {
+        double mn = psi[0];
+        for (long i = 1; i < n; ++i) if (psi[i] < mn || isnan(psi[i])) mn = psi[i];
+        psi_edge = mn;
+    }
+    double denom = psi_edge - psi_axis;
+    if (fabs(denom) < 1e-9) denom = 1e-9;
+    double *rho2 = dalloc(n), *jb = dalloc(n);
+    for (long i = 0; i < n; ++i) {
+        double pn = (psi[i] - psi_axis) / denom;
+        pn = fmin(fmax(pn, 0.0), 1.0);
+        rho2[i] = sqrt(pn);
+    }
+    orc_np_interp(rho2, n, rho, pressure_1d, n_rho, pressure_2d);
+    orc_np_interp(rho2, n, rho, jbs_1d, n_rho, jb);
+    for (int iz = 0; iz < nz; ++iz)
+        for (int ir = 0; ir < nr; ++ir) j_phi[IDX(iz, ir)] = (pressure_2d[IDX(iz, ir)] * r_axis[ir]) + jb[IDX(iz, ir)];
+    double i_curr = orc_np_sum(j_phi, n) * dr * dz;
+    if (fabs(i_curr) > 1e-9) {
+        double s = i_target / i_curr;
+        for (long i = 0; i < n; ++i) j_phi[i] *= s;
+    }
+    free(rho2); free(jb);
+    return i_curr;
+}
+
+/* LAPACK dgtsv (one right-hand side) -- what scipy.linalg.solve_banded((1,1), ...) calls (SciPy 1.15.3 linalg/_basic.py).
+ * dl[n-1], d[n], du[n-1], b[n] are overwritten; returns info (0 ok, i>0: U(i,i) exactly zero) */
+int orc_gtsv(int n, double *dl, double *d, double *du, double *b) {
+    if (n == 0) return 0;
+    for (int i = 0; i < n - 2; ++i) {
+        if (fabs(d[i]) >= fabs(dl[i])) {
+            if (d[i] != 0.0) {
+                double fact = dl[i] / d[i];
+                d[i + 1] = d[i + 1] - fact * du[i];
+                b[i + 1] = b[i + 1] - fact * b[i];
+            } else return i + 1;
+            dl[i] = 0.0;
+        } else {
+            double fact = d[i] / dl[i];
+            d[i] = dl[i];
+            double temp = d[i + 1];
+            d[i + 1] = du[i] - fact * temp;
+            dl[i] = du[i + 1];
+            du[i + 1] = -fact * dl[i];
+            du[i] = temp;
+            temp = b[i];
+            b[i] = b[i + 1];
+            b[i + 1] = temp - fact * b[i + 1];
+        }
+    }
+    if (n > 1) {
+        int i = n - 2;
+        if (fabs(d[i]) >= fabs(dl[i])) {
+            if (d[i] != 0.0) {
+                double fact = dl[i] / d[i];
+                d[i + 1] = d[i + 1] - fact * du[i];
+                b[i + 1] = b[i + 1] - fact * b[i];
+            } else return i + 1;
+        } else {
+            double fact = d[i] / dl[i];
+            d[i] = dl[i];
+            double temp = d[i + 1];
+            d[i + 1] = du[i] - fact * temp;
+            du[i] = temp;
+            temp = b[i];
+            b[i] = b[i + 1];
+            b[i + 1] = temp - fact * b[i + 1];
+        }
+    }
+    if (d[n - 1] == 0.0) return n;
+    b[n - 1] = b[n - 1] / d[n - 1];
+    if (n > 1) b[n - 2] = (b[n - 2] - du[n - 2] * b[n - 1]) / d[n - 2];
+    for (int i = n - 3; i >= 0; --i) b[i] = (b[i] - du[i] * b[i + 1] - dl[i] * b[i + 2]) / d[i];
+    return 0;
+}
+
+/* core/current_diffusion.py:175-207 neoclassical_resistivity (Sauter) */
+double orc_neoclassical_resistivity(double te_kev, double ne_19, double z_eff, double epsilon) {
+    te_kev = fmax(te_kev, 1e-3);
+    ne_19 = fmax(ne_19, 1e-3);
+    epsilon = fmax(epsilon, 1e-6);
+    (void)ne_19;
+    double ln_lambda = 17.0;
+    double eta_sp = 1.65e-9 * z_eff * ln_lambda / pow(te_kev, 1.5);
+    double f_t = 1.0 - pow(1.0 - epsilon, 2.0) / (sqrt(1.0 - pow(epsilon, 2.0)) * (1.0 + 1.46 * sqrt(epsilon)));
+    f_t = fmax(0.0, fmin(f_t, 1.0));
+    double c_r = 1.0 - (1.0 + 0.36 / z_eff) * f_t + (0.59 / z_eff) * pow(f_t, 2.0);
+    double eta_neo = eta_sp / (1.0 - f_t) * c_r;
+    return fmax(eta_neo, eta_sp);
+}
+
+/* core/current_diffusion.py:210-233 q_from_psi */
+void orc_q_from_psi(const double *rho, const double *psi, int n, double r0, double a, double b0, double *q) {
+    double drho = rho[1] - rho[0];
+    double *g = dalloc(n);
+    g[0] = (psi[1] - psi[0]) / drho;
+    g[n - 1] = (psi[n - 1] - psi[n - 2]) / drho;
+    for (int i = 1; i < n - 1; ++i) g[i] = (psi[i + 1] - psi[i - 1]) / (2.0 * drho);
+    q[0] = 0.0;
+    for (int i = 1; i < n; ++i) {
+        double denom = r0 * g[i];
+        if (fabs(denom) < 1e-12) q[i] = i > 1 ? q[i - 1] : 1.0;
+        else q[i] = -rho[i] * pow(a, 2.0) * b0 / denom;
+    }
+    double d2 = (psi[2] - 2 * psi[1] + psi[0]) / pow(drho, 2.0);
+    if (fabs(d2) > 1e-12) q[0] = -pow(a, 2.0) * b0 / (r0 * d2);
+    else q[0] = q[1];
+    for (int i = 0; i < n; ++i) q[i] = fabs(q[i]);
+    free(g);
+}
+
+/* core/current_diffusion.py:277-353 CurrentDiffusionSolver.step; psi in/out; returns dgtsv info */
+int orc_current_diffusion_step(const double *rho, double *psi, int n, double r0, double a, double b0, double dt,
+                               const double *te, const double *ne, double z_eff, const double *j_bs, const double *j_cd,
+                               const double *j_ext) {
+    const double mu0 = 4.0 * M_PI * 1e-7;
+    double drho = rho[1] - rho[0];
+    double *q = dalloc(n), *eta = dalloc(n), *D = dalloc(n), *sub = dalloc(n), *diag = dalloc(n), *sup = dalloc(n),
+           *rhs = dalloc(n), *jt = dalloc(n);
+    for (int i = 0; i < n; ++i) jt[i] = (j_bs[i] + j_cd[i]) + (j_ext ? j_ext[i] : 0.0);
+    orc_q_from_psi(rho, psi, n, r0, a, b0, q);
+    for (int i = 0; i < n; ++i) {
+        double eps = rho[i] * a / r0;
+        eta[i] = orc_neoclassical_resistivity(te[i], ne[i], z_eff, eps);
+        D[i] = eta[i] / (mu0 * pow(a, 2.0));
+    }
+    double alpha = dt / 2.0, drho2 = pow(drho, 2.0);
+    diag[0] = 1.0 + alpha * 4.0 * D[0] / drho2;
+    sup[0] = -alpha * 4.0 * D[0] / drho2;
+    rhs[0] = psi[0] + alpha * 4.0 * D[0] * (psi[1] - psi[0]) / drho2 + dt * r0 * eta[0] * jt[0];
+    for (int i = 1; i < n - 1; ++i) {
+        double r = rho[i];
+        double cp = D[i] * (1.0 / drho2 - 1.0 / (2.0 * r * drho));
+        double cc = D[i] * (-2.0 / drho2);
+        double cn = D[i] * (1.0 / drho2 + 1.0 / (2.0 * r * drho));
+        sub[i] = -alpha * cp;
+        diag[i] = 1.0 - alpha * cc;
+        sup[i] = -alpha * cn;
+        double l = cp * psi[i - 1] + cc * psi[i] + cn * psi[i + 1];
+        rhs[i] = psi[i] + alpha * l + dt * r0 * eta[i] * jt[i];
+    }
+    diag[n - 1] = 1.0;
+    sub[n - 1] = 0.0;
+    rhs[n - 1] = psi[n - 1];
+    /* ab[0,1:] = sup[:-1]; ab[1,:] = diag; ab[2,:-1] = sub[1:]  ->  gtsv(dl = sub[1:], d = diag, du = sup[:-1], b = rhs) */
+    int info = orc_gtsv(n, sub + 1, diag, sup, rhs);
+    memcpy(psi, rhs, sizeof(double) * (size_t)n);
+    free(q); free(eta); free(D); free(sub); free(diag); free(sup); free(rhs); free(jt);
+    return info;
+}

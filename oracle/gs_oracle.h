@@ -229,6 +229,22 @@ void orc_probe_response(int n_coils, const double *coil_r, const double *coil_z,
                         const double *fr, const double *fz, int n_b, const double *br, const double *bz,
                         const int *bdir, double *out);
 
+/* ---- transport coupling --------------------------------------------------------
+ * numpy.interp (third-party NumPy 2.2.6, compiled_base.c arr_interp) */
+void orc_np_interp(const double *x, long n, const double *xp, const double *fp, int m, double *out);
+/* core/integrated_transport_solver_coupling.py:39-73 map_profiles_to_2d */
+double orc_map_profiles_to_2d(const double *psi, const double *r_axis, const double *z_axis, int nz, int nr, double dr,
+                              double dz, double z_min_cfg, double i_target, const double *rho, const double *pressure_1d,
+                              const double *jbs_1d, int n_rho, double *pressure_2d, double *j_phi);
+/* LAPACK dgtsv, the routine behind scipy.linalg.solve_banded((1, 1), ...) (third-party SciPy 1.15.3 / LAPACK 3.11) */
+int orc_gtsv(int n, double *dl, double *d, double *du, double *b);
+/* core/current_diffusion.py:175-207, 210-233, 277-353 */
+double orc_neoclassical_resistivity(double te_kev, double ne_19, double z_eff, double epsilon);
+void orc_q_from_psi(const double *rho, const double *psi, int n, double r0, double a, double b0, double *q);
+int orc_current_diffusion_step(const double *rho, double *psi, int n, double r0, double a, double b0, double dt,
+                               const double *te, const double *ne, double z_eff, const double *j_bs, const double *j_cd,
+                               const double *j_ext);
+
 #ifdef __cplusplus
 }
 #endif

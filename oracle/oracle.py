@@ -100,6 +100,14 @@ def lib() -> C.CDLL:
         L.orc_b_field.argtypes = [_dp, _dp, _i, _i, _d, _d, _dp, _dp]
         L.orc_probe_response.argtypes = [_i, _dp, _dp, C.c_void_p, _i, C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_void_p,
                                          C.c_void_p, _dp]
+        L.orc_np_interp.argtypes = [_dp, C.c_long, _dp, _dp, _i, _dp]
+        L.orc_map_profiles_to_2d.restype = _d
+        L.orc_map_profiles_to_2d.argtypes = [_dp, _dp, _dp, _i, _i, _d, _d, _d, _d, _dp, _dp, _dp, _i, _dp, _dp]
+        L.orc_gtsv.argtypes = [_i, _dp, _dp, _dp, _dp]
+        L.orc_neoclassical_resistivity.restype = _d
+        L.orc_neoclassical_resistivity.argtypes = [_d, _d, _d, _d]
+        L.orc_q_from_psi.argtypes = [_dp, _dp, _i, _d, _d, _d, _dp]
+        L.orc_current_diffusion_step.argtypes = [_dp, _dp, _i, _d, _d, _d, _d, _dp, _dp, _d, _dp, _dp, C.c_void_p]
         L.orc_dlartg.argtypes = [_d, _d, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]
         L.orc_gmres_gs.argtypes = [_dp, _dp, _i, _i, _d, _d, _dp, C.c_void_p, _i, _i, _d, _d, _dp, C.POINTER(C.c_long)]
         L.orc_profile_jacobian.argtypes = [_dp, _dp, _dp, _i, _i, _d, _d, _d, _d, _d, _i, _dp]
@@ -426,6 +434,35 @@ def probe_response(coil_r, coil_z, turns, flux_points=None, b_points=None, b_dir
     lib().orc_probe_response(len(cr), cr, cz, None if ct is None else ct.ctypes.data, len(fr), fr.ctypes.data, fz.ctypes.data,
                              len(br), br.ctypes.data, bz.ctypes.data, bd.ctypes.data, out)
     return out
+
+
+def np_interp(x, xp, fp):
+    x = _c(x)
+    out = np.zeros_like(x)
+    lib().orc_np_interp(x.ravel(), x.size, _c(xp), _c(fp), len(xp), out.reshape(-1))
+    return out
+
+
+def map_profiles_to_2d(psi, r_axis, z_axis, dr, dz, z_min_cfg, i_target, rho, pressure_1d, jbs_1d):
+    psi = _c(psi)
+    p2, j = np.zeros_like(psi), np.zeros_like(psi)
+    ic = lib().orc_map_profiles_to_2d(psi, _c(r_axis), _c(z_axis), psi.shape[0], psi.shape[1], dr, dz, z_min_cfg, i_target,
+                                      _c(rho), _c(pressure_1d), _c(jbs_1d), len(rho), p2, j)
+    return p2, j, ic
+
+
+def gtsv(dl, d, du, b):
+    dl, d, du, b = (_c(a).copy() for a in (dl, d, du, b))
+    info = lib().orc_gtsv(len(d), dl, d, du, b)
+    return b, info
+
+
+def current_diffusion_step(rho, psi, r0, a, b0, dt, te, ne, z_eff, j_bs, j_cd, j_ext=None):
+    psi = _c(psi).copy()
+    je = None if j_ext is None else _c(j_ext)
+    info = lib().orc_current_diffusion_step(_c(rho), psi, len(psi), r0, a, b0, dt, _c(te), _c(ne), z_eff, _c(j_bs), _c(j_cd),
+                                            None if je is None else je.ctypes.data)
+    return psi, info
 
 
 def free_boundary_solve(cfg, coils_r, coils_z, coils_i, turns, *, psi0=None, max_outer=20, tol=1e-4):

@@ -96,6 +96,8 @@ SIGNATURES = {
     "scpn_sor_step": (_i, [_dp, _dp, _dp, _i, _i, _i, _d, _d, _d, _dp]),
     "scpn_coil_flux": (_i, [_dp, _dp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _i, _dp]),
     "scpn_green_points": (_i, [_i, _dp, _dp, _i, _dp, _dp, _dp]),
+    "scpn_tridiag_solve": (_i, [_i, _i, _vp, _dp, _vp, _dp, _dp, _vp]),
+    "scpn_current_diffusion_step": (_i, [_i, _i, _dp, _dp, _d, _d, _d, _d, _dp, _dp, _d, _dp, _dp, _vp, _vp]),
     "scpn_probe_response": (_i, [_i, _dp, _dp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _dp]),
     "scpn_gs_solve_np": (_i, [_d, _d, _d, _d, _i, _i, _dp, _dp, _vp, _d, _d, _i, _i, _d, _d, _d, _dp]),
     # resident ensemble solver
@@ -120,6 +122,7 @@ SIGNATURES = {
     "scpn_gs_vcycle": (_i, [_vp, _d, _i, _i, _i]),
     "scpn_gs_compute_b_field": (_i, [_vp, _i, _dp, _dp]),
     "scpn_gs_sample_psi": (_i, [_vp, _i, _dp, _dp, _dp]),
+    "scpn_gs_map_profiles": (_i, [_vp, _d, _i, _dp, _dp, _dp, _vp, _vp]),
     "scpn_gs_fill_psi": (_i, [_vp, _d]),
     "scpn_gs_pack_psi_device": (_i, [_vp, C.POINTER(_vp)]),
     "scpn_gs_profile": (_i, [_vp, _i]),

@@ -2046,4 +2046,219 @@ __global__ void k_probe_response(double* out, int n_coils, const double* coil_r,
     out[(long)row * n_coils + c] = v;
 }
 
+
+// ---------------------------------------------------------------- f4: transport coupling
+// numpy.interp at one abscissa (compiled_base.c arr_interp): xp ascending (m knots), left = fp[0], right = fp[m-1]
+__device__ __forceinline__ int interp_interval(const double* xp, int m, double x) {  // largest j with xp[j] <= x (x within range)
+    int lo = 0, hi = m;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (xp[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ double np_interp1(const double* xp, const double* fp, int m, double x, int j) {
+    if (x != x) return x;
+    if (x > xp[m - 1]) return fp[m - 1];
+    if (x < xp[0]) return fp[0];
+    if (j == m - 1) return fp[j];
+    if (xp[j] == x) return fp[j];
+    const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    double r = slope * (x - xp[j]) + fp[j];
+    if (r != r) {
+        r = slope * (x - xp[j + 1]) + fp[j + 1];
+        if (r != r && fp[j] == fp[j + 1]) r = fp[j];
+    }
+    return r;
+}
+// map_profiles_to_2d topology (core/integrated_transport_solver_coupling.py:41-52): psi_axis = max psi (no floor), psi_edge =
+// X-point flux, replaced by min psi when within 1.0 of the axis value; denom floored at 1e-9.  one block per member
+__global__ void __launch_bounds__(256) k_map_topo_final(Fld psiF, Member* st, const TopoPart* part, int nblk, int nr, int ld) {
+    __shared__ VI shv[4];
+    __shared__ double shd[4];
+    const int b = blockIdx.x;
+    VI mx{0.0, -1}, mn{0.0, -1};
+    double minpsi = INFINITY;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        TopoPart t = part[(long)b * nblk + i];
+        mx = vi_max(mx, VI{t.maxv, t.maxi});
+        mn = vi_min(mn, VI{t.minb, t.mini});
+        minpsi = fmin(minpsi, t.minpsi);
+    }
+    VI rmx = block_vi<true, 256>(mx, shv);
+    VI rmn = block_vi<false, 256>(mn, shv);
+    double rmp = -block_max<256>(-minpsi, shd);
+    if (threadIdx.x == 0) {
+        Member& m = st[b];
+        const double* psi = psiF.at(b);
+        const double pa = rmx.i >= 0 ? rmx.v : 0.0;
+        double pe;
+        if (rmn.i >= 0) {
+            int iz = (int)(rmn.i / nr), ir = (int)(rmn.i - (long)iz * nr);
+            pe = psi[(long)iz * ld + ir];
+            if (!finite_d(pe)) pe = nan_to_num300(pe);
+        } else pe = rmp;
+        if (fabs(pe - pa) < 1.0) pe = rmp;
+        double denom = pe - pa;
+        if (fabs(denom) < 1e-9) denom = 1e-9;
+        m.psi_axis = pa; m.psi_bnd = pe; m.denom = denom; m.x_idx = rmn.i;
+    }
+}
+// rho_2d = sqrt(clip((psi - psi_axis)/denom, 0, 1)); Pressure_2D = interp(rho_2d, rho, p1d); J = Pressure_2D*R + interp(rho_2d,
+// rho, jbs1d) (:53-68); per-block partial sums of J.  knots staged in LDS (n_rho <= MAP_MAX_RHO).  grid (nblk, B)
+constexpr int MAP_MAX_RHO = 1024;
+__global__ void __launch_bounds__(256) k_map_profiles(Fld jF, double* p2d_out, Fld psiF, const Member* st, int nz, int nr, int ld,
+                                                      const double* r_axis, int n_rho, const double* rho, const double* p1d,
+                                                      const double* jbs1d, double* part, int nblk) {
+    __shared__ double sh[4];
+    __shared__ double s_rho[MAP_MAX_RHO], s_p[MAP_MAX_RHO], s_j[MAP_MAX_RHO];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < n_rho; i += 256) {
+        s_rho[i] = rho[i];
+        s_p[i] = p1d[(long)b * n_rho + i];
+        s_j[i] = jbs1d[(long)b * n_rho + i];
+    }
+    __syncthreads();
+    const double* psi = psiF.at(b);
+    double* jo = jF.at(b);
+    const double pa = st[b].psi_axis, denom = st[b].denom;
+    const long n = (long)nz * nr;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (q < n) {
+            int iz = (int)(q / nr), ir = (int)(q - (long)iz * nr);
+            double pn = (psi[(long)iz * ld + ir] - pa) / denom;
+            pn = fmin(fmax(pn, 0.0), 1.0);
+            if (pn != pn) pn = NAN;
+            const double x = sqrt(pn);
+            const int j = (x == x && x <= s_rho[n_rho - 1] && x >= s_rho[0]) ? interp_interval(s_rho, n_rho, x) : 0;
+            const double pv = np_interp1(s_rho, s_p, n_rho, x, j);
+            const double jb = np_interp1(s_rho, s_j, n_rho, x, j);
+            const double jv = (pv * r_axis[ir]) + jb;
+            jo[(long)iz * ld + ir] = jv;
+            if (p2d_out) p2d_out[(long)b * n + q] = pv;
+            s += jv;
+        }
+    }
+    double bs = block_sum<256>(s, sh);
+    if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = bs;
+}
+// J *= I_target / I_curr when |I_curr| > 1e-9 (:70-72); every block finishes I_curr = sum(J)*dR*dZ from the partials
+__global__ void __launch_bounds__(256) k_map_scale(Fld jF, Member* st, int nz, int nr, int ld, double dr, double dz, const double* part,
+                                                   int nblk) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += part[(long)b * nblk + i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const double ic = (((sh[0] + sh[1]) + (sh[2] + sh[3])) * dr) * dz;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st[b].i_current = ic; st[b].jscale = fabs(ic) > 1e-9 ? st[b].i_target / ic : 1.0; }
+    if (!(fabs(ic) > 1e-9)) return;
+    const double sc = st[b].i_target / ic;
+    double* jo = jF.at(b);
+    const long n = (long)nz * nr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (q < n) {
+            int iz = (int)(q / nr), ir = (int)(q - (long)iz * nr);
+            jo[(long)iz * ld + ir] *= sc;
+        }
+    }
+}
+
+// LAPACK dgtsv for one right-hand side (what scipy.linalg.solve_banded((1,1), ...) calls): Gaussian elimination with partial
+// pivoting; dl, d, du, b are overwritten (b <- x); returns info
+__device__ __forceinline__ int gtsv1(int n, double* dl, double* d, double* du, double* b) {
+    if (n == 0) return 0;
+    for (int i = 0; i < n - 1; ++i) {
+        const bool last = i == n - 2;
+        if (fabs(d[i]) >= fabs(dl[i])) {
+            if (d[i] != 0.0) {
+                const double fact = dl[i] / d[i];
+                d[i + 1] = d[i + 1] - fact * du[i];
+                b[i + 1] = b[i + 1] - fact * b[i];
+            } else return i + 1;
+            if (!last) dl[i] = 0.0;
+        } else {
+            const double fact = d[i] / dl[i];
+            d[i] = dl[i];
+            double temp = d[i + 1];
+            d[i + 1] = du[i] - fact * temp;
+            if (!last) {
+                dl[i] = du[i + 1];
+                du[i + 1] = -fact * dl[i];
+            }
+            du[i] = temp;
+            temp = b[i];
+            b[i] = b[i + 1];
+            b[i + 1] = temp - fact * b[i + 1];
+        }
+    }
+    if (d[n - 1] == 0.0) return n;
+    b[n - 1] = b[n - 1] / d[n - 1];
+    if (n > 1) b[n - 2] = (b[n - 2] - du[n - 2] * b[n - 1]) / d[n - 2];
+    for (int i = n - 3; i >= 0; --i) b[i] = (b[i] - du[i] * b[i + 1] - dl[i] * b[i + 2]) / d[i];
+    return 0;
+}
+// batched tridiagonal solve: one thread per system; work arrays [batch][n] (dl, du use n-1 entries)
+__global__ void k_gtsv(int batch, int n, double* dl, double* d, double* du, double* b, int* info) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= batch) return;
+    info[s] = gtsv1(n, dl + (long)s * n, d + (long)s * n, du + (long)s * n, b + (long)s * n);
+}
+// CurrentDiffusionSolver.step (core/current_diffusion.py:277-353) for `batch` independent profiles: Sauter resistivity
+// (:175-207), Crank-Nicolson assembly, dgtsv.  one thread per member; scratch [batch][4n]
+struct CdConst { double r0, a, dt, z_eff, mu0_a2; };
+__global__ void k_current_diffusion(int batch, int n, const double* rho, double* psi, CdConst c, const double* te, const double* ne,
+                                    const double* j_bs, const double* j_cd, const double* j_ext, double* scratch, int* info) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= batch) return;
+    double* p = psi + (long)s * n;
+    double* sub = scratch + (long)s * 4 * n;
+    double* diag = sub + n;
+    double* sup = diag + n;
+    double* rhs = sup + n;
+    const double drho = rho[1] - rho[0];
+    const double drho2 = drho * drho;
+    const double alpha = c.dt / 2.0;
+    // q_from_psi (:210-233) only feeds the collisionality nu_star_e, which the reference computes and discards (:199, noqa F841)
+    for (int i = 0; i < n; ++i) {
+        const long o = (long)s * n + i;
+        double tk = fmax(te[o], 1e-3), eps = fmax(rho[i] * c.a / c.r0, 1e-6);
+        const double eta_sp = 1.65e-9 * c.z_eff * 17.0 / pow(tk, 1.5);
+        double ft = 1.0 - ((1.0 - eps) * (1.0 - eps)) / (sqrt(1.0 - eps * eps) * (1.0 + 1.46 * sqrt(eps)));
+        ft = fmax(0.0, fmin(ft, 1.0));
+        const double cr = 1.0 - (1.0 + 0.36 / c.z_eff) * ft + (0.59 / c.z_eff) * (ft * ft);
+        const double eta = fmax(eta_sp / (1.0 - ft) * cr, eta_sp);
+        const double D = eta / c.mu0_a2;
+        const double jt = (j_bs[o] + j_cd[o]) + (j_ext ? j_ext[o] : 0.0);
+        if (i == 0) {
+            diag[0] = 1.0 + alpha * 4.0 * D / drho2;
+            rhs[0] = p[0] + alpha * 4.0 * D * (p[1] - p[0]) / drho2 + c.dt * c.r0 * eta * jt;
+            sup[0] = -alpha * 4.0 * D / drho2;
+        } else if (i < n - 1) {
+            const double r = rho[i];
+            const double cp = D * (1.0 / drho2 - 1.0 / (2.0 * r * drho));
+            const double cc = D * (-2.0 / drho2);
+            const double cn = D * (1.0 / drho2 + 1.0 / (2.0 * r * drho));
+            sub[i] = -alpha * cp;
+            diag[i] = 1.0 - alpha * cc;
+            const double l = cp * p[i - 1] + cc * p[i] + cn * p[i + 1];
+            rhs[i] = p[i] + alpha * l + c.dt * c.r0 * eta * jt;
+            sup[i] = -alpha * cn;
+        } else {
+            diag[n - 1] = 1.0;
+            sub[n - 1] = 0.0;
+            rhs[n - 1] = p[n - 1];
+        }
+    }
+    info[s] = gtsv1(n, sub + 1, diag, sup, rhs);
+    for (int i = 0; i < n; ++i) p[i] = rhs[i];
+}
+
 }  // namespace gs

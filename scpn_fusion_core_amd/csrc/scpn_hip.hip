@@ -1571,6 +1571,46 @@ static int S_compute_b_field(Solver* h, int member, double* b_r, double* b_z) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     API_END
 }
+// map_profiles_to_2d of every member (core/integrated_transport_solver_coupling.py:39-73): device J_phi <- profiles
+static int S_map_profiles(Solver* h, double z_min_cfg, int n_rho, const double* rho, const double* p1d, const double* jbs1d,
+                          double* p2d_out, double* i_current_out) {
+    if (!h || !rho || !p1d || !jbs1d) return fail(SCPN_E_ARG, "null arguments");
+    if (n_rho < 2 || n_rho > MAP_MAX_RHO) return fail(SCPN_E_ARG, "n_rho must be in [2, 1024]");
+    API_BEGIN
+    ensure_picard_bufs(h);
+    const int B = h->B, nz = h->nz, nr = h->nr, ld = h->ld;
+    const int nblk1 = h->nblk1();
+    hipStream_t st = h->stream;
+    std::vector<Member> ms(B);
+    for (int b = 0; b < B; ++b) { std::memset(&ms[b], 0, sizeof(Member)); ms[b].active = 1; ms[b].i_target = h->i_target[b]; }
+    DBuf<Member> d_ms;
+    d_ms.alloc(B);
+    HIP_TRY(hipMemcpyAsync(d_ms.p, ms.data(), sizeof(Member) * B, hipMemcpyHostToDevice, st));
+    DBuf<double> d_rho, d_p, d_j, d_p2, d_part;
+    d_rho.alloc(n_rho); d_p.alloc((size_t)n_rho * B); d_j.alloc((size_t)n_rho * B); d_part.alloc((size_t)B * nblk1);
+    HIP_TRY(hipMemcpyAsync(d_rho.p, rho, sizeof(double) * n_rho, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_p.p, p1d, sizeof(double) * n_rho * B, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_j.p, jbs1d, sizeof(double) * n_rho * B, hipMemcpyHostToDevice, st));
+    if (p2d_out) d_p2.alloc((size_t)B * nz * nr);
+    int n_mask_rows = 0;
+    for (int iz = 0; iz < nz; ++iz) if ((z_min_cfg * 0.5) > h->z_axis[iz]) n_mask_rows = iz + 1;
+    Fld curF = h->slot_fld(h->d_cur.p), jF = h->plain(h->jphi.p);
+    {
+        ProfScope ps(h, "map_profiles", 4);
+        hipLaunchKernelGGL(k_topology, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)d_ms.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
+                           h->d_topo.p, nblk1);
+        hipLaunchKernelGGL(k_map_topo_final, dim3(B), dim3(256), 0, st, curF, d_ms.p, (const TopoPart*)h->d_topo.p, nblk1, nr, ld);
+        hipLaunchKernelGGL(k_map_profiles, dim3(nblk1, B), dim3(256), 0, st, jF, p2d_out ? d_p2.p : (double*)nullptr, curF, (const Member*)d_ms.p,
+                           nz, nr, ld, (const double*)h->d_r.p, n_rho, (const double*)d_rho.p, (const double*)d_p.p, (const double*)d_j.p, d_part.p,
+                           nblk1);
+        hipLaunchKernelGGL(k_map_scale, dim3(nblk1, B), dim3(256), 0, st, jF, d_ms.p, nz, nr, ld, h->dr, h->dz, (const double*)d_part.p, nblk1);
+    }
+    if (p2d_out) HIP_TRY(hipMemcpyAsync(p2d_out, d_p2.p, sizeof(double) * B * nz * nr, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ms.data(), d_ms.p, sizeof(Member) * B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (i_current_out) for (int b = 0; b < B; ++b) i_current_out[b] = ms[b].i_current;
+    API_END
+}
 // interp_psi of every member at n_pts points (core/fusion_kernel_free_boundary.py:156-159, 562-580); out [B][n_pts]
 static int S_sample_psi(Solver* h, int n_pts, const double* pts_r, const double* pts_z, double* out) {
     if (!h || n_pts < 1 || !pts_r || !pts_z || !out) return fail(SCPN_E_ARG, "bad arguments");
@@ -1817,6 +1857,16 @@ int scpn_gs_compute_b_field(scpn_gs* g, int member, double* b_r, double* b_z) {
     }
     int local = 0, gi = locate(g, member, &local);
     return S_compute_b_field(g->kids[gi], local, b_r, b_z);
+}
+int scpn_gs_map_profiles(scpn_gs* g, double z_min_cfg, int n_rho, const double* rho, const double* pressure_1d, const double* jbs_1d,
+                         double* pressure_2d_out, double* i_current_out) {
+    if (!g) return fail(SCPN_E_ARG, "null handle");
+    const size_t n = (size_t)g->nz * g->nr;
+    return each_group(g, [&](int gi, Solver* k) {
+        const size_t o = (size_t)g->off[gi];
+        return S_map_profiles(k, z_min_cfg, n_rho, rho, pressure_1d ? pressure_1d + o * n_rho : nullptr, jbs_1d ? jbs_1d + o * n_rho : nullptr,
+                              pressure_2d_out ? pressure_2d_out + o * n : nullptr, i_current_out ? i_current_out + o : nullptr);
+    });
 }
 int scpn_gs_sample_psi(scpn_gs* g, int n_pts, const double* pts_r, const double* pts_z, double* out) {
     if (!g) return fail(SCPN_E_ARG, "null handle");
@@ -2124,6 +2174,58 @@ int scpn_coil_flux(const double* r_axis, const double* z_axis, int nz, int nr, i
                        (const double*)dz_.p, n_coils, (const double*)cr.p, (const double*)cz.p, (const double*)ci.p,
                        coil_turns ? (const double*)ct.p : (const double*)nullptr, mu0, mode);
     HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * n * batch, hipMemcpyDeviceToHost));
+    API_END
+}
+int scpn_tridiag_solve(int batch, int n, const double* dl, const double* d, const double* du, const double* b, double* x, int* info) {
+    if (batch < 1 || n < 1 || !d || !b || !x || (n > 1 && (!dl || !du))) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available");
+    HIP_TRY(hipSetDevice(g_device));
+    const size_t tot = (size_t)batch * n;
+    DBuf<double> w;  // dl, d, du, b padded to n per system
+    DBuf<int> di;
+    w.alloc(4 * tot);
+    di.alloc(batch);
+    HIP_TRY(hipMemset(w.p, 0, sizeof(double) * 4 * tot));
+    if (n > 1) {
+        HIP_TRY(hipMemcpy2D(w.p, sizeof(double) * n, dl, sizeof(double) * (n - 1), sizeof(double) * (n - 1), batch, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy2D(w.p + 2 * tot, sizeof(double) * n, du, sizeof(double) * (n - 1), sizeof(double) * (n - 1), batch, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(w.p + tot, d, sizeof(double) * tot, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(w.p + 3 * tot, b, sizeof(double) * tot, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_gtsv, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, w.p, w.p + tot, w.p + 2 * tot, w.p + 3 * tot, di.p);
+    HIP_TRY(hipMemcpy(x, w.p + 3 * tot, sizeof(double) * tot, hipMemcpyDeviceToHost));
+    if (info) HIP_TRY(hipMemcpy(info, di.p, sizeof(int) * batch, hipMemcpyDeviceToHost));
+    API_END
+}
+int scpn_current_diffusion_step(int batch, int n, const double* rho, double* psi, double r0, double a, double b0, double dt, const double* te,
+                                const double* ne, double z_eff, const double* j_bs, const double* j_cd, const double* j_ext, int* info) {
+    (void)b0;
+    (void)ne;  // B0 and n_e enter only q / the collisionality, which the reference evaluates and discards
+    if (batch < 1 || n < 3 || !rho || !psi || !te || !j_bs || !j_cd) return fail(SCPN_E_ARG, "bad arguments");
+    API_BEGIN
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available");
+    HIP_TRY(hipSetDevice(g_device));
+    const size_t tot = (size_t)batch * n;
+    DBuf<double> drho_, dpsi, dte, djb, djc, dje, scratch;
+    DBuf<int> di;
+    drho_.alloc(n); dpsi.alloc(tot); dte.alloc(tot); djb.alloc(tot); djc.alloc(tot); scratch.alloc(4 * tot); di.alloc(batch);
+    HIP_TRY(hipMemcpy(drho_.p, rho, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dpsi.p, psi, sizeof(double) * tot, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dte.p, te, sizeof(double) * tot, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(djb.p, j_bs, sizeof(double) * tot, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(djc.p, j_cd, sizeof(double) * tot, hipMemcpyHostToDevice));
+    if (j_ext) { dje.alloc(tot); HIP_TRY(hipMemcpy(dje.p, j_ext, sizeof(double) * tot, hipMemcpyHostToDevice)); }
+    CdConst c;
+    const double mu0 = (4.0 * 3.141592653589793) * 1e-7;  // core/current_diffusion.py:20
+    c.r0 = r0; c.a = a; c.dt = dt; c.z_eff = z_eff; c.mu0_a2 = mu0 * (a * a);
+    hipLaunchKernelGGL(k_current_diffusion, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, (const double*)drho_.p, dpsi.p, c, (const double*)dte.p,
+                       (const double*)nullptr, (const double*)djb.p, (const double*)djc.p, j_ext ? (const double*)dje.p : (const double*)nullptr,
+                       scratch.p, di.p);
+    HIP_TRY(hipMemcpy(psi, dpsi.p, sizeof(double) * tot, hipMemcpyDeviceToHost));
+    if (info) HIP_TRY(hipMemcpy(info, di.p, sizeof(int) * batch, hipMemcpyDeviceToHost));
     API_END
 }
 int scpn_probe_response(int n_coils, const double* coil_r, const double* coil_z, const double* coil_turns, int n_flux, const double* flux_r,

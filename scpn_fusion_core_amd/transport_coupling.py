@@ -1,0 +1,133 @@
+"""Batched transport-coupling kernels: the pieces of the GS <-> transport loop that touch the
+2-D flux map or solve a linear system, so an ensemble's coupled outer iteration needs no host round trip of fields.
+
+Mirrors (reference file:line):
+  * ``TransportSolverCouplingMixin.map_profiles_to_2d``  core/integrated_transport_solver_coupling.py:39-73
+  * the GS step of ``run_self_consistent``                :129-147 (map -> solve_equilibrium -> relative psi change)
+  * ``scipy.linalg.solve_banded((1, 1), ab, b)`` as used by core/current_diffusion.py:347-352 (LAPACK dgtsv)
+  * ``CurrentDiffusionSolver``                            core/current_diffusion.py:262-353
+
+The 1-D transport physics itself (chi models, sources, bootstrap-current formulae) stays with the caller: it hands over
+``ne*(Ti+Te)`` and the bootstrap profile, exactly the two arrays ``map_profiles_to_2d`` interpolates.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_f64, check, ptr
+from .ensemble import EnsembleSolver
+
+MU_0 = 4.0 * np.pi * 1e-7  # core/current_diffusion.py:20
+
+
+def map_profiles_to_2d(es: EnsembleSolver, rho, pressure_1d, j_bs_1d, *, return_pressure: bool = False):
+    """Project 1-D profiles of every member onto its resident flux map and leave ``J_phi`` on the device.
+
+    ``pressure_1d`` (= ``ne * (Ti + Te)``) and ``j_bs_1d`` are ``(batch, n_rho)`` (or ``(n_rho,)`` for all members).
+    Returns ``(I_current, Pressure_2D or None)``; ``es.get_jphi()`` reads the mapped current density.
+    """
+    rho = np.ascontiguousarray(as_f64(rho).reshape(-1))
+    n = rho.size
+
+    def per_member(a):
+        a = as_f64(a)
+        if a.ndim == 1:
+            a = np.broadcast_to(a, (es.batch, n))
+        if a.shape != (es.batch, n):
+            raise ValueError(f"profile arrays must have shape ({es.batch}, {n}) or ({n},)")
+        if not np.all(np.isfinite(a)):
+            raise ValueError("profiles must contain finite values only.")
+        return np.ascontiguousarray(a)
+
+    if n < 2 or not np.all(np.diff(rho) > 0.0):
+        raise ValueError("rho must be strictly increasing with at least two points")
+    p1, jb = per_member(pressure_1d), per_member(j_bs_1d)
+    p2 = np.empty((es.batch, es.NZ, es.NR)) if return_pressure else None
+    ic = np.empty(es.batch)
+    check(es._L.scpn_gs_map_profiles(es._h, float(es.cfg["dimensions"]["Z_min"]), n, rho, p1, jb, ptr(p2), ptr(ic)))
+    return ic, p2
+
+
+def gs_transport_outer_step(es: EnsembleSolver, rho, pressure_1d, j_bs_1d) -> tuple[np.ndarray, list[dict]]:
+    """One GS leg of ``run_self_consistent`` (:129-147) for every member: map the profiles, re-solve the equilibrium in
+    ``external_profile_mode`` (the transport solver's setting, ``_integrated_transport_solver_init.py:28``) and return the
+    relative flux change ``||psi - psi_old|| / ||psi_old||`` per member with the solver results."""
+    psi_old = es.get_psi()
+    norm_old = np.linalg.norm(psi_old.reshape(es.batch, -1), axis=1)
+    norm_old = np.where(norm_old < 1e-30, 1.0, norm_old)
+    map_profiles_to_2d(es, rho, pressure_1d, j_bs_1d)
+    prev = es.external_profile_mode
+    es.external_profile_mode = True
+    try:
+        res = es.solve_equilibrium()
+    finally:
+        es.external_profile_mode = prev
+    psi = es.get_psi()
+    resid = np.linalg.norm((psi - psi_old).reshape(es.batch, -1), axis=1) / norm_old
+    return resid, res
+
+
+def solve_banded_tridiagonal(dl, d, du, b):
+    """``scipy.linalg.solve_banded((1, 1), ab, b)`` for a batch of systems on the device (LAPACK dgtsv order, bit-identical).
+    ``d``/``b``: (batch, n) or (n,); ``dl`` (sub-diagonal) / ``du`` (super-diagonal): (..., n-1).  Raises
+    ``numpy.linalg.LinAlgError`` like SciPy when a pivot is exactly zero."""
+    L = _lib.require_gpu()
+    d_, b_ = as_f64(d), as_f64(b)
+    single = d_.ndim == 1
+    d2, b2 = np.atleast_2d(d_), np.atleast_2d(b_)
+    batch, n = d2.shape
+    dl2 = np.atleast_2d(as_f64(dl)) if n > 1 else None
+    du2 = np.atleast_2d(as_f64(du)) if n > 1 else None
+    if b2.shape != (batch, n) or (n > 1 and (dl2.shape != (batch, n - 1) or du2.shape != (batch, n - 1))):
+        raise ValueError("inconsistent tridiagonal system shapes")
+    x = np.empty((batch, n))
+    info = np.zeros(batch, dtype=np.int32)
+    check(L.scpn_tridiag_solve(batch, n, ptr(None if dl2 is None else np.ascontiguousarray(dl2)), np.ascontiguousarray(d2),
+                               ptr(None if du2 is None else np.ascontiguousarray(du2)), np.ascontiguousarray(b2), x, ptr(info)))
+    if np.any(info != 0):
+        raise np.linalg.LinAlgError(f"singular matrix: resolution failed at diagonal {int(info[info != 0][0]) - 1}")
+    return x[0] if single else x
+
+
+class CurrentDiffusionSolver:
+    """Batched implicit Crank-Nicolson poloidal-flux diffusion (core/current_diffusion.py:262-353): ``batch`` independent
+    profiles on one ``rho`` grid advance per ``step`` in one device launch."""
+
+    def __init__(self, rho, R0: float, a: float, B0: float, batch: int = 1):
+        self.rho = np.ascontiguousarray(as_f64(rho).reshape(-1))
+        self.R0, self.a, self.B0 = float(R0), float(a), float(B0)
+        self.nr = len(self.rho)
+        self.batch = int(batch)
+        self.drho = self.rho[1] - self.rho[0]
+        psi = np.zeros(self.nr)
+        for i in range(1, self.nr):  # :268-275 initial q = 1 + 2 rho^2 flux profile
+            r = self.rho[i]
+            q_r = 1.0 + 2.0 * r**2
+            dpsi = -r * self.a**2 * self.B0 / (self.R0 * q_r)
+            psi[i] = psi[i - 1] + dpsi * self.drho
+        psi -= psi[-1]
+        self.psi = np.tile(psi, (self.batch, 1))
+
+    def step(self, dt: float, Te, ne, Z_eff: float, j_bs, j_cd, j_ext=None) -> np.ndarray:
+        L = _lib.require_gpu()
+
+        def per_member(arr):
+            arr = as_f64(arr)
+            if arr.ndim == 1:
+                arr = np.broadcast_to(arr, (self.batch, self.nr))
+            if arr.shape != (self.batch, self.nr):
+                raise ValueError(f"profiles must have shape ({self.batch}, {self.nr}) or ({self.nr},)")
+            return np.ascontiguousarray(arr)
+
+        te, ne_, jb, jc = per_member(Te), per_member(ne), per_member(j_bs), per_member(j_cd)
+        je = None if j_ext is None else per_member(j_ext)
+        psi = np.ascontiguousarray(self.psi)
+        info = np.zeros(self.batch, dtype=np.int32)
+        check(L.scpn_current_diffusion_step(self.batch, self.nr, self.rho, psi, self.R0, self.a, self.B0, float(dt), te, ne_,
+                                            float(Z_eff), jb, jc, ptr(je), ptr(info)))
+        if np.any(info != 0):
+            raise np.linalg.LinAlgError("singular Crank-Nicolson system in current diffusion step")
+        self.psi = psi
+        return self.psi

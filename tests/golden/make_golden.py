@@ -470,6 +470,70 @@ def gen_products():
     save("products.npz", **out)
 
 
+# ── (f4) transport coupling: map_profiles_to_2d, solve_banded tridiagonal, CurrentDiffusionSolver.step ──
+def gen_transport():
+    """core/integrated_transport_solver_coupling.py:39-73; core/current_diffusion.py:175-233, 262-353."""
+    from scipy.linalg import solve_banded
+
+    from scpn_fusion.core.current_diffusion import CurrentDiffusionSolver, neoclassical_resistivity, q_from_psi
+    from scpn_fusion.core.integrated_transport_solver import TransportSolver
+
+    out = {}
+    cfg = iter_cfg(33, tol=1e-6, max_iter=300)
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False, dir="/tmp") as f:
+        json.dump(cfg, f)
+        path = f.name
+    ts = TransportSolver(path, nr=50)
+    os.unlink(path)
+    ts.solve_equilibrium()
+    rng = np.random.default_rng(4)
+    for tag, scale in (("a", 1.0), ("b", 2.5)):
+        ts.Te = scale * (1 - ts.rho**2) + 0.05
+        ts.Ti = 0.8 * scale * (1 - ts.rho**2) ** 1.5 + 0.05
+        ts.ne = 5.0 * (1 - 0.9 * ts.rho**2) ** 0.5
+        r0 = (cfg["dimensions"]["R_min"] + cfg["dimensions"]["R_max"]) / 2.0
+        b_pol = (1.256e-6 * cfg["physics"]["plasma_current_target"]) / (
+            2 * np.pi * 0.5 * (cfg["dimensions"]["R_max"] - cfg["dimensions"]["R_min"]))
+        jbs = ts.calculate_bootstrap_current(r0, b_pol)
+        psi_in = ts.Psi.copy()
+        ts.map_profiles_to_2d()
+        out[f"map_{tag}_psi"], out[f"map_{tag}_rho"] = psi_in, ts.rho.copy()
+        out[f"map_{tag}_p1d"], out[f"map_{tag}_jbs1d"] = ts.ne * (ts.Ti + ts.Te), np.asarray(jbs, dtype=float)
+        out[f"map_{tag}_p2d"], out[f"map_{tag}_jphi"] = ts.Pressure_2D.copy(), ts.J_phi.copy()
+        ts.Psi = ts.Psi + 0.05 * rng.normal(size=ts.Psi.shape)  # second case: perturbed flux map (different topology branch)
+    out["_configs"] = np.array(json.dumps({"iter33": cfg}))
+    # np.interp unit vectors incl. the exact-knot, out-of-range and NaN branches
+    xp = np.linspace(0, 1, 17)
+    fp = rng.normal(size=17)
+    x = np.concatenate([rng.uniform(-0.2, 1.2, 200), xp, [np.nan, 0.0, 1.0, -1.0, 2.0]])
+    out["interp_x"], out["interp_xp"], out["interp_fp"], out["interp_y"] = x, xp, fp, np.interp(x, xp, fp)
+    # tridiagonal systems: diagonally dominant (no interchanges) and general (row interchanges), n = 2, 3, 50
+    tri = {}
+    for name, n, dom in (("dom50", 50, True), ("piv50", 50, False), ("piv3", 3, False), ("piv2", 2, False), ("dom7", 7, True)):
+        dl, du = rng.normal(size=n - 1), rng.normal(size=n - 1)
+        d = rng.normal(size=n) + (4.0 if dom else 0.0) * np.sign(rng.normal(size=n))
+        b = rng.normal(size=n)
+        ab = np.zeros((3, n))
+        ab[0, 1:], ab[1, :], ab[2, :-1] = du, d, dl
+        out[f"tri_{name}_dl"], out[f"tri_{name}_d"], out[f"tri_{name}_du"], out[f"tri_{name}_b"] = dl, d, du, b
+        out[f"tri_{name}_x"] = solve_banded((1, 1), ab, b)
+    # current diffusion: 6 steps
+    rho = np.linspace(0, 1, 40)
+    cd = CurrentDiffusionSolver(rho, R0=6.2, a=2.0, B0=5.3)
+    te, ne = 8.0 * (1 - rho**2) + 0.1, 9.0 * (1 - 0.8 * rho**2)
+    jbs, jcd = 2e5 * rho * (1 - rho), 1e5 * np.exp(-((rho - 0.3) / 0.1) ** 2)
+    out["cd_rho"], out["cd_psi0"], out["cd_te"], out["cd_ne"], out["cd_jbs"], out["cd_jcd"] = rho, cd.psi.copy(), te, ne, jbs, jcd
+    out["cd_q0"] = q_from_psi(rho, cd.psi, 6.2, 2.0, 5.3)
+    out["cd_eta"] = np.array([neoclassical_resistivity(float(te[i]), float(ne[i]), 1.7, rho[i] * 2.0 / 6.2, float(out["cd_q0"][i]), 6.2)
+                              for i in range(rho.size)])
+    hist = []
+    for _ in range(6):
+        hist.append(cd.step(0.5, te, ne, 1.7, jbs, jcd).copy())
+    out["cd_hist"] = np.array(hist)
+    print("transport", out["map_a_jphi"].sum(), out["cd_hist"][-1][:3])
+    save("transport.npz", **out)
+
+
 # ── (f1) Newton-Kantorovich + GMRES  core/fusion_kernel_newton_solver.py:104-372 ──
 def gen_newton():
     """Full Newton dispatch runs (residual histories, psi) + unit vectors for the profile Jacobian,
@@ -579,6 +643,6 @@ def gen_newton():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["smooth", "operators", "mgsolve", "polyglot", "picard", "pieces", "green",
-                             "free_boundary", "fastsolver", "anderson", "shape", "eqdsk", "newton", "products"]
+                             "free_boundary", "fastsolver", "anderson", "shape", "eqdsk", "newton", "products", "transport"]
     for w in which:
         globals()[f"gen_{w}"]()

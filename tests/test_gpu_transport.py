@@ -1,0 +1,153 @@
+"""GPU parity tests of the batched transport-coupling kernels against fixtures generated from
+the reference (tests/golden/transport.npz: TransportSolver.map_profiles_to_2d, scipy.linalg.solve_banded, CurrentDiffusionSolver)
+and the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests._problems import configs_from, iter_like_cfg  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import scpn_fusion_core_amd as pkg
+    from scpn_fusion_core_amd import _lib
+
+    _lib.require_gpu()
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+
+    return oracle
+
+
+def test_map_profiles_to_2d_golden(hip, golden):
+    """Pressure_2D is bit-exact (np.interp restated exactly); J_phi carries one global sum (device order != NumPy pairwise),
+    so it is compared at 1e-13 relative.  Members with different flux maps / profiles are mapped in one call."""
+    from scpn_fusion_core_amd import transport_coupling as tc
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    g = golden("transport.npz")
+    cfg = configs_from(g)["iter33"]
+    with EnsembleSolver(cfg, batch=2) as es:
+        es.set_psi(np.stack([g["map_a_psi"], g["map_b_psi"]]))
+        ic, p2 = tc.map_profiles_to_2d(es, g["map_a_rho"], np.stack([g["map_a_p1d"], g["map_b_p1d"]]),
+                                       np.stack([g["map_a_jbs1d"], g["map_b_jbs1d"]]), return_pressure=True)
+        j = es.get_jphi()
+    for b, t in enumerate("ab"):
+        assert np.array_equal(p2[b], g[f"map_{t}_p2d"]), t
+        ref = g[f"map_{t}_jphi"]
+        assert np.abs(j[b] - ref).max() <= 1e-13 * np.abs(ref).max(), t
+        assert (j[b].sum() * es.dR * es.dZ) == pytest.approx(cfg["physics"]["plasma_current_target"], rel=1e-12)
+    with pytest.raises(ValueError):
+        tc.map_profiles_to_2d(es, [0.0, 0.5, 0.4], np.zeros(3), np.zeros(3))
+
+
+def test_map_profiles_large_grid_vs_oracle(hip, orc):
+    """513^2, 3 members: against the oracle on the same inputs, plus the size-independent property sum(J) dR dZ = I_target."""
+    from scpn_fusion_core_amd import transport_coupling as tc
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    n = 513
+    cfg = iter_like_cfg(n)
+    d = cfg["dimensions"]
+    r, z = np.linspace(d["R_min"], d["R_max"], n), np.linspace(d["Z_min"], d["Z_max"], n)
+    rr, zz = np.meshgrid(r, z)
+    rng = np.random.default_rng(12)
+    base = 40.0 * np.exp(-((rr - 6.0) ** 2 / 3.0 + zz**2 / 8.0)) - 0.3 * np.exp(-((rr - 5.0) ** 2 + (zz + 5.2) ** 2) / 0.5)
+    psi = np.stack([base, 0.7 * base + 0.01 * rng.normal(size=base.shape), base[::-1].copy()])
+    rho = np.linspace(0, 1, 64)
+    p1 = np.stack([5.0 * (1 - rho**2) * (s + 1 - rho**2) for s in (1.0, 2.0, 0.5)])
+    jb = np.stack([1e-2 * rho * (1 - rho) * s for s in (1.0, -1.0, 3.0)])
+    targets = np.array([15.0, 12.0, 9.0])
+    with EnsembleSolver(cfg, batch=3, current_targets=targets) as es:
+        es.set_psi(psi)
+        ic, p2 = tc.map_profiles_to_2d(es, rho, p1, jb, return_pressure=True)
+        j = es.get_jphi()
+    for b in range(3):
+        rp2, rj, ric = orc.map_profiles_to_2d(psi[b], r, z, r[1] - r[0], z[1] - z[0], d["Z_min"], targets[b], rho, p1[b], jb[b])
+        assert np.array_equal(p2[b], rp2), b
+        assert np.abs(j[b] - rj).max() <= 1e-12 * np.abs(rj).max(), b
+        assert ic[b] == pytest.approx(ric, rel=1e-12)
+        assert j[b].sum() * es.dR * es.dZ == pytest.approx(targets[b], rel=1e-11)
+
+
+def test_tridiagonal_solve_golden_bit_exact(hip, golden):
+    from scpn_fusion_core_amd import transport_coupling as tc
+
+    g = golden("transport.npz")
+    for name in ("dom50", "piv50", "piv3", "piv2", "dom7"):
+        x = tc.solve_banded_tridiagonal(g[f"tri_{name}_dl"], g[f"tri_{name}_d"], g[f"tri_{name}_du"], g[f"tri_{name}_b"])
+        assert np.array_equal(x, g[f"tri_{name}_x"]), name
+    # batched: both 50-point systems at once
+    x = tc.solve_banded_tridiagonal(np.stack([g["tri_dom50_dl"], g["tri_piv50_dl"]]), np.stack([g["tri_dom50_d"], g["tri_piv50_d"]]),
+                                    np.stack([g["tri_dom50_du"], g["tri_piv50_du"]]), np.stack([g["tri_dom50_b"], g["tri_piv50_b"]]))
+    assert np.array_equal(x[0], g["tri_dom50_x"]) and np.array_equal(x[1], g["tri_piv50_x"])
+    with pytest.raises(np.linalg.LinAlgError):
+        tc.solve_banded_tridiagonal([0.0, 0.0], [0.0, 1.0, 1.0], [0.0, 0.0], [1.0, 1.0, 1.0])
+
+
+def test_tridiagonal_solve_large_batch_vs_oracle(hip, orc):
+    from scpn_fusion_core_amd import transport_coupling as tc
+
+    rng = np.random.default_rng(21)
+    B, n = 4096, 200
+    dl, du = rng.normal(size=(B, n - 1)), rng.normal(size=(B, n - 1))
+    d = rng.normal(size=(B, n)) + 3.0 * np.sign(rng.normal(size=(B, n)))
+    b = rng.normal(size=(B, n))
+    x = tc.solve_banded_tridiagonal(dl, d, du, b)
+    for s in rng.integers(0, B, 40):
+        ref, info = orc.gtsv(dl[s], d[s], du[s], b[s])
+        assert info == 0 and np.array_equal(x[s], ref), s
+    # residual property on every system
+    ax = d * x
+    ax[:, 1:] += dl * x[:, :-1]
+    ax[:, :-1] += du * x[:, 1:]
+    assert np.abs(ax - b).max() <= 1e-9 * max(1.0, np.abs(x).max())
+
+
+def test_current_diffusion_step_golden(hip, golden, orc):
+    """Six Crank-Nicolson steps against the reference history.  Floating point with one libm call (Te**1.5) per cell whose
+    device implementation may differ in the last bit: tolerance 1e-13 relative."""
+    from scpn_fusion_core_amd import transport_coupling as tc
+
+    g = golden("transport.npz")
+    cd = tc.CurrentDiffusionSolver(g["cd_rho"], R0=6.2, a=2.0, B0=5.3, batch=3)
+    assert np.array_equal(cd.psi[0], g["cd_psi0"])
+    te = np.stack([g["cd_te"], 0.5 * g["cd_te"], g["cd_te"]])
+    for k in range(6):
+        psi = cd.step(0.5, te, g["cd_ne"], 1.7, g["cd_jbs"], g["cd_jcd"], j_ext=None if k % 2 else np.zeros_like(g["cd_rho"]))
+        ref = g["cd_hist"][k]
+        assert np.abs(psi[0] - ref).max() <= 1e-13 * np.abs(ref).max(), k
+        assert np.array_equal(psi[0], psi[2])
+    p1 = g["cd_psi0"].copy()
+    for k in range(6):
+        p1, info = orc.current_diffusion_step(g["cd_rho"], p1, 6.2, 2.0, 5.3, 0.5, 0.5 * g["cd_te"], g["cd_ne"], 1.7, g["cd_jbs"], g["cd_jcd"])
+    assert np.abs(cd.psi[1] - p1).max() <= 1e-13 * np.abs(p1).max()
+
+
+def test_gs_transport_outer_step(hip, orc):
+    """map -> external-profile re-solve -> relative flux change, for 2 members, against the same sequence on the oracle."""
+    from scpn_fusion_core_amd import transport_coupling as tc
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    cfg = iter_like_cfg(33, tol=1e-6, max_iter=120)
+    rho = np.linspace(0, 1, 50)
+    p1 = np.stack([5.0 * (1 - rho**2) ** 1.5 * 2.0, 4.0 * (1 - rho**2)])
+    jb = np.stack([1e-3 * rho * (1 - rho), np.zeros_like(rho)])
+    with EnsembleSolver(cfg, batch=2) as es:
+        es.solve_equilibrium()
+        psi0 = es.get_psi()
+        resid, res = tc.gs_transport_outer_step(es, rho, p1, jb)
+        psi1 = es.get_psi()
+    d = cfg["dimensions"]
+    r, z = np.linspace(d["R_min"], d["R_max"], 33), np.linspace(d["Z_min"], d["Z_max"], 33)
+    for b in range(2):
+        ref = orc.picard_solve(cfg, external_profile_mode=True)  # the reference's seed overrides the mapped J
+        assert res[b]["iterations"] == ref["iterations"]
+        assert np.abs(psi1[b] - ref["psi"]).max() <= 1e-10 * np.abs(ref["psi"]).max()
+        assert resid[b] == pytest.approx(np.linalg.norm(ref["psi"] - psi0[b]) / np.linalg.norm(psi0[b]), rel=1e-6)

@@ -296,3 +296,27 @@ def test_field_products(golden):
     # B-probe rows are central differences with eps 1e-5: the 1e-12 Green's-function agreement is amplified by ~1/eps
     np.testing.assert_allclose(resp[n_flux:], g["response"][n_flux:], rtol=1e-6, atol=1e-7 * np.abs(g["response"][n_flux:]).max())
     np.testing.assert_allclose(resp[:n_flux].T, g["mutual"], rtol=1e-12)
+
+
+# ── SURVEY 8 row f4: transport coupling ───────────────────────────────────────────────────────────────────
+def test_transport_coupling_pieces(golden):
+    """np.interp, map_profiles_to_2d, solve_banded((1,1)) = LAPACK dgtsv (with and without row interchanges) and six
+    CurrentDiffusionSolver steps: every restatement is bit-exact against the reference run (gen_transport)."""
+    g = golden("transport.npz")
+    cfg = configs_from(g)["iter33"]
+    d = cfg["dimensions"]
+    r, z = np.linspace(d["R_min"], d["R_max"], 33), np.linspace(d["Z_min"], d["Z_max"], 33)
+    assert np.array_equal(orc.np_interp(g["interp_x"], g["interp_xp"], g["interp_fp"]), g["interp_y"], equal_nan=True)
+    for t in "ab":
+        p2, j, _ = orc.map_profiles_to_2d(g[f"map_{t}_psi"], r, z, r[1] - r[0], z[1] - z[0], d["Z_min"],
+                                          cfg["physics"]["plasma_current_target"], g[f"map_{t}_rho"], g[f"map_{t}_p1d"], g[f"map_{t}_jbs1d"])
+        assert np.array_equal(p2, g[f"map_{t}_p2d"]) and np.array_equal(j, g[f"map_{t}_jphi"])
+    for name in ("dom50", "piv50", "piv3", "piv2", "dom7"):
+        x, info = orc.gtsv(g[f"tri_{name}_dl"], g[f"tri_{name}_d"], g[f"tri_{name}_du"], g[f"tri_{name}_b"])
+        assert info == 0 and np.array_equal(x, g[f"tri_{name}_x"]), name
+    _, info = orc.gtsv([0.0, 0.0], [0.0, 1.0, 1.0], [0.0, 0.0], [1.0, 1.0, 1.0])
+    assert info == 1
+    psi = g["cd_psi0"].copy()
+    for k in range(6):
+        psi, info = orc.current_diffusion_step(g["cd_rho"], psi, 6.2, 2.0, 5.3, 0.5, g["cd_te"], g["cd_ne"], 1.7, g["cd_jbs"], g["cd_jcd"])
+        assert info == 0 and np.array_equal(psi, g["cd_hist"][k]), k
