@@ -472,11 +472,14 @@ struct DefectDst {
     const double* r_safe = nullptr;
     const double* r_inv = nullptr;
 };
-template <int S, bool PROLONG, bool SRCGEN, bool DEFECT, bool BLEND>
-__global__ void __launch_bounds__(64 * TILE_NW, (PROLONG ? TILE_WPE_P : TILE_WPE)) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
+// LZT rows x 128 columns per tile, NWT waves per workgroup, WPEU = minimum waves per SIMD the register allocation must allow
+// (78/16/1: one 16-wave workgroup per CU; 40/8/4: two 8-wave workgroups per CU, so one loads while the other computes)
+template <int S, bool PROLONG, bool SRCGEN, bool DEFECT, bool BLEND, int LZT = TILE_LZ, int NWT = TILE_NW,
+          int WPEU = (PROLONG ? TILE_WPE_P : TILE_WPE)>
+__global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
                                                      const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, SrcGen sg,
                                                      DefectDst dd, BlendArgs ba) {
-    constexpr int LZ = TILE_LZ, H = 2 * S + ((DEFECT || BLEND) ? 2 : 0), NW = TILE_NW, NROWS = (LZ + NW - 1) / NW;
+    constexpr int LZ = LZT, H = 2 * S + ((DEFECT || BLEND) ? 2 : 0), NW = NWT, NROWS = (LZ + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* A0 = lds;            // colour 0: (iz + ir) even
     double* A1 = lds + LZ * 64;  // colour 1

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -315,18 +316,41 @@ struct DefectOut {  // coarse rhs / coarse correction produced by the fused defe
     Fld rhs{nullptr, nullptr, 0, 0}, e{nullptr, nullptr, 0, 0};
     int nz_c = 0, nr_c = 0, ld_c = 0;
 };
-template <int S, bool PROLONG, bool SRCGEN, bool DEFECT, bool BLEND>
+// tile geometry variants: 0 = 78 rows / 16 waves (one workgroup per CU), 1 = 40 rows / 8 waves (two per CU), 2 = 46 rows / 16 waves
+struct TileGeo { int lz, nw; };
+static int tile_variant_for(const Lvl& L) {
+    // SCPN_HIP_TILE="v0,v1,v2": variant for level 0, 1, 2+.  Default 1,1,1: measured on MI355X (513^2, 16 members per
+    // launch) the 40-row / 8-wave tile runs the fused pre-smoother in 49 us and the post-smoother in 40.5 us against
+    // 60 / 50 us for the 78-row / 16-wave tile, although its halo overhead is 21 % higher: with several workgroups per
+    // CU one loads its tile while another is in its LDS sweeps.
+    static const std::array<int, 3> cfg = [] {
+        std::array<int, 3> c{1, 1, 1};
+        if (const char* e = std::getenv("SCPN_HIP_TILE")) {
+            int a = 0, b = 0, d = 0;
+            int n = std::sscanf(e, "%d,%d,%d", &a, &b, &d);
+            if (n >= 1) c[0] = a;
+            if (n >= 2) c[1] = b;
+            if (n >= 3) c[2] = d;
+        }
+        return c;
+    }();
+    const int lvl = L.nz > 300 ? 0 : (L.nz > 150 ? 1 : 2);
+    return cfg[lvl];
+}
+template <int S, bool PROLONG, bool SRCGEN, bool DEFECT, bool BLEND, int LZT = TILE_LZ, int NWT = TILE_NW,
+          int WPEU = (PROLONG ? TILE_WPE_P : TILE_WPE)>
 static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
                         const SrcGen* sg, const DefectOut* dfo, const BlendArgs* bl = nullptr) {
     static bool attr_done = false;
-    const size_t lds = (size_t)TILE_LZ * 128 * sizeof(double) + (BLEND ? 2048 : 0);  // + reduction scratch of the blend stage
+    const size_t lds = (size_t)LZT * 128 * sizeof(double) + (BLEND ? 2048 : 0);  // + reduction scratch of the blend stage
+    auto kern = &k_smooth_tile<S, PROLONG, SRCGEN, DEFECT, BLEND, LZT, NWT, WPEU>;
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_tile<S, PROLONG, SRCGEN, DEFECT, BLEND>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     constexpr int H = 2 * S + ((DEFECT || BLEND) ? 2 : 0);
-    dim3 g(cdiv(L.nr, 128 - 2 * H), cdiv(L.nz, TILE_LZ - 2 * H), h->B);
+    static_assert(LZT - 2 * H >= 2, "tile too short for its halo");
+    dim3 g(cdiv(L.nr, 128 - 2 * H), cdiv(L.nz, LZT - 2 * H), h->B);
     DefectDst dd;
     Fld cF = ps.c;
     int nz_c = ps.nz_c, nr_c = ps.nr_c, ld_c = ps.ld_c;
@@ -340,8 +364,27 @@ static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, doubl
     }
     BlendArgs ba = bl ? *bl : BlendArgs{};
     if (BLEND && (int)(g.x * g.y) != ba.nblk) throw std::runtime_error("blend partial layout mismatch");
-    hipLaunchKernelGGL((k_smooth_tile<S, PROLONG, SRCGEN, DEFECT, BLEND>), g, dim3(64 * TILE_NW), lds, h->stream, out, in, src, L, omega,
-                       1.0 - omega, active, cF, nz_c, nr_c, ld_c, sg ? *sg : SrcGen{}, dd, ba);
+    hipLaunchKernelGGL(kern, g, dim3(64 * NWT), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c, ld_c,
+                       sg ? *sg : SrcGen{}, dd, ba);
+}
+// the three production roles (plain / +prolongation / +defect) exist in every geometry; the opt-in fusions only in the default one
+template <int S, bool PROLONG, bool DEFECT>
+static void launch_tile_geo(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
+                            const DefectOut* dfo) {
+    switch (tile_variant_for(L)) {
+        case 1: launch_tile<S, PROLONG, false, DEFECT, false, 40, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
+        case 2: launch_tile<S, PROLONG, false, DEFECT, false, 46, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
+#ifdef TILE_EXPERIMENTS
+        case 3: launch_tile<S, PROLONG, false, DEFECT, false, 48, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
+        case 4: launch_tile<S, PROLONG, false, DEFECT, false, 56, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
+        case 5: launch_tile<S, PROLONG, false, DEFECT, false, 64, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
+        case 6: launch_tile<S, PROLONG, false, DEFECT, false, 32, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
+        case 7: launch_tile<S, PROLONG, false, DEFECT, false, 40, 4, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
+        case 8: launch_tile<S, PROLONG, false, DEFECT, false, 36, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
+        case 9: launch_tile<S, PROLONG, false, DEFECT, false, 44, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
+#endif
+        default: launch_tile<S, PROLONG, false, DEFECT, false>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
+    }
 }
 template <int S>
 static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
@@ -349,10 +392,10 @@ static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
     if (bl && ps.c.base) launch_tile<S, true, false, false, true>(h, L, out, in, src, omega, active, ps, nullptr, nullptr, bl);
     else if (bl) launch_tile<S, false, false, false, true>(h, L, out, in, src, omega, active, ps, nullptr, nullptr, bl);
     else if (dfo && sg) launch_tile<S, false, true, true, false>(h, L, out, in, src, omega, active, ps, sg, dfo);
-    else if (dfo) launch_tile<S, false, false, true, false>(h, L, out, in, src, omega, active, ps, nullptr, dfo);
+    else if (dfo) launch_tile_geo<S, false, true>(h, L, out, in, src, omega, active, ps, dfo);
     else if (sg) launch_tile<S, false, true, false, false>(h, L, out, in, src, omega, active, ps, sg, nullptr);
-    else if (ps.c.base) launch_tile<S, true, false, false, false>(h, L, out, in, src, omega, active, ps, nullptr, nullptr);
-    else launch_tile<S, false, false, false, false>(h, L, out, in, src, omega, active, ps, nullptr, nullptr);
+    else if (ps.c.base) launch_tile_geo<S, true, false>(h, L, out, in, src, omega, active, ps, nullptr);
+    else launch_tile_geo<S, false, false>(h, L, out, in, src, omega, active, ps, nullptr);
 }
 // tiles per member of the blend-fused post-smoother (its partial arrays are indexed by tile)
 static int blend_tiles(const Lvl& L, int post) {
