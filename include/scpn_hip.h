@@ -158,6 +158,7 @@ typedef struct scpn_picard_params {
     int fail_on_diverge;
     int skip_seed;       /* 1: do not run _seed_plasma (not a reference behaviour; benchmarking aid) */
     int anderson_m;      /* solver.anderson_depth (default 5, at most 5) */
+    int xpoint_saddle;   /* solver.xpoint_use_saddle_detection (core/fusion_kernel.py:284-329), default 0 */
 } scpn_picard_params;
 
 typedef struct scpn_picard_result {

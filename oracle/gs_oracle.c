@@ -513,6 +513,68 @@ void orc_find_x_point(const double *psi, const double *z_axis, int nz, int nr, d
     *psi_x = m;
 }
 
+/* masked |grad psi| at one point (the quantity find_x_point minimises), +inf outside the divertor mask / non-finite */
+static double masked_b_at(const double *psi, const double *z_axis, int nz, int nr, double dr, double dz, double zthr, int iz, int ir) {
+    if (!(zthr > z_axis[iz])) return INFINITY;
+#define P(a, b) nan_to_num300(psi[IDX(a, b)])
+    double gz, gr;
+    if (iz == 0) gz = (P(1, ir) - P(0, ir)) / dz;
+    else if (iz == nz - 1) gz = (P(nz - 1, ir) - P(nz - 2, ir)) / dz;
+    else gz = (P(iz + 1, ir) - P(iz - 1, ir)) / (2.0 * dz);
+    if (ir == 0) gr = (P(iz, 1) - P(iz, 0)) / dr;
+    else if (ir == nr - 1) gr = (P(iz, nr - 1) - P(iz, nr - 2)) / dr;
+    else gr = (P(iz, ir + 1) - P(iz, ir - 1)) / (2.0 * dr);
+#undef P
+    double b = hypot(gr, gz);
+    return isfinite(b) ? b : INFINITY;
+}
+
+/* core/fusion_kernel.py:284-329: solver.xpoint_use_saddle_detection -- among the (up to) 16 smallest masked |grad psi| points
+ * prefer the smallest one that is an interior saddle (det Hessian < 0); otherwise the plain minimum.  Candidates are taken in
+ * ascending (|grad psi|, index) order, so the first saddle met is the reference's min over saddle_hits. */
+void orc_find_x_point_saddle(const double *psi, const double *z_axis, int nz, int nr, double dr, double dz,
+                             double z_min_cfg, long *idx_out, double *psi_x) {
+    long plain_idx;
+    double plain_psi;
+    orc_find_x_point(psi, z_axis, nz, nr, dr, dz, z_min_cfg, &plain_idx, &plain_psi);
+    *idx_out = plain_idx;
+    *psi_x = plain_psi;
+    if (plain_idx < 0) return;
+    double zthr = z_min_cfg * 0.5;
+    long n = (long)nz * nr;
+    double last_b = -1.0;
+    long last_i = -1;
+    for (int k = 0; k < 16; ++k) {
+        long best = -1;
+        double bestv = INFINITY;
+        for (long q = 0; q < n; ++q) {
+            int iz = (int)(q / nr), ir = (int)(q % nr);
+            double b = masked_b_at(psi, z_axis, nz, nr, dr, dz, zthr, iz, ir);
+            if (!isfinite(b)) continue;
+            if (b < last_b || (b == last_b && q <= last_i)) continue; /* already taken */
+            if (best < 0 || b < bestv) { best = q; bestv = b; }
+        }
+        if (best < 0) break; /* fewer than 16 finite candidates */
+        last_b = bestv;
+        last_i = best;
+        int iz = (int)(best / nr), ir = (int)(best % nr);
+        if (iz <= 0 || iz >= nz - 1 || ir <= 0 || ir >= nr - 1) continue;
+#define P(a, b) nan_to_num300(psi[IDX(a, b)])
+        double d2r = (P(iz, ir + 1) - 2.0 * P(iz, ir) + P(iz, ir - 1)) / (dr * dr);
+        double d2z = (P(iz + 1, ir) - 2.0 * P(iz, ir) + P(iz - 1, ir)) / (dz * dz);
+        double drz = (P(iz + 1, ir + 1) - P(iz + 1, ir - 1) - P(iz - 1, ir + 1) + P(iz - 1, ir - 1)) / (4.0 * dr * dz);
+#undef P
+        double det = d2r * d2z - drz * drz;
+        if (isfinite(det) && det < 0.0) {
+            double v = psi[best];
+            if (!isfinite(v)) v = nan_to_num300(v);
+            *idx_out = best;
+            *psi_x = v;
+            return;
+        }
+    }
+}
+
 static double mtanh1(double x, const double *p) { /* core/fusion_kernel.py:359-390 */
     double y = (p[0] - x) / p[1];
     y = fmin(fmax(y, -20.0), 20.0);
@@ -681,7 +743,8 @@ int orc_picard_solve(const orc_picard_params *p, double *psi, const double *boun
         double psi_axis, psi_bnd;
         long xidx;
         orc_find_axis(psi, nz, nr, &aiz, &air, &psi_axis);
-        orc_find_x_point(psi, z_axis, nz, nr, dr, dz, p->z_min, &xidx, &psi_bnd);
+        if (p->xpoint_saddle) orc_find_x_point_saddle(psi, z_axis, nz, nr, dr, dz, p->z_min, &xidx, &psi_bnd);
+        else orc_find_x_point(psi, z_axis, nz, nr, dr, dz, p->z_min, &xidx, &psi_bnd);
         if (fabs(psi_axis - psi_bnd) < 0.1) psi_bnd = psi_axis * 0.1;
         double i_current = NAN;
         if (!p->external_profile_mode)
@@ -1137,7 +1200,8 @@ static void newton_topology_source(const nctx *c, const double *psi, double *j_p
     int aiz, air;
     long xidx;
     orc_find_axis(psi, p->nz, p->nr, &aiz, &air, psi_axis);
-    orc_find_x_point(psi, c->z_axis, p->nz, p->nr, c->dr, c->dz, p->z_min, &xidx, psi_bnd);
+    if (p->xpoint_saddle) orc_find_x_point_saddle(psi, c->z_axis, p->nz, p->nr, c->dr, c->dz, p->z_min, &xidx, psi_bnd);
+    else orc_find_x_point(psi, c->z_axis, p->nz, p->nr, c->dr, c->dz, p->z_min, &xidx, psi_bnd);
     if (fabs(*psi_axis - *psi_bnd) < 0.1) *psi_bnd = *psi_axis * 0.1;
     if (!p->external_profile_mode)
         orc_update_source(psi, c->r_axis, p->nz, p->nr, c->dr, c->dz, *psi_axis, *psi_bnd, p->mu0, p->i_target,

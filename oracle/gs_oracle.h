@@ -103,6 +103,10 @@ void orc_find_axis(const double *psi, int nz, int nr, int *iz, int *ir, double *
 void orc_find_x_point(const double *psi, const double *z_axis, int nz, int nr, double dr, double dz,
                       double z_min_cfg, long *idx_out, double *psi_x);
 
+/* core/fusion_kernel.py:284-329 find_x_point with solver.xpoint_use_saddle_detection = True */
+void orc_find_x_point_saddle(const double *psi, const double *z_axis, int nz, int nr, double dr, double dz,
+                             double z_min_cfg, long *idx_out, double *psi_x);
+
 /* core/fusion_kernel.py:359-444 update_plasma_source_nonlinear; hmode!=0 selects mtanh.
  * ped_p / ped_ff = {ped_top, ped_width, ped_height, core_alpha}.  Writes J_phi; returns
  * I_current (before renormalisation) */
@@ -130,6 +134,7 @@ typedef struct orc_picard_params {
     int n_coils;               /* cfg["coils"] used for calculate_vacuum_field */
     const double *coil_r, *coil_z, *coil_i;
     int anderson_m; /* solver.anderson_depth (default 5) */
+    int xpoint_saddle; /* solver.xpoint_use_saddle_detection (default 0) */
 } orc_picard_params;
 
 typedef struct orc_picard_result {

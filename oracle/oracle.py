@@ -33,7 +33,7 @@ class PicardParams(C.Structure):
         ("preserve_initial_state", _i), ("has_boundary_flux", _i), ("external_profile_mode", _i),
         ("n_coils", _i),
         ("coil_r", C.POINTER(_d)), ("coil_z", C.POINTER(_d)), ("coil_i", C.POINTER(_d)),
-        ("anderson_m", _i),
+        ("anderson_m", _i), ("xpoint_saddle", _i),
     ]
 
 
@@ -86,6 +86,7 @@ def lib() -> C.CDLL:
         L.orc_external_flux.argtypes = [_dp, _dp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp]
         L.orc_find_axis.argtypes = [_dp, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_d)]
         L.orc_find_x_point.argtypes = [_dp, _dp, _i, _i, _d, _d, _d, C.POINTER(C.c_long), C.POINTER(_d)]
+        L.orc_find_x_point_saddle.argtypes = [_dp, _dp, _i, _i, _d, _d, _d, C.POINTER(C.c_long), C.POINTER(_d)]
         L.orc_update_source.restype = _d
         L.orc_update_source.argtypes = [_dp, _dp, _i, _i, _d, _d, _d, _d, _d, _d, _i, _dp, _dp, _dp]
         L.orc_picard_solve.argtypes = [C.POINTER(PicardParams), _dp, C.c_void_p, _dp,
@@ -254,6 +255,13 @@ def find_axis(psi):
     return iz.value, ir.value, v.value
 
 
+def find_x_point_saddle(psi, z_axis, dr, dz, z_min_cfg):
+    psi = _c(psi)
+    idx, px = C.c_long(), _d()
+    lib().orc_find_x_point_saddle(psi, _c(z_axis), psi.shape[0], psi.shape[1], dr, dz, z_min_cfg, C.byref(idx), C.byref(px))
+    return idx.value, px.value
+
+
 def find_x_point(psi, z_axis, dr, dz, z_min_cfg):
     psi = _c(psi)
     idx, v = C.c_long(), _d()
@@ -304,6 +312,7 @@ def make_params(cfg: dict, *, preserve=False, has_bc=False, external_profile_mod
     coils = cfg.get("coils", [])
     p.n_coils = len(coils)
     p.anderson_m = int(sol.get("anderson_depth", 5))
+    p.xpoint_saddle = int(bool(sol.get("xpoint_use_saddle_detection", False)))
     keep = [np.array([c[k] for c in coils], dtype=np.float64) for k in ("r", "z", "current")]
     p.coil_r, p.coil_z, p.coil_i = [a.ctypes.data_as(C.POINTER(_d)) for a in keep]
     p._keep = keep  # keep the arrays alive

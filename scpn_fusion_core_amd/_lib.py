@@ -39,7 +39,7 @@ class PicardParams(C.Structure):
         ("require_gs_residual", _i), ("gs_tol", _d),
         ("hmode", _i), ("ped_p", _d * 4), ("ped_ff", _d * 4),
         ("preserve_initial_state", _i), ("has_boundary_flux", _i), ("external_profile_mode", _i),
-        ("check_every", _i), ("fail_on_diverge", _i), ("skip_seed", _i), ("anderson_m", _i),
+        ("check_every", _i), ("fail_on_diverge", _i), ("skip_seed", _i), ("anderson_m", _i), ("xpoint_saddle", _i),
     ]
 
 

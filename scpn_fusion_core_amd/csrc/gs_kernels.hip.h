@@ -1242,6 +1242,75 @@ __global__ void __launch_bounds__(256) k_topology_final(Fld psiF, Member* st, co
     }
 }
 
+// solver.xpoint_use_saddle_detection (core/fusion_kernel.py:284-329): after k_topology_final picked the minimum of the masked
+// |grad psi|, walk the (up to) 16 smallest candidates in ascending (|grad psi|, index) order and take the first one that is an
+// interior saddle (det Hessian < 0); none -> the minimum stays.  One block of 1024 threads per member.
+__global__ void __launch_bounds__(1024) k_xpoint_saddle(Fld psiF, Member* st, int nz, int nr, int ld, double dr, double dz,
+                                                        int n_mask_rows, const double* r_axis, const double* z_axis) {
+    __shared__ VI shv[16];
+    __shared__ VI cand;
+    __shared__ int done;
+    const int b = blockIdx.x;
+    if (!st[b].active || st[b].x_idx < 0) return;
+    const double* psi = psiF.at(b);
+    const long nm = (long)n_mask_rows * nr;  // masked rows are iz < n_mask_rows (Z ascending)
+    double last_b = -1.0;
+    long last_q = -1;
+    for (int k = 0; k < 16; ++k) {
+        VI mn{0.0, -1};
+        for (long q = threadIdx.x; q < nm; q += 1024) {
+            const int iz = (int)(q / nr), ir = (int)(q - (long)iz * nr);
+            const long c = (long)iz * ld + ir;
+            const double p = psi[c];
+            double gz, gr;
+            if (iz == 0) gz = (nan_to_num300(psi[c + ld]) - nan_to_num300(p)) / dz;
+            else if (iz == nz - 1) gz = (nan_to_num300(p) - nan_to_num300(psi[c - ld])) / dz;
+            else gz = (nan_to_num300(psi[c + ld]) - nan_to_num300(psi[c - ld])) / (2.0 * dz);
+            if (ir == 0) gr = (nan_to_num300(psi[c + 1]) - nan_to_num300(p)) / dr;
+            else if (ir == nr - 1) gr = (nan_to_num300(p) - nan_to_num300(psi[c - 1])) / dr;
+            else gr = (nan_to_num300(psi[c + 1]) - nan_to_num300(psi[c - 1])) / (2.0 * dr);
+            const double bm = hypot(gr, gz);
+            if (!finite_d(bm)) continue;
+            if (bm < last_b || (bm == last_b && q <= last_q)) continue;  // already visited
+            mn = vi_min(mn, VI{bm, q});
+        }
+        VI r = block_vi<false, 1024>(mn, shv);
+        if (threadIdx.x == 0) {
+            cand = r;
+            done = 0;
+            if (r.i < 0) done = 1;  // fewer finite candidates than 16
+            else {
+                const int iz = (int)(r.i / nr), ir = (int)(r.i - (long)iz * nr);
+                if (iz > 0 && iz < nz - 1 && ir > 0 && ir < nr - 1) {
+                    const long c = (long)iz * ld + ir;
+#define PS(o) nan_to_num300(psi[c + (o)])
+                    const double d2r = (PS(1) - 2.0 * PS(0) + PS(-1)) / (dr * dr);
+                    const double d2z = (PS(ld) - 2.0 * PS(0) + PS(-ld)) / (dz * dz);
+                    const double drz = (PS(ld + 1) - PS(ld - 1) - PS(-ld + 1) + PS(-ld - 1)) / (4.0 * dr * dz);
+#undef PS
+                    const double det = d2r * d2z - drz * drz;
+                    if (finite_d(det) && det < 0.0) {
+                        Member& m = st[b];
+                        double pb = psi[c];
+                        if (!finite_d(pb)) pb = nan_to_num300(pb);
+                        const double pa = m.psi_axis;
+                        if (fabs(pa - pb) < 0.1) pb = pa * 0.1;
+                        double denom = pb - pa;
+                        if (fabs(denom) < 1e-9) denom = 1e-9;
+                        m.psi_bnd = pb; m.denom = denom; m.inv_denom = 1.0 / denom; m.x_idx = r.i; m.x_r = r_axis[ir]; m.x_z = z_axis[iz];
+                        done = 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (done) return;
+        last_b = cand.v;
+        last_q = cand.i;
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- Picard: source (a9)
 // partial sums of J_raw.  Each thread owns a column pair (16-B loads) of 4 rows: block = 64 pairs x 4 row-lanes,
 // 16 rows per block.  grid (ceil(nr/128), ceil(nz/16), B); partial index = blockIdx.y * gridDim.x + blockIdx.x

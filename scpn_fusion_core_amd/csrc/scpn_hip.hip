@@ -860,15 +860,18 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     }
     auto iteration = [&](bool first) {
         {
-            ProfScope ps(h, "topology", first || !h->use_fused || p->method == 3 ? 2 : 1);
+            ProfScope ps(h, "topology", first || !h->use_fused || p->method == 3 || p->xpoint_saddle ? 2 : 1);
             int ntopo = topo_count;  // partial count produced by the previous iteration's fused tail
-            if (first || !h->use_fused || p->method == 3) {  // later iterations get their partials from the fused blend kernel
+            if (first || !h->use_fused || p->method == 3 || p->xpoint_saddle) {  // later iterations get their partials from the fused blend kernel
                 ntopo = nblk1;
                 hipLaunchKernelGGL(k_topology, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, h->dr, h->dz,
                                    n_mask_rows, h->d_topo.p, nblk1);
             }
             hipLaunchKernelGGL(k_topology_final, dim3(B), dim3(256), 0, st, curF, h->d_st.p, (const TopoPart*)h->d_topo.p, ntopo, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_z.p);
+            if (p->xpoint_saddle)
+                hipLaunchKernelGGL(k_xpoint_saddle, dim3(B), dim3(1024), 0, st, curF, h->d_st.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
+                                   (const double*)h->d_r.p, (const double*)h->d_z.p);
         }
         // source generation inside the pre-smoother is implemented and bit-exact, but its 160-VGPR footprint drops the
         // tile kernel to one workgroup per CU and it measured slower (61.8 vs 48.9 us per launch): opt-in only
@@ -1157,6 +1160,9 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
                                n_mask_rows, h->d_topo.p, nblk1);
             hipLaunchKernelGGL(k_topology_final, dim3(B), dim3(256), 0, st, curF, h->d_st.p, (const TopoPart*)h->d_topo.p, nblk1, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_z.p);
+            if (p->xpoint_saddle)
+                hipLaunchKernelGGL(k_xpoint_saddle, dim3(B), dim3(1024), 0, st, curF, h->d_st.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
+                                   (const double*)h->d_r.p, (const double*)h->d_z.p);
         }
         if (!p->external_profile_mode) {
             ProfScope ps(h, "source", 3);

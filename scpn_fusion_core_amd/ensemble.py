@@ -57,6 +57,7 @@ def picard_params_from_cfg(cfg: dict, *, preserve_initial_state=False, has_bound
     p.fail_on_diverge = int(bool(sol.get("fail_on_diverge", False)))
     p.skip_seed = 0
     p.anderson_m = int(sol.get("anderson_depth", 5))
+    p.xpoint_saddle = int(bool(sol.get("xpoint_use_saddle_detection", False)))
     return p
 
 

@@ -136,7 +136,7 @@ class FusionKernel:
                                   [c["current"] for c in coils], mu0=mu0, mode="vacuum")
 
     def find_x_point(self, Psi) -> tuple[tuple[float, float], float]:
-        """Default (no saddle detection) path of core/fusion_kernel.py:255-340, evaluated on the host for a single
+        """core/fusion_kernel.py:255-340 (incl. ``solver.xpoint_use_saddle_detection``), evaluated on the host for a single
         field (inside the solve it runs on the device every iteration)."""
         psi_raw = np.asarray(Psi, dtype=np.float64)
         finite = np.isfinite(psi_raw)
@@ -149,9 +149,24 @@ class FusionKernel:
         if np.any(mask):
             masked = np.where(mask, bmag, np.inf)
             if int(np.isfinite(masked).sum()) > 0:
-                if self.cfg.get("solver", {}).get("xpoint_use_saddle_detection", False):
-                    raise NotImplementedError("xpoint_use_saddle_detection is not on the HIP path")
                 iz, ir = np.unravel_index(int(np.argmin(masked)), psi_raw.shape)
+                if self.cfg.get("solver", {}).get("xpoint_use_saddle_detection", False):
+                    # the 16 smallest |grad psi| points in ascending (value, index) order; first interior saddle wins
+                    nzz, nrr = psi_raw.shape
+                    flat = masked.ravel()
+                    order = np.lexsort((np.arange(flat.size), flat))[: min(16, int(np.isfinite(flat).sum()))]
+                    for q in order:
+                        a, c = divmod(int(q), nrr)
+                        if a <= 0 or a >= nzz - 1 or c <= 0 or c >= nrr - 1:
+                            continue
+                        d2r = (psi_safe[a, c + 1] - 2.0 * psi_safe[a, c] + psi_safe[a, c - 1]) / (self.dR**2)
+                        d2z = (psi_safe[a + 1, c] - 2.0 * psi_safe[a, c] + psi_safe[a - 1, c]) / (self.dZ**2)
+                        drz = (psi_safe[a + 1, c + 1] - psi_safe[a + 1, c - 1] - psi_safe[a - 1, c + 1] + psi_safe[a - 1, c - 1]) / (
+                            4.0 * self.dR * self.dZ)
+                        det = float(d2r * d2z - drz * drz)
+                        if np.isfinite(det) and det < 0.0:
+                            iz, ir = a, c
+                            break
                 px = float(psi_raw[iz, ir])
                 if not np.isfinite(px):
                     px = float(psi_safe[iz, ir])

@@ -415,6 +415,44 @@ def gen_fastsolver():
     save("fastsolver.npz", **out)
 
 
+# ── (a8, optional) X-point by saddle detection  core/fusion_kernel.py:284-329 ──
+def gen_saddle():
+    out, cfgs = {}, {}
+    rng = np.random.default_rng(17)
+    # unit: find_x_point with the saddle test on assorted flux maps (solved state, perturbed, monotone -> no saddle, NaN hole)
+    cfg = iter_cfg(33, tol=1e-6, max_iter=200)
+    cfg["solver"]["xpoint_use_saddle_detection"] = True
+    k = make_kernel(cfg)
+    k.solve_equilibrium()
+    base = k.Psi.copy()
+    fields = {"solved": base, "noisy": base + 0.02 * rng.normal(size=base.shape), "monotone": 0.3 * k.RR + 0.1 * k.ZZ,
+              "bowl": (k.RR - 6.0) ** 2 + (k.ZZ + 5.0) ** 2, "saddle": (k.RR - 6.0) ** 2 - (k.ZZ + 5.0) ** 2}
+    hole = base.copy()
+    hole[4, 7] = np.nan
+    fields["nanhole"] = hole
+    for name, f in fields.items():
+        (rx, zx), px = k.find_x_point(f)
+        out[f"unit_{name}_psi"] = f
+        out[f"unit_{name}_x"] = np.array([rx, zx, px])
+        k.cfg["solver"]["xpoint_use_saddle_detection"] = False
+        (r0, z0), p0 = k.find_x_point(f)
+        k.cfg["solver"]["xpoint_use_saddle_detection"] = True
+        out[f"unit_{name}_x_plain"] = np.array([r0, z0, p0])
+        print(name, (rx, zx, px), (r0, z0, p0))
+    out["unit_dims"] = np.array([k.R[0], k.R[-1], k.Z[0], k.Z[-1], k.dR, k.dZ, cfg["dimensions"]["Z_min"]])
+    for name, c in {"iter33_saddle": iter_cfg(33), "iter65_saddle": iter_cfg(65), "d3d33_saddle": d3d_cfg(33)}.items():
+        c["solver"]["xpoint_use_saddle_detection"] = True
+        kk = make_kernel(c)
+        res, rec = traced_solve(kk)
+        cfgs[name] = c
+        out[f"{name}_psi"], out[f"{name}_axis_bnd"] = res["psi"], rec
+        out[f"{name}_diff"] = np.array(res["residual_history"])
+        out[f"{name}_stats"] = np.array([float(res["converged"]), res["iterations"], res["residual"]])
+        print(name, res["iterations"], res["converged"])
+    out["_configs"] = np.array(json.dumps(cfgs))
+    save("saddle.npz", **out)
+
+
 # ── (f3) field products: psi sampling, B field, diagnostic response matrices, probe-based reconstruction ──
 def gen_products():
     """core/fusion_kernel.py:450-456; core/fusion_kernel_free_boundary.py:137-159, 162-270, 285-488, 562-580."""
@@ -643,6 +681,6 @@ def gen_newton():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["smooth", "operators", "mgsolve", "polyglot", "picard", "pieces", "green",
-                             "free_boundary", "fastsolver", "anderson", "shape", "eqdsk", "newton", "products", "transport"]
+                             "free_boundary", "fastsolver", "anderson", "shape", "eqdsk", "newton", "products", "transport", "saddle"]
     for w in which:
         globals()[f"gen_{w}"]()

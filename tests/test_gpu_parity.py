@@ -283,6 +283,43 @@ def test_picard_golden(hip, golden, name):
     assert res["residual"] == pytest.approx(resid, rel=1e-5)
 
 
+@pytest.mark.parametrize("name", ["iter33_saddle", "iter65_saddle", "d3d33_saddle"])
+def test_picard_saddle_detection_golden(hip, golden, name):
+    """solver.xpoint_use_saddle_detection (core/fusion_kernel.py:284-329) on the device: same X-point sequence, iteration count
+    and psi as the reference."""
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    g = golden("saddle.npz")
+    cfg = configs_from(g)[name]
+    with EnsembleSolver(cfg, batch=2, current_targets=np.array([cfg["physics"]["plasma_current_target"]] * 2)) as es:
+        res = es.solve_equilibrium(history=True, trace=True, check_every=4)
+        psi = es.get_psi()
+    st = g[f"{name}_stats"]
+    for b in range(2):
+        assert res[b]["iterations"] == int(st[1]) and res[b]["converged"] == bool(st[0])
+        np.testing.assert_allclose(res[b]["trace"][:, 0:2], g[f"{name}_axis_bnd"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(res[b]["residual_history"], g[f"{name}_diff"], rtol=1e-6, atol=1e-15)
+        assert np.abs(psi[b] - g[f"{name}_psi"]).max() <= 1e-11 * np.abs(g[f"{name}_psi"]).max()
+
+
+def test_find_x_point_saddle_host_mirror(hip, golden, tmp_path):
+    import json
+
+    from scpn_fusion_core_amd.fusion_kernel import FusionKernel
+
+    g = golden("saddle.npz")
+    cfg = configs_from(g)["iter33_saddle"]
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps(cfg))
+    k = FusionKernel(str(p))
+    for name in ("solved", "noisy", "monotone", "bowl", "saddle", "nanhole"):
+        (rx, zx), px = k.find_x_point(g[f"unit_{name}_psi"])
+        assert [rx, zx, px] == list(g[f"unit_{name}_x"]), name
+    k.cfg["solver"]["xpoint_use_saddle_detection"] = False
+    (rx, zx), px = k.find_x_point(g["unit_solved_psi"])
+    assert [rx, zx, px] == list(g["unit_solved_x_plain"])
+
+
 def test_picard_ensemble_members_match_single_solves(hip, orc):
     from scpn_fusion_core_amd.ensemble import EnsembleSolver
 

@@ -320,3 +320,24 @@ def test_transport_coupling_pieces(golden):
     for k in range(6):
         psi, info = orc.current_diffusion_step(g["cd_rho"], psi, 6.2, 2.0, 5.3, 0.5, g["cd_te"], g["cd_ne"], 1.7, g["cd_jbs"], g["cd_jcd"])
         assert info == 0 and np.array_equal(psi, g["cd_hist"][k]), k
+
+
+# ── row a8, optional path: solver.xpoint_use_saddle_detection ─────────────────────────────────────────────
+def test_xpoint_saddle_detection(golden):
+    """core/fusion_kernel.py:284-329: unit flux maps (solved, noisy, monotone = no saddle, bowl, pure saddle, NaN hole) give the
+    reference's X-point exactly, and full Picard runs with the option reproduce the reference (the option changes the
+    iteration count: 220 vs 204 on the 33^2 ITER-like case)."""
+    g = golden("saddle.npz")
+    r0, r1, z0, z1, dr, dz, zmin = g["unit_dims"]
+    r, z = np.linspace(r0, r1, 33), np.linspace(z0, z1, 33)
+    for name in ("solved", "noisy", "monotone", "bowl", "saddle", "nanhole"):
+        idx, px = orc.find_x_point_saddle(g[f"unit_{name}_psi"], z, dr, dz, zmin)
+        assert (r[idx % 33], z[idx // 33], px) == tuple(g[f"unit_{name}_x"]), name
+        idx0, px0 = orc.find_x_point(g[f"unit_{name}_psi"], z, dr, dz, zmin)
+        assert (r[idx0 % 33], z[idx0 // 33], px0) == tuple(g[f"unit_{name}_x_plain"]), name
+    for name, cfg in configs_from(g).items():
+        out = orc.picard_solve(cfg, trace=True)
+        st = g[f"{name}_stats"]
+        assert out["iterations"] == int(st[1]) and out["converged"] == bool(st[0])
+        np.testing.assert_allclose(out["trace"][:, 0:2], g[f"{name}_axis_bnd"], rtol=1e-11, atol=1e-13)
+        assert np.abs(out["psi"] - g[f"{name}_psi"]).max() <= 1e-12 * np.abs(g[f"{name}_psi"]).max()
