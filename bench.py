@@ -133,41 +133,67 @@ def main() -> int:
         es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
         fam = es.profile_report()
         es.profile(False)
-        dom = max(fam, key=lambda k: fam[k]["ms"]) if fam else None
+        # Families are per level and role; a KERNEL (one symbol in a rocprofv3 trace) is the set of families with the same
+        # role: smooth_tile_L*_pre is k_smooth_tile<3,false,false,true,...> on levels 0,1,2, and so on.  The dominant kernel
+        # is the symbol with the largest summed device time, as `rocprofv3 --kernel-trace --stats` ranks them.
+        import re
+
+        def symbol(name):
+            m = re.match(r"smooth_tile_L\d+(_pre|_post)?$", name)
+            return "smooth_tile" + (m.group(1) or "") if m else name
+
+        def level(name):
+            m = re.match(r".*_L(\d+)", name)
+            return int(m.group(1)) if m else 0
+
+        # ALGORITHMIC bytes per point and launch = SURVEY 8(d) per-point figures x what one launch does:
+        #   RB-SOR sweep 24 B/pt, residual 24, full-weight restriction 10, prolong-add 18, blend+norms 40, one colour pass 16.
+        #   smooth_tile_pre  = 3 sweeps + residual + restriction        -> 3*24 + 24 + 10 = 106 B/pt
+        #   smooth_tile_post = prolong-add + 3 sweeps                   -> 18 + 3*24      =  90 B/pt
+        # "fused_compulsory" = the bytes the FUSED kernel itself must move once (psi, src in; psi (+coarse rhs/e) out).
+        per_point = {"smooth_tile_pre": (106.0, 28.0), "smooth_tile_post": (90.0, 26.0), "smooth_tile": (72.0, 24.0),
+                     "blend_fused": (40.0, 32.0), "source": (24.0, 24.0)}
+        groups: dict = {}
+        for name, v in fam.items():
+            groups.setdefault(symbol(name), []).append((name, v))
+        dom = max(groups, key=lambda k: sum(v["ms"] for _, v in groups[k])) if groups else None
         if dom:
-            # ALGORITHMIC bytes per launch = SURVEY 8(d) per-point figures x what one launch processes:
-            #   RB-SOR sweep 24 B/pt, residual 24, full-weight restriction 10, prolong-add 18, blend+norms 40, one colour pass 16.
-            #   smooth_tile_*_pre  = 3 sweeps + residual + restriction        -> 3*24 + 24 + 10 = 106 B/pt
-            #   smooth_tile_*_post = prolong-add + 3 sweeps                   -> 18 + 3*24      =  90 B/pt
-            # "fused_compulsory" = the bytes the FUSED kernel itself must move once (psi, src in; psi (+coarse rhs/e) out).
-            if dom.endswith("_pre"):
-                per_pt, fused_pt = 106.0, 28.0
-            elif dom.endswith("_post"):
-                per_pt, fused_pt = 90.0, 26.0
-            elif dom.startswith("smooth_tile"):
-                per_pt, fused_pt = 72.0, 24.0
-            elif dom.startswith("blend_fused"):
-                per_pt, fused_pt = 40.0, 32.0
-            else:
-                per_pt, fused_pt = 16.0, 16.0
+            per_pt, fused_pt = per_point.get(dom, (16.0, 16.0))
             members = B / es.num_groups  # one launch covers one group's members
-            avg_s = fam[dom]["ms"] * 1e-3 / fam[dom]["launches"]
-            alg_bytes = per_pt * n_pts * members
-            ach = alg_bytes / avg_s / 1e9
-            traffic = None  # HBM bytes per launch from the committed PMC passes (same kernel, same grid)
             try:
                 pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-                if pmc.get("grid") == args.grid and dom in pmc["hbm_bytes_per_member_launch"]:
-                    traffic = round(pmc["hbm_bytes_per_member_launch"][dom] * members)
-            except (OSError, ValueError, KeyError):
-                pass
+                if pmc.get("grid") != args.grid:
+                    pmc = None
+            except (OSError, ValueError):
+                pmc = None
+            tot_ms = tot_launch = 0.0
+            alg_bytes = fused_bytes = 0.0
+            traffic_bytes, traffic_ok = 0.0, pmc is not None
+            levels = {}
+            for name, v in groups[dom]:
+                lv = level(name)
+                pts = ((args.grid - 1) // (2 ** lv) + 1) ** 2 if dom.startswith("smooth_tile") else n_pts
+                tot_ms += v["ms"]
+                tot_launch += v["launches"]
+                alg_bytes += per_pt * pts * members * v["launches"]
+                fused_bytes += fused_pt * pts * members * v["launches"]
+                per_member = pmc["hbm_bytes_per_member_launch"].get(name) if pmc else None
+                if per_member is None:
+                    traffic_ok = False
+                else:
+                    traffic_bytes += per_member * members * v["launches"]
+                levels[name] = {"avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "launches": v["launches"],
+                                "achieved": round(per_pt * pts * members / (1e-3 * v["ms"] / v["launches"]) / 1e9, 1)}
+            ach = alg_bytes / (tot_ms * 1e-3) / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "alg_bytes_per_point": per_pt, "alg_bytes_per_launch": alg_bytes,
+                        "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": round(traffic_bytes / tot_launch) if traffic_ok else None,
+                        "alg_bytes_per_point": per_pt, "alg_bytes_per_launch": round(alg_bytes / tot_launch),
                         "fused_compulsory_bytes_per_point": fused_pt,
-                        "achieved_fused_compulsory": round(fused_pt * n_pts * members / avg_s / 1e9, 1),
-                        "avg_launch_us": round(avg_s * 1e6, 2), "groups": es.num_groups, "members_per_launch": int(members),
-                        "isolated_kernel_timing": True, "families_ms": fam}
+                        "achieved_fused_compulsory": round(fused_bytes / (tot_ms * 1e-3) / 1e9, 1),
+                        "avg_launch_us": round(1e3 * tot_ms / tot_launch, 2), "launches": int(tot_launch),
+                        "groups": es.num_groups, "members_per_launch": int(members), "isolated_kernel_timing": True,
+                        "per_level": levels, "families_ms": fam}
 
     # ---- CPU baseline: the C oracle (port of the reference algorithm), one full free-boundary solve of
     #      member 0 on one host core
