@@ -121,6 +121,20 @@ __device__ __forceinline__ double block_max(double v, double* sh) {
     __syncthreads();
     return r;
 }
+// block max returned to every thread
+template <int NT>
+__device__ __forceinline__ double block_max_all(double v, double* sh) {
+    v = wave_max(v);
+    v = __shfl(v, 0, 64);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = sh[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) r = fmax(r, sh[i]);
+    return r;
+}
 // (value, index) reductions with numpy's first-occurrence tie rule
 struct VI {
     double v;
@@ -272,7 +286,9 @@ __global__ void k_residual(Fld outF, Fld psiF, Fld srcF, Lvl L) {
     if (iz > 0 && iz < L.nz - 1 && ir > 0 && ir < L.nr - 1) v = resid_at(psiF.at(b), srcF.at(b), L, iz, ir);
     outF.at(b)[(long)iz * L.ld + ir] = v;
 }
-// partial max|r| and sum r^2 over the interior: grid (nblk, B), 256 threads x 4 points
+// partial max|r| and overflow-safe partial sum over the interior: grid (nblk, B), 256 threads x 4 points.
+// stable_rms (core/fusion_kernel_numerics.py:28-37) is max * sqrt(mean((r/max)^2)); each block stores its own max m_b and
+// s_b = sum (r/m_b)^2, the consumer combines M = max m_b, sum s_b (m_b/M)^2 -- no r^2 is ever formed (|r| up to 1e250).
 __global__ void __launch_bounds__(256) k_resid_norms(Fld psiF, Fld srcF, Lvl L, double* pmax,
                                                      double* psum, int nblk, const int* active) {
     __shared__ double sh[4];
@@ -282,18 +298,24 @@ __global__ void __launch_bounds__(256) k_resid_norms(Fld psiF, Fld srcF, Lvl L, 
     const double* src = srcF.at(b);
     const int ni = L.nr - 2;
     const long nint = (long)(L.nz - 2) * ni;
-    double m = 0.0, s = 0.0;
+    double m = 0.0, rv[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        rv[k] = 0.0;
         if (q < nint) {
             int iz = 1 + (int)(q / ni), ir = 1 + (int)(q - (long)(iz - 1) * ni);
-            double r = sanitize1(resid_at(psi, src, L, iz, ir));
-            m = fmax(m, fabs(r));
-            s += r * r;
+            rv[k] = sanitize1(resid_at(psi, src, L, iz, ir));
+            m = fmax(m, fabs(rv[k]));
         }
     }
-    double bm = block_max<256>(m, sh);
+    const double bm = block_max_all<256>(m, sh);
+    double s = 0.0;
+    if (bm > 0.0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double t = rv[k] / bm; s += t * t; }
+    }
+    __syncthreads();
     double bs = block_sum<256>(s, sh);
     if (threadIdx.x == 0) {
         pmax[(long)b * nblk + blockIdx.x] = bm;
@@ -876,7 +898,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             ba.psum[o] = a;
             ba.pbad[o] = bd;
             ba.rmax[o] = m1;
-            ba.rsum[o] = c2;
+            ba.rsum[o] = m1 > 0.0 ? c2 / (m1 * m1) : 0.0;  // (max, sum (r/max)^2) convention of k_resid_norms
             TopoPart tp;
             tp.maxv = vmx.v; tp.maxi = vmx.i; tp.minb = vmn.v; tp.mini = vmn.i; tp.minpsi = mp; tp.pad = 0;
             ba.topo[o] = tp;
@@ -1511,12 +1533,13 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
     }
     if (bad) atomicOr(&shbad, 1);
     __syncthreads();
-    double m = 0.0, s2 = 0.0;
+    double m = 0.0, s2 = 0.0, rv[BT_Z / 4];
     const int tx = tid & 63, ty = tid >> 6;
 #pragma unroll
     for (int k = 0; k < BT_Z / 4; ++k) {
         const int lz = 1 + ty + 4 * k, lr = 1 + tx;
         const int gz = z0 + lz, gr = r0 + lr;
+        rv[k] = 0.0;
         if (gz >= nz || gr >= nr) continue;
         const double p = t[lz][lr];
         if (gz >= 1 && gz <= nz - 2 && gr >= 1 && gr <= nr - 2) {
@@ -1527,7 +1550,7 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
             const double lpsi = d2r - divc(d1r, L.r_safe[gr], L.r_inv[gr]) + d2z;
             const double r = sanitize1(lpsi - src[(long)gz * ld + gr]);
             m = fmax(m, fabs(r));
-            s2 += r * r;
+            rv[k] = r;
         }
         if (gz < n_mask_rows) {  // np.gradient + hypot inside the divertor rows (fusion_kernel.py:276-288)
             double gzv, grv;
@@ -1543,7 +1566,12 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
         }
     }
     const double bsum = block_sum<256>(dsum, shd);
-    const double bmax = block_max<256>(m, shd);
+    const double bmax = block_max_all<256>(m, shd);  // overflow-safe residual sum: (max, sum (r/max)^2), see k_resid_norms
+    if (bmax > 0.0) {
+#pragma unroll
+        for (int k = 0; k < BT_Z / 4; ++k) { const double t = rv[k] / bmax; s2 += t * t; }
+    }
+    __syncthreads();
     const double bs2 = block_sum<256>(s2, shd);
     const double bminp = -block_max<256>(-minpsi, shd);
     const VI rmx = block_vi<true, 256>(mx, shv);
@@ -1705,14 +1733,18 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
         s += psum[(long)b * nblk + i];
         bad |= pbad[(long)b * nblk + i];
     }
-    for (int i = threadIdx.x; i < nblk_r; i += 256) {
-        rs += rsum[(long)b * nblk_r + i];
-        rm = fmax(rm, rmax[(long)b * nblk_r + i]);
-    }
+    for (int i = threadIdx.x; i < nblk_r; i += 256) rm = fmax(rm, rmax[(long)b * nblk_r + i]);
     if (bad) atomicOr(&shbad, 1);
+    const double rmx_all = block_max_all<256>(rm, sh);  // M = max_b m_b
+    if (rmx_all > 0.0)
+        for (int i = threadIdx.x; i < nblk_r; i += 256) {
+            const double f = rmax[(long)b * nblk_r + i] / rmx_all;
+            rs += rsum[(long)b * nblk_r + i] * (f * f);
+        }
+    __syncthreads();
     double tot = block_sum<256>(s, sh);
     double rtot = block_sum<256>(rs, sh);
-    double rmx = block_max<256>(rm, sh);
+    double rmx = rmx_all;
     if (threadIdx.x == 0) {
         Member& m = st[b];
         const int it = m.iterations;  // iteration index lives on the device: kernel arguments stay constant (HIP graph replay)
@@ -1729,9 +1761,8 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
             return;
         }
         double diff = tot / (double)ctl.n_total;
-        // stable_rms (fusion_kernel_numerics.py:28-37) evaluated as sqrt(sum r^2 / n); identical up to
-        // rounding for the magnitudes that occur (no overflow below 1e150)
-        double gs = rmx <= 0.0 ? 0.0 : sqrt(rtot / (double)ctl.n_interior);
+        // stable_rms (fusion_kernel_numerics.py:28-37): max * sqrt(mean((r/max)^2)), overflow-safe up to |r| = 1e250
+        double gs = rmx <= 0.0 ? 0.0 : rmx * sqrt(rtot / (double)ctl.n_interior);
         m.diff = diff;
         m.gs = gs;
         if (gs < m.gs_best) m.gs_best = gs;

@@ -2034,11 +2034,14 @@ static void resid_norms_host(Solver* h, Fld psi, Fld src, std::vector<double>& m
     HIP_TRY(hipMemcpyAsync(pm.data(), h->d_part1.p, sizeof(double) * B * nb, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(ps.data(), h->d_part2.p, sizeof(double) * B * nb, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    for (int b = 0; b < B; ++b)
-        for (int i = 0; i < nb; ++i) {
-            mx[b] = std::fmax(mx[b], pm[(size_t)b * nb + i]);
-            ss[b] += ps[(size_t)b * nb + i];
-        }
+    for (int b = 0; b < B; ++b) {  // (m_b, s_b = sum (r/m_b)^2) -> M = max m_b, ss = sum (r/M)^2
+        for (int i = 0; i < nb; ++i) mx[b] = std::fmax(mx[b], pm[(size_t)b * nb + i]);
+        if (mx[b] > 0.0)
+            for (int i = 0; i < nb; ++i) {
+                const double f = pm[(size_t)b * nb + i] / mx[b];
+                ss[b] += ps[(size_t)b * nb + i] * (f * f);
+            }
+    }
 }
 int scpn_residual_linf(const double* psi, const double* source, const double* r_axis, int nz, int nr, int batch, double dr, double dz,
                        double* linf) {
@@ -2062,7 +2065,7 @@ int scpn_gs_residual_rms(const double* psi, const double* source, const double* 
     std::vector<double> mx, ss;
     resid_norms_host(t.h, t.h->slot_fld(nullptr), t.h->plain(t.h->src.p), mx, ss);
     long ni = (long)(nz - 2) * (nr - 2);
-    for (int b = 0; b < batch; ++b) rms[b] = (ni <= 0 || mx[b] <= 0.0) ? 0.0 : std::sqrt(ss[b] / (double)ni);
+    for (int b = 0; b < batch; ++b) rms[b] = (ni <= 0 || mx[b] <= 0.0) ? 0.0 : mx[b] * std::sqrt(ss[b] / (double)ni);  // stable_rms
     API_END
 }
 int scpn_restrict_full_weight(const double* fine, int nz_f, int nr_f, int batch, double* coarse) {

@@ -412,50 +412,94 @@ def optimize_coil_currents(kernel: Any, coils: CoilSet, target_flux, tikhonov_al
     return np.asarray(result.x, dtype=np.float64)
 
 
+def _kernel_boundary_points(kernel: Any) -> np.ndarray:
+    """Unique computational-boundary points in (R, Z) order: bottom row, right column, top row reversed, left column reversed
+    (core/fusion_kernel_free_boundary.py:608-620)."""
+    r, z = np.asarray(kernel.R, dtype=np.float64), np.asarray(kernel.Z, dtype=np.float64)
+    if r.ndim != 1 or z.ndim != 1 or r.size < 2 or z.size < 2:
+        raise ValueError("kernel R/Z axes must be one-dimensional with at least two points.")
+    if not np.all(np.isfinite(r)) or not np.all(np.isfinite(z)):
+        raise ValueError("kernel R/Z axes must contain finite values only.")
+    bottom = np.column_stack([r, np.full(r.shape, z[0])])
+    right = np.column_stack([np.full(z[1:].shape, r[-1]), z[1:]])
+    top = np.column_stack([r[-2::-1], np.full(r[-2::-1].shape, z[-1])])
+    left = np.column_stack([np.full(z[-2:0:-1].shape, r[0]), z[-2:0:-1]])
+    return np.vstack([bottom, right, top, left]).astype(np.float64, copy=False)
+
+
 def solve_free_boundary(kernel: Any, coils: CoilSet, max_outer_iter: int = 20, tol: float = 1e-4,
-                        optimize_shape: bool = False, tikhonov_alpha: float = 1e-4, **_unused) -> dict[str, Any]:
-    """core/fusion_kernel_free_boundary.py:623-739.  ``optimize_shape=False``: the whole outer loop runs on the device.
-    ``optimize_shape=True``: each outer iteration is a device Picard solve followed by the host-side bounded
-    least-squares update of the coil currents (the reference's structure)."""
+                        optimize_shape: bool = False, tikhonov_alpha: float = 1e-4, limiter_points=None, axis_point=None,
+                        x_points=None) -> dict[str, Any]:
+    """core/fusion_kernel_free_boundary.py:623-739.  With this package's ``FusionKernel`` and ``optimize_shape=False`` the whole
+    outer loop runs on the device; with ``optimize_shape=True`` (or any other kernel object exposing ``Psi``, ``R``, ``Z`` and
+    ``solve_equilibrium``) each outer iteration is the kernel's solve followed by the host-side bounded least-squares update
+    of the coil currents, as in the reference.  The closing boundary-flux reconstruction diagnostics (:708-739) are
+    evaluated from the device Green's-function kernel."""
     if max_outer_iter < 1:
         raise ValueError("max_outer_iter must be >= 1.")
     if not np.isfinite(tol) or tol < 0.0:
         raise ValueError("tol must be finite and >= 0.")
-    if not (optimize_shape and coils.target_flux_points is not None):
-        return kernel._solve_free_boundary_device(coils, max_outer_iter, tol)
-    psi_ext = compute_external_flux(kernel, coils)
-    diff, outer, shape_optimization = float("inf"), 0, None
-    for outer in range(max_outer_iter):
-        kernel.Psi[0, :], kernel.Psi[-1, :] = psi_ext[0, :], psi_ext[-1, :]
-        kernel.Psi[:, 0], kernel.Psi[:, -1] = psi_ext[:, 0], psi_ext[:, -1]
-        psi_old = kernel.Psi.copy()
-        kernel.solve_equilibrium(preserve_initial_state=True, boundary_flux=psi_ext)
-        target_psi = resolve_shape_target_flux(kernel, coils)
-        response = build_mutual_inductance_matrix(kernel, coils, coils.target_flux_points)
-        new_currents = np.asarray(optimize_coil_currents(kernel, coils, target_psi, tikhonov_alpha=tikhonov_alpha),
-                                  dtype=np.float64).reshape(-1)
-        if new_currents.shape != (len(coils.positions),):
-            raise ValueError("optimised coil current vector length must match coil count.")
-        if not np.all(np.isfinite(new_currents)):
-            raise ValueError("optimised coil currents must contain finite values only.")
-        achieved = response.T @ new_currents
-        residual = achieved - target_psi
-        flux_rmse = float(np.sqrt(np.mean(residual**2)))
-        shape_optimization = {
-            "solver_mode": "free_boundary_solver_shape_current_optimization",
-            "target_point_count": int(target_psi.shape[0]), "coil_count": int(len(coils.positions)),
-            "flux_rmse": flux_rmse, "flux_relative_rmse": float(flux_rmse / max(float(np.sqrt(np.mean(target_psi**2))), 1.0)),
-            "max_abs_flux_residual": float(np.max(np.abs(residual))), "target_flux": target_psi.copy(), "achieved_flux": achieved,
-        }
-        coils.currents = new_currents
+    shape_optimization = None
+    extra: dict[str, Any] = {}
+    if not (optimize_shape and coils.target_flux_points is not None) and hasattr(kernel, "_solve_free_boundary_device"):
+        extra = kernel._solve_free_boundary_device(coils, max_outer_iter, tol)
+        outer_iterations, diff = extra["outer_iterations"], extra["final_diff"]
         psi_ext = compute_external_flux(kernel, coils)
-        diff = float(np.max(np.abs(kernel.Psi - psi_old)))
-        if diff < tol:
-            break
-    return {"outer_iterations": outer + 1, "final_diff": diff, "coil_currents": coils.currents.copy(),
-            "shape_optimization": shape_optimization}
+    else:
+        psi_ext = compute_external_flux(kernel, coils)
+        diff, outer = float("inf"), 0
+        for outer in range(max_outer_iter):
+            kernel.Psi[0, :], kernel.Psi[-1, :] = psi_ext[0, :], psi_ext[-1, :]
+            kernel.Psi[:, 0], kernel.Psi[:, -1] = psi_ext[:, 0], psi_ext[:, -1]
+            psi_old = kernel.Psi.copy()
+            kernel.solve_equilibrium(preserve_initial_state=True, boundary_flux=psi_ext)
+            if optimize_shape and coils.target_flux_points is not None:
+                target_psi = resolve_shape_target_flux(kernel, coils)
+                response = build_mutual_inductance_matrix(kernel, coils, coils.target_flux_points)
+                optimise = getattr(kernel, "optimize_coil_currents", None)  # kernel method first: keeps caller hooks working
+                new_currents = (optimise(coils, target_psi, tikhonov_alpha=tikhonov_alpha) if optimise is not None
+                                else optimize_coil_currents(kernel, coils, target_psi, tikhonov_alpha=tikhonov_alpha))
+                new_currents = np.asarray(new_currents, dtype=np.float64).reshape(-1)
+                if new_currents.shape != (len(coils.positions),):
+                    raise ValueError("optimised coil current vector length must match coil count.")
+                if not np.all(np.isfinite(new_currents)):
+                    raise ValueError("optimised coil currents must contain finite values only.")
+                achieved = response.T @ new_currents
+                residual = achieved - target_psi
+                flux_rmse = float(np.sqrt(np.mean(residual**2)))
+                active_bounds = 0
+                if coils.current_limits is not None:
+                    limits = _as_finite_vector(coils.current_limits, name="current_limits", length=len(coils.positions))
+                    active_bounds = int(np.count_nonzero(np.isclose(np.abs(new_currents), limits, rtol=0.0)))
+                shape_optimization = {
+                    "solver_mode": "free_boundary_solver_shape_current_optimization",
+                    "target_point_count": int(target_psi.shape[0]), "coil_count": int(len(coils.positions)),
+                    "response_rank": int(np.linalg.matrix_rank(response.T)), "response_condition": float(np.linalg.cond(response.T)),
+                    "flux_rmse": flux_rmse,
+                    "flux_relative_rmse": float(flux_rmse / max(float(np.sqrt(np.mean(target_psi**2))), 1.0)),
+                    "max_abs_flux_residual": float(np.max(np.abs(residual))), "active_current_bounds": active_bounds,
+                    "target_flux": target_psi.copy(), "achieved_flux": achieved.astype(np.float64, copy=False),
+                }
+                coils.currents = new_currents
+                psi_ext = compute_external_flux(kernel, coils)
+            diff = float(np.max(np.abs(kernel.Psi - psi_old)))
+            if diff < tol:
+                break
+        outer_iterations = outer + 1
+    boundary_target = np.concatenate([psi_ext[0, :], psi_ext[1:, -1], psi_ext[-1, -2::-1], psi_ext[-2:0:-1, 0]]).astype(np.float64)
+    boundary_reconstruction = reconstruct_boundary_flux_from_coils(
+        kernel, coils, boundary_points=_kernel_boundary_points(kernel), limiter_points=limiter_points, axis_point=axis_point,
+        x_points=x_points, target_flux=boundary_target)
+    out = {"outer_iterations": outer_iterations, "final_diff": diff, "coil_currents": np.asarray(coils.currents, dtype=np.float64).copy(),
+           "vacuum_boundary_abs_error": boundary_reconstruction["max_abs_error"], "boundary_reconstruction": boundary_reconstruction,
+           "shape_optimization": shape_optimization}
+    for key in ("picard_iterations", "converged"):  # device-loop telemetry (not in the reference's dict)
+        if key in extra:
+            out[key] = extra[key]
+    return out
 
 
 __all__ = ["CoilSet", "coil_flux_grid", "green_points", "green_function", "compute_external_flux",
-           "build_mutual_inductance_matrix", "interp_psi", "resolve_shape_target_flux", "optimize_coil_currents",
-           "solve_free_boundary"]
+           "build_mutual_inductance_matrix", "build_magnetic_probe_response_matrix", "sample_flux_at_points", "sample_psi_grid",
+           "reconstruct_boundary_flux_from_coils", "reconstruct_coil_currents_from_magnetic_probes", "interp_psi",
+           "resolve_shape_target_flux", "optimize_coil_currents", "solve_free_boundary"]
