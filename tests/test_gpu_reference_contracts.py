@@ -270,3 +270,68 @@ def test_fusion_kernel_free_boundary_reports_boundary_reconstruction(hip, tmp_pa
     br = r["boundary_reconstruction"]
     assert br["point_count"] == 2 * (k.NR - 1) + 2 * (k.NZ - 1) and r["vacuum_boundary_abs_error"] <= 1e-12 * np.abs(br["target_flux"]).max()
     assert r["outer_iterations"] in (1, 2) and np.all(np.isfinite(k.Psi))
+
+
+# ---- tests/test_multigrid_solve.py ------------------------------------------------------------------------------
+def _solovev_problem(nr=65, nz=65):
+    r_min, r_max, z_min, z_max = 1.2, 2.2, -0.5, 0.5
+    rr, zz = np.meshgrid(np.linspace(r_min, r_max, nr), np.linspace(z_min, z_max, nz))
+    return -rr * np.exp(-((rr - 1.7) ** 2 + zz**2) / 0.05), r_min, r_max, z_min, z_max, nr, nz
+
+
+def test_multigrid_solve_contract(hip):
+    from scpn_fusion_core_amd import multigrid_solve as mgs
+
+    source, r_min, r_max, z_min, z_max, nr, nz = _solovev_problem()
+    psi, residual, n_cycles, converged = mgs.multigrid_solve(source, np.zeros((nz, nr)), r_min, r_max, z_min, z_max, nr, nz, tol=1e-6,
+                                                             max_cycles=200)  # :34-43
+    assert converged is True and residual < 1e-6 and 0 < n_cycles < 50 and np.all(np.isfinite(psi))
+    rr, _ = np.meshgrid(np.linspace(r_min, r_max, nr), np.linspace(z_min, z_max, nz))
+    dr, dz = (r_max - r_min) / (nr - 1), (z_max - z_min) / (nz - 1)
+    assert residual == pytest.approx(mgs.residual_linf(psi, source, rr, dr, dz), rel=1e-12)  # :62-75
+    bc = np.zeros((nz, nr))
+    bc[0, :] = bc[-1, :] = bc[:, 0] = bc[:, -1] = 0.4  # :46-59
+    psi, *_ = mgs.multigrid_solve(source, bc, r_min, r_max, z_min, z_max, nr, nz, tol=1e-6, max_cycles=200)
+    assert float(psi[0, 0]) == 0.4 and float(psi[-1, -1]) == 0.4
+    np.testing.assert_array_equal(psi[0, :], 0.4)
+    np.testing.assert_array_equal(psi[:, -1], 0.4)
+    for src_shape, psi_shape in (((10, 12), (65, 65)), ((65, 65), (10, 12))):  # :78-83
+        with pytest.raises(ValueError, match="shape"):
+            mgs.multigrid_solve(np.zeros(src_shape), np.zeros(psi_shape), 1.0, 2.0, -1.0, 1.0, 65, 65)
+    for tol in (0.0, -1e-6, np.inf, np.nan):  # :86-90
+        with pytest.raises(ValueError, match="tol"):
+            mgs.multigrid_solve(np.zeros((33, 33)), np.zeros((33, 33)), 1.0, 9.0, -5.0, 5.0, 33, 33, tol=tol)
+    with pytest.raises(ValueError, match="max_cycles"):  # :93-97
+        mgs.multigrid_solve(np.zeros((33, 33)), np.zeros((33, 33)), 1.0, 9.0, -5.0, 5.0, 33, 33, max_cycles=0)
+    for omega in (0.0, 0.999999, 2.0, np.inf, np.nan):  # :121-123
+        with pytest.raises(ValueError, match="omega"):
+            mgs.validate_sor_omega(omega)
+
+
+def test_residual_linf_exact_solution_and_empty_interior(hip):
+    from scpn_fusion_core_amd import multigrid_solve as mgs
+
+    r, z = np.linspace(1.0, 2.0, 17), np.linspace(-0.5, 0.5, 17)  # :100-109
+    rr, zz = np.meshgrid(r, z)
+    dr, dz = float(r[1] - r[0]), float(z[1] - z[0])
+    psi = 0.03125 * rr**4 - 0.125 * zz**2 + 0.05 * rr**2 * zz**2
+    source = mgs.mg_residual(psi, np.zeros_like(psi), rr, dr, dz)
+    assert mgs.residual_linf(psi, source, rr, dr, dz) < 1e-12
+    tiny = np.zeros((2, 2))  # :126-130
+    assert mgs.residual_linf(tiny, tiny, np.array([[1.0, 2.0], [1.0, 2.0]]), 1.0, 1.0) == 0.0
+
+
+# ---- tests/test_jax_gs_solver.py TestGsSolveNumpy (the CPU "polyglot" lane) -----------------------------------------
+def test_polyglot_lane_properties(hip):
+    from scpn_fusion_core_amd.polyglot import gs_solve_hip
+
+    args = (0.1, 2.0, -1.5, 1.5, 17, 17, 1e6)  # :32-38 R_MIN, R_MAX, Z_MIN, Z_MAX, NR, NZ, IP_TARGET
+    psi = gs_solve_hip(*args, n_picard=20, n_jacobi=50)  # :44-69
+    assert psi.shape == (17, 17) and np.all(np.isfinite(psi)) and np.max(np.abs(psi[1:-1, 1:-1])) > 0.0
+    for edge in (psi[0, :], psi[-1, :], psi[:, 0], psi[:, -1]):
+        assert np.allclose(edge, 0.0)
+    sym = gs_solve_hip(*args, n_picard=40, n_jacobi=100)  # :71-76
+    np.testing.assert_allclose(sym, sym[::-1, :], atol=1e-4 * max(1.0, np.abs(sym).max()))
+    hi = gs_solve_hip(0.1, 2.0, -1.5, 1.5, 17, 17, 2e6, n_picard=20, n_jacobi=50)  # :78-94
+    assert np.max(np.abs(hi)) > np.max(np.abs(psi))
+    assert np.all(np.isfinite(gs_solve_hip(0.1, 2.0, -1.5, 1.5, 33, 33, 1e6, n_picard=20, n_jacobi=50)))  # :96-101
