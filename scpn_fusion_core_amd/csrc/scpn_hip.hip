@@ -367,30 +367,26 @@ static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, doubl
     hipLaunchKernelGGL(kern, g, dim3(64 * NWT), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c, ld_c,
                        sg ? *sg : SrcGen{}, dd, ba);
 }
-// the three production roles (plain / +prolongation / +defect) exist in every geometry; the opt-in fusions only in the default one
-template <int S, bool PROLONG, bool DEFECT>
+// the production roles (plain / +prolongation / +defect) and the blend-fused post-smoother exist in every geometry; source
+// generation only in the default one
+template <int S, bool PROLONG, bool DEFECT, bool BLEND = false>
 static void launch_tile_geo(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                            const DefectOut* dfo) {
+                            const DefectOut* dfo, const BlendArgs* bl = nullptr) {
     switch (tile_variant_for(L)) {
-        case 1: launch_tile<S, PROLONG, false, DEFECT, false, 40, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
-        case 2: launch_tile<S, PROLONG, false, DEFECT, false, 46, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
-#ifdef TILE_EXPERIMENTS
-        case 3: launch_tile<S, PROLONG, false, DEFECT, false, 48, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
-        case 4: launch_tile<S, PROLONG, false, DEFECT, false, 56, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
-        case 5: launch_tile<S, PROLONG, false, DEFECT, false, 64, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
-        case 6: launch_tile<S, PROLONG, false, DEFECT, false, 32, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
-        case 7: launch_tile<S, PROLONG, false, DEFECT, false, 40, 4, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
-        case 8: launch_tile<S, PROLONG, false, DEFECT, false, 36, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
-        case 9: launch_tile<S, PROLONG, false, DEFECT, false, 44, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
-#endif
-        default: launch_tile<S, PROLONG, false, DEFECT, false>(h, L, out, in, src, omega, active, ps, nullptr, dfo); break;
+        case 1: launch_tile<S, PROLONG, false, DEFECT, BLEND, 40, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+        case 2: launch_tile<S, PROLONG, false, DEFECT, BLEND, 46, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+        default: launch_tile<S, PROLONG, false, DEFECT, BLEND>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
     }
+}
+static int tile_rows_for(const Lvl& L) {
+    const int v = tile_variant_for(L);
+    return v == 1 ? 40 : (v == 2 ? 46 : TILE_LZ);
 }
 template <int S>
 static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
                           const SrcGen* sg, const DefectOut* dfo, const BlendArgs* bl) {
-    if (bl && ps.c.base) launch_tile<S, true, false, false, true>(h, L, out, in, src, omega, active, ps, nullptr, nullptr, bl);
-    else if (bl) launch_tile<S, false, false, false, true>(h, L, out, in, src, omega, active, ps, nullptr, nullptr, bl);
+    if (bl && ps.c.base) launch_tile_geo<S, true, false, true>(h, L, out, in, src, omega, active, ps, nullptr, bl);
+    else if (bl) launch_tile_geo<S, false, false, true>(h, L, out, in, src, omega, active, ps, nullptr, bl);
     else if (dfo && sg) launch_tile<S, false, true, true, false>(h, L, out, in, src, omega, active, ps, sg, dfo);
     else if (dfo) launch_tile_geo<S, false, true>(h, L, out, in, src, omega, active, ps, dfo);
     else if (sg) launch_tile<S, false, true, false, false>(h, L, out, in, src, omega, active, ps, sg, nullptr);
@@ -400,7 +396,7 @@ static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
 // tiles per member of the blend-fused post-smoother (its partial arrays are indexed by tile)
 static int blend_tiles(const Lvl& L, int post) {
     const int S = ((post - 1) % 3) + 1, H = 2 * S + 2;
-    return cdiv(L.nr, 128 - 2 * H) * cdiv(L.nz, TILE_LZ - 2 * H);
+    return cdiv(L.nr, 128 - 2 * H) * cdiv(L.nz, tile_rows_for(L) - 2 * H);
 }
 
 // n_sweeps red-black SOR sweeps of (in, src).  Returns the field that holds the result: `in` itself for the
