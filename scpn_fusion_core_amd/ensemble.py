@@ -311,6 +311,9 @@ class EnsembleSolver:
             raise ValueError("max_outer_iter must be >= 1.")
         if not np.isfinite(tol) or tol < 0.0:
             raise ValueError("tol must be finite and >= 0.")
+        if self.cfg.get("solver", {}).get("solver_method", "multigrid") == "newton":
+            raise NotImplementedError("the resident free-boundary loop drives the Picard methods; with solver_method='newton' use "
+                                      "free_boundary.solve_free_boundary(FusionKernel, ...) (outer loop on the host, Newton on the device)")
 
         def bc(a, default):
             a = default if a is None else as_f64(a)

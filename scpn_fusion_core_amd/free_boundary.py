@@ -441,7 +441,8 @@ def solve_free_boundary(kernel: Any, coils: CoilSet, max_outer_iter: int = 20, t
         raise ValueError("tol must be finite and >= 0.")
     shape_optimization = None
     extra: dict[str, Any] = {}
-    if not (optimize_shape and coils.target_flux_points is not None) and hasattr(kernel, "_solve_free_boundary_device"):
+    newton = getattr(kernel, "cfg", {}).get("solver", {}).get("solver_method", "multigrid") == "newton"
+    if not (optimize_shape and coils.target_flux_points is not None) and hasattr(kernel, "_solve_free_boundary_device") and not newton:
         extra = kernel._solve_free_boundary_device(coils, max_outer_iter, tol)
         outer_iterations, diff = extra["outer_iterations"], extra["final_diff"]
         psi_ext = compute_external_flux(kernel, coils)
