@@ -126,6 +126,11 @@ int scpn_tridiag_solve(int batch, int n, const double *dl, const double *d, cons
 int scpn_current_diffusion_step(int batch, int n, const double *rho, double *psi, double r0, double a, double b0,
                                 double dt, const double *te, const double *ne, double z_eff, const double *j_bs,
                                 const double *j_cd, const double *j_ext, int *info);
+/* core/current_diffusion.py:141-158: the time recurrence of solve_flux_evolution_nonadiabatic for `batch` profiles.  rate =
+ * 1/tau_psi and source = R_null*E_theta - eta*J_theta sampled at the n_steps+1 time points ([batch][n_steps+1][n]); psi0
+ * [batch][n]; psi out [batch][n_steps+1][n]; inc / drop / resid out [batch][n_steps][n] (may be NULL) */
+int scpn_flux_evolution(int batch, int n, int n_steps, double dt, const double *rate, const double *source,
+                        const double *psi0, double *psi, double *inc, double *drop, double *resid);
 /* core/jax_gs_solver.py:126-167 gs_solve_np (polyglot Picard + damped-Jacobi lane), batch=1 */
 int scpn_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int nr, int nz,
                      const double *r_axis, const double *z_axis, const double *psi_seed,

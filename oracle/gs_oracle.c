@@ -1653,3 +1653,26 @@ int orc_current_diffusion_step(const double *rho, double *psi, int n, double r0,
     free(q); free(eta); free(D); free(sub); free(diag); free(sup); free(rhs); free(jt);
     return info;
 }
+
+/* core/current_diffusion.py:55-172 solve_flux_evolution_nonadiabatic, the time recurrence (:141-158) given the sampled
+ * damping rate 1/tau_psi and source R_null*E_theta - eta*J_theta at the n_steps+1 time points ((n_steps+1) x n rows):
+ *   gamma = (rate[k]+rate[k+1])/2, s = (source[k]+source[k+1])/2, decay = exp(-gamma dt),
+ *   inc = gamma > 0 ? s (1-decay)/gamma : dt s,  drop = psi (1-decay),  psi' = psi - drop + inc.
+ * psi: (n_steps+1) x n (row 0 = psi0 on entry); inc / drop / resid: n_steps x n */
+void orc_flux_evolution(int n, int n_steps, double dt, const double *rate, const double *source, double *psi, double *inc,
+                        double *drop, double *resid) {
+    for (int k = 0; k < n_steps; ++k)
+        for (int i = 0; i < n; ++i) {
+            double gamma = 0.5 * (rate[(long)k * n + i] + rate[(long)(k + 1) * n + i]);
+            double s = 0.5 * (source[(long)k * n + i] + source[(long)(k + 1) * n + i]);
+            double decay = exp(-gamma * dt);
+            double di = gamma > 0.0 ? s * (1.0 - decay) / gamma : dt * s;
+            double p = psi[(long)k * n + i];
+            double dd = p * (1.0 - decay);
+            double nx = p - dd + di;
+            psi[(long)(k + 1) * n + i] = nx;
+            inc[(long)k * n + i] = di;
+            drop[(long)k * n + i] = dd;
+            resid[(long)k * n + i] = nx - nx;
+        }
+}

@@ -250,6 +250,11 @@ int orc_current_diffusion_step(const double *rho, double *psi, int n, double r0,
                                const double *te, const double *ne, double z_eff, const double *j_bs, const double *j_cd,
                                const double *j_ext);
 
+/* core/current_diffusion.py:141-158 time recurrence of solve_flux_evolution_nonadiabatic (rate = 1/tau_psi, source =
+ * R_null*E_theta - eta*J_theta sampled at the n_steps+1 time points) */
+void orc_flux_evolution(int n, int n_steps, double dt, const double *rate, const double *source, double *psi, double *inc,
+                        double *drop, double *resid);
+
 #ifdef __cplusplus
 }
 #endif

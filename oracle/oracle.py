@@ -109,6 +109,7 @@ def lib() -> C.CDLL:
         L.orc_neoclassical_resistivity.argtypes = [_d, _d, _d, _d]
         L.orc_q_from_psi.argtypes = [_dp, _dp, _i, _d, _d, _d, _dp]
         L.orc_current_diffusion_step.argtypes = [_dp, _dp, _i, _d, _d, _d, _d, _dp, _dp, _d, _dp, _dp, C.c_void_p]
+        L.orc_flux_evolution.argtypes = [_i, _i, _d, _dp, _dp, _dp, _dp, _dp, _dp]
         L.orc_dlartg.argtypes = [_d, _d, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]
         L.orc_gmres_gs.argtypes = [_dp, _dp, _i, _i, _d, _d, _dp, C.c_void_p, _i, _i, _d, _d, _dp, C.POINTER(C.c_long)]
         L.orc_profile_jacobian.argtypes = [_dp, _dp, _dp, _i, _i, _d, _d, _d, _d, _d, _i, _dp]
@@ -472,6 +473,16 @@ def current_diffusion_step(rho, psi, r0, a, b0, dt, te, ne, z_eff, j_bs, j_cd, j
     info = lib().orc_current_diffusion_step(_c(rho), psi, len(psi), r0, a, b0, dt, _c(te), _c(ne), z_eff, _c(j_bs), _c(j_cd),
                                             None if je is None else je.ctypes.data)
     return psi, info
+
+
+def flux_evolution(psi0, rate, source, dt):
+    rate, source = _c(rate), _c(source)
+    n_steps, n = rate.shape[0] - 1, rate.shape[1]
+    psi = np.zeros((n_steps + 1, n))
+    psi[0] = psi0
+    inc, drop, resid = np.zeros((n_steps, n)), np.zeros((n_steps, n)), np.zeros((n_steps, n))
+    lib().orc_flux_evolution(n, n_steps, float(dt), rate, source, psi, inc, drop, resid)
+    return psi, inc, drop, resid
 
 
 def free_boundary_solve(cfg, coils_r, coils_z, coils_i, turns, *, psi0=None, max_outer=20, tol=1e-4):

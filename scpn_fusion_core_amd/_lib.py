@@ -98,6 +98,7 @@ SIGNATURES = {
     "scpn_green_points": (_i, [_i, _dp, _dp, _i, _dp, _dp, _dp]),
     "scpn_tridiag_solve": (_i, [_i, _i, _vp, _dp, _vp, _dp, _dp, _vp]),
     "scpn_current_diffusion_step": (_i, [_i, _i, _dp, _dp, _d, _d, _d, _d, _dp, _dp, _d, _dp, _dp, _vp, _vp]),
+    "scpn_flux_evolution": (_i, [_i, _i, _i, _d, _dp, _dp, _dp, _dp, _vp, _vp, _vp]),
     "scpn_probe_response": (_i, [_i, _dp, _dp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _dp]),
     "scpn_gs_solve_np": (_i, [_d, _d, _d, _d, _i, _i, _dp, _dp, _vp, _d, _d, _i, _i, _d, _d, _d, _dp]),
     # resident ensemble solver

@@ -2364,4 +2364,30 @@ __global__ void k_current_diffusion(int batch, int n, const double* rho, double*
     for (int i = 0; i < n; ++i) p[i] = rhs[i];
 }
 
+
+// time recurrence of solve_flux_evolution_nonadiabatic (core/current_diffusion.py:141-158) for `batch` profiles: one thread per
+// (profile, rho) walks the n_steps steps; rate / source are [batch][n_steps+1][n], psi [batch][n_steps+1][n] (row 0 = psi0),
+// inc / drop / resid [batch][n_steps][n].  Consecutive lanes own consecutive rho: every row access is coalesced.
+__global__ void k_flux_evolution(int batch, int n, int n_steps, double dt, const double* rate, const double* source, double* psi,
+                                 double* inc, double* drop, double* resid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= n || b >= batch) return;
+    const long o1 = (long)b * (n_steps + 1) * n + i, o0 = (long)b * n_steps * n + i;
+    double p = psi[o1];
+    double r0 = rate[o1], s0 = source[o1];
+    for (int k = 0; k < n_steps; ++k) {
+        const double r1 = rate[o1 + (long)(k + 1) * n], s1 = source[o1 + (long)(k + 1) * n];
+        const double gamma = 0.5 * (r0 + r1), s = 0.5 * (s0 + s1);
+        const double decay = exp(-gamma * dt);
+        const double di = gamma > 0.0 ? s * (1.0 - decay) / gamma : dt * s;
+        const double dd = p * (1.0 - decay);
+        const double nx = p - dd + di;
+        psi[o1 + (long)(k + 1) * n] = nx;
+        inc[o0 + (long)k * n] = di;
+        drop[o0 + (long)k * n] = dd;
+        resid[o0 + (long)k * n] = nx - nx;
+        p = nx; r0 = r1; s0 = s1;
+    }
+}
+
 }  // namespace gs

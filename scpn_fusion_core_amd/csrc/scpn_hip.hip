@@ -2276,6 +2276,28 @@ int scpn_current_diffusion_step(int batch, int n, const double* rho, double* psi
     if (info) HIP_TRY(hipMemcpy(info, di.p, sizeof(int) * batch, hipMemcpyDeviceToHost));
     API_END
 }
+int scpn_flux_evolution(int batch, int n, int n_steps, double dt, const double* rate, const double* source, const double* psi0,
+                        double* psi, double* inc, double* drop, double* resid) {
+    if (batch < 1 || n < 1 || n_steps < 1 || !rate || !source || !psi0 || !psi) return fail(SCPN_E_ARG, "bad arguments");
+    if (!(dt > 0.0) || !std::isfinite(dt)) return fail(SCPN_E_ARG, "dt must be positive");
+    API_BEGIN
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available");
+    HIP_TRY(hipSetDevice(g_device));
+    const size_t n1 = (size_t)batch * (n_steps + 1) * n, n0 = (size_t)batch * n_steps * n;
+    DBuf<double> d_rate, d_src, d_psi, d_inc, d_drop, d_res;
+    d_rate.alloc(n1); d_src.alloc(n1); d_psi.alloc(n1); d_inc.alloc(n0); d_drop.alloc(n0); d_res.alloc(n0);
+    HIP_TRY(hipMemcpy(d_rate.p, rate, sizeof(double) * n1, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_src.p, source, sizeof(double) * n1, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy2D(d_psi.p, sizeof(double) * (n_steps + 1) * n, psi0, sizeof(double) * n, sizeof(double) * n, batch, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_flux_evolution, dim3(cdiv(n, 64), batch), dim3(64), 0, 0, batch, n, n_steps, dt, (const double*)d_rate.p,
+                       (const double*)d_src.p, d_psi.p, d_inc.p, d_drop.p, d_res.p);
+    HIP_TRY(hipMemcpy(psi, d_psi.p, sizeof(double) * n1, hipMemcpyDeviceToHost));
+    if (inc) HIP_TRY(hipMemcpy(inc, d_inc.p, sizeof(double) * n0, hipMemcpyDeviceToHost));
+    if (drop) HIP_TRY(hipMemcpy(drop, d_drop.p, sizeof(double) * n0, hipMemcpyDeviceToHost));
+    if (resid) HIP_TRY(hipMemcpy(resid, d_res.p, sizeof(double) * n0, hipMemcpyDeviceToHost));
+    API_END
+}
 int scpn_probe_response(int n_coils, const double* coil_r, const double* coil_z, const double* coil_turns, int n_flux, const double* flux_r,
                         const double* flux_z, int n_b, const double* b_r, const double* b_z, const int* b_dir, double* out) {
     if (n_coils < 1 || !coil_r || !coil_z || !out) return fail(SCPN_E_ARG, "CoilSet.positions must contain at least one coil.");

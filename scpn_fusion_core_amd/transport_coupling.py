@@ -6,12 +6,15 @@ Mirrors (reference file:line):
   * the GS step of ``run_self_consistent``                :129-147 (map -> solve_equilibrium -> relative psi change)
   * ``scipy.linalg.solve_banded((1, 1), ab, b)`` as used by core/current_diffusion.py:347-352 (LAPACK dgtsv)
   * ``CurrentDiffusionSolver``                            core/current_diffusion.py:262-353
+  * ``solve_flux_evolution_nonadiabatic``                 core/current_diffusion.py:55-172 (benchmarks/bench_current_diffusion_nonadiabatic.py)
 
 The 1-D transport physics itself (chi models, sources, bootstrap-current formulae) stays with the caller: it hands over
 ``ne*(Ti+Te)`` and the bootstrap profile, exactly the two arrays ``map_profiles_to_2d`` interpolates.
 """
 
 from __future__ import annotations
+
+from dataclasses import dataclass
 
 import numpy as np
 
@@ -89,6 +92,101 @@ def solve_banded_tridiagonal(dl, d, du, b):
     if np.any(info != 0):
         raise np.linalg.LinAlgError(f"singular matrix: resolution failed at diagonal {int(info[info != 0][0]) - 1}")
     return x[0] if single else x
+
+
+@dataclass(frozen=True)
+class FluxEvolutionTrajectory:
+    """Time history of the non-adiabatic flux carrier (fields of core/current_diffusion.py:29-53); arrays carry a leading batch
+    axis only when the solve was batched."""
+
+    time_s: np.ndarray
+    rho: np.ndarray
+    psi: np.ndarray
+    hall_drive: np.ndarray
+    resistive_loss: np.ndarray
+    source: np.ndarray
+    damping_rate: np.ndarray
+    source_increment: np.ndarray
+    damping_decrement: np.ndarray
+    update_residual: np.ndarray
+    dt_s: float
+
+
+def _as_profile(values, n: int, name: str, *, allow_infinite: bool = False) -> np.ndarray:
+    prof = np.asarray(values, dtype=np.float64)
+    if prof.ndim == 0:
+        prof = np.full(n, float(prof), dtype=np.float64)
+    if prof.shape != (n,):
+        raise ValueError(f"{name} must be scalar or shape ({n},)")
+    ok = np.isfinite(prof) | np.isposinf(prof) if allow_infinite else np.isfinite(prof)
+    if not np.all(ok):
+        raise ValueError(f"{name} must contain " + ("finite values or np.inf" if allow_infinite else "finite values"))
+    return prof
+
+
+def flux_evolution_batched(psi0, damping_rate, source, dt: float):
+    """The recurrence psi[k+1] = psi[k] - psi[k](1 - e^{-gamma dt}) + s (1 - e^{-gamma dt}) / gamma  (dt*s where gamma = 0) of
+    core/current_diffusion.py:141-158 for a batch of profiles on the device: ``psi0`` (batch, n), ``damping_rate`` / ``source``
+    (batch, n_steps+1, n) sampled at the step end points.  Returns (psi, source_increment, damping_decrement, update_residual)."""
+    L = _lib.require_gpu()
+    rate, src, p0 = np.ascontiguousarray(as_f64(damping_rate)), np.ascontiguousarray(as_f64(source)), np.ascontiguousarray(as_f64(psi0))
+    if rate.ndim != 3 or src.shape != rate.shape or p0.shape != (rate.shape[0], rate.shape[2]) or rate.shape[1] < 2:
+        raise ValueError("expected psi0 (batch, n) and damping_rate / source (batch, n_steps+1, n)")
+    if not np.isfinite(dt) or dt <= 0.0:
+        raise ValueError("dt must be positive")
+    batch, n1, n = rate.shape
+    psi = np.empty((batch, n1, n))
+    inc, drop, resid = np.empty((batch, n1 - 1, n)), np.empty((batch, n1 - 1, n)), np.empty((batch, n1 - 1, n))
+    check(L.scpn_flux_evolution(batch, n, n1 - 1, float(dt), rate, src, p0, psi, ptr(inc), ptr(drop), ptr(resid)))
+    return psi, inc, drop, resid
+
+
+def solve_flux_evolution_nonadiabatic(rho, psi0, *, tau_psi_fn, R_null_t, E_theta_t, eta_spitzer_fn, J_theta_t, dt: float,
+                                      n_steps: int) -> FluxEvolutionTrajectory:
+    """core/current_diffusion.py:55-172 with the same call-back contract: the (Python) drive functions are sampled on the host
+    at the n_steps+1 time points, the time recurrence runs on the device."""
+    rho_grid = np.asarray(rho, dtype=np.float64)
+    if rho_grid.ndim != 1:
+        raise ValueError("rho must be one-dimensional")
+    if rho_grid.size < 2:
+        raise ValueError("rho must contain at least two points")
+    if not np.all(np.isfinite(rho_grid)):
+        raise ValueError("rho must contain finite values")
+    if not np.all(np.diff(rho_grid) > 0.0):
+        raise ValueError("rho must be strictly increasing")
+    n = rho_grid.size
+    psi_initial = _as_profile(psi0, n, "psi0")
+    if not np.isfinite(dt) or dt <= 0.0:
+        raise ValueError("dt must be positive")
+    if n_steps <= 0:
+        raise ValueError("n_steps must be positive")
+    time_s = np.linspace(0.0, dt * n_steps, n_steps + 1, dtype=np.float64)
+    hall, loss, rate = np.zeros((n_steps + 1, n)), np.zeros((n_steps + 1, n)), np.zeros((n_steps + 1, n))
+    for k, t in enumerate(time_s):
+        try:
+            tau_raw = tau_psi_fn(t, rho_grid)
+        except TypeError:
+            tau_raw = tau_psi_fn(t)
+        tau = _as_profile(tau_raw, n, "tau", allow_infinite=True)
+        if np.any(np.isneginf(tau) | ((tau <= 0.0) & ~np.isposinf(tau))):
+            raise ValueError("tau_psi_fn must return positive finite values or np.inf")
+        with np.errstate(divide="ignore"):
+            rate[k] = np.where(np.isinf(tau), 0.0, 1.0 / tau)
+        r_null = float(R_null_t(float(t)))
+        if not np.isfinite(r_null) or r_null < 0.0:
+            raise ValueError("R_null_t must return a finite non-negative radius")
+        e_theta = _as_profile(E_theta_t(float(t), rho_grid), n, "E_theta_t")
+        eta = _as_profile(eta_spitzer_fn(rho_grid), n, "eta_spitzer_fn")
+        if np.any(eta < 0.0):
+            raise ValueError("eta_spitzer_fn must return non-negative resistivity")
+        j_theta = _as_profile(J_theta_t(float(t), rho_grid), n, "J_theta_t")
+        hall[k] = r_null * e_theta
+        loss[k] = eta * j_theta
+    source = hall - loss
+    psi, inc, drop, resid = flux_evolution_batched(psi_initial[None], rate[None], source[None], dt)
+    return FluxEvolutionTrajectory(time_s=time_s, rho=rho_grid, psi=psi[0], hall_drive=hall, resistive_loss=loss, source=source,
+                                   damping_rate=rate, source_increment=inc[0], damping_decrement=drop[0], update_residual=resid[0],
+                                   dt_s=float(dt))
 
 
 class CurrentDiffusionSolver:

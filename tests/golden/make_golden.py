@@ -568,7 +568,21 @@ def gen_transport():
     for _ in range(6):
         hist.append(cd.step(0.5, te, ne, 1.7, jbs, jcd).copy())
     out["cd_hist"] = np.array(hist)
-    print("transport", out["map_a_jphi"].sum(), out["cd_hist"][-1][:3])
+    # non-adiabatic flux carrier (benchmarks/bench_current_diffusion_nonadiabatic.py:43-72 case + space-dependent / infinite tau)
+    from scpn_fusion.core.current_diffusion import solve_flux_evolution_nonadiabatic
+
+    for tag, n_rho, n_steps, tau in (("bench", 64, 128, lambda t, g: 2.0e-6), ("inf", 33, 20, lambda t, g: np.inf),
+                                     ("rho", 48, 40, lambda t, g: np.where(g < 0.5, 1.0e-6 * (1 + g), np.inf))):
+        rho = np.linspace(0.0, 1.0, n_rho)
+        psi0 = 0.08 - 0.02 * rho**2
+        dt = 1.0e-8
+        tr = solve_flux_evolution_nonadiabatic(
+            rho, psi0, tau_psi_fn=tau, R_null_t=lambda t: 0.18, E_theta_t=lambda t, g: 25.0 + t / (n_steps * dt) + g,
+            eta_spitzer_fn=lambda g: np.full_like(g, 2.5e-6), J_theta_t=lambda t, g: 1.0e5 * (1.0 - 0.3 * g), dt=dt, n_steps=n_steps)
+        out[f"fx_{tag}_psi"], out[f"fx_{tag}_rate"], out[f"fx_{tag}_source"] = tr.psi, tr.damping_rate, tr.source
+        out[f"fx_{tag}_inc"], out[f"fx_{tag}_drop"], out[f"fx_{tag}_resid"] = tr.source_increment, tr.damping_decrement, tr.update_residual
+        out[f"fx_{tag}_hall"], out[f"fx_{tag}_loss"], out[f"fx_{tag}_time"] = tr.hall_drive, tr.resistive_loss, tr.time_s
+    print("transport", out["map_a_jphi"].sum(), out["cd_hist"][-1][:3], out["fx_bench_psi"][-1][:2])
     save("transport.npz", **out)
 
 

@@ -151,3 +151,66 @@ def test_gs_transport_outer_step(hip, orc):
         assert res[b]["iterations"] == ref["iterations"]
         assert np.abs(psi1[b] - ref["psi"]).max() <= 1e-10 * np.abs(ref["psi"]).max()
         assert resid[b] == pytest.approx(np.linalg.norm(ref["psi"] - psi0[b]) / np.linalg.norm(psi0[b]), rel=1e-6)
+
+
+def test_flux_evolution_nonadiabatic_golden(hip, golden, orc):
+    """solve_flux_evolution_nonadiabatic (core/current_diffusion.py:55-172) with the reference benchmark's drive functions
+    (benchmarks/bench_current_diffusion_nonadiabatic.py:43-72), an undamped case (tau = inf) and a rho-dependent tau.  One exp per
+    cell and step: 1e-14 relative against NumPy (SIMD exp) and the oracle (libm exp); the exact-balance contract
+    psi[n+1] = psi[n] - damping_decrement[n] + source_increment[n] holds bit-exactly (update_residual == 0)."""
+    from scpn_fusion_core_amd import transport_coupling as tc
+
+    g = golden("transport.npz")
+    for tag, n_rho, n_steps, tau in (("bench", 64, 128, lambda t, gr: 2.0e-6), ("inf", 33, 20, lambda t, gr: np.inf),
+                                     ("rho", 48, 40, lambda t, gr: np.where(gr < 0.5, 1.0e-6 * (1 + gr), np.inf))):
+        rho = np.linspace(0.0, 1.0, n_rho)
+        dt = 1.0e-8
+        tr = tc.solve_flux_evolution_nonadiabatic(
+            rho, 0.08 - 0.02 * rho**2, tau_psi_fn=tau, R_null_t=lambda t: 0.18, E_theta_t=lambda t, gr: 25.0 + t / (n_steps * dt) + gr,
+            eta_spitzer_fn=lambda gr: np.full_like(gr, 2.5e-6), J_theta_t=lambda t, gr: 1.0e5 * (1.0 - 0.3 * gr), dt=dt, n_steps=n_steps)
+        assert np.array_equal(tr.time_s, g[f"fx_{tag}_time"]) and np.array_equal(tr.damping_rate, g[f"fx_{tag}_rate"])
+        assert np.array_equal(tr.source, g[f"fx_{tag}_source"]) and np.array_equal(tr.hall_drive, g[f"fx_{tag}_hall"])
+        assert np.array_equal(tr.resistive_loss, g[f"fx_{tag}_loss"])
+        scale = np.abs(g[f"fx_{tag}_psi"]).max()
+        assert np.abs(tr.psi - g[f"fx_{tag}_psi"]).max() <= 1e-14 * scale, tag
+        np.testing.assert_allclose(tr.source_increment, g[f"fx_{tag}_inc"], rtol=1e-12, atol=1e-30)
+        np.testing.assert_allclose(tr.damping_decrement, g[f"fx_{tag}_drop"], rtol=1e-12, atol=1e-30)
+        assert np.array_equal(tr.update_residual, np.zeros_like(tr.update_residual))
+        assert np.array_equal(tr.psi[1:], tr.psi[:-1] - tr.damping_decrement + tr.source_increment)
+        ref = orc.flux_evolution(g[f"fx_{tag}_psi"][0], g[f"fx_{tag}_rate"], g[f"fx_{tag}_source"], dt)[0]
+        assert np.abs(tr.psi - ref).max() <= 1e-14 * scale
+    # zero drive, zero damping: psi stays constant (current_diffusion.py:76-78)
+    rho = np.linspace(0, 1, 16)
+    tr = tc.solve_flux_evolution_nonadiabatic(rho, 0.05 + rho, tau_psi_fn=lambda t: np.inf, R_null_t=lambda t: 0.0,
+                                              E_theta_t=lambda t, gr: 0.0, eta_spitzer_fn=lambda gr: 0.0, J_theta_t=lambda t, gr: 0.0,
+                                              dt=1e-6, n_steps=7)
+    assert np.array_equal(tr.psi, np.tile(0.05 + rho, (8, 1)))
+    for bad in ({"dt": 0.0}, {"n_steps": 0}):
+        kw = dict(tau_psi_fn=lambda t: 1.0, R_null_t=lambda t: 0.1, E_theta_t=lambda t, gr: 0.0, eta_spitzer_fn=lambda gr: 0.0,
+                  J_theta_t=lambda t, gr: 0.0, dt=1e-6, n_steps=3)
+        kw.update(bad)
+        with pytest.raises(ValueError):
+            tc.solve_flux_evolution_nonadiabatic(rho, rho, **kw)
+    with pytest.raises(ValueError):
+        tc.solve_flux_evolution_nonadiabatic(rho, rho, tau_psi_fn=lambda t: -1.0, R_null_t=lambda t: 0.1, E_theta_t=lambda t, gr: 0.0,
+                                             eta_spitzer_fn=lambda gr: 0.0, J_theta_t=lambda t, gr: 0.0, dt=1e-6, n_steps=3)
+
+
+def test_flux_evolution_large_batch_properties(hip, orc):
+    """4096 profiles x 1024 rho x 128 steps in one launch: members are independent (equal inputs -> bit-equal outputs), sampled
+    members equal the oracle to 1e-14, and the discrete balance holds exactly."""
+    from scpn_fusion_core_amd import transport_coupling as tc
+
+    rng = np.random.default_rng(8)
+    B, n, steps, dt = 512, 1024, 128, 1e-8
+    rate = np.abs(rng.normal(size=(B, 1, n))) * 5e5 * np.ones((1, steps + 1, 1))
+    rate[::7] = 0.0
+    src = rng.normal(size=(B, steps + 1, n)) * 1e3
+    psi0 = rng.normal(size=(B, n))
+    rate[1], src[1], psi0[1] = rate[0], src[0], psi0[0]
+    psi, inc, drop, resid = tc.flux_evolution_batched(psi0, rate, src, dt)
+    assert np.array_equal(psi[0], psi[1]) and np.array_equal(resid, np.zeros_like(resid))
+    assert np.array_equal(psi[:, 1:], psi[:, :-1] - drop + inc)
+    for b in (0, 7, 100, 511):
+        ref = orc.flux_evolution(psi0[b], rate[b], src[b], dt)[0]
+        assert np.abs(psi[b] - ref).max() <= 1e-14 * np.abs(ref).max(), b

@@ -341,3 +341,16 @@ def test_xpoint_saddle_detection(golden):
         assert out["iterations"] == int(st[1]) and out["converged"] == bool(st[0])
         np.testing.assert_allclose(out["trace"][:, 0:2], g[f"{name}_axis_bnd"], rtol=1e-11, atol=1e-13)
         assert np.abs(out["psi"] - g[f"{name}_psi"]).max() <= 1e-12 * np.abs(g[f"{name}_psi"]).max()
+
+
+def test_flux_evolution_nonadiabatic_oracle(golden):
+    """core/current_diffusion.py:141-158 recurrence: exact for the benchmark case (constant tau) and the undamped case;
+    1e-14 where NumPy's SIMD exp sees many distinct arguments (rho-dependent tau)."""
+    g = golden("transport.npz")
+    for tag, exact in (("bench", True), ("inf", True), ("rho", False)):
+        psi, inc, drop, resid = orc.flux_evolution(g[f"fx_{tag}_psi"][0], g[f"fx_{tag}_rate"], g[f"fx_{tag}_source"], 1e-8)
+        if exact:
+            assert np.array_equal(psi, g[f"fx_{tag}_psi"]) and np.array_equal(inc, g[f"fx_{tag}_inc"]) and np.array_equal(drop, g[f"fx_{tag}_drop"])
+        else:
+            assert np.abs(psi - g[f"fx_{tag}_psi"]).max() <= 1e-14 * np.abs(psi).max()
+        assert np.array_equal(resid, g[f"fx_{tag}_resid"])
