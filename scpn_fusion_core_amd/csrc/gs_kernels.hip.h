@@ -500,14 +500,27 @@ template <int S, bool PROLONG, bool SRCGEN, bool DEFECT, bool BLEND, int LZT = T
           int WPEU = (PROLONG ? TILE_WPE_P : TILE_WPE)>
 __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
                                                      const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, SrcGen sg,
-                                                     DefectDst dd, BlendArgs ba) {
+                                                     DefectDst dd, BlendArgs ba, int xcd_remap) {
     constexpr int LZ = LZT, H = 2 * S + ((DEFECT || BLEND) ? 2 : 0), NW = NWT, NROWS = (LZ + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* A0 = lds;            // colour 0: (iz + ir) even
     double* A1 = lds + LZ * 64;  // colour 1
-    const int b = blockIdx.z;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs in linear-id order, so consecutive ids would put
+    // neighbouring tiles (which share halo rows / columns) on different L2s.  xcd_remap gives XCD k a contiguous run of
+    // tiles (whole members), so a tile's halo is usually still in that XCD's L2 from the neighbour that loaded it.
+    int bx_, by_, b;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+        const unsigned total = gx * gy * gz;
+        unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        if (xcd_remap && (total & 7u) == 0u) lin = (lin & 7u) * (total >> 3) + (lin >> 3);
+        bx_ = (int)(lin % gx);
+        const unsigned t = lin / gx;
+        by_ = (int)(t % gy);
+        b = (int)(t / gy);
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int z0 = blockIdx.y * (LZ - 2 * H) - H, r0 = blockIdx.x * (128 - 2 * H) - H;  // both even
+    const int z0 = by_ * (LZ - 2 * H) - H, r0 = bx_ * (128 - 2 * H) - H;  // both even
     const int nz = L.nz, nr = L.nr, ld = L.ld;
     const double* in = inF.at(b);
     double* out = outF.at(b);
@@ -545,7 +558,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         const Member& m = sg.st[b];
         g_pa = m.psi_axis; g_den = m.denom; g_iden = m.inv_denom;
         g_sc = fabs(ic) > 1e-9 ? m.i_target / ic : 0.0;
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sg.st[b].i_current = ic; sg.st[b].jscale = g_sc; }
+        if (bx_ == 0 && by_ == 0 && threadIdx.x == 0) { sg.st[b].i_current = ic; sg.st[b].jscale = g_sc; }
     }
     double ae0 = 0.0, ae1 = 0.0, aw0 = 0.0, aw1 = 0.0;
     if (c0 >= 1 && c0 <= nr - 2) { ae0 = L.a_e[c0]; aw0 = L.a_w[c0]; }
@@ -894,7 +907,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
                 bd |= r_bad[i];
                 if (i) { vmx = vi_max(vmx, r_mx[i]); vmn = vi_min(vmn, r_mn[i]); }
             }
-            const long o = (long)b * ba.nblk + (long)blockIdx.y * gridDim.x + blockIdx.x;
+            const long o = (long)b * ba.nblk + (long)by_ * gridDim.x + bx_;
             ba.psum[o] = a;
             ba.pbad[o] = bd;
             ba.rmax[o] = m1;
@@ -1495,12 +1508,22 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
     __shared__ VI shv[4];
     __shared__ double shd[4];
     __shared__ int shbad;
-    const int b = blockIdx.z;
+    // XCD-aware tile order (see k_smooth_tile): XCD k gets a contiguous run of tiles so halo rows are re-read from its own L2
+    int bx_, by_, b;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        if ((total & 7u) == 0u) lin = (lin & 7u) * (total >> 3) + (lin >> 3);
+        bx_ = (int)(lin % gx);
+        const unsigned t_ = lin / gx;
+        by_ = (int)(t_ % gy);
+        b = (int)(t_ / gy);
+    }
     if (!st[b].active) return;
     const int tid = threadIdx.x;
     if (tid == 0) shbad = 0;
     const int nz = L.nz, nr = L.nr, ld = L.ld;
-    const int z0 = blockIdx.y * BT_Z - 1, r0 = blockIdx.x * BT_R - 1;
+    const int z0 = by_ * BT_Z - 1, r0 = bx_ * BT_R - 1;
     const double* cur = curF.at(b);
     const double* nw = newF.at(b);
     const double* bc = bcF.at(b);
@@ -1577,7 +1600,7 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
     const VI rmx = block_vi<true, 256>(mx, shv);
     const VI rmn = block_vi<false, 256>(mn, shv);
     if (tid == 0) {
-        const long o = (long)b * nblk + (long)blockIdx.y * gridDim.x + blockIdx.x;
+        const long o = (long)b * nblk + (long)by_ * gridDim.x + bx_;
         psum[o] = bsum;
         pbad[o] = shbad;
         rmax[o] = bmax;

@@ -364,8 +364,9 @@ static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, doubl
     }
     BlendArgs ba = bl ? *bl : BlendArgs{};
     if (BLEND && (int)(g.x * g.y) != ba.nblk) throw std::runtime_error("blend partial layout mismatch");
+    static const int xcd_env = [] { const char* e = std::getenv("SCPN_HIP_XCD"); return e ? std::atoi(e) : 1; }();
     hipLaunchKernelGGL(kern, g, dim3(64 * NWT), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c, ld_c,
-                       sg ? *sg : SrcGen{}, dd, ba);
+                       sg ? *sg : SrcGen{}, dd, ba, xcd_env);
 }
 // the production roles (plain / +prolongation / +defect) and the blend-fused post-smoother exist in every geometry; source
 // generation only in the default one
