@@ -376,12 +376,21 @@ static void launch_tile_geo(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, d
     switch (tile_variant_for(L)) {
         case 1: launch_tile<S, PROLONG, false, DEFECT, BLEND, 40, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
         case 2: launch_tile<S, PROLONG, false, DEFECT, BLEND, 46, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+#ifdef TILE_EXPERIMENTS
+        case 3: launch_tile<S, PROLONG, false, DEFECT, BLEND, 48, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+        case 4: launch_tile<S, PROLONG, false, DEFECT, BLEND, 56, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+        case 5: launch_tile<S, PROLONG, false, DEFECT, BLEND, 64, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+        case 6: launch_tile<S, PROLONG, false, DEFECT, BLEND, 32, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+        case 7: launch_tile<S, PROLONG, false, DEFECT, BLEND, 56, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+        case 8: launch_tile<S, PROLONG, false, DEFECT, BLEND, 64, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+#endif
         default: launch_tile<S, PROLONG, false, DEFECT, BLEND>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
     }
 }
 static int tile_rows_for(const Lvl& L) {
     const int v = tile_variant_for(L);
-    return v == 1 ? 40 : (v == 2 ? 46 : TILE_LZ);
+    switch (v) { case 1: return 40; case 2: return 46; case 3: return 48; case 4: return 56; case 5: return 64; case 6: return 32;
+                 case 7: return 56; case 8: return 64; default: return TILE_LZ; }
 }
 template <int S>
 static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,

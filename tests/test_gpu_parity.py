@@ -413,6 +413,29 @@ def test_free_boundary_golden(hip, golden, name):
     assert res["final_diff"] < 1e-4
 
 
+@pytest.mark.parametrize("name,n", [("d3d33", 129), ("iter33", 129), ("d3d33", 257), ("d3d33", 513)])
+def test_free_boundary_larger_grids_vs_oracle(hip, golden, orc, name, n):
+    """BASELINE config 3 geometry (DIII-D, validation/diiid_config.json, taken from the golden config) and the ITER-like case on
+    finer grids: device free-boundary loop vs the oracle on the same config -- identical outer / Picard iteration counts,
+    psi within 1e-10 of max|psi|."""
+    import copy
+
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    cfg = copy.deepcopy(configs_from(golden("free_boundary.npz"))[name])
+    cfg["grid_resolution"] = [n, n]
+    if n == 257:
+        cfg["solver"]["convergence_threshold"] = 1e-6  # (513: the full BASELINE config 3 setting, tol 1e-8, ~5 s on the CPU oracle)
+    co = cfg["coils"]
+    ref = orc.free_boundary_solve(cfg, [c["r"] for c in co], [c["z"] for c in co], [c["current"] for c in co], [1.0] * len(co))
+    with EnsembleSolver(cfg, batch=2) as es:
+        res = es.solve_free_boundary(max_outer_iter=20, tol=1e-4)
+        psi = es.get_psi()
+    for b in range(2):
+        assert res[b]["outer_iterations"] == ref["outer_iterations"] and res[b]["picard_iterations"] == ref["picard_iterations"]
+        assert np.abs(psi[b] - ref["psi"]).max() <= 1e-10 * np.abs(ref["psi"]).max()
+
+
 def test_polyglot_lane_golden(hip, golden):
     from scpn_fusion_core_amd.polyglot import gs_solve_hip
 
