@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -341,13 +342,12 @@ template <int S, bool PROLONG, bool SRCGEN, bool DEFECT, bool BLEND, int LZT = T
           int WPEU = (PROLONG ? TILE_WPE_P : TILE_WPE)>
 static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
                         const SrcGen* sg, const DefectOut* dfo, const BlendArgs* bl = nullptr) {
-    static bool attr_done = false;
+    static std::once_flag attr_once;  // (two stream-group threads may reach a first launch at the same time)
     const size_t lds = (size_t)LZT * 128 * sizeof(double) + (BLEND ? 2048 : 0);  // + reduction scratch of the blend stage
     auto kern = &k_smooth_tile<S, PROLONG, SRCGEN, DEFECT, BLEND, LZT, NWT, WPEU>;
-    if (!attr_done) {
+    std::call_once(attr_once, [&] {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    });
     constexpr int H = 2 * S + ((DEFECT || BLEND) ? 2 : 0);
     static_assert(LZT - 2 * H >= 2, "tile too short for its halo");
     dim3 g(cdiv(L.nr, 128 - 2 * H), cdiv(L.nz, LZT - 2 * H), h->B);
@@ -542,11 +542,10 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
     }
     int top;  // coarsest level solved so far
     if (lc <= k) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [] {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vcycle_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_done = true;
-        }
+        });
         ProfScope ps(h, "vcycle_coarse", 1);
         hipLaunchKernelGGL(k_vcycle_coarse, dim3(B), dim3(1024), H.cv_lds, h->stream, cur[lc], rhs_of(lc), H.cv, omega, 1.0 - omega, pre, post, active);
         top = lc;
