@@ -1167,6 +1167,80 @@ __global__ void k_jacobi(Fld outF, Fld psiF, Fld srcF, Lvl L, const int* active)
     }
     outF.at(b)[c] = v;
 }
+// S Jacobi steps per launch (temporal blocking of the 50-step seed relaxation, core/fusion_kernel_iterative_solver.py:408-410):
+// a (JT_Z+2S) x (JT_R+2S) tile of psi and src is staged in LDS, every step updates the whole tile out of place (the stale rim
+// moves inward one cell per step and never reaches the JT_Z x JT_R core), the Dirichlet ring keeps its (sanitised) value.
+// Same arithmetic as k_jacobi (x / a_c through divc: bit-identical for finite x).  grid (ceil(nr/JT_R), ceil(nz/JT_Z), B)
+constexpr int JT_Z = 32, JT_R = 64;
+template <int S>
+__global__ void __launch_bounds__(256) k_jacobi_tile(Fld outF, Fld psiF, Fld srcF, Lvl L, const int* active) {
+    constexpr int WZ = JT_Z + 2 * S, WR = JT_R + 2 * S, LDW = WR + 1, NPT = (WZ * WR + 255) / 256;
+    __shared__ double bufA[WZ * LDW], bufB[WZ * LDW];
+    const int b = blockIdx.z;
+    if (active && !active[b]) return;
+    const double* psi = psiF.at(b);
+    const double* src = srcF.at(b);
+    const int nz = L.nz, nr = L.nr, ld = L.ld;
+    const int z0 = blockIdx.y * JT_Z - S, r0 = blockIdx.x * JT_R - S;
+    // kind: 0 outside the domain / tile rim (never updated), 1 Dirichlet ring, 2 interior
+    int lidx[NPT];
+    double ae[NPT], aw[NPT], svr[NPT];  // coefficients and source of the thread's points stay in registers
+    unsigned kind = 0;  // 2 bits per point
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        lidx[j] = -1;
+        ae[j] = aw[j] = svr[j] = 0.0;
+        if (i < WZ * WR) {
+            const int lz = i / WR, lr = i - lz * WR;
+            const int gz = z0 + lz, gr = r0 + lr;
+            const int li = lz * LDW + lr;
+            lidx[j] = li;
+            double v = 0.0, sv = 0.0;
+            unsigned kd = 0;
+            if (gz >= 0 && gz < nz && gr >= 0 && gr < nr) {
+                const long c = (long)gz * ld + gr;
+                v = sanitize1(psi[c]);
+                sv = sanitize1(src[c]);
+                const bool ring = gz == 0 || gz == nz - 1 || gr == 0 || gr == nr - 1;
+                const bool rim = lz == 0 || lz == WZ - 1 || lr == 0 || lr == WR - 1;
+                kd = ring ? 1u : (rim ? 0u : 2u);
+                if (!ring) { ae[j] = L.a_e[gr]; aw[j] = L.a_w[gr]; }
+            }
+            kind |= kd << (2 * j);
+            bufA[li] = v;
+            bufB[li] = v;
+            svr[j] = sv;
+        }
+    }
+    __syncthreads();
+    double* cur = bufA;
+    double* nxt = bufB;
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            if (((kind >> (2 * j)) & 3u) == 2u) {
+                const int li = lidx[j];
+                double v = divc(ae[j] * cur[li + 1] + aw[j] * cur[li - 1] + L.a_ns * cur[li - LDW] + L.a_ns * cur[li + LDW] - svr[j],
+                                L.a_c, L.inv_a_c);
+                nxt[li] = fmin(fmax(v, -CAP), CAP);
+            }
+        }
+        __syncthreads();
+        double* t = cur; cur = nxt; nxt = t;
+    }
+    double* out = outF.at(b);
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < WZ * WR) {
+            const int lz = i / WR, lr = i - lz * WR;
+            const int gz = z0 + lz, gr = r0 + lr;
+            if (lz >= S && lz < S + JT_Z && lr >= S && lr < S + JT_R && gz < nz && gr < nr) out[(long)gz * ld + gr] = cur[lidx[j]];
+        }
+    }
+}
 // damped Jacobi of the polyglot lane, core/jax_gs_solver.py:58-86 (a_NS*(S+N) association)
 __global__ void k_jacobi_damped(Fld outF, Fld psiF, Fld srcF, Lvl L, double omega_j, double om1) {
     int b = blockIdx.z;
