@@ -42,6 +42,14 @@ __device__ __forceinline__ double divc(double x, double d, double r) {
     return __builtin_fma(e, r, q);
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin in linear-id order (id i runs on XCD i % 8).  xcd_contiguous maps the
+// hardware id to a logical id such that XCD k works through one contiguous run of logical ids (a bijection for any total):
+// XCD k owns ceil((total - k) / 8) ids starting at k*(total/8) + min(k, total%8).
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned lin, unsigned total) {
+    const unsigned k = lin & 7u, q = total >> 3, r = total & 7u;
+    return k * q + (k < r ? k : r) + (lin >> 3);
+}
+
 // A batched field whose member b may live in one of several ping-pong slots.
 struct Fld {
     double* base;
@@ -513,7 +521,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
         const unsigned total = gx * gy * gz;
         unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        if (xcd_remap && (total & 7u) == 0u) lin = (lin & 7u) * (total >> 3) + (lin >> 3);
+        if (xcd_remap) lin = xcd_contiguous(lin, total);
         bx_ = (int)(lin % gx);
         const unsigned t = lin / gx;
         by_ = (int)(t % gy);
@@ -1587,7 +1595,7 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
     {
         const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
         unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        if ((total & 7u) == 0u) lin = (lin & 7u) * (total >> 3) + (lin >> 3);
+        lin = xcd_contiguous(lin, total);
         bx_ = (int)(lin % gx);
         const unsigned t_ = lin / gx;
         by_ = (int)(t_ % gy);
