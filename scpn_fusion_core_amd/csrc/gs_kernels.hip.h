@@ -1184,12 +1184,19 @@ template <int S>
 __global__ void __launch_bounds__(256) k_jacobi_tile(Fld outF, Fld psiF, Fld srcF, Lvl L, const int* active) {
     constexpr int WZ = JT_Z + 2 * S, WR = JT_R + 2 * S, LDW = WR + 1, NPT = (WZ * WR + 255) / 256;
     __shared__ double bufA[WZ * LDW], bufB[WZ * LDW];
-    const int b = blockIdx.z;
+    int bx_, by_, b;  // XCD-contiguous tile order (halo cells come from the XCD's own L2)
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        const unsigned lin = xcd_contiguous(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+        bx_ = (int)(lin % gx);
+        by_ = (int)((lin / gx) % gy);
+        b = (int)(lin / (gx * gy));
+    }
     if (active && !active[b]) return;
     const double* psi = psiF.at(b);
     const double* src = srcF.at(b);
     const int nz = L.nz, nr = L.nr, ld = L.ld;
-    const int z0 = blockIdx.y * JT_Z - S, r0 = blockIdx.x * JT_R - S;
+    const int z0 = by_ * JT_Z - S, r0 = bx_ * JT_R - S;
     // kind: 0 outside the domain / tile rim (never updated), 1 Dirichlet ring, 2 interior
     int lidx[NPT];
     double ae[NPT], aw[NPT], svr[NPT];  // coefficients and source of the thread's points stay in registers

@@ -466,11 +466,18 @@ __global__ void __launch_bounds__(256) k_gm_matvec(double* out, const double* vi
                                                    const double* rhs, long stride, Lvl L, const GmState* gm, int precond, int resid_mode,
                                                    double* part) {
     __shared__ double sh[4];
-    const int b = blockIdx.z;
+    int bx_, by_, b;  // XCD-contiguous block order: the rows above / below a 64x4 block come from the same XCD's L2
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        const unsigned lin = xcd_contiguous(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+        bx_ = (int)(lin % gx);
+        by_ = (int)((lin / gx) % gy);
+        b = (int)(lin / (gx * gy));
+    }
     if (!gm[b].solve_on) return;
     if (!resid_mode && !gm[b].inner_on) return;
     const long off = (long)b * stride;
-    const int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    const int ir = bx_ * 64 + threadIdx.x, iz = by_ * 4 + threadIdx.y;
     double v = 0.0;
     if (iz > 0 && iz < L.nz - 1 && ir > 0 && ir < L.nr - 1) {
         const long c = (long)iz * L.ld + ir;
@@ -482,7 +489,7 @@ __global__ void __launch_bounds__(256) k_gm_matvec(double* out, const double* vi
     }
     const int nblk = gridDim.x * gridDim.y;
     double bs = block_sum_flat(v * v, sh);
-    if (threadIdx.x == 0 && threadIdx.y == 0) part[(long)b * nblk + blockIdx.y * gridDim.x + blockIdx.x] = bs;
+    if (threadIdx.x == 0 && threadIdx.y == 0) part[(long)b * nblk + by_ * gridDim.x + bx_] = bs;
 }
 // one modified Gram-Schmidt step of column `col` (scipy gmres: "for k in range(col+1): tmp = dot(v[k], w); w -= tmp*v[k]"):
 //   every block first finishes the PREVIOUS launch's reduction from `part_in` (k == 0: h0 = ||w||, else h[col][k-1] = <v[k-1], w>),
