@@ -1,0 +1,45 @@
+"""The bench.py output contract, checked on the committed line of the last measured run (profiles/*_bench.json): keys and
+types the driver parses, the roofline / cpu_baseline objects, and internal consistency (value = members / time,
+frac = achieved / peak).  No GPU needed; bench.py itself runs only on the GPU box."""
+import json
+
+from tests.conftest import ROOT
+
+
+def _latest():
+    files = sorted((ROOT / "profiles").glob("r*_bench.json"))
+    assert files, "no committed bench line under profiles/"
+    return json.loads(files[-1].read_text())
+
+
+def test_bench_line_contract():
+    d = _latest()
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(d[key], typ), key
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    members = d["config"]["global_members"]
+    assert abs(d["value"] - members / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+    assert d["config"]["converged_members_rank0"] == d["config"]["members_per_gpu"]
+
+
+def test_roofline_and_cpu_baseline_objects():
+    d = _latest()
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 8000.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert r["kernel"].startswith("smooth_tile") and r["avg_launch_us"] > 0 and r["launches"] > 0
+    # algorithmic bytes per launch = per-point figure x points x members, averaged over the levels the kernel ran on
+    assert r["alg_bytes_per_launch"] > r["fused_compulsory_bytes_per_point"] * 513 * 513 * r["members_per_launch"] / 3
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_pmc_traffic_file_matches_the_families_bench_reports():
+    pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+    assert pmc["grid"] == 513
+    fam = _latest()["roofline"]["families_ms"]
+    for name in pmc["hbm_bytes_per_member_launch"]:
+        assert name in fam, name
