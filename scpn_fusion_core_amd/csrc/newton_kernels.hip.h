@@ -616,6 +616,368 @@ __global__ void __launch_bounds__(256) k_gm_update_x(double* x, const double* V,
         }
     }
 }
+// ---- small grids: one whole restart cycle per launch -----------------------------------------------------------------------
+// For grids up to a few 10^4 points the multi-launch pipeline above is launch-bound (~27 launches of ~7 us per Krylov
+// column).  Here ONE 1024-thread workgroup per member runs a complete restart cycle -- v0, up to `restart` columns of
+// operator + modified Gram-Schmidt + rotation, the triangular solve, x += V y, the true residual and the restart / exit
+// logic of scipy's gmres -- with workgroup barriers instead of kernel boundaries.  Vectors stay in global memory (L2).
+template <int NT>
+__device__ __forceinline__ double block_sum_bcast(double v, double* sh) {  // sum over the NT threads, returned to all
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) r += sh[i];
+    return r;
+}
+constexpr int GM_SMALL_PTS = 5;  // register variant: up to 5 points per thread (65^2); larger small grids use k_gm_cycle_lds
+template <int MP>
+__global__ void __launch_bounds__(1024) k_gm_cycle_small(double* Vb, double* xb, double* rb, const double* rhsb, const double* dtermb,
+                                                         const double* ivdb, long stride, int B, Lvl L, GmState* gm, NtMember* nt,
+                                                         int precond, int maxiter, int* n_solve) {
+    constexpr int NT = 1024;
+    __shared__ double sh[NT / 64];
+    __shared__ int s_done;
+    const int b = blockIdx.x;
+    if (!gm[b].solve_on) return;
+    GmState& g = gm[b];
+    const long off = (long)b * stride;
+    double* x = xb + off;
+    double* r = rb + off;
+    const double* rhs = rhsb + off;
+    const double* dterm = dtermb + off;
+    const double* ivd = ivdb + off;
+    const int nz = L.nz, nr = L.nr, ld = L.ld, ni = nr - 2;
+    const long nint = (long)(nz - 2) * ni;
+    const double eps = 2.220446049250313e-16;
+    auto vec = [&](int j) { return Vb + ((long)j * B + b) * stride; };
+    const int tid = threadIdx.x;
+    // this thread's grid points (fixed for the whole cycle); w lives in registers, one entry per point
+    int cix[MP];
+    double wr[MP];
+#pragma unroll
+    for (int j = 0; j < MP; ++j) {
+        const long q = tid + (long)j * NT;
+        cix[j] = -1;
+        wr[j] = 0.0;
+        if (q < nint) {
+            const int iz = 1 + (int)(q / ni), ir = 1 + (int)(q - (long)(iz - 1) * ni);
+            cix[j] = iz * ld + ir;
+        }
+    }
+    // ---- v0 = M^-1 r / ||M^-1 r||
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < MP; ++j)
+        if (cix[j] >= 0) {
+            double v = r[cix[j]];
+            if (precond) v = ivd[cix[j]] * v;
+            wr[j] = v;
+            s += v * v;
+        }
+    const double tmp = sqrt(block_sum_bcast<NT>(s, sh));
+    {
+        const double f = 1.0 / tmp;
+        double* v0 = vec(0);
+#pragma unroll
+        for (int j = 0; j < MP; ++j)
+            if (cix[j] >= 0) v0[cix[j]] = wr[j] * f;
+    }
+    if (tid == 0) {
+        g.tmp = tmp;
+        for (int i = 0; i <= GM_R; ++i) g.S[i] = 0.0;
+        g.S[0] = tmp;
+        g.breakdown = 0;
+        s_done = 0;
+    }
+    __syncthreads();
+    int col = 0;
+    for (col = 0; col < g.restart; ++col) {
+        const double* vc = vec(col);
+        // operator + preconditioner, h0 = ||w||
+        s = 0.0;
+#pragma unroll
+        for (int j = 0; j < MP; ++j)
+            if (cix[j] >= 0) {
+                const int iz = cix[j] / ld, ir = cix[j] - iz * ld;
+                double av = lop_at(vc, L, iz, ir) - dterm[cix[j]] * vc[cix[j]];
+                if (precond) av = ivd[cix[j]] * av;
+                wr[j] = av;
+                s += av * av;
+            }
+        const double h0 = sqrt(block_sum_bcast<NT>(s, sh));
+        // modified Gram-Schmidt: v_k is read once per step (dot, then the update from the same registers)
+        for (int k = 0; k <= col; ++k) {
+            const double* vk = vec(k);
+            double vr[MP];
+            s = 0.0;
+#pragma unroll
+            for (int j = 0; j < MP; ++j) {
+                vr[j] = cix[j] >= 0 ? vk[cix[j]] : 0.0;
+                s += vr[j] * wr[j];
+            }
+            const double t = block_sum_bcast<NT>(s, sh);
+            if (tid == 0) g.h[col * (GM_R + 1) + k] = t;
+#pragma unroll
+            for (int j = 0; j < MP; ++j) wr[j] -= t * vr[j];
+        }
+        s = 0.0;
+#pragma unroll
+        for (int j = 0; j < MP; ++j) s += wr[j] * wr[j];
+        const double h1 = sqrt(block_sum_bcast<NT>(s, sh));
+        const bool breakdown = h1 <= eps * h0;
+        if (col + 1 < g.restart) {  // v[col+1] = w (scaled unless breakdown); the last column's successor is never used
+            const double f = 1.0 / h1;
+            double* vn = vec(col + 1);
+#pragma unroll
+            for (int j = 0; j < MP; ++j)
+                if (cix[j] >= 0) vn[cix[j]] = breakdown ? wr[j] : wr[j] * f;
+        }
+        if (tid == 0) {
+            double* hc = g.h + col * (GM_R + 1);
+            hc[col + 1] = breakdown ? 0.0 : h1;
+            g.breakdown = breakdown ? 1 : 0;
+            for (int j = 0; j < col; ++j) {
+                const double c = g.giv[2 * j], s_ = g.giv[2 * j + 1];
+                const double n0 = hc[j], n1 = hc[j + 1];
+                hc[j] = c * n0 + s_ * n1;
+                hc[j + 1] = -s_ * n0 + c * n1;
+            }
+            double c, s_, mag;
+            dlartg(hc[col], hc[col + 1], c, s_, mag);
+            g.giv[2 * col] = c;
+            g.giv[2 * col + 1] = s_;
+            hc[col] = mag;
+            hc[col + 1] = 0.0;
+            const double t2 = -s_ * g.S[col];
+            g.S[col] = c * g.S[col];
+            g.S[col + 1] = t2;
+            g.presid = fabs(t2);
+            g.inner_total += 1;
+            g.col_final = col;
+            s_done = (g.presid <= g.ptol || breakdown) ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_done) break;
+    }
+    if (col == g.restart) col = g.restart - 1;
+    // ---- y = trsv(h^T, S) with the pseudo-solve of singular cases, x += V y
+    if (tid == 0) {
+        if (g.h[col * (GM_R + 1) + col] == 0.0) g.S[col] = 0.0;
+        for (int j = 0; j <= col; ++j) g.y[j] = g.S[j];
+        for (int j = col; j > 0; --j)
+            if (g.y[j] != 0.0) {
+                g.y[j] /= g.h[j * (GM_R + 1) + j];
+                const double t = g.y[j];
+                for (int i = 0; i < j; ++i) g.y[i] -= t * g.h[j * (GM_R + 1) + i];
+            }
+        if (g.y[0] != 0.0) g.y[0] /= g.h[0];
+    }
+    __syncthreads();
+    {
+        double acc[MP];
+#pragma unroll
+        for (int j = 0; j < MP; ++j) acc[j] = 0.0;
+        for (int k = 0; k <= col; ++k) {
+            const double yk = g.y[k];
+            const double* vk = vec(k);
+#pragma unroll
+            for (int j = 0; j < MP; ++j)
+                if (cix[j] >= 0) acc[j] += yk * vk[cix[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < MP; ++j)
+            if (cix[j] >= 0) x[cix[j]] += acc[j];
+    }
+    __syncthreads();
+    // ---- true residual r = b - A x, restart / exit logic
+    s = 0.0;
+#pragma unroll
+    for (int j = 0; j < MP; ++j)
+        if (cix[j] >= 0) {
+            const int iz = cix[j] / ld, ir = cix[j] - iz * ld;
+            const double v = rhs[cix[j]] - (lop_at(x, L, iz, ir) - dterm[cix[j]] * x[cix[j]]);
+            r[cix[j]] = v;
+            s += v * v;
+        }
+    const double rnorm = sqrt(block_sum_bcast<NT>(s, sh));
+    if (tid == 0) {
+        g.rnorm = rnorm;
+        g.cycles += 1;
+        bool stop = false;
+        if (g.rnorm <= g.atol) stop = true;
+        else if (g.breakdown) stop = true;
+        else if (g.presid <= g.ptol) g.ptol_max_factor = fmax(eps, 0.25 * g.ptol_max_factor);
+        else g.ptol_max_factor = fmin(1.0, 1.5 * g.ptol_max_factor);
+        if (!stop) g.ptol = g.presid * fmin(g.ptol_max_factor, g.atol / g.rnorm);
+        if (stop || g.cycles >= maxiter) {
+            g.solve_on = 0;
+            g.info = (g.rnorm <= g.atol) ? 0 : maxiter;
+            NtMember& m = nt[b];
+            m.gm_last_info = g.info;
+            if (g.info > 0) m.gm_nonconv += 1;
+            m.gm_inner += g.inner_total;
+            atomicSub(n_solve, 1);
+        }
+    }
+}
+
+// same cycle for grids up to 129^2: the work vector w lives in LDS (one 8-byte slot per interior point, 127 KB at 129^2),
+// the loops over the thread's points are rolled (no register arrays)
+__global__ void __launch_bounds__(1024) k_gm_cycle_lds(double* Vb, double* xb, double* rb, const double* rhsb, const double* dtermb,
+                                                       const double* ivdb, long stride, int B, Lvl L, GmState* gm, NtMember* nt, int precond,
+                                                       int maxiter, int* n_solve) {
+    constexpr int NT = 1024;
+    extern __shared__ __attribute__((aligned(16))) double wl[];  // w, indexed by interior point number q
+    __shared__ double sh[NT / 64];
+    __shared__ int s_done;
+    const int b = blockIdx.x;
+    if (!gm[b].solve_on) return;
+    GmState& g = gm[b];
+    const long off = (long)b * stride;
+    double* x = xb + off;
+    double* r = rb + off;
+    const double* rhs = rhsb + off;
+    const double* dterm = dtermb + off;
+    const double* ivd = ivdb + off;
+    const int nz = L.nz, nr = L.nr, ld = L.ld, ni = nr - 2;
+    const int nint = (nz - 2) * ni;
+    const double eps = 2.220446049250313e-16;
+    auto vec = [&](int j) { return Vb + ((long)j * B + b) * stride; };
+    const int tid = threadIdx.x;
+#define GM_FOR_OWN for (int q = tid; q < nint; q += NT)
+#define GM_CELL const int iz = 1 + q / ni, ir = 1 + (q - (iz - 1) * ni); const long c = (long)iz * ld + ir
+    double s = 0.0;
+    GM_FOR_OWN {
+        GM_CELL;
+        double v = r[c];
+        if (precond) v = ivd[c] * v;
+        wl[q] = v;
+        s += v * v;
+    }
+    const double tmp = sqrt(block_sum_bcast<NT>(s, sh));
+    {
+        const double f = 1.0 / tmp;
+        double* v0 = vec(0);
+        GM_FOR_OWN { GM_CELL; v0[c] = wl[q] * f; }
+    }
+    if (tid == 0) {
+        g.tmp = tmp;
+        for (int i = 0; i <= GM_R; ++i) g.S[i] = 0.0;
+        g.S[0] = tmp;
+        g.breakdown = 0;
+        s_done = 0;
+    }
+    __syncthreads();
+    int col = 0;
+    for (col = 0; col < g.restart; ++col) {
+        const double* vc = vec(col);
+        s = 0.0;
+        GM_FOR_OWN {
+            GM_CELL;
+            double av = lop_at(vc, L, iz, ir) - dterm[c] * vc[c];
+            if (precond) av = ivd[c] * av;
+            wl[q] = av;
+            s += av * av;
+        }
+        const double h0 = sqrt(block_sum_bcast<NT>(s, sh));
+        for (int k = 0; k <= col; ++k) {
+            const double* vk = vec(k);
+            s = 0.0;
+            GM_FOR_OWN { GM_CELL; s += vk[c] * wl[q]; }
+            const double t = block_sum_bcast<NT>(s, sh);
+            if (tid == 0) g.h[col * (GM_R + 1) + k] = t;
+            GM_FOR_OWN { GM_CELL; wl[q] -= t * vk[c]; }
+        }
+        s = 0.0;
+        GM_FOR_OWN { const double v = wl[q]; s += v * v; }
+        const double h1 = sqrt(block_sum_bcast<NT>(s, sh));
+        const bool breakdown = h1 <= eps * h0;
+        if (col + 1 < g.restart) {
+            const double f = 1.0 / h1;
+            double* vn = vec(col + 1);
+            GM_FOR_OWN { GM_CELL; vn[c] = breakdown ? wl[q] : wl[q] * f; }
+        }
+        if (tid == 0) {
+            double* hc = g.h + col * (GM_R + 1);
+            hc[col + 1] = breakdown ? 0.0 : h1;
+            g.breakdown = breakdown ? 1 : 0;
+            for (int j = 0; j < col; ++j) {
+                const double c_ = g.giv[2 * j], s_ = g.giv[2 * j + 1];
+                const double n0 = hc[j], n1 = hc[j + 1];
+                hc[j] = c_ * n0 + s_ * n1;
+                hc[j + 1] = -s_ * n0 + c_ * n1;
+            }
+            double c_, s_, mag;
+            dlartg(hc[col], hc[col + 1], c_, s_, mag);
+            g.giv[2 * col] = c_;
+            g.giv[2 * col + 1] = s_;
+            hc[col] = mag;
+            hc[col + 1] = 0.0;
+            const double t2 = -s_ * g.S[col];
+            g.S[col] = c_ * g.S[col];
+            g.S[col + 1] = t2;
+            g.presid = fabs(t2);
+            g.inner_total += 1;
+            g.col_final = col;
+            s_done = (g.presid <= g.ptol || breakdown) ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_done) break;
+    }
+    if (col == g.restart) col = g.restart - 1;
+    if (tid == 0) {
+        if (g.h[col * (GM_R + 1) + col] == 0.0) g.S[col] = 0.0;
+        for (int j = 0; j <= col; ++j) g.y[j] = g.S[j];
+        for (int j = col; j > 0; --j)
+            if (g.y[j] != 0.0) {
+                g.y[j] /= g.h[j * (GM_R + 1) + j];
+                const double t = g.y[j];
+                for (int i = 0; i < j; ++i) g.y[i] -= t * g.h[j * (GM_R + 1) + i];
+            }
+        if (g.y[0] != 0.0) g.y[0] /= g.h[0];
+    }
+    __syncthreads();
+    GM_FOR_OWN {
+        GM_CELL;
+        double acc = 0.0;
+        for (int k = 0; k <= col; ++k) acc += g.y[k] * vec(k)[c];
+        x[c] += acc;
+    }
+    __syncthreads();
+    s = 0.0;
+    GM_FOR_OWN {
+        GM_CELL;
+        const double v = rhs[c] - (lop_at(x, L, iz, ir) - dterm[c] * x[c]);
+        r[c] = v;
+        s += v * v;
+    }
+#undef GM_FOR_OWN
+#undef GM_CELL
+    const double rnorm = sqrt(block_sum_bcast<NT>(s, sh));
+    if (tid == 0) {
+        g.rnorm = rnorm;
+        g.cycles += 1;
+        bool stop = false;
+        if (g.rnorm <= g.atol) stop = true;
+        else if (g.breakdown) stop = true;
+        else if (g.presid <= g.ptol) g.ptol_max_factor = fmax(eps, 0.25 * g.ptol_max_factor);
+        else g.ptol_max_factor = fmin(1.0, 1.5 * g.ptol_max_factor);
+        if (!stop) g.ptol = g.presid * fmin(g.ptol_max_factor, g.atol / g.rnorm);
+        if (stop || g.cycles >= maxiter) {
+            g.solve_on = 0;
+            g.info = (g.rnorm <= g.atol) ? 0 : maxiter;
+            NtMember& m = nt[b];
+            m.gm_last_info = g.info;
+            if (g.info > 0) m.gm_nonconv += 1;
+            m.gm_inner += g.inner_total;
+            atomicSub(n_solve, 1);
+        }
+    }
+}
+
 // number of members whose solve is still running (start of a cycle: the host polls this; they all enter the inner loop)
 __global__ void k_gm_count(const GmState* gm, int B, int* n_solve, int* n_inner) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {

@@ -1219,6 +1219,36 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
                 tail(1, P0, nbf);
             }
         }
+        // small grids: one launch per restart cycle (k_gm_cycle_small); SCPN_HIP_GMRES_SMALL=<max points> (default 20000, 0 = off)
+        static const long small_max = [] { const char* e = std::getenv("SCPN_HIP_GMRES_SMALL"); return e ? std::atol(e) : 20000L; }();
+        // (one workgroup per member: always for <= 65^2; up to 129^2 when there are enough members to occupy several CUs)
+        const long npts = (long)nz * nr;
+        if (npts <= std::min(small_max, 20000L) && (npts <= 4500 || B >= 4)) {
+            hipLaunchKernelGGL(k_gm_count, dim3(1), dim3(64), 0, st, (const GmState*)h->nt_gm.p, B, d_nsolve, d_ninner);
+            int left = poll(d_nsolve);
+            for (int cyc = 0; cyc < maxit && left > 0; ++cyc) {
+                ProfScope ps(h, "gmres_cycle_small", 1);
+                const long nint = (long)(nz - 2) * (nr - 2);
+                auto launch = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, dim3(B), dim3(1024), 0, st, V, buf(XV), buf(RES), (const double*)buf(RHS), (const double*)buf(DG),
+                                       (const double*)buf(IVD), stride, B, L0, h->nt_gm.p, h->nt_st.p, precond, maxit, d_nsolve);
+                };
+                if (nint <= 1024L * 2) launch(k_gm_cycle_small<2>);
+                else if (nint <= 1024L * GM_SMALL_PTS) launch(k_gm_cycle_small<GM_SMALL_PTS>);
+                else {
+                    static std::once_flag once;
+                    std::call_once(once, [] {
+                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gm_cycle_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    160 * 1024 - 256));
+                    });
+                    hipLaunchKernelGGL(k_gm_cycle_lds, dim3(B), dim3(1024), sizeof(double) * nint, st, V, buf(XV), buf(RES), (const double*)buf(RHS),
+                                       (const double*)buf(DG), (const double*)buf(IVD), stride, B, L0, h->nt_gm.p, h->nt_st.p, precond, maxit,
+                                       d_nsolve);
+                }
+                if ((cyc & 3) == 3 || cyc + 1 == maxit) left = poll(d_nsolve);  // finished members return at once; poll every 4 cycles
+            }
+            return;
+        }
         for (int cyc = 0; cyc < maxit; ++cyc) {
             hipLaunchKernelGGL(k_gm_count, dim3(1), dim3(64), 0, st, (const GmState*)h->nt_gm.p, B, d_nsolve, d_ninner);
             if (poll(d_nsolve) == 0) break;
