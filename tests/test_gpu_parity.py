@@ -436,6 +436,33 @@ def test_free_boundary_larger_grids_vs_oracle(hip, golden, orc, name, n):
         assert np.abs(psi[b] - ref["psi"]).max() <= 1e-10 * np.abs(ref["psi"]).max()
 
 
+@pytest.mark.parametrize("nr,nz,batch", [(97, 161, 3), (200, 141, 5), (130, 67, 2), (65, 257, 7)])
+def test_picard_and_free_boundary_non_square_grids_odd_batches(hip, orc, nr, nz, batch):
+    """Non-square / even-sized grids (tile and coarse-level edge handling, XCD order for grids that are not multiples of 8) and
+    ensemble sizes that split unevenly over the two stream groups: every member must match its own CPU solve."""
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    cfg = iter_like_cfg(33, tol=1e-6, max_iter=300)
+    cfg["grid_resolution"] = [nr, nz]
+    targets = 15.0 * (1.0 + 0.05 * np.linspace(-1, 1, batch))
+    with EnsembleSolver(cfg, batch=batch, current_targets=targets) as es:
+        res = es.solve_equilibrium(check_every=7)
+        psi = es.get_psi()
+        fres = es.solve_free_boundary(max_outer_iter=3, tol=1e-4)
+        fpsi = es.get_psi()
+    assert psi.shape == (batch, nz, nr)
+    co = cfg["coils"]
+    for b in range(batch):
+        c = {**cfg, "physics": dict(cfg["physics"], plasma_current_target=float(targets[b]))}
+        ref = orc.picard_solve(c)
+        assert res[b]["iterations"] == ref["iterations"] and res[b]["converged"] == ref["converged"], b
+        assert np.abs(psi[b] - ref["psi"]).max() <= 1e-10 * np.abs(ref["psi"]).max(), b
+        fref = orc.free_boundary_solve(c, [k["r"] for k in co], [k["z"] for k in co], [k["current"] for k in co], [1.0] * len(co),
+                                       psi0=ref["psi"], max_outer=3, tol=1e-4)
+        assert fres[b]["picard_iterations"] == fref["picard_iterations"], b
+        assert np.abs(fpsi[b] - fref["psi"]).max() <= 1e-10 * np.abs(fref["psi"]).max(), b
+
+
 def test_polyglot_lane_golden(hip, golden):
     from scpn_fusion_core_amd.polyglot import gs_solve_hip
 
