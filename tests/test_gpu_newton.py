@@ -174,3 +174,24 @@ def test_newton_inside_free_boundary_outer_loop(hip, orc, tmp_path):
     assert np.abs(psih - psi).max() <= 5e-2 * np.abs(psi).max()
     with EnsembleSolver(cfg, batch=2) as es, pytest.raises(NotImplementedError):
         es.solve_free_boundary()
+
+
+@pytest.mark.parametrize("n", [6, 8, 16])
+@pytest.mark.parametrize("extra", [{}, {"gmres_preconditioner": "diagonal"}, {"newton_line_search": True}])
+def test_newton_tiny_grids(hip, orc, n, extra):
+    """Grids whose interior is smaller than the GMRES restart length (6x6: 16 unknowns -> restart = 16, SciPy's
+    ``restart = min(restart, n)``) and the reference test sizes 16x16 (tests/test_fusion_kernel_newton_dispatch.py:36), for the
+    plain, diagonally preconditioned and line-search variants, against the oracle."""
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    cfg = iter_like_cfg(n, method="newton", omega=1.6, tol=1e-4, max_iter=12, alpha=0.1)
+    cfg["solver"].update(extra)
+    ref = orc.newton_solve(cfg)
+    with EnsembleSolver(cfg, batch=2) as es:
+        res = es.solve_newton()
+        psi = es.get_psi()
+    for b in range(2):
+        assert res[b]["iterations"] == ref["iterations"] and res[b]["converged"] == ref["converged"]
+        assert len(res[b]["residual_history"]) == len(ref["residual_history"])
+        assert np.all(np.isfinite(psi[b]))
+        np.testing.assert_allclose(res[b]["residual_history"][:7], ref["residual_history"][:7], rtol=1e-6)
