@@ -78,7 +78,7 @@ def main() -> int:
     _lib.require_gpu()
     cfg = make_cfg(args.grid)
     B = args.batch
-    from scpn_fusion_core_amd.distributed import DevicePointer, gather_blocks, shard_range
+    from scpn_fusion_core_amd.distributed import DevicePointer, gather_blocks_async, shard_range
 
     lo, hi = shard_range(B * world, rank, world)
     all_currents, all_targets = member_table(cfg, B * world)
@@ -86,22 +86,34 @@ def main() -> int:
     es = EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, device=local_rank)
     n_pts = args.grid * args.grid
 
+    pending = {"work": None, "out": None}  # the psi gather of the previous step, overlapping the current solve
+
+    def finish_gather():
+        if pending["work"] is not None:
+            import torch
+
+            pending["work"].wait()
+            torch.cuda.current_stream().synchronize()
+            pending["work"] = None
+
     def barrier():
         es.sync()
         if dist is not None:
             import torch
 
+            finish_gather()
             dist.barrier()
             torch.cuda.synchronize()
 
     def step():
         es.fill_psi(0.0)
         res = es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
-        if dist is not None:  # ensemble gather of the psi blocks over RCCL/xGMI (the path's only exchange step)
-            import torch
+        if dist is not None:  # ensemble gather of the psi blocks over RCCL/xGMI (the path's only exchange step): launched
+            import torch      # asynchronously, it runs while the next step solves; every gather ends inside the timed region
 
+            finish_gather()  # the previous gather still reads the packed buffer
             send = torch.as_tensor(DevicePointer(es.pack_psi_device(), (B, args.grid, args.grid)), device=f"cuda:{local_rank}")
-            gather_blocks(send, B * world)
+            pending["work"], pending["out"] = gather_blocks_async(send, B * world, out=pending["out"])
         return res
 
     for _ in range(args.warmup):

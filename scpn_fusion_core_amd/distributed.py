@@ -57,3 +57,28 @@ def gather_blocks(local, total: int, group=None):
     dist.all_gather_into_tensor(out, t.contiguous(), group=group)
     out = out[:total]
     return out.numpy() if was_numpy else out
+
+
+def gather_blocks_async(local, total: int, out=None, group=None):
+    """Non-blocking form of :func:`gather_blocks` for torch tensors: launches the all-gather and returns ``(work, out)``
+    immediately so the collective (RCCL over xGMI) overlaps the next solve.  ``work.wait()`` followed by a synchronisation of
+    the current torch stream must precede any reuse of ``local``'s storage or of ``out`` (pass the previous ``out`` back in
+    to reuse its allocation).  Members are padded per rank exactly as in :func:`gather_blocks`; ``out[:total]`` is the result."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per = -(-total // world)
+    start, stop = shard_range(total, rank, world)
+    t = local
+    if t.shape[0] != stop - start:
+        raise ValueError(f"rank {rank} holds {t.shape[0]} members, expected {stop - start}")
+    if t.shape[0] < per:
+        pad = torch.zeros((per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        t = torch.cat([t, pad], dim=0)
+    shape = (world * per,) + tuple(t.shape[1:])
+    if out is None or tuple(out.shape) != shape or out.dtype != t.dtype or out.device != t.device:
+        out = torch.empty(shape, dtype=t.dtype, device=t.device)
+    work = dist.all_gather_into_tensor(out, t.contiguous(), group=group, async_op=True)
+    return work, out

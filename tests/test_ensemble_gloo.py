@@ -37,14 +37,22 @@ def solve_block(start, stop):
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from scpn_fusion_core_amd.distributed import gather_blocks, shard_range
+    from scpn_fusion_core_amd.distributed import gather_blocks, gather_blocks_async, shard_range
 
     a, b = shard_range(TOTAL, rank, world)
     psi, table = solve_block(a, b)
     all_psi = gather_blocks(psi, TOTAL)
     all_tab = gather_blocks(table, TOTAL)
+    # the overlapped form bench.py uses: launch, do other work, wait; the output buffer is reused across steps
+    work, out = gather_blocks_async(torch.from_numpy(psi), TOTAL)
+    _ = solve_block(a, a)  # "next step" placeholder between launch and wait
+    work.wait()
+    first = out[:TOTAL].numpy().copy()
+    work, out2 = gather_blocks_async(torch.from_numpy(2.0 * psi), TOTAL, out=out)
+    work.wait()
+    assert out2 is out or out2.data_ptr() == out.data_ptr()
     dist.barrier()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), psi=all_psi, table=all_tab)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), psi=all_psi, table=all_tab, psi_async=first, psi_async2=out2[:TOTAL].numpy())
     dist.destroy_process_group()
 
 
@@ -59,3 +67,4 @@ def test_two_rank_sharded_ensemble_matches_serial(tmp_path):
         got = np.load(tmp_path / f"rank{rank}.npz")
         assert got["psi"].shape == (TOTAL, 17, 17)
         assert np.array_equal(got["psi"], psi_ref) and np.array_equal(got["table"], tab_ref)
+        assert np.array_equal(got["psi_async"], psi_ref) and np.array_equal(got["psi_async2"], 2.0 * psi_ref)
