@@ -344,6 +344,95 @@ class EnsembleSolver:
         return out
 
     # -- resident operators (zero-copy smoother benchmark path) ------------------------------------
+    def solve_free_boundary_shape(self, coils_per_member, *, max_outer_iter=20, tol=1e-4, tikhonov_alpha=1e-4) -> list[dict[str, Any]]:
+        """``solve_free_boundary(optimize_shape=True)`` of every member (core/fusion_kernel_free_boundary.py:623-739): the shape
+        scan of an ensemble.  ``coils_per_member`` is one :class:`~scpn_fusion_core_amd.free_boundary.CoilSet` per member
+        (positions / turns / limits / target points may differ; ``currents`` are updated in place like the reference does).
+
+        Per outer iteration the equilibrium solves of all members that still iterate run in ONE device call
+        (per-member Dirichlet maps, frozen members keep their state through ``preserve_initial_state``), the isoflux targets
+        are sampled on the device, the coil responses come from the device Green's-function kernel, and only the tiny bounded
+        least-squares problems (n_points + n_coils rows) are solved on the host, member by member, as in the reference."""
+        from . import free_boundary as fb
+
+        if len(coils_per_member) != self.batch:
+            raise ValueError("one CoilSet per ensemble member is required")
+        if max_outer_iter < 1:
+            raise ValueError("max_outer_iter must be >= 1.")
+        if not np.isfinite(tol) or tol < 0.0:
+            raise ValueError("tol must be finite and >= 0.")
+        for c in coils_per_member:
+            if c.target_flux_points is None:
+                raise ValueError("CoilSet.target_flux_points must be set for shape optimisation.")
+
+        class _Axes:  # what the free-boundary helpers read from a kernel
+            R, Z, NR, NZ, dR, dZ = self.R, self.Z, self.NR, self.NZ, self.dR, self.dZ
+
+        def ext_flux(b):
+            return fb.compute_external_flux(_Axes, coils_per_member[b])
+
+        B = self.batch
+        psi_ext = np.stack([ext_flux(b) for b in range(B)])
+        diff = np.full(B, np.inf)
+        outer_done = np.zeros(B, dtype=int)
+        active = np.ones(B, dtype=bool)
+        shape_info: list[Any] = [None] * B
+        last_res: list[Any] = [None] * B
+        for outer in range(max_outer_iter):
+            psi = self.get_psi()
+            psi[:, 0, :], psi[:, -1, :], psi[:, :, 0], psi[:, :, -1] = psi_ext[:, 0, :], psi_ext[:, -1, :], psi_ext[:, :, 0], psi_ext[:, :, -1]
+            psi_old = psi.copy()
+            saved = psi.copy()
+            self.set_psi(psi)
+            res = self.solve_equilibrium(preserve_initial_state=True, boundary_flux=psi_ext)
+            new = self.get_psi()
+            if not active.all():  # members that already converged keep their final state
+                new[~active] = saved[~active]
+                self.set_psi(new)
+            for b in np.flatnonzero(active):
+                cs = coils_per_member[b]
+                pts = np.asarray(cs.target_flux_points, dtype=np.float64)
+                if cs.target_flux_values is not None:
+                    target = fb.resolve_shape_target_flux(None, cs)
+                else:  # isoflux: mean of the bilinear samples (device sampling of member b)
+                    target = None
+                shape_info[b] = (pts, target)
+            need = [b for b in np.flatnonzero(active) if shape_info[b][1] is None]
+            if need:
+                # one device sampling call per distinct point set; members usually share it
+                cache: dict[bytes, np.ndarray] = {}
+                for b in need:
+                    key = shape_info[b][0].tobytes()
+                    if key not in cache:
+                        cache[key] = self.sample_psi(shape_info[b][0])
+                    samples = cache[key][b]
+                    shape_info[b] = (shape_info[b][0], np.full(samples.shape[0], float(np.mean(samples))))
+            for b in np.flatnonzero(active):
+                cs = coils_per_member[b]
+                pts, target = shape_info[b]
+                response = fb.build_mutual_inductance_matrix(None, cs, pts)
+                new_cur = np.asarray(fb.optimize_coil_currents(None, cs, target, tikhonov_alpha=tikhonov_alpha), dtype=np.float64).reshape(-1)
+                achieved = response.T @ new_cur
+                residual = achieved - target
+                rmse = float(np.sqrt(np.mean(residual**2)))
+                shape_info[b] = {"solver_mode": "free_boundary_solver_shape_current_optimization", "target_point_count": int(target.shape[0]),
+                                 "coil_count": len(cs.positions), "flux_rmse": rmse,
+                                 "flux_relative_rmse": float(rmse / max(float(np.sqrt(np.mean(target**2))), 1.0)),
+                                 "max_abs_flux_residual": float(np.max(np.abs(residual))), "target_flux": target.copy(),
+                                 "achieved_flux": achieved}
+                cs.currents = new_cur
+                psi_ext[b] = ext_flux(b)
+                diff[b] = float(np.max(np.abs(new[b] - psi_old[b])))
+                outer_done[b] = outer + 1
+                last_res[b] = res[b]
+                if diff[b] < tol:
+                    active[b] = False
+            if not active.any():
+                break
+        return [{"outer_iterations": int(outer_done[b]), "final_diff": float(diff[b]),
+                 "coil_currents": np.asarray(coils_per_member[b].currents, dtype=np.float64).copy(), "shape_optimization": shape_info[b],
+                 "converged": bool(last_res[b]["converged"]) if last_res[b] else False} for b in range(B)]
+
     def rb_sor(self, omega: float, n_sweeps: int):
         check(self._L.scpn_gs_rb_sor(self._h, float(omega), int(n_sweeps)))
 

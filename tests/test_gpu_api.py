@@ -114,6 +114,42 @@ def test_shape_optimisation_outer_loop_golden(golden):
     k.close()
 
 
+def test_ensemble_shape_scan_matches_single_kernel_runs(golden):
+    """EnsembleSolver.solve_free_boundary_shape: three members with different starting coil currents / targets; member 0
+    is the golden case (reference run), the others are checked against the single-member FusionKernel path."""
+    import copy
+
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+    from scpn_fusion_core_amd.free_boundary import CoilSet
+    from scpn_fusion_core_amd.fusion_kernel import FusionKernel
+
+    g = golden("shape.npz")
+    cfg = configs_from(g)["shape33"]
+    base = np.array([c["current"] for c in cfg["coils"]])
+    starts = [base, base * 1.1, base * np.array([0.9, 1.05, 1.0, 1.1, 0.95])[: base.size]]
+    pts = [g["points"], g["points"], g["points"] * np.array([1.0, 0.9])]
+
+    def coilset(i):
+        return CoilSet(positions=[(c["r"], c["z"]) for c in cfg["coils"]], currents=starts[i].copy(), turns=[1] * base.size,
+                       current_limits=np.full(base.size, 5.0e7), target_flux_points=pts[i])
+
+    sets = [coilset(i) for i in range(3)]
+    with EnsembleSolver(cfg, batch=3) as es:
+        out = es.solve_free_boundary_shape(sets, max_outer_iter=4, tol=1e-6)
+        psi = es.get_psi()
+    assert out[0]["outer_iterations"] == int(g["stats"][0])
+    np.testing.assert_allclose(out[0]["coil_currents"], g["currents"], rtol=1e-6, atol=1e-9)
+    assert np.abs(psi[0] - g["psi"]).max() <= 1e-8 * np.abs(g["psi"]).max()
+    for i in (1, 2):
+        k = FusionKernel(copy.deepcopy(cfg))
+        ref = k.solve_free_boundary(coilset(i), max_outer_iter=4, tol=1e-6, optimize_shape=True)
+        assert out[i]["outer_iterations"] == ref["outer_iterations"]
+        np.testing.assert_allclose(out[i]["coil_currents"], ref["coil_currents"], rtol=1e-8, atol=1e-9)
+        assert np.abs(psi[i] - k.Psi).max() <= 1e-9 * np.abs(k.Psi).max()
+        assert out[i]["shape_optimization"]["flux_rmse"] == pytest.approx(ref["shape_optimization"]["flux_rmse"], rel=1e-6, abs=1e-14)
+        k.close()
+
+
 def test_fail_on_diverge_and_revert(orc):
     from scpn_fusion_core_amd.fusion_kernel import FusionKernel
 
