@@ -383,6 +383,8 @@ static void launch_tile_geo(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, d
         case 6: launch_tile<S, PROLONG, false, DEFECT, BLEND, 32, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
         case 7: launch_tile<S, PROLONG, false, DEFECT, BLEND, 56, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
         case 8: launch_tile<S, PROLONG, false, DEFECT, BLEND, 64, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+        case 9: launch_tile<S, PROLONG, false, DEFECT, BLEND, 40, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+        case 10: launch_tile<S, PROLONG, false, DEFECT, BLEND, 32, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
 #endif
         default: launch_tile<S, PROLONG, false, DEFECT, BLEND>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
     }
@@ -390,7 +392,7 @@ static void launch_tile_geo(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, d
 static int tile_rows_for(const Lvl& L) {
     const int v = tile_variant_for(L);
     switch (v) { case 1: return 40; case 2: return 46; case 3: return 48; case 4: return 56; case 5: return 64; case 6: return 32;
-                 case 7: return 56; case 8: return 64; default: return TILE_LZ; }
+                 case 7: return 56; case 8: return 64; case 9: return 40; case 10: return 32; default: return TILE_LZ; }
 }
 template <int S>
 static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
