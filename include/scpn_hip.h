@@ -116,6 +116,12 @@ int scpn_green_points(int n_coils, const double *coil_r, const double *coil_z, i
 int scpn_probe_response(int n_coils, const double *coil_r, const double *coil_z, const double *coil_turns,
                         int n_flux, const double *flux_r, const double *flux_z, int n_b, const double *b_r,
                         const double *b_z, const int *b_dir, double *out);
+/* polyglot lane diagnostics, core/jax_gs_solver.py:196-316: gs_delta_star_np (zero ring; out [nz][nr]) and
+ * gs_equation_residual_np (out3 = abs_max, relative_max, relative_l2 of the discrete equation imbalance with the lane's own
+ * source normalisation) */
+int scpn_np_delta_star(const double *psi, int nz, int nr, const double *r_axis, double dr, double dz, double *out);
+int scpn_np_equation_residual(const double *psi, int nz, int nr, const double *r_axis, const double *z_axis,
+                              double ip_target, double mu0, double beta_mix, double *out3);
 /* ---- transport coupling ----
  * scipy.linalg.solve_banded((1, 1), ab, b) of `batch` independent tridiagonal systems, i.e. LAPACK dgtsv (partial pivoting,
  * bit-identical operation order): dl/du [batch][n-1], d/b/x [batch][n]; info[batch] (0, or i>0: U(i,i) == 0) may be NULL */

@@ -856,6 +856,84 @@ int orc_free_boundary_solve(const orc_picard_params *p, double *psi, double *j_p
     return outer;
 }
 
+/* _compute_source_np, core/jax_gs_solver.py:89-123 */
+static void np_lane_source(const double *psi, const double *r_axis, int nz, int nr, double dr, double dz,
+                           double mu0, double ip_target, double beta_mix, double *jraw, double *source) {
+    long n = (long)nz * nr;
+    double psi_axis = -INFINITY;
+    for (int iz = 1; iz < nz - 1; ++iz)
+        for (int ir = 1; ir < nr - 1; ++ir)
+            if (psi[IDX(iz, ir)] > psi_axis) psi_axis = psi[IDX(iz, ir)];
+    double denom = 0.0 - psi_axis;
+    if (fabs(denom) < 1e-9) denom = denom != 0 ? (denom > 0 ? 1e-9 : -1e-9) : 1e-9;
+    for (int iz = 0; iz < nz; ++iz)
+        for (int ir = 0; ir < nr; ++ir) {
+            double R = r_axis[ir];
+            double x = (psi[IDX(iz, ir)] - psi_axis) / denom;
+            x = fmin(fmax(x, 0.0), 1.0);
+            double prof = (x >= 0.0 && x < 1.0) ? 1.0 - x : 0.0;
+            double r_safe = fmax(R, 1e-10);
+            double j_p = R * prof;
+            double j_f = prof / (mu0 * r_safe);
+            jraw[IDX(iz, ir)] = beta_mix * j_p + (1.0 - beta_mix) * j_f;
+        }
+    double i_cur = (orc_np_sum(jraw, n) * dr) * dz;
+    double scale = ip_target / fmax(fabs(i_cur), 1e-9);
+    for (int iz = 0; iz < nz; ++iz)
+        for (int ir = 0; ir < nr; ++ir)
+            source[IDX(iz, ir)] = ((-mu0) * r_axis[ir]) * (jraw[IDX(iz, ir)] * scale);
+}
+
+/* gs_delta_star_np, core/jax_gs_solver.py:196-217: centred operator with this lane's association, zero ring */
+void orc_np_delta_star(const double *psi, int nz, int nr, double r_min, double r_max, double z_min,
+                       double z_max, double *out) {
+    double *r_axis = dalloc(nr);
+    orc_linspace(r_min, r_max, nr, r_axis);
+    double dr = (r_max - r_min) / (nr - 1), dz = (z_max - z_min) / (nz - 1);
+    for (long i = 0; i < (long)nz * nr; ++i) out[i] = 0.0;
+    for (int iz = 1; iz < nz - 1; ++iz)
+        for (int ir = 1; ir < nr - 1; ++ir) {
+            double c = psi[IDX(iz, ir)];
+            double d2r = (psi[IDX(iz, ir + 1)] - 2.0 * c + psi[IDX(iz, ir - 1)]) / (dr * dr);
+            double d1r = (psi[IDX(iz, ir + 1)] - psi[IDX(iz, ir - 1)]) / ((2.0 * dr) * r_axis[ir]);
+            double d2z = (psi[IDX(iz + 1, ir)] - 2.0 * c + psi[IDX(iz - 1, ir)]) / (dz * dz);
+            out[IDX(iz, ir)] = d2r - d1r + d2z;
+        }
+    free(r_axis);
+}
+
+/* gs_equation_residual_np, core/jax_gs_solver.py:251-316; out3 = abs_max, relative_max, relative_l2.
+ * The L2 norms are plain left-to-right sums here (the reference's go through BLAS ddot, whose order is unspecified). */
+void orc_np_equation_residual(const double *psi, int nz, int nr, double r_min, double r_max, double z_min,
+                              double z_max, double ip_target, double mu0, double beta_mix, double *out3) {
+    long n = (long)nz * nr;
+    double *r_axis = dalloc(nr), *z_axis = dalloc(nz), *jraw = dalloc(n), *source = dalloc(n);
+    orc_linspace(r_min, r_max, nr, r_axis);
+    orc_linspace(z_min, z_max, nz, z_axis);
+    double dr = r_axis[1] - r_axis[0], dz = z_axis[1] - z_axis[0];
+    np_lane_source(psi, r_axis, nz, nr, dr, dz, mu0, ip_target, beta_mix, jraw, source);
+    double dr2 = dr * dr, dz2 = dz * dz;
+    double a_ns = 1.0 / dz2, a_c = 2.0 / dr2 + 2.0 / dz2;
+    double rm = 0.0, r2 = 0.0, sm = 0.0, s2 = 0.0;
+    for (int iz = 1; iz < nz - 1; ++iz)
+        for (int ir = 1; ir < nr - 1; ++ir) {
+            double r_safe = fmax(r_axis[ir], 1.0e-10);
+            double t = 1.0 / ((2.0 * r_safe) * dr);
+            double a_e = 1.0 / dr2 - t, a_w = 1.0 / dr2 + t;
+            double sv = source[IDX(iz, ir)];
+            double res = a_e * psi[IDX(iz, ir + 1)] + a_w * psi[IDX(iz, ir - 1)] +
+                         a_ns * (psi[IDX(iz - 1, ir)] + psi[IDX(iz + 1, ir)]) - a_c * psi[IDX(iz, ir)] - sv;
+            if (fabs(res) > rm) rm = fabs(res);
+            if (fabs(sv) > sm) sm = fabs(sv);
+            r2 += res * res;
+            s2 += sv * sv;
+        }
+    out3[0] = rm;
+    out3[1] = rm / (sm + 1.0e-30);
+    out3[2] = sqrt(r2) / (sqrt(s2) + 1.0e-30);
+    free(r_axis); free(z_axis); free(jraw); free(source);
+}
+
 void orc_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int nr, int nz,
                      double ip_target, double mu0, int n_picard, int n_jacobi, double alpha,
                      double omega_j, double beta_mix, double *psi) {
@@ -876,29 +954,7 @@ void orc_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int
     double dr2 = dr * dr, dz2 = dz * dz;
     double a_ns = 1.0 / dz2, a_c = 2.0 / dr2 + 2.0 / dz2;
     for (int it = 0; it < n_picard; ++it) {
-        /* _compute_source_np, core/jax_gs_solver.py:89-123 */
-        double psi_axis = -INFINITY;
-        for (int iz = 1; iz < nz - 1; ++iz)
-            for (int ir = 1; ir < nr - 1; ++ir)
-                if (psi[IDX(iz, ir)] > psi_axis) psi_axis = psi[IDX(iz, ir)];
-        double denom = 0.0 - psi_axis;
-        if (fabs(denom) < 1e-9) denom = denom != 0 ? (denom > 0 ? 1e-9 : -1e-9) : 1e-9;
-        for (int iz = 0; iz < nz; ++iz)
-            for (int ir = 0; ir < nr; ++ir) {
-                double R = r_axis[ir];
-                double x = (psi[IDX(iz, ir)] - psi_axis) / denom;
-                x = fmin(fmax(x, 0.0), 1.0);
-                double prof = (x >= 0.0 && x < 1.0) ? 1.0 - x : 0.0;
-                double r_safe = fmax(R, 1e-10);
-                double j_p = R * prof;
-                double j_f = prof / (mu0 * r_safe);
-                jraw[IDX(iz, ir)] = beta_mix * j_p + (1.0 - beta_mix) * j_f;
-            }
-        double i_cur = (orc_np_sum(jraw, n) * dr) * dz;
-        double scale = ip_target / fmax(fabs(i_cur), 1e-9);
-        for (int iz = 0; iz < nz; ++iz)
-            for (int ir = 0; ir < nr; ++ir)
-                source[IDX(iz, ir)] = ((-mu0) * r_axis[ir]) * (jraw[IDX(iz, ir)] * scale);
+        np_lane_source(psi, r_axis, nz, nr, dr, dz, mu0, ip_target, beta_mix, jraw, source);
         memcpy(pe, psi, sizeof(double) * (size_t)n);
         for (int jt = 0; jt < n_jacobi; ++jt) {
             /* _jacobi_gs_step_np, core/jax_gs_solver.py:58-86 */

@@ -167,6 +167,10 @@ int orc_free_boundary_solve(const orc_picard_params *p, double *psi, double *j_p
 void orc_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int nr, int nz,
                      double ip_target, double mu0, int n_picard, int n_jacobi, double alpha,
                      double omega_j, double beta_mix, double *psi_out);
+void orc_np_delta_star(const double *psi, int nz, int nr, double r_min, double r_max, double z_min,
+                       double z_max, double *out);
+void orc_np_equation_residual(const double *psi, int nz, int nr, double r_min, double r_max, double z_min,
+                              double z_max, double ip_target, double mu0, double beta_mix, double *out3);
 
 /* hpc/solver.cpp:63-199 FastSolver semantics (legacy C ABI): `iterations` sweeps at omega on the
  * persistent psi state with constant Dirichlet ring; source = -1.0*R*J; returns last max|dpsi| */

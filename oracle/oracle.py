@@ -94,6 +94,8 @@ def lib() -> C.CDLL:
         L.orc_free_boundary_solve.argtypes = [C.POINTER(PicardParams), _dp, _dp, _i, _dp, _dp, _dp, _dp,
                                               _i, _d, C.POINTER(_d), C.POINTER(_i), C.POINTER(PicardResult)]
         L.orc_gs_solve_np.argtypes = [_d, _d, _d, _d, _i, _i, _d, _d, _i, _i, _d, _d, _d, _dp]
+        L.orc_np_delta_star.argtypes = [_dp, _i, _i, _d, _d, _d, _d, _dp]
+        L.orc_np_equation_residual.argtypes = [_dp, _i, _i, _d, _d, _d, _d, _d, _d, _d, _dp]
         L.orc_fastsolver_sweeps.restype = _d
         L.orc_fastsolver_sweeps.argtypes = [_dp, _dp, _i, _i, _d, _d, _d, _d, _d, _d, _i, _d, C.POINTER(_i)]
         L.orc_interp_psi.restype = _d
@@ -505,6 +507,22 @@ def gs_solve_np(R_min, R_max, Z_min, Z_max, NR, NZ, Ip_target, mu0=4e-7 * np.pi,
     lib().orc_gs_solve_np(R_min, R_max, Z_min, Z_max, NR, NZ, Ip_target, mu0, n_picard, n_jacobi, alpha, omega_j,
                           beta_mix, out)
     return out
+
+
+def np_delta_star(psi, R_min, R_max, Z_min, Z_max):
+    """gs_delta_star_np, core/jax_gs_solver.py:196-217."""
+    psi = _c(psi)
+    out = np.empty_like(psi)
+    lib().orc_np_delta_star(psi, psi.shape[0], psi.shape[1], R_min, R_max, Z_min, Z_max, out)
+    return out
+
+
+def np_equation_residual(psi, R_min, R_max, Z_min, Z_max, Ip_target, mu0=4e-7 * np.pi, beta_mix=0.5):
+    """gs_equation_residual_np, core/jax_gs_solver.py:251-316."""
+    psi = _c(psi)
+    out = np.empty(3)
+    lib().orc_np_equation_residual(psi, psi.shape[0], psi.shape[1], R_min, R_max, Z_min, Z_max, Ip_target, mu0, beta_mix, out)
+    return {"abs_max": float(out[0]), "relative_max": float(out[1]), "relative_l2": float(out[2])}
 
 
 def fastsolver_sweeps(psi_state, j, nr, nz, r_min, r_max, z_min, z_max, boundary_value, omega, iterations, tol=-1.0):

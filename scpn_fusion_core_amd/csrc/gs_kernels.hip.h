@@ -550,6 +550,14 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     }
     TILE_STAMP(0);
     const double* src = srcF.at(b);
+    // lazy-source mode (!SRCGEN && sg.st): srcF holds J_raw of k_jsum; Source = (-mu0 R) * (J_raw * scale) is formed on load
+    // with the expression of k_source, so the separate source pass over the fine grid disappears.  Otherwise scale = nm = 1.
+    double lz_sc = 1.0, lz_n0 = 1.0, lz_n1 = 1.0;
+    if (!SRCGEN && sg.st) {
+        lz_sc = sg.st[b].jscale;
+        lz_n0 = (c0 >= 0 && c0 < nr) ? sg.neg_mu0R[c0] : 0.0;
+        lz_n1 = (c0 + 1 >= 0 && c0 + 1 < nr) ? sg.neg_mu0R[c0 + 1] : 0.0;
+    }
     double g_pa = 0.0, g_den = 1.0, g_iden = 1.0, g_sc = 0.0;
     if (SRCGEN) {
         __shared__ double shj[4];
@@ -620,7 +628,12 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             if (lz < LZ) {
                 const bool rowok = gz >= 0 && gz < nz;
                 double vx = (rowok && okx) ? pv[j].x : 0.0, vy = (rowok && oky) ? pv[j].y : 0.0;
-                const double sx = (rowok && okx) ? sv2[j].x : 0.0, sy = (rowok && oky) ? sv2[j].y : 0.0;
+                double sx = (rowok && okx) ? sv2[j].x : 0.0, sy = (rowok && oky) ? sv2[j].y : 0.0;
+                if (!SRCGEN && sg.st) {  // wave-uniform
+                    const double tx_ = sx * lz_sc, ty_ = sy * lz_sc;
+                    sx = (rowok && okx) ? lz_n0 * (lz_sc != 0.0 ? tx_ : 0.0) : 0.0;
+                    sy = (rowok && oky) ? lz_n1 * (lz_sc != 0.0 ? ty_ : 0.0) : 0.0;
+                }
                 if (PROLONG && rowok) {
                     // bilinear prolongation, core/multigrid_solve.py:117-143 (same expressions as prolong_at)
                     double px, py;
@@ -1441,11 +1454,12 @@ __global__ void __launch_bounds__(1024) k_xpoint_saddle(Fld psiF, Member* st, in
 constexpr int JS_ROWS = 16;
 __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz, int nr, int ld,
                                               const double* r_axis, const double* inv_mu0R, Prof pf,
-                                              double* part, int nblk) {
+                                              double* part, int nblk, Fld rawF) {
     __shared__ double sh[4];
     int b = blockIdx.z;
     if (!st[b].active) return;
     const double* psi = psiF.at(b);
+    double* raw = rawF.base ? rawF.at(b) : nullptr;  // lazy-source mode: J_raw is kept, consumers apply scale and -mu0 R
     const double pa = st[b].psi_axis, den = st[b].denom, iden = st[b].inv_denom;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c0 = (blockIdx.x * 64 + tx) * 2;
@@ -1459,8 +1473,14 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
             const int iz = blockIdx.y * JS_ROWS + ty + 4 * k;
             if (iz < nz) {
                 const double2 v = *reinterpret_cast<const double2*>(psi + (long)iz * ld + c0);
-                s += j_raw_at(v.x, R0, m0, pa, den, iden, pf);
-                if (two) s += j_raw_at(v.y, R1, m1, pa, den, iden, pf);
+                const double j0 = j_raw_at(v.x, R0, m0, pa, den, iden, pf);
+                s += j0;
+                double j1 = 0.0;
+                if (two) { j1 = j_raw_at(v.y, R1, m1, pa, den, iden, pf); s += j1; }
+                if (raw) {
+                    if (two) *reinterpret_cast<double2*>(raw + (long)iz * ld + c0) = double2{j0, j1};
+                    else raw[(long)iz * ld + c0] = j0;
+                }
             }
         }
     }
@@ -1592,7 +1612,7 @@ __global__ void __launch_bounds__(256) k_blend(Fld nxtF, Fld curF, Fld newF, Fld
 constexpr int BT_Z = 16, BT_R = 64;
 __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
                                                      double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
-                                                     double* rmax, double* rsum, TopoPart* topo, int nblk) {
+                                                     double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm) {
     __shared__ double t[BT_Z + 2][BT_R + 2 + 1];
     __shared__ VI shv[4];
     __shared__ double shd[4];
@@ -1660,7 +1680,9 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
             const double d1r = divc(e - w, L.two_dr, L.inv_two_dr);
             const double d2z = divc(n - 2.0 * p + so, L.dz2, L.inv_dz2);
             const double lpsi = d2r - divc(d1r, L.r_safe[gr], L.r_inv[gr]) + d2z;
-            const double r = sanitize1(lpsi - src[(long)gz * ld + gr]);
+            double sv = src[(long)gz * ld + gr];
+            if (lazy_nm) { const double sc = st[b].jscale; sv = lazy_nm[gr] * (sc != 0.0 ? sv * sc : 0.0); }  // srcF holds J_raw (see k_smooth_tile)
+            const double r = sanitize1(lpsi - sv);
             m = fmax(m, fabs(r));
             rv[k] = r;
         }
@@ -2199,6 +2221,54 @@ __global__ void k_b_field(double* br, double* bz, Fld psiF, int member, int nz, 
     bz[(long)iz * nr + ir] = (1.0 / rs) * gr;
 }
 
+
+// polyglot lane diagnostics (core/jax_gs_solver.py:196-316).
+// gs_delta_star_np: d2/dR2 - (1/R) d/dR + d2/dZ2 with THIS lane's association ((E-W)/(2 dR R), dR*dR); zero ring
+__global__ void k_np_delta_star(double* out, Fld psiF, int nz, int nr, int ld, double dr, double dz, const double* r_axis) {
+    const int ir = blockIdx.x * 64 + threadIdx.x, iz = blockIdx.y * 4 + threadIdx.y;
+    if (ir >= nr || iz >= nz) return;
+    const double* psi = psiF.at(0);
+    double v = 0.0;
+    if (iz >= 1 && iz <= nz - 2 && ir >= 1 && ir <= nr - 2) {
+        const long c = (long)iz * ld + ir;
+        const double d2r = (psi[c + 1] - 2.0 * psi[c] + psi[c - 1]) / (dr * dr);
+        const double d1r = (psi[c + 1] - psi[c - 1]) / ((2.0 * dr) * r_axis[ir]);
+        const double d2z = (psi[c + ld] - 2.0 * psi[c] + psi[c - ld]) / (dz * dz);
+        v = d2r - d1r + d2z;
+    }
+    out[(long)iz * nr + ir] = v;
+}
+// gs_equation_residual_np: a_E psi_E + a_W psi_W + a_NS (psi_S + psi_N) - a_C psi_C - source on the interior; per-block
+// max|res|, sum res^2, max|source|, sum source^2.  grid (nblk, 1), 256 threads x 4 interior points
+__global__ void __launch_bounds__(256) k_np_eq_residual(Fld psiF, Fld srcF, Lvl L, double* part, int nblk) {
+    __shared__ double sh[4];
+    const double* psi = psiF.at(0);
+    const double* src = srcF.at(0);
+    const int ni = L.nr - 2;
+    const long nint = (long)(L.nz - 2) * ni;
+    double rm = 0.0, r2 = 0.0, sm = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (q < nint) {
+            const int iz = 1 + (int)(q / ni), ir = 1 + (int)(q - (long)(iz - 1) * ni);
+            const long c = (long)iz * L.ld + ir;
+            const double sv = src[c];
+            const double r = L.a_e[ir] * psi[c + 1] + L.a_w[ir] * psi[c - 1] + L.a_ns * (psi[c - L.ld] + psi[c + L.ld]) - L.a_c * psi[c] - sv;
+            rm = fmax(rm, fabs(r));
+            r2 += r * r;
+            sm = fmax(sm, fabs(sv));
+            s2 += sv * sv;
+        }
+    }
+    const double brm = block_max<256>(rm, sh), br2 = block_sum<256>(r2, sh), bsm = block_max<256>(sm, sh), bs2 = block_sum<256>(s2, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = brm;
+        part[nblk + blockIdx.x] = br2;
+        part[2 * nblk + blockIdx.x] = bsm;
+        part[3 * nblk + blockIdx.x] = bs2;
+    }
+}
 
 // ---------------------------------------------------------------- f3: flux sampling and diagnostic response matrices
 // numpy.searchsorted(a, x) (side="left") on an ascending axis: first index i with a[i] >= x

@@ -126,6 +126,7 @@ struct Solver {
 
     // multigrid hierarchies keyed by min_grid
     std::map<int, Hier> hier;
+    const double* lazy_src = nullptr;  // base of the level-0 source field while it holds J_raw (lazy-source Picard iterations)
     bool use_fused = true;  // SCPN_HIP_FUSED=0 selects the one-pass-per-launch kernels (A/B testing)
     // fields (B members each)
     DBuf<double> psi_slots;  // 3 ping-pong slots
@@ -365,8 +366,10 @@ static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, doubl
     BlendArgs ba = bl ? *bl : BlendArgs{};
     if (BLEND && (int)(g.x * g.y) != ba.nblk) throw std::runtime_error("blend partial layout mismatch");
     static const int xcd_env = [] { const char* e = std::getenv("SCPN_HIP_XCD"); return e ? std::atoi(e) : 1; }();
+    SrcGen sgv = sg ? *sg : SrcGen{};
+    if (!SRCGEN && h->lazy_src && src.base == h->lazy_src) { sgv.st = h->d_st.p; sgv.neg_mu0R = h->d_neg_mu0R.p; }
     hipLaunchKernelGGL(kern, g, dim3(64 * NWT), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c, ld_c,
-                       sg ? *sg : SrcGen{}, dd, ba, xcd_env);
+                       sgv, dd, ba, xcd_env);
 }
 // the production roles (plain / +prolongation / +defect) and the blend-fused post-smoother exist in every geometry; source
 // generation only in the default one
@@ -472,6 +475,13 @@ static bool vcycle_can_blend(Solver* h, int post, int min_grid) {
     Hier& H = get_hier(h, min_grid);
     const Lvl& L0 = H.lv[0]->dev;
     return h->use_fused && H.lv.size() > 1 && post > 0 && (long)L0.nz * L0.nr > SMALL_MAX;
+}
+// every level-0 consumer of the source inside the V-cycle is a tile kernel (pre-smoother with fused defect, post-smoother)
+static bool vcycle_lazy_ok(Solver* h, int pre, int post, int min_grid) {
+    Hier& H = get_hier(h, min_grid);
+    const Lvl& L0 = H.lv[0]->dev;
+    const char* e = std::getenv("SCPN_HIP_DEFECT_MINLVL");
+    return h->use_fused && H.lv.size() > 1 && pre > 0 && pre <= 3 && post > 0 && (long)L0.nz * L0.nr > SMALL_MAX && !(e && std::atoi(e) > 0);
 }
 static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega, int pre, int post, int min_grid,
                   const int* active, const SrcGen* srcgen = nullptr, const BlendArgs* blend = nullptr,
@@ -872,6 +882,20 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         h->and_alpha.alloc((size_t)B * AND_MAX);
         h->and_fb.alloc(B);
     }
+    // lazy source: k_jsum keeps J_raw in the source field and the level-0 consumers (tile pre / post smoother, fused tail)
+    // apply (-mu0 R) * (J_raw * scale) on load -- the k_source pass over the fine grid disappears.  Bit-identical, but measured
+    // neutral to slightly slower on MI355X (186.0 vs 187.8 eq/s): the J_raw store costs what the source store did and the psi
+    // re-read it saves was an L2 / MALL hit.  Opt-in: SCPN_HIP_LAZYSRC=1
+    static const bool lazy_env = [] { const char* e = std::getenv("SCPN_HIP_LAZYSRC"); return e && e[0] == '1'; }();
+    static const bool srcgen_env0 = [] { const char* e = std::getenv("SCPN_HIP_SRCGEN"); return e && e[0] == '1'; }();
+    static const bool blend_env0 = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1'; }();
+    const bool lazy = lazy_env && !srcgen_env0 && !blend_env0 && h->use_fused && p->method == 0 && !p->external_profile_mode &&
+                      vcycle_lazy_ok(h, 3, 3, 5);
+    struct LazyGuard {
+        Solver* h;
+        ~LazyGuard() { h->lazy_src = nullptr; }
+    } lazy_guard{h};
+    if (lazy) h->lazy_src = srcF.base;
     auto iteration = [&](bool first) {
         {
             ProfScope ps(h, "topology", first || !h->use_fused || p->method == 3 || p->xpoint_saddle ? 2 : 1);
@@ -893,10 +917,12 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         const bool gen = srcgen_env && !p->external_profile_mode && p->method == 0 && vcycle_can_srcgen(h, 3, 5);
         SrcGen sg{};
         if (!p->external_profile_mode) {
-            ProfScope ps(h, "source", gen ? 1 : 3);
+            ProfScope ps(h, "source", gen ? 1 : (lazy ? 2 : 3));
             hipLaunchKernelGGL(k_jsum, gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
-                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj);
-            if (gen) {  // scale + source are evaluated inside the pre-smoother's tile load
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, lazy ? srcF : Fld{nullptr, nullptr, 0, 0});
+            if (lazy) {  // the V-cycle's level-0 tiles and the fused tail form the source from J_raw on load
+                hipLaunchKernelGGL(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
+            } else if (gen) {  // scale + source are evaluated inside the pre-smoother's tile load
                 sg.r_axis = h->d_r.p; sg.inv_mu0R = h->d_inv_mu0R.p; sg.neg_mu0R = h->d_neg_mu0R.p; sg.part = h->d_jpart.p;
                 sg.st = h->d_st.p; sg.nblk = nblkj; sg.dr = h->dr; sg.dz = h->dz; sg.pf = pf;
             } else {
@@ -935,7 +961,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             nb_d = nb_r = nblk2;
             hipLaunchKernelGGL(k_blend_fused, dim3(cdiv(nr, BT_R), cdiv(nz, BT_Z), B), dim3(256), 0, st, nxtF, curF, newF, bcF, srcF,
                                (const Member*)h->d_st.p, L0, p->alpha, om_alpha, n_mask_rows, h->d_part1.p, h->d_pbad.p, h->d_part2.p,
-                               h->d_part3.p, h->d_topo.p, nblk2);
+                               h->d_part3.p, h->d_topo.p, nblk2, lazy ? (const double*)h->d_neg_mu0R.p : (const double*)nullptr);
         } else {
             ProfScope ps(h, "blend_norms", 2);
             hipLaunchKernelGGL(k_blend, dim3(nblk1, B), dim3(256), 0, st, nxtF, curF, newF, bcF, (const Member*)h->d_st.p, nz, nr, ld, p->alpha,
@@ -1033,6 +1059,9 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             HIP_TRY(hipMemcpyAsync(d_tmp.p, tmp.data(), sizeof(Member) * B, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_source, gjs, dim3(256), 0, st, src2F, jF, 1, prevF, (const Member*)d_tmp.p, nz, nr, ld, (const double*)h->d_r.p,
                                (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
+            if (lazy)  // the source field held J_raw during the iterations: leave the last source in it, as the eager path does
+                hipLaunchKernelGGL(k_source, gjs, dim3(256), 0, st, srcF, jF, 0, prevF, (const Member*)d_tmp.p, nz, nr, ld, (const double*)h->d_r.p,
+                                   (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
             HIP_TRY(hipStreamSynchronize(st));
         }
         for (int b = 0; b < B; ++b)
@@ -1181,7 +1210,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         if (!p->external_profile_mode) {
             ProfScope ps(h, "source", 3);
             hipLaunchKernelGGL(k_jsum, gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
-                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj);
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0});
             hipLaunchKernelGGL(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
             hipLaunchKernelGGL(k_source, gjs, dim3(256), 0, st, dstSrc, jF, 1, curF, (const Member*)h->d_st.p, nz, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
@@ -2435,6 +2464,56 @@ int scpn_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int
         hipLaunchKernelGGL(k_axpby, g2, BLK2D, 0, st, psiF, psiF, in, 1.0 - alpha, alpha, nz, nr, h->ld);
     }
     download(h, h->psi_slots.p, 0, psi_out);
+    API_END
+}
+
+// polyglot lane diagnostics (core/jax_gs_solver.py:196-316)
+int scpn_np_delta_star(const double* psi, int nz, int nr, const double* r_axis, double dr, double dz, double* out) {
+    if (!psi || !r_axis || !out || nr < 3 || nz < 3) return fail(SCPN_E_ARG, "psi shape must be at least 3x3 for centered GS diagnostics");
+    API_BEGIN
+    TempSolver t(nr, nz, 1, r_axis, nullptr, dr, dz);
+    Solver* h = t.h;
+    upload(h, h->psi_slots.p, 0, psi);
+    DBuf<double> d;
+    d.alloc((size_t)nz * nr);
+    hipLaunchKernelGGL(k_np_delta_star, grid2d(nr, nz, 1), BLK2D, 0, h->stream, d.p, h->slot_fld(nullptr), nz, nr, h->ld, dr, dz, (const double*)h->d_r.p);
+    HIP_TRY(hipMemcpyAsync(out, d.p, sizeof(double) * nz * nr, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    API_END
+}
+int scpn_np_equation_residual(const double* psi, int nz, int nr, const double* r_axis, const double* z_axis, double ip_target, double mu0,
+                              double beta_mix, double* out3) {
+    if (!psi || !r_axis || !z_axis || !out3 || nr < 3 || nz < 3) return fail(SCPN_E_ARG, "Grad-Shafranov residual requires at least a 3 x 3 grid");
+    API_BEGIN
+    const double dr = r_axis[1] - r_axis[0], dz = z_axis[1] - z_axis[0];
+    TempSolver t(nr, nz, 1, r_axis, z_axis, dr, dz);
+    Solver* h = t.h;
+    ensure_picard_bufs(h);
+    upload(h, h->psi_slots.p, 0, psi);
+    auto& lv = get_hierarchy(h, 1 << 30);
+    Lvl L = lv[0]->dev;
+    hipStream_t st = h->stream;
+    Fld psiF = h->slot_fld(nullptr), srcF = h->plain(h->src.p);
+    const int nb = h->nblk(), nbi = std::max(h->nblk_int(), 1);
+    // _compute_source_np (jax_gs_solver.py:88-123): psi_axis = max interior, L-mode profile, sum J renormalised to Ip
+    hipLaunchKernelGGL(k_max_interior, dim3(nbi, 1), dim3(256), 0, st, psiF, nz, nr, h->ld, h->d_part1.p, nbi);
+    hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, h->d_scal.p, (const double*)h->d_part1.p, nbi, 0, dr, dz, ip_target);
+    hipLaunchKernelGGL(k_np_jsum, dim3(nb, 1), dim3(256), 0, st, psiF, (const double*)h->d_scal.p, nz, nr, h->ld, (const double*)h->d_r.p, mu0, beta_mix,
+                       h->d_part2.p, nb);
+    hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, h->d_scal.p, (const double*)h->d_part2.p, nb, 1, dr, dz, ip_target);
+    hipLaunchKernelGGL(k_np_source, grid2d(nr, nz, 1), BLK2D, 0, st, srcF, psiF, (const double*)h->d_scal.p, nz, nr, h->ld, (const double*)h->d_r.p, mu0,
+                       beta_mix);
+    DBuf<double> part;
+    part.alloc((size_t)4 * nbi);
+    hipLaunchKernelGGL(k_np_eq_residual, dim3(nbi, 1), dim3(256), 0, st, psiF, srcF, L, part.p, nbi);
+    std::vector<double> hp((size_t)4 * nbi);
+    HIP_TRY(hipMemcpyAsync(hp.data(), part.p, sizeof(double) * 4 * nbi, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    double rm = 0, r2 = 0, sm = 0, s2 = 0;
+    for (int i = 0; i < nbi; ++i) { rm = std::fmax(rm, hp[i]); r2 += hp[nbi + i]; sm = std::fmax(sm, hp[2 * nbi + i]); s2 += hp[3 * nbi + i]; }
+    out3[0] = rm;
+    out3[1] = rm / (sm + 1.0e-30);
+    out3[2] = std::sqrt(r2) / (std::sqrt(s2) + 1.0e-30);
     API_END
 }
 

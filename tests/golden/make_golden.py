@@ -34,7 +34,8 @@ from scpn_fusion.core.fusion_kernel_free_boundary import (  # noqa: E402
     green_function,
 )
 from scpn_fusion.core.fusion_kernel_solver_runtime import compute_gs_residual_rms  # noqa: E402
-from scpn_fusion.core.jax_gs_solver import gs_solve_np  # noqa: E402
+from scpn_fusion.core.jax_gs_solver import (  # noqa: E402
+    gs_delta_star_np, gs_equation_residual_np, gs_solve_np, gs_toroidal_current_density_np, gs_total_toroidal_current_np)
 from validation.benchmark_vs_freegs import TokamakCase, build_config  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
@@ -157,6 +158,18 @@ def gen_polyglot():
         out[f"psi{n}"] = gs_solve_np(NR=n, NZ=n, **kw)
     out["params"] = np.array([kw[k] for k in ("R_min", "R_max", "Z_min", "Z_max", "Ip_target", "mu0", "n_picard",
                                              "n_jacobi", "alpha", "omega_j", "beta_mix")])
+    # lane diagnostics (core/jax_gs_solver.py:196-316) on the solved fields and on a seeded random field
+    box = (kw["R_min"], kw["R_max"], kw["Z_min"], kw["Z_max"])
+    rng = np.random.default_rng(1305)
+    fields = {"s17": out["psi17"], "s65": out["psi65"], "rnd": rng.normal(size=(29, 41)) * 0.3}
+    out["rnd_psi"] = fields["rnd"]
+    for tag, f in fields.items():
+        nz, nr = f.shape
+        out[f"ds_{tag}"] = gs_delta_star_np(f, *box)
+        out[f"jd_{tag}"] = gs_toroidal_current_density_np(f, *box, mu0=kw["mu0"])
+        out[f"it_{tag}"] = np.array(gs_total_toroidal_current_np(f, *box, mu0=kw["mu0"]))
+        m = gs_equation_residual_np(f, *box, nr, nz, kw["Ip_target"], kw["mu0"], kw["beta_mix"])
+        out[f"er_{tag}"] = np.array([m["abs_max"], m["relative_max"], m["relative_l2"]])
     save("polyglot.npz", **out)
 
 

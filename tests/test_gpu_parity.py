@@ -494,6 +494,28 @@ def test_polyglot_lane_golden(hip, golden):
             assert abs(psi.max() - 0.042651828900105285) < 1e-13
 
 
+@pytest.mark.gpu
+def test_polyglot_lane_diagnostics_golden(hip, golden, orc):
+    """Device gs_delta_star / current density / total current / equation residual vs the reference's outputs."""
+    from scpn_fusion_core_amd import polyglot as pg
+
+    g = golden("polyglot.npz")
+    p = g["params"]
+    box = (p[0], p[1], p[2], p[3])
+    for tag, f in (("s17", g["psi17"]), ("s65", g["psi65"]), ("rnd", g["rnd_psi"])):
+        nz, nr = f.shape
+        np.testing.assert_array_equal(pg.gs_delta_star_hip(f, *box), g[f"ds_{tag}"])
+        np.testing.assert_array_equal(pg.gs_toroidal_current_density_hip(f, *box, mu0=p[5]), g[f"jd_{tag}"])
+        assert pg.gs_total_toroidal_current_hip(f, *box, mu0=p[5]) == float(g[f"it_{tag}"])
+        m = pg.gs_equation_residual_hip(f, *box, nr, nz, p[4], p[5], p[10])
+        er = g[f"er_{tag}"]
+        assert m["abs_max"] == er[0] and m["relative_max"] == er[1]
+        assert m["relative_l2"] == pytest.approx(er[2], rel=1e-12)
+        mo = orc.np_equation_residual(f, *box, p[4], p[5], p[10])
+        assert m["abs_max"] == mo["abs_max"] and m["relative_max"] == mo["relative_max"]
+
+
+
 # ----------------------------------------------------------------------------- a14 legacy ABI
 def test_legacy_abi_golden_bit_exact(hip, golden):
     from scpn_fusion_core_amd.hpc_bridge import HPCBridge

@@ -335,3 +335,74 @@ def test_polyglot_lane_properties(hip):
     hi = gs_solve_hip(0.1, 2.0, -1.5, 1.5, 17, 17, 2e6, n_picard=20, n_jacobi=50)  # :78-94
     assert np.max(np.abs(hi)) > np.max(np.abs(psi))
     assert np.all(np.isfinite(gs_solve_hip(0.1, 2.0, -1.5, 1.5, 33, 33, 1e6, n_picard=20, n_jacobi=50)))  # :96-101
+
+
+# ---- tests/test_jax_gs_solver.py:104-265 (lane diagnostics: equation residual, Delta*, J_phi, total current) --------------
+@pytest.mark.gpu
+def test_polyglot_equation_residual_contract(hip):
+    from scpn_fusion_core_amd.polyglot import gs_equation_residual_hip
+
+    mu0 = 4e-7 * np.pi
+    imbalanced = np.zeros((3, 3))
+    imbalanced[1, 1] = 1.0
+    bal = gs_equation_residual_hip(np.zeros((3, 3)), 1.0, 3.0, -1.0, 1.0, 3, 3, 0.0, mu0, 0.5)
+    imb = gs_equation_residual_hip(imbalanced, 1.0, 3.0, -1.0, 1.0, 3, 3, 0.0, mu0, 0.5)
+    assert bal["abs_max"] == 0.0
+    assert imb["abs_max"] == pytest.approx(4.0)
+    assert imb["relative_max"] > 1.0
+    with pytest.raises(ValueError, match="psi shape"):
+        gs_equation_residual_hip(np.zeros((4, 3)), 1.0, 3.0, -1.0, 1.0, 3, 3, 0.0)
+    with pytest.raises(ValueError, match="positive, increasing"):
+        gs_equation_residual_hip(np.zeros((3, 3)), 0.0, 3.0, -1.0, 1.0, 3, 3, 0.0)
+    bad = np.zeros((3, 3))
+    bad[1, 1] = np.nan
+    with pytest.raises(ValueError, match="finite"):
+        gs_equation_residual_hip(bad, 1.0, 3.0, -1.0, 1.0, 3, 3, 0.0)
+
+
+@pytest.mark.gpu
+def test_polyglot_delta_star_manufactured_fluxes(hip):
+    from scpn_fusion_core_amd import polyglot as pg
+
+    mu0 = 4e-7 * np.pi
+    box = (1.0, 3.0, -1.0, 1.0)
+    # z-quadratic flux: Delta* = 2 c, zero ring, J = -2c/(mu0 R)
+    nr, nz, c = 11, 13, -0.25
+    r, z = np.linspace(1.0, 3.0, nr), np.linspace(-1.0, 1.0, nz)
+    _, zz = np.meshgrid(r, z)
+    psi = c * zz**2
+    ds, jd = pg.gs_delta_star_hip(psi, *box), pg.gs_toroidal_current_density_hip(psi, *box)
+    np.testing.assert_allclose(ds[1:-1, 1:-1], 2.0 * c, rtol=1e-12, atol=1e-12)
+    for edge in (ds[0, :], ds[-1, :], ds[:, 0], ds[:, -1]):
+        np.testing.assert_allclose(edge, 0.0, atol=0.0)
+    np.testing.assert_allclose(jd[1:-1, 1:-1], np.broadcast_to(-2.0 * c / (mu0 * r[None, 1:-1]), jd[1:-1, 1:-1].shape), rtol=1e-12, atol=1e-6)
+    # total current closure
+    nr, nz, c = 17, 19, -0.125
+    r, z = np.linspace(1.0, 3.0, nr), np.linspace(-1.0, 1.0, nz)
+    _, zz = np.meshgrid(r, z)
+    dr, dz = 2.0 / (nr - 1), 2.0 / (nz - 1)
+    expected = float(np.sum(-2.0 * c / (mu0 * r[None, 1:-1])) * (nz - 2) * dr * dz)
+    assert pg.gs_total_toroidal_current_hip(c * zz**2, *box) == pytest.approx(expected, rel=1e-12)
+    # radial quartic and mixed Solov'ev fluxes
+    nr, nz = 15, 17
+    r, z = np.linspace(1.0, 3.0, nr), np.linspace(-1.0, 1.0, nz)
+    rr, zz = np.meshgrid(r, z)
+    dr = 2.0 / (nr - 1)
+    a, b = 0.03125, -0.125
+    ds = pg.gs_delta_star_hip(a * rr**4 + b * zz**2, *box)
+    np.testing.assert_allclose(ds[1:-1, 1:-1], 8.0 * a * rr[1:-1, 1:-1] ** 2 + 2.0 * b - 2.0 * a * dr**2, rtol=1e-12, atol=1e-12)
+    m = 0.05
+    psi = m * rr**2 * zz**2 + b * zz**2
+    ds, jd = pg.gs_delta_star_hip(psi, *box), pg.gs_toroidal_current_density_hip(psi, *box)
+    exp = 2.0 * m * rr[1:-1, 1:-1] ** 2 + 2.0 * b
+    np.testing.assert_allclose(ds[1:-1, 1:-1], exp, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(jd[1:-1, 1:-1], -exp / (mu0 * rr[1:-1, 1:-1]), rtol=1e-12, atol=1e-6)
+    # validation contract (core/jax_gs_solver.py:168-193)
+    with pytest.raises(ValueError, match="two-dimensional"):
+        pg.gs_delta_star_hip(np.zeros(5), *box)
+    with pytest.raises(ValueError, match="at least 3x3"):
+        pg.gs_delta_star_hip(np.zeros((2, 5)), *box)
+    with pytest.raises(ValueError, match="R_min and R_max"):
+        pg.gs_delta_star_hip(np.zeros((5, 5)), 0.0, 3.0, -1.0, 1.0)
+    with pytest.raises(ValueError, match="mu0"):
+        pg.gs_toroidal_current_density_hip(np.zeros((5, 5)), *box, mu0=0.0)

@@ -113,6 +113,21 @@ def test_polyglot_lane(golden):
     assert abs(psi17.max() - 0.042651828900105285) < 1e-15
 
 
+def test_polyglot_lane_diagnostics(golden):
+    """gs_delta_star_np / gs_equation_residual_np (core/jax_gs_solver.py:196-316) restated in the oracle."""
+    g = golden("polyglot.npz")
+    p = g["params"]
+    box = (p[0], p[1], p[2], p[3])
+    for tag, f in (("s17", g["psi17"]), ("s65", g["psi65"]), ("rnd", g["rnd_psi"])):
+        ds = orc.np_delta_star(f, *box)
+        np.testing.assert_array_equal(ds, g[f"ds_{tag}"])
+        m = orc.np_equation_residual(f, *box, p[4], p[5], p[10])
+        er = g[f"er_{tag}"]
+        assert m["abs_max"] == er[0] and m["relative_max"] == er[1]
+        assert m["relative_l2"] == pytest.approx(er[2], rel=1e-13)
+
+
+
 def test_pieces(golden):
     g = golden("pieces.npz")
     psi = g["psi"]
