@@ -11,6 +11,7 @@
 //   * wave = 64 lanes; reductions are fixed-shape trees (run-to-run deterministic).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace gs {
@@ -90,15 +91,46 @@ __device__ __forceinline__ double nan_to_num300(double x) {  // fusion_kernel.py
 __device__ __forceinline__ bool finite_d(double x) { return fabs(x) <= 1.7976931348623157e308; }
 
 // ---------------------------------------------------------------- block reductions (256 thr)
+// Wave reductions on the DPP cross-lane network (row_shr within the 16-lane rows, then row_bcast:15 / row_bcast:31 across
+// rows; the total lands in lane 63 and is broadcast through an SGPR).  A __shfl_down butterfly costs two ds_bpermute
+// round trips per step for a double; the DPP moves are ordinary VALU instructions, which matters in the fused Picard tail
+// where every workgroup reduces seven quantities.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_f64(double keep, double v) {  // lanes without a valid source (or masked off) get `keep`
+    int kl = __double2loint(keep), kh = __double2hiint(keep), l = __double2loint(v), h = __double2hiint(v);
+    l = __builtin_amdgcn_update_dpp(kl, l, CTRL, ROW_MASK, BANK_MASK, false);
+    h = __builtin_amdgcn_update_dpp(kh, h, CTRL, ROW_MASK, BANK_MASK, false);
+    return __hiloint2double(h, l);
+}
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ long dpp_i64(long keep, long v) {
+    int kl = (int)(keep & 0xffffffffL), kh = (int)(keep >> 32), l = (int)(v & 0xffffffffL), h = (int)(v >> 32);
+    l = __builtin_amdgcn_update_dpp(kl, l, CTRL, ROW_MASK, BANK_MASK, false);
+    h = __builtin_amdgcn_update_dpp(kh, h, CTRL, ROW_MASK, BANK_MASK, false);
+    return (long)(((unsigned long)(unsigned)h << 32) | (unsigned long)(unsigned)l);
+}
+__device__ __forceinline__ double lane63_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+// DPP controls: 0x111/0x112/0x114/0x118 = row_shr:1/2/4/8, 0x142 = row_bcast:15, 0x143 = row_bcast:31
+#define SCPN_DPP_REDUCE(X, OP, KEEP)                                       \
+    X = OP(X, (dpp_f64<0x111, 0xf, 0xf>(KEEP(X), X)));                     \
+    X = OP(X, (dpp_f64<0x112, 0xf, 0xf>(KEEP(X), X)));                     \
+    X = OP(X, (dpp_f64<0x114, 0xf, 0xf>(KEEP(X), X)));                     \
+    X = OP(X, (dpp_f64<0x118, 0xf, 0xf>(KEEP(X), X)));                     \
+    X = OP(X, (dpp_f64<0x142, 0xa, 0xf>(KEEP(X), X)));                     \
+    X = OP(X, (dpp_f64<0x143, 0xc, 0xf>(KEEP(X), X)));
+#define SCPN_OP_ADD(a, b) ((a) + (b))
+#define SCPN_KEEP_ZERO(x) 0.0
+#define SCPN_KEEP_SELF(x) (x)
+// total of the wave in every lane
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    SCPN_DPP_REDUCE(v, SCPN_OP_ADD, SCPN_KEEP_ZERO)
+    return lane63_f64(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-    return v;
+    SCPN_DPP_REDUCE(v, fmax, SCPN_KEEP_SELF)
+    return lane63_f64(v);
 }
 template <int NT>
 __device__ __forceinline__ double block_sum(double v, double* sh) {
@@ -133,7 +165,6 @@ __device__ __forceinline__ double block_max(double v, double* sh) {
 template <int NT>
 __device__ __forceinline__ double block_max_all(double v, double* sh) {
     v = wave_max(v);
-    v = __shfl(v, 0, 64);
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) sh[w] = v;
@@ -156,16 +187,26 @@ __device__ __forceinline__ VI vi_min(VI a, VI b) {
     bool tb = (b.i >= 0) && (a.i < 0 || b.v < a.v || (b.v == a.v && b.i < a.i));
     return tb ? b : a;
 }
+template <bool MAX, int CTRL, int ROW_MASK>
+__device__ __forceinline__ VI vi_dpp_step(VI x) {
+    VI y;
+    y.v = dpp_f64<CTRL, ROW_MASK, 0xf>(x.v, x.v);  // invalid / masked lanes see themselves: the operations are idempotent
+    y.i = dpp_i64<CTRL, ROW_MASK, 0xf>(x.i, x.i);
+    return MAX ? vi_max(x, y) : vi_min(x, y);
+}
 template <bool MAX>
-__device__ __forceinline__ VI wave_vi(VI x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        VI y;
-        y.v = __shfl_down(x.v, o, 64);
-        y.i = __shfl_down((long long)x.i, o, 64);
-        x = MAX ? vi_max(x, y) : vi_min(x, y);
-    }
-    return x;
+__device__ __forceinline__ VI wave_vi(VI x) {  // result in every lane
+    x = vi_dpp_step<MAX, 0x111, 0xf>(x);
+    x = vi_dpp_step<MAX, 0x112, 0xf>(x);
+    x = vi_dpp_step<MAX, 0x114, 0xf>(x);
+    x = vi_dpp_step<MAX, 0x118, 0xf>(x);
+    x = vi_dpp_step<MAX, 0x142, 0xa>(x);
+    x = vi_dpp_step<MAX, 0x143, 0xc>(x);
+    VI r;
+    r.v = lane63_f64(x.v);
+    const int il = (int)(x.i & 0xffffffffL), ih = (int)(x.i >> 32);
+    r.i = (long)(((unsigned long)(unsigned)__builtin_amdgcn_readlane(ih, 63) << 32) | (unsigned long)(unsigned)__builtin_amdgcn_readlane(il, 63));
+    return r;
 }
 template <bool MAX, int NT>
 __device__ __forceinline__ VI block_vi(VI x, VI* sh) {
@@ -681,9 +722,10 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     }
     __syncthreads();
     TILE_STAMP(1);
-#pragma unroll 1
-    for (int hs = 0; hs < 2 * S; ++hs) {
-        const int c = hs & 1;
+    // one half-sweep of colour c (compile-time, so the per-colour coefficients, source registers, column predicate and LDS
+    // addresses are loop-invariant: the sweep loop is VALU-issue bound and every select / address add costs 4 cycles per row)
+    auto half_sweep = [&](auto colour, const int hs) {
+        constexpr int c = decltype(colour)::value;
         double* mine = c ? A1 : A0;
         const double* oth = c ? A0 : A1;
         const int pr = (c + w) & 1;  // column parity of colour c in this wave's rows
@@ -704,8 +746,15 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
                 if (colok) mine[lz * 64 + lane] = nw;
             }
         }
+    };
+#pragma unroll 1
+    for (int sw = 0; sw < S; ++sw) {
+        half_sweep(std::integral_constant<int, 0>{}, 2 * sw);
         __syncthreads();
-        TILE_STAMP(2 + hs);
+        TILE_STAMP(2 + 2 * sw);
+        half_sweep(std::integral_constant<int, 1>{}, 2 * sw + 1);
+        __syncthreads();
+        TILE_STAMP(3 + 2 * sw);
     }
     if (!BLEND)
 #pragma unroll
@@ -1607,16 +1656,20 @@ __global__ void __launch_bounds__(256) k_blend(Fld nxtF, Fld curF, Fld newF, Fld
 //   partial sum |new-cur|, non-finite flag                             newton_solver.py:518,535
 //   partial max|r|, sum r^2 of r = L*nxt - src over the interior       fusion_kernel_solver_runtime.py:25-51
 //   topology partials of nxt for the NEXT iteration (argmax psi, masked argmin |grad psi|, min psi)
-// A 256-thread workgroup blends a (16+2) x (64+2) tile into LDS (1-cell halo recomputed from cur/new) and
-// evaluates the residual / np.gradient stencils from LDS.  grid (ceil(nr/64), ceil(nz/16), B).
-constexpr int BT_Z = 16, BT_R = 64;
+// A 256-thread workgroup blends a (BT_Z+2) x (64+2) tile into LDS (1-cell halo recomputed from cur/new) and evaluates the
+// residual / np.gradient stencils from LDS.  grid (ceil(nr/64), ceil(nz/BT_Z), B).  All seven workgroup reductions share two
+// barriers: wave-level DPP reductions -> LDS -> barrier -> (block max, rescaled sum of squares) -> LDS -> barrier -> thread 0.
+#ifndef BLEND_BT_Z
+#define BLEND_BT_Z 32
+#endif
+constexpr int BT_Z = BLEND_BT_Z, BT_R = 64;
 __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
                                                      double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
                                                      double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm) {
     __shared__ double t[BT_Z + 2][BT_R + 2 + 1];
-    __shared__ VI shv[4];
-    __shared__ double shd[4];
-    __shared__ int shbad;
+    __shared__ VI sh_mx[4], sh_mn[4];
+    __shared__ double sh_dsum[4], sh_m[4], sh_minp[4], sh_s2[4];
+    __shared__ int sh_bad[4];
     // XCD-aware tile order (see k_smooth_tile): XCD k gets a contiguous run of tiles so halo rows are re-read from its own L2
     int bx_, by_, b;
     {
@@ -1630,7 +1683,7 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
     }
     if (!st[b].active) return;
     const int tid = threadIdx.x;
-    if (tid == 0) shbad = 0;
+    const int tx = tid & 63, ty = tid >> 6;
     const int nz = L.nz, nr = L.nr, ld = L.ld;
     const int z0 = by_ * BT_Z - 1, r0 = bx_ * BT_R - 1;
     const double* cur = curF.at(b);
@@ -1641,7 +1694,6 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
     double dsum = 0.0, minpsi = INFINITY;
     int bad = 0;
     VI mx{0.0, -1}, mn{0.0, -1};
-    __syncthreads();
     for (int i = tid; i < (BT_Z + 2) * (BT_R + 2); i += 256) {
         const int lz = i / (BT_R + 2), lr = i - lz * (BT_R + 2);
         const int gz = z0 + lz, gr = r0 + lr;
@@ -1663,10 +1715,9 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
         }
         t[lz][lr] = v;
     }
-    if (bad) atomicOr(&shbad, 1);
     __syncthreads();
-    double m = 0.0, s2 = 0.0, rv[BT_Z / 4];
-    const int tx = tid & 63, ty = tid >> 6;
+    double m = 0.0, rv[BT_Z / 4];
+    const double lz_sc = lazy_nm ? st[b].jscale : 1.0;
 #pragma unroll
     for (int k = 0; k < BT_Z / 4; ++k) {
         const int lz = 1 + ty + 4 * k, lr = 1 + tx;
@@ -1681,7 +1732,7 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
             const double d2z = divc(n - 2.0 * p + so, L.dz2, L.inv_dz2);
             const double lpsi = d2r - divc(d1r, L.r_safe[gr], L.r_inv[gr]) + d2z;
             double sv = src[(long)gz * ld + gr];
-            if (lazy_nm) { const double sc = st[b].jscale; sv = lazy_nm[gr] * (sc != 0.0 ? sv * sc : 0.0); }  // srcF holds J_raw (see k_smooth_tile)
+            if (lazy_nm) sv = lazy_nm[gr] * (lz_sc != 0.0 ? sv * lz_sc : 0.0);  // srcF holds J_raw (see k_smooth_tile)
             const double r = sanitize1(lpsi - sv);
             m = fmax(m, fabs(r));
             rv[k] = r;
@@ -1699,17 +1750,29 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
             if (finite_d(bm)) mn = vi_min(mn, VI{bm, (long)gz * nr + gr});
         }
     }
-    const double bsum = block_sum<256>(dsum, shd);
-    const double bmax = block_max_all<256>(m, shd);  // overflow-safe residual sum: (max, sum (r/max)^2), see k_resid_norms
+    // wave-level reductions (results in every lane), one LDS hand-over per wave
+    const double w_dsum = wave_sum(dsum), w_m = wave_max(m), w_minp = -wave_max(-minpsi);
+    const VI w_mx = wave_vi<true>(mx), w_mn = wave_vi<false>(mn);
+    const int w_bad = __any(bad) ? 1 : 0;
+    if (tx == 0) { sh_dsum[ty] = w_dsum; sh_m[ty] = w_m; sh_minp[ty] = w_minp; sh_mx[ty] = w_mx; sh_mn[ty] = w_mn; sh_bad[ty] = w_bad; }
+    __syncthreads();
+    // overflow-safe residual sum: (max, sum (r/max)^2) with the WORKGROUP max, see k_resid_norms
+    const double bmax = fmax(fmax(sh_m[0], sh_m[1]), fmax(sh_m[2], sh_m[3]));
+    double s2 = 0.0;
     if (bmax > 0.0) {
 #pragma unroll
-        for (int k = 0; k < BT_Z / 4; ++k) { const double t = rv[k] / bmax; s2 += t * t; }
+        for (int k = 0; k < BT_Z / 4; ++k) { const double q = rv[k] / bmax; s2 += q * q; }
     }
+    const double w_s2 = wave_sum(s2);
+    if (tx == 0) sh_s2[ty] = w_s2;
     __syncthreads();
-    const double bs2 = block_sum<256>(s2, shd);
-    const double bminp = -block_max<256>(-minpsi, shd);
-    const VI rmx = block_vi<true, 256>(mx, shv);
-    const VI rmn = block_vi<false, 256>(mn, shv);
+    const double bsum = sh_dsum[0] + sh_dsum[1] + sh_dsum[2] + sh_dsum[3];
+    const double bs2 = sh_s2[0] + sh_s2[1] + sh_s2[2] + sh_s2[3];
+    const double bminp = fmin(fmin(sh_minp[0], sh_minp[1]), fmin(sh_minp[2], sh_minp[3]));
+    const int shbad = sh_bad[0] | sh_bad[1] | sh_bad[2] | sh_bad[3];
+    VI rmx = sh_mx[0], rmn = sh_mn[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) { rmx = vi_max(rmx, sh_mx[i]); rmn = vi_min(rmn, sh_mn[i]); }
     if (tid == 0) {
         const long o = (long)b * nblk + (long)by_ * gridDim.x + bx_;
         psum[o] = bsum;

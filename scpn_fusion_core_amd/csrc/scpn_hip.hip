@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -117,7 +118,26 @@ struct ProfEntry {
     long launches;
 };
 
+// Phase alternation of two stream groups.  A Picard iteration has a bandwidth-bound phase (level-0 post-smoother, fused
+// tail, scalar tails, J sums, source, level-0 pre-smoother of the next iteration: contiguous across the iteration boundary)
+// and a latency-bound phase (levels >= 1 incl. the one-workgroup-per-member coarse kernel).  Left alone, the two groups drift
+// into phase and fight for HBM, then idle together.  With the alternation the bandwidth phases of the groups are chained
+// A(k) -> B(k) -> A(k+1) by events, so each group's latency phase runs under the other's bandwidth phase.
+// seq counts the releases (end of a bandwidth phase); an event is recorded BEFORE seq is published, and a waiter only waits
+// on events it has seen published, so every hipStreamWaitEvent refers to an already-recorded event (no cycles possible).
+struct PhaseSync {
+    static constexpr int RING = 64;
+    std::atomic<long> seq{0};
+    std::atomic<int> in_loop{0};
+    hipEvent_t ev[RING] = {};
+    bool ready = false;
+};
+
 struct Solver {
+    PhaseSync phase;
+    Solver* partner = nullptr;  // the other stream group (exactly two groups), or nullptr
+    int phase_role = 0;         // 0: leader (waits partner.seq >= seq), 1: follower (waits partner.seq >= seq + 1)
+    bool phase_active = false;  // set by the Picard driver for the duration of its loop
     int nr = 0, nz = 0, B = 0, ld = 0;
     long stride = 0;
     double dr = 0, dz = 0;
@@ -172,6 +192,8 @@ struct Solver {
         for (auto& kv : hier)
             for (auto* l : kv.second.lv) delete l;
         for (auto& e : prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        if (phase.ready)
+            for (auto& e : phase.ev) (void)hipEventDestroy(e);
         if (h_nactive) (void)hipHostFree(h_nactive);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -320,6 +342,9 @@ struct DefectOut {  // coarse rhs / coarse correction produced by the fused defe
 };
 // tile geometry variants: 0 = 78 rows / 16 waves (one workgroup per CU), 1 = 40 rows / 8 waves (two per CU), 2 = 46 rows / 16 waves
 struct TileGeo { int lz, nw; };
+#ifndef TILE_WPE_V1
+#define TILE_WPE_V1 4  // minimum waves per SIMD of the 40-row / 8-wave tile kernels (register cap 512 / TILE_WPE_V1)
+#endif
 static int tile_variant_for(const Lvl& L) {
     // SCPN_HIP_TILE="v0,v1,v2": variant for level 0, 1, 2+.  Default 1,1,1: measured on MI355X (513^2, 16 members per
     // launch) the 40-row / 8-wave tile runs the fused pre-smoother in 49 us and the post-smoother in 40.5 us against
@@ -377,7 +402,7 @@ template <int S, bool PROLONG, bool DEFECT, bool BLEND = false>
 static void launch_tile_geo(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
                             const DefectOut* dfo, const BlendArgs* bl = nullptr) {
     switch (tile_variant_for(L)) {
-        case 1: launch_tile<S, PROLONG, false, DEFECT, BLEND, 40, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+        case 1: launch_tile<S, PROLONG, false, DEFECT, BLEND, 40, 8, TILE_WPE_V1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
         case 2: launch_tile<S, PROLONG, false, DEFECT, BLEND, 46, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
 #ifdef TILE_EXPERIMENTS
         case 3: launch_tile<S, PROLONG, false, DEFECT, BLEND, 48, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
@@ -464,6 +489,30 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
     return in;
 }
 
+// end of this group's bandwidth phase (called after the level-0 pre-smoother has been enqueued)
+static void phase_release(Solver* h) {
+    if (!h->phase_active) return;
+    PhaseSync& ps = h->phase;
+    const long next = ps.seq.load(std::memory_order_relaxed) + 1;
+    HIP_TRY(hipEventRecord(ps.ev[next % PhaseSync::RING], h->stream));
+    ps.seq.store(next, std::memory_order_release);
+}
+// start of this group's bandwidth phase (called before the level-0 post-smoother is enqueued)
+static void phase_acquire(Solver* h) {
+    if (!h->phase_active) return;
+    PhaseSync& mine = h->phase;
+    PhaseSync& other = h->partner->phase;
+    const long target = mine.seq.load(std::memory_order_relaxed) + h->phase_role;
+    long seen = other.seq.load(std::memory_order_acquire);
+    // the partner's host thread may not have enqueued that release yet: wait for it (bounded by the partner leaving its loop)
+    while (seen < target && other.in_loop.load(std::memory_order_acquire)) {
+        std::this_thread::yield();
+        seen = other.seq.load(std::memory_order_acquire);
+    }
+    if (seen >= target && seen - target < PhaseSync::RING - 1)
+        HIP_TRY(hipStreamWaitEvent(h->stream, other.ev[target % PhaseSync::RING], 0));
+}
+
 // One V-cycle (core/multigrid_solve.py:252-335) of (in0, src0) on level 0.  in0 is left untouched; the improved
 // estimate is produced in bufA or bufB (returned).  `active` (may be null) freezes members.
 static bool vcycle_can_srcgen(Solver* h, int pre, int min_grid) {
@@ -511,11 +560,12 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
         return d;
     };
     // level 0: first smoothing pass reads in0 and writes a work buffer
-    bool defect_done0 = false;
+    bool defect_done0 = false, tile0_done = false;
     {
         const Lvl& L0 = lv[0]->dev;
         const int n0 = (k == 0) ? 50 : pre;  // base case: 50 sweeps (multigrid_solve.py:292-293)
         const bool tile0 = fused && (long)L0.nz * L0.nr > SMALL_MAX && n0 > 0;
+        tile0_done = tile0 && k > 0;
         if (tile0) {
             DefectOut d0;
             const bool df = k > 0 && defect_fusable(0);
@@ -527,6 +577,7 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
                 cur[0] = smooth(h, L0, r, bufB, src0, omega, n0 - 3, active, false, 0, nullptr, nullptr, df ? &d0 : nullptr);
             }
             defect_done0 = df;
+            if (k > 0) phase_release(h);
         } else {
             ProfScope ps(h, "copy", 1);
             hipLaunchKernelGGL(k_copy, grid2d(L0.nr, L0.nz, B), BLK2D, 0, h->stream, bufA, in0, L0.nz, L0.nr, L0.ld, (const int*)nullptr);
@@ -569,6 +620,7 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
         const Lvl& Lf = lv[l]->dev;
         const Lvl& Lc = lv[l + 1]->dev;
         const bool tile_post = fused && post > 0 && (long)Lf.nz * Lf.nr > SMALL_MAX;
+        if (l == 0 && tile0_done) phase_acquire(h);
         if (tile_post) {  // prolongation fused into the post-smoother's tile load
             ProlongSrc pso;
             pso.c = cur[l + 1]; pso.nz_c = Lc.nz; pso.nr_c = Lc.nr; pso.ld_c = Lc.ld;
@@ -896,6 +948,28 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         ~LazyGuard() { h->lazy_src = nullptr; }
     } lazy_guard{h};
     if (lazy) h->lazy_src = srcF.base;
+    // phase alternation with the partner stream group (see PhaseSync).  Measured on MI355X: 177.5 vs 188.4 eq/s -- the level-0
+    // kernels are bound by workgroup residency on the CUs rather than by HBM, so chaining the groups' bandwidth phases only
+    // removes overlap.  Opt-in: SCPN_HIP_PHASE=1
+    static const bool phase_env = [] {
+        const char* e = std::getenv("SCPN_HIP_PHASE");
+        const char* g = std::getenv("SCPN_HIP_GRAPH");  // (events of another stream cannot be waited on inside a capture)
+        return e && e[0] == '1' && !(g && g[0] == '1');
+    }();
+    struct PhaseGuard {
+        Solver* h;
+        ~PhaseGuard() {
+            h->phase_active = false;
+            h->phase.in_loop.store(0, std::memory_order_release);
+        }
+    } phase_guard{h};
+    if (phase_env && h->partner && h->phase.ready && h->partner->phase.ready && p->method == 0 && h->use_fused && !h->prof_on) {
+        // align the release counters (they drift when the groups run different iteration counts)
+        const long other = h->partner->phase.seq.load(std::memory_order_acquire);
+        if (other > h->phase.seq.load(std::memory_order_relaxed)) h->phase.seq.store(other, std::memory_order_release);
+        h->phase_active = true;
+        h->phase.in_loop.store(1, std::memory_order_release);
+    }
     auto iteration = [&](bool first) {
         {
             ProfScope ps(h, "topology", first || !h->use_fused || p->method == 3 || p->xpoint_saddle ? 2 : 1);
@@ -1042,6 +1116,8 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             n_act = h->h_nactive[0];
         }
     }
+    h->phase_active = false;
+    h->phase.in_loop.store(0, std::memory_order_release);
     HIP_TRY(hipStreamSynchronize(st));
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (graph) (void)hipGraphDestroy(graph);
@@ -1888,6 +1964,16 @@ int scpn_gs_create(scpn_gs** out, int nr, int nz, int batch, const double* r_axi
         done += cnt;
     }
     g->off.push_back(done);
+    if (ng == 2) {
+        for (int gi = 0; gi < 2; ++gi) {
+            Solver* k = g->kids[gi];
+            for (auto& e : k->phase.ev)
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete g; return fail(SCPN_E_DEVICE, "hipEventCreate failed"); }
+            k->phase.ready = true;
+            k->partner = g->kids[1 - gi];
+            k->phase_role = gi;
+        }
+    }
     *out = g;
     return SCPN_OK;
 }

@@ -20,6 +20,8 @@ SWITCHES = [
     {"SCPN_HIP_SRCGEN": "1"},
     {"SCPN_HIP_BLENDFUSE": "1"},
     {"SCPN_HIP_GRAPH": "1"},
+    {"SCPN_HIP_GROUPS": "2"},
+    {"SCPN_HIP_PHASE": "1", "SCPN_HIP_GROUPS": "2"},
     {"SCPN_HIP_DEFECT_MINLVL": "9"},
 ]
 
