@@ -491,9 +491,10 @@ struct SrcGen {
 };
 #ifdef CV_STAMPS
 __device__ unsigned long long g_cv_stamps[64];
-__device__ unsigned long long g_tile_stamps[64];
+__device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (dispatch-order ids 1, 511, 1021, ...) x 16 stamps
 #define CV_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cv_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define TILE_STAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && threadIdx.x == 0) g_tile_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TILE_STAMP(i) do { const unsigned lin__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+        if (threadIdx.x == 0 && lin__ % 510 == 1 && lin__ / 510 < 8) g_tile_stamps[(lin__ / 510) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CV_STAMP(i)
 #define TILE_STAMP(i)
@@ -722,13 +723,22 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     }
     __syncthreads();
     TILE_STAMP(1);
+#ifdef CV_STAMPS_DRAIN
+    __builtin_amdgcn_s_waitcnt(0);  // every counter to zero: is the long first pass a wait for loads still in flight?
+    __syncthreads();
+    TILE_STAMP(11);
+#endif
     // one half-sweep of colour c (compile-time, so the per-colour coefficients, source registers, column predicate and LDS
     // addresses are loop-invariant: the sweep loop is VALU-issue bound and every select / address add costs 4 cycles per row)
+    // Every LDS address of the sweep is (one per-colour base pointer) + (compile-time row offset): the bases cost four
+    // registers per colour and the row offsets become DS immediates.
+    const int rb = w * 64 + lane;  // slot of this lane in the wave's first row
     auto half_sweep = [&](auto colour, const int hs) {
         constexpr int c = decltype(colour)::value;
-        double* mine = c ? A1 : A0;
-        const double* oth = c ? A0 : A1;
         const int pr = (c + w) & 1;  // column parity of colour c in this wave's rows
+        double* mine = (c ? A1 : A0) + rb;
+        const double* oth = (c ? A0 : A1) + rb;
+        const double* othWE = oth + (pr - 1);
         const double ae = c ? aeC1 : aeC0, aw = c ? awC1 : awC0;
         const int col = 2 * lane + pr, gc = r0 + col;
         const bool colok = col >= 1 && col <= 126 && gc >= 1 && gc <= nr - 2;
@@ -736,14 +746,15 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
 #pragma unroll
         for (int i = 0; i < NROWS; ++i) {
             const int lz = w + NW * i, gz = z0 + lz;
+            constexpr int RS = NW * 64;  // doubles between two rows of a wave
             if (lz >= hs + 1 && lz <= LZ - 2 - hs && gz >= 1 && gz <= nz - 2) {  // wave-uniform
-                const double W = oth[lz * 64 + lane - 1 + pr], E = oth[lz * 64 + lane + pr];
-                const double Sv = oth[(lz - 1) * 64 + lane], N = oth[(lz + 1) * 64 + lane];
-                const double C = mine[lz * 64 + lane];
+                const double W = othWE[i * RS], E = othWE[i * RS + 1];
+                const double Sv = oth[i * RS - 64], N = oth[i * RS + 64];
+                const double C = mine[i * RS];
                 const double sv = c ? sC1[i] : sC0[i];
                 const double gsv = divc(ae * E + aw * W + a_ns * Sv + a_ns * N - sv, a_c, inv_a_c);
                 const double nw = om1 * C + omega * gsv;
-                if (colok) mine[lz * 64 + lane] = nw;
+                if (colok) mine[i * RS] = nw;
             }
         }
     };

@@ -2083,7 +2083,7 @@ int scpn_gs_sample_psi(scpn_gs* g, int n_pts, const double* pts_r, const double*
 #ifdef CV_STAMPS
 int scpn_debug_tile_stamps(unsigned long long* out) {
     (void)hipDeviceSynchronize();
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -2;
 }
 int scpn_debug_cv_stamps(unsigned long long* out) {
     (void)hipDeviceSynchronize();

@@ -5,19 +5,26 @@ sys.path.insert(0, ".")
 import numpy as np
 from scpn_fusion_core_amd.ensemble import EnsembleSolver
 from tests._problems import iter_like_cfg, bench_problem
-for n, B in ((513, 32), (257, 16)):
+for n, B in ((513, 32),):
     es = EnsembleSolver(iter_like_cfg(n), batch=B)
     psi0, src, rr, r, z = bench_problem(n, n)
     es.set_psi(np.broadcast_to(psi0, (B, n, n)).copy()); es.set_source(np.broadcast_to(src, (B, n, n)).copy())
     for _ in range(5): es.rb_sor(1.3, 3)
     L = C.CDLL(os.environ["SCPN_HIP_LIB"])
-    buf = (C.c_ulonglong * 64)()
+    buf = (C.c_ulonglong * 128)()
     L.scpn_debug_tile_stamps(buf)
-    st = list(buf)
-    names = ["start", "loaded"] + [f"pass {i}" for i in range(6)] + ["", "", "stored"]
-    prev = st[0]
-    print(f"--- n={n} B={B} tile (1,1) of member 0")
-    for i in (0, 1, 2, 3, 4, 5, 6, 7, 10):
-        print(f"{names[i]:10s} +{(st[i]-prev)*0.01:6.2f} us  (t={(st[i]-st[0])*0.01:6.2f})")
-        prev = st[i]
+    names = ["start", "loaded"] + [f"pass {i}" for i in range(6)] + ["", "", "stored", "drain"]
+    idx = (0, 1, 11, 2, 3, 4, 5, 6, 7, 10) if os.environ.get("STAMPS_DRAIN") else (0, 1, 2, 3, 4, 5, 6, 7, 10)
+    print(f"--- n={n} B={B}: per-phase us of 8 sampled workgroups (dispatch ids 1, 511, ...); last column = start offset")
+    rows = []
+    for g in range(8):
+        st = list(buf)[g * 16:(g + 1) * 16]
+        if st[0] == 0:
+            continue
+        d = [(st[idx[j]] - st[idx[j - 1]]) * 0.01 for j in range(1, len(idx))]
+        rows.append((g, d, (st[10] - st[0]) * 0.01, st[0]))
+    t0 = min(r[3] for r in rows)
+    print("wg   " + " ".join(f"{names[i]:>7s}" for i in idx[1:]) + "   total   start")
+    for g, d, tot, s0 in rows:
+        print(f"{g:2d}   " + " ".join(f"{x:7.2f}" for x in d) + f" {tot:7.2f} {(s0 - t0) * 0.01:7.2f}")
     es.close()
