@@ -493,7 +493,13 @@ struct SrcGen {
 __device__ unsigned long long g_cv_stamps[64];
 __device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (dispatch-order ids 1, 511, 1021, ...) x 16 stamps
 #define CV_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cv_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define TILE_STAMP(i) do { const unsigned lin__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+#ifndef STAMP_DEFECT
+#define STAMP_DEFECT false
+#endif
+#ifndef STAMP_PROLONG
+#define STAMP_PROLONG false
+#endif
+#define TILE_STAMP(i) do { if (DEFECT != STAMP_DEFECT || PROLONG != STAMP_PROLONG || L.nz < 300) break; const unsigned lin__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
         if (threadIdx.x == 0 && lin__ % 510 == 1 && lin__ / 510 < 8) g_tile_stamps[(lin__ / 510) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CV_STAMP(i)
@@ -791,6 +797,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             }
         }
     }
+    TILE_STAMP(8);
     if (DEFECT) {
         // (1) defect d = -(L*psi - src) of this wave's rows, both colours, into the source registers
         double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0;  // r_safe / its reciprocal of the lane's even / odd column
@@ -830,6 +837,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             if (lz < LZ) { A0[lz * 64 + lane] = sC0[i]; A1[lz * 64 + lane] = sC1[i]; }
         }
         __syncthreads();
+        TILE_STAMP(9);
         // (3) full-weighting restriction of the window's even/even points; coarse ring = injected -0.0
         constexpr int CZ = (LZ - 2 * H) / 2, CR = (128 - 2 * H) / 2;
         double* rc = coarseF.at(b);
