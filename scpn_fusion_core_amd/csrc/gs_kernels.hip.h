@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
         const unsigned total = gx * gy * gz;
         unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        if (xcd_remap) lin = xcd_contiguous(lin, total);
+        if (xcd_remap & 1) lin = xcd_contiguous(lin, total);
         bx_ = (int)(lin % gx);
         const unsigned t = lin / gx;
         by_ = (int)(t % gy);
@@ -699,8 +699,12 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
                     if (oky) vy = vy + py;
                 }
                 // even column has colour (gz & 1) == (lz & 1) == e0 ? 1 : 0 since z0, c0 are even
-                if (e0) { A1[lz * 64 + lane] = vx; A0[lz * 64 + lane] = vy; sC1[i] = sx; sC0[i] = sy; }
-                else { A0[lz * 64 + lane] = vx; A1[lz * 64 + lane] = vy; sC0[i] = sx; sC1[i] = sy; }
+                double* const pe = (e0 ? A1 : A0) + (w * 64 + lane);  // plane of the even column
+                double* const po = (e0 ? A0 : A1) + (w * 64 + lane);
+                pe[i * NW * 64] = vx;
+                po[i * NW * 64] = vy;
+                if (e0) { sC1[i] = sx; sC0[i] = sy; }
+                else { sC0[i] = sx; sC1[i] = sy; }
             }
         }
         if (PROLONG) __builtin_amdgcn_sched_barrier(0);  // keep the next group's loads behind this group's LDS writes
@@ -779,8 +783,8 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         const int lz = w + NW * i, gz = z0 + lz;
         if (lz >= H && lz < LZ - H && gz < nz) {
             double vx, vy;
-            if (e0) { vx = A1[lz * 64 + lane]; vy = A0[lz * 64 + lane]; }
-            else { vx = A0[lz * 64 + lane]; vy = A1[lz * 64 + lane]; }
+            if (e0) { vx = (A1 + rb)[i * NW * 64]; vy = (A0 + rb)[i * NW * 64]; }
+            else { vx = (A0 + rb)[i * NW * 64]; vy = (A1 + rb)[i * NW * 64]; }
             const int col = 2 * lane;
             long o = (long)gz * ld + c0;
             if (col >= H && col + 1 < 128 - H && c0 + 1 < nr) {
@@ -805,20 +809,22 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { rs1 = dd.r_safe[c0 + 1]; ri1 = dd.r_inv[c0 + 1]; }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const double* mine = c ? A1 : A0;
-            const double* oth = c ? A0 : A1;
             const int pr = (c + w) & 1;
+            const double* mine = (c ? A1 : A0) + rb;  // per-colour bases + compile-time row offsets, as in the sweeps
+            const double* oth = (c ? A0 : A1) + rb;
+            const double* othWE = oth + (pr - 1);
             const int col = 2 * lane + pr, gc = r0 + col;
             const bool colok = col >= 1 && col <= 126 && gc >= 1 && gc <= nr - 2;
             const double rs = pr ? rs1 : rs0, ri = pr ? ri1 : ri0;
 #pragma unroll
             for (int i = 0; i < NROWS; ++i) {
                 const int lz = w + NW * i, gz = z0 + lz;
+                constexpr int RS = NW * 64;
                 double d = -0.0;
                 if (lz >= H - 1 && lz <= LZ - H && gz >= 1 && gz <= nz - 2) {  // wave-uniform
-                    const double W = oth[lz * 64 + lane - 1 + pr], E = oth[lz * 64 + lane + pr];
-                    const double Sv = oth[(lz - 1) * 64 + lane], N = oth[(lz + 1) * 64 + lane];
-                    const double C = mine[lz * 64 + lane];
+                    const double W = othWE[i * RS], E = othWE[i * RS + 1];
+                    const double Sv = oth[i * RS - 64], N = oth[i * RS + 64];
+                    const double C = mine[i * RS];
                     const double sv = c ? sC1[i] : sC0[i];
                     const double d2r = divc(E - 2.0 * C + W, dd.dr2, dd.inv_dr2);
                     const double d1r = divc(E - W, dd.two_dr, dd.inv_two_dr);
@@ -834,7 +840,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
 #pragma unroll
         for (int i = 0; i < NROWS; ++i) {
             const int lz = w + NW * i;
-            if (lz < LZ) { A0[lz * 64 + lane] = sC0[i]; A1[lz * 64 + lane] = sC1[i]; }
+            if (lz < LZ) { (A0 + rb)[i * NW * 64] = sC0[i]; (A1 + rb)[i * NW * 64] = sC1[i]; }
         }
         __syncthreads();
         TILE_STAMP(9);

@@ -343,7 +343,8 @@ struct DefectOut {  // coarse rhs / coarse correction produced by the fused defe
 // tile geometry variants: 0 = 78 rows / 16 waves (one workgroup per CU), 1 = 40 rows / 8 waves (two per CU), 2 = 46 rows / 16 waves
 struct TileGeo { int lz, nw; };
 #ifndef TILE_WPE_V1
-#define TILE_WPE_V1 4  // minimum waves per SIMD of the 40-row / 8-wave tile kernels (register cap 512 / TILE_WPE_V1)
+#define TILE_WPE_V1 6  // minimum waves per SIMD of the 40-row / 8-wave tile kernels: at most 80 VGPRs = three workgroups per CU
+                       // (tools/isa_regs.py on the hipcc -S output shows the allocation and any scratch the cap would force)
 #endif
 static int tile_variant_for(const Lvl& L) {
     // SCPN_HIP_TILE="v0,v1,v2": variant for level 0, 1, 2+.  Default 1,1,1: measured on MI355X (513^2, 16 members per
