@@ -116,6 +116,9 @@ int scpn_green_points(int n_coils, const double *coil_r, const double *coil_z, i
 int scpn_probe_response(int n_coils, const double *coil_r, const double *coil_z, const double *coil_turns,
                         int n_flux, const double *flux_r, const double *flux_z, int n_b, const double *b_r,
                         const double *b_z, const int *b_dir, double *out);
+/* Verification hook: the two division-by-reciprocal sequences of the kernels (5 and 4 instructions, see csrc/gs_kernels.hip.h
+ * divc / divc4) applied to caller-supplied x[i] / d[i]; both must equal IEEE division (NumPy's `/`) bit for bit. */
+int scpn_verify_division(const double *x, const double *d, int n, double *q5, double *q4);
 /* polyglot lane diagnostics, core/jax_gs_solver.py:196-316: gs_delta_star_np (zero ring; out [nz][nr]) and
  * gs_equation_residual_np (out3 = abs_max, relative_max, relative_l2 of the discrete equation imbalance with the lane's own
  * source normalisation) */

@@ -96,6 +96,7 @@ SIGNATURES = {
     "scpn_sor_step": (_i, [_dp, _dp, _dp, _i, _i, _i, _d, _d, _d, _dp]),
     "scpn_coil_flux": (_i, [_dp, _dp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _i, _dp]),
     "scpn_green_points": (_i, [_i, _dp, _dp, _i, _dp, _dp, _dp]),
+    "scpn_verify_division": (_i, [_dp, _dp, _i, _dp, _dp]),
     "scpn_np_delta_star": (_i, [_dp, _i, _i, _dp, _d, _d, _dp]),
     "scpn_np_equation_residual": (_i, [_dp, _i, _i, _dp, _dp, _d, _d, _d, _dp]),
     "scpn_tridiag_solve": (_i, [_i, _i, _vp, _dp, _vp, _dp, _dp, _vp]),

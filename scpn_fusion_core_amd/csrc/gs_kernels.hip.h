@@ -23,10 +23,12 @@ struct Lvl {
     long stride;
     double a_ns, a_c, dr2, dz2, two_dr, dr, dz;
     double inv_a_c, inv_dr2, inv_dz2, inv_two_dr;  // correctly rounded reciprocals (host IEEE division) for divc()
+    double lo_a_c, lo_dr2, lo_dz2, lo_two_dr;      // second words of the reciprocals (1/d - RN(1/d)) for divc4()
     const double* a_e;
     const double* a_w;
     const double* r_safe;
-    const double* r_inv;  // RN(1/r_safe[ir])
+    const double* r_inv;     // RN(1/r_safe[ir])
+    const double* r_inv_lo;  // 1/r_safe[ir] - r_inv[ir]
 };
 
 // x / d for a divisor whose correctly rounded reciprocal r = RN(1/d) is known.  q0 = RN(x*r) is within
@@ -41,6 +43,23 @@ __device__ __forceinline__ double divc(double x, double d, double r) {
     q = __builtin_fma(e, r, q);
     e = __builtin_fma(-q, d, x);
     return __builtin_fma(e, r, q);
+}
+
+// The same quotient in 4 instructions for the hot loops: with the reciprocal as a double-double (r + rl = 1/d to ~2^-106),
+// q0 = RN(x*r + RN(x*rl)) is already within 0.5 ulp + 2^-105 of x/d, i.e. faithful, so ONE Markstein correction with the
+// correctly rounded r gives the correctly rounded quotient (same theorem as the last step of divc).
+__device__ __forceinline__ double divc4(double x, double d, double r, double rl) {
+    double q = __builtin_fma(x, r, x * rl);
+    double e = __builtin_fma(-q, d, x);
+    return __builtin_fma(e, r, q);
+}
+
+// verification hook (tests/test_gpu_division.py): both sequences against IEEE division on arbitrary (x, d) pairs
+__global__ void k_verify_div(const double* x, const double* d, const double* r, const double* rl, int n, double* q5, double* q4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    q5[i] = divc(x[i], d[i], r[i]);
+    q4[i] = divc4(x[i], d[i], r[i], rl[i]);
 }
 
 // Workgroups are dealt to the 8 XCDs round-robin in linear-id order (id i runs on XCD i % 8).  xcd_contiguous maps the
@@ -546,9 +565,10 @@ struct BlendArgs {
 };
 struct DefectDst {
     Fld e{nullptr, nullptr, 0, 0};
-    double dr2 = 1, dz2 = 1, two_dr = 1, inv_dr2 = 1, inv_dz2 = 1, inv_two_dr = 1;
+    double dr2 = 1, dz2 = 1, two_dr = 1, inv_dr2 = 1, inv_dz2 = 1, inv_two_dr = 1, lo_dr2 = 0, lo_dz2 = 0, lo_two_dr = 0;
     const double* r_safe = nullptr;
     const double* r_inv = nullptr;
+    const double* r_inv_lo = nullptr;
 };
 // LZT rows x 128 columns per tile, NWT waves per workgroup, WPEU = minimum waves per SIMD the register allocation must allow
 // (78/16/1: one 16-wave workgroup per CU; 40/8/4: two 8-wave workgroups per CU, so one loads while the other computes)
@@ -627,7 +647,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     double ae0 = 0.0, ae1 = 0.0, aw0 = 0.0, aw1 = 0.0;
     if (c0 >= 1 && c0 <= nr - 2) { ae0 = L.a_e[c0]; aw0 = L.a_w[c0]; }
     if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { ae1 = L.a_e[c0 + 1]; aw1 = L.a_w[c0 + 1]; }
-    const double a_ns = L.a_ns, a_c = L.a_c, inv_a_c = L.inv_a_c;
+    const double a_ns = L.a_ns, a_c = L.a_c, inv_a_c = L.inv_a_c, lo_a_c = L.lo_a_c;
     // every row of this wave has the parity of w (lz = w + 8i), so the lane's element (0: even column, 1: odd
     // column) that carries colour c is e(c) = (c + w) & 1 for all rows: per-colour registers, no per-row selects
     const int e0 = w & 1;  // element index of colour 0
@@ -762,7 +782,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
                 const double Sv = oth[i * RS - 64], N = oth[i * RS + 64];
                 const double C = mine[i * RS];
                 const double sv = c ? sC1[i] : sC0[i];
-                const double gsv = divc(ae * E + aw * W + a_ns * Sv + a_ns * N - sv, a_c, inv_a_c);
+                const double gsv = divc4(ae * E + aw * W + a_ns * Sv + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
                 const double nw = om1 * C + omega * gsv;
                 if (colok) mine[i * RS] = nw;
             }
@@ -804,9 +824,9 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     TILE_STAMP(8);
     if (DEFECT) {
         // (1) defect d = -(L*psi - src) of this wave's rows, both colours, into the source registers
-        double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0;  // r_safe / its reciprocal of the lane's even / odd column
-        if (c0 >= 1 && c0 <= nr - 2) { rs0 = dd.r_safe[c0]; ri0 = dd.r_inv[c0]; }
-        if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { rs1 = dd.r_safe[c0 + 1]; ri1 = dd.r_inv[c0 + 1]; }
+        double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0;  // r_safe / its reciprocal (two words) of the lane's even / odd column
+        if (c0 >= 1 && c0 <= nr - 2) { rs0 = dd.r_safe[c0]; ri0 = dd.r_inv[c0]; rl0 = dd.r_inv_lo[c0]; }
+        if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { rs1 = dd.r_safe[c0 + 1]; ri1 = dd.r_inv[c0 + 1]; rl1 = dd.r_inv_lo[c0 + 1]; }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int pr = (c + w) & 1;
@@ -815,7 +835,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             const double* othWE = oth + (pr - 1);
             const int col = 2 * lane + pr, gc = r0 + col;
             const bool colok = col >= 1 && col <= 126 && gc >= 1 && gc <= nr - 2;
-            const double rs = pr ? rs1 : rs0, ri = pr ? ri1 : ri0;
+            const double rs = pr ? rs1 : rs0, ri = pr ? ri1 : ri0, rl = pr ? rl1 : rl0;
 #pragma unroll
             for (int i = 0; i < NROWS; ++i) {
                 const int lz = w + NW * i, gz = z0 + lz;
@@ -826,10 +846,10 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
                     const double Sv = oth[i * RS - 64], N = oth[i * RS + 64];
                     const double C = mine[i * RS];
                     const double sv = c ? sC1[i] : sC0[i];
-                    const double d2r = divc(E - 2.0 * C + W, dd.dr2, dd.inv_dr2);
-                    const double d1r = divc(E - W, dd.two_dr, dd.inv_two_dr);
-                    const double d2z = divc(N - 2.0 * C + Sv, dd.dz2, dd.inv_dz2);
-                    const double lpsi = d2r - divc(d1r, rs, ri) + d2z;
+                    const double d2r = divc4(E - 2.0 * C + W, dd.dr2, dd.inv_dr2, dd.lo_dr2);
+                    const double d1r = divc4(E - W, dd.two_dr, dd.inv_two_dr, dd.lo_two_dr);
+                    const double d2z = divc4(N - 2.0 * C + Sv, dd.dz2, dd.inv_dz2, dd.lo_dz2);
+                    const double lpsi = d2r - divc4(d1r, rs, ri, rl) + d2z;
                     if (colok) d = -(lpsi - sv);
                 }
                 if (c) sC1[i] = d; else sC0[i] = d;
@@ -1752,10 +1772,10 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
         const double p = t[lz][lr];
         if (gz >= 1 && gz <= nz - 2 && gr >= 1 && gr <= nr - 2) {
             const double e = t[lz][lr + 1], w = t[lz][lr - 1], n = t[lz + 1][lr], so = t[lz - 1][lr];
-            const double d2r = divc(e - 2.0 * p + w, L.dr2, L.inv_dr2);
-            const double d1r = divc(e - w, L.two_dr, L.inv_two_dr);
-            const double d2z = divc(n - 2.0 * p + so, L.dz2, L.inv_dz2);
-            const double lpsi = d2r - divc(d1r, L.r_safe[gr], L.r_inv[gr]) + d2z;
+            const double d2r = divc4(e - 2.0 * p + w, L.dr2, L.inv_dr2, L.lo_dr2);
+            const double d1r = divc4(e - w, L.two_dr, L.inv_two_dr, L.lo_two_dr);
+            const double d2z = divc4(n - 2.0 * p + so, L.dz2, L.inv_dz2, L.lo_dz2);
+            const double lpsi = d2r - divc4(d1r, L.r_safe[gr], L.r_inv[gr], L.r_inv_lo[gr]) + d2z;
             double sv = src[(long)gz * ld + gr];
             if (lazy_nm) sv = lazy_nm[gr] * (lz_sc != 0.0 ? sv * lz_sc : 0.0);  // srcF holds J_raw (see k_smooth_tile)
             const double r = sanitize1(lpsi - sv);

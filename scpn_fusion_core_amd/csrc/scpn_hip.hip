@@ -97,7 +97,7 @@ struct LevelHost {
     long stride;
     double dr, dz;
     std::vector<double> r;  // 1-D R of this level (interior columns follow the full-weighting of the finer R)
-    DBuf<double> a_e, a_w, r_safe, r_inv;
+    DBuf<double> a_e, a_w, r_safe, r_inv, r_inv_lo;
     DBuf<double> psi, psi2, rhs;  // level >= 1: correction e (+ ping-pong twin) and restricted defect
     Lvl dev{};
 };
@@ -228,7 +228,9 @@ struct ProfScope {
 static void build_level_tables(LevelHost* L) {
     // core/multigrid_solve.py:181-189 (dr**2 is libm pow in CPython)
     const double dr2 = std::pow(L->dr, 2.0), dz2 = std::pow(L->dz, 2.0);
-    std::vector<double> ae(L->nr, 0.0), aw(L->nr, 0.0), rs(L->nr, 1.0), ri(L->nr, 1.0);
+    std::vector<double> ae(L->nr, 0.0), aw(L->nr, 0.0), rs(L->nr, 1.0), ri(L->nr, 1.0), rl(L->nr, 0.0);
+    // second word of a reciprocal: 1 - d*RN(1/d) is exact in one FMA; divided by d it gives 1/d - RN(1/d) to 53 bits
+    auto recip_lo = [](double d) { return std::fma(-d, 1.0 / d, 1.0) / d; };
     for (int ir = 0; ir < L->nr; ++ir) {
         double r_safe = std::fmax(L->r[ir], 1e-10);
         double t = 1.0 / ((2.0 * r_safe) * L->dr);
@@ -236,12 +238,15 @@ static void build_level_tables(LevelHost* L) {
         aw[ir] = 1.0 / dr2 + t;
         rs[ir] = r_safe;
         ri[ir] = 1.0 / r_safe;
+        rl[ir] = recip_lo(r_safe);
     }
     L->a_e.alloc(L->nr);
     L->a_w.alloc(L->nr);
     L->r_safe.alloc(L->nr);
     L->r_inv.alloc(L->nr);
+    L->r_inv_lo.alloc(L->nr);
     HIP_TRY(hipMemcpy(L->r_inv.p, ri.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(L->r_inv_lo.p, rl.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(L->a_e.p, ae.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(L->a_w.p, aw.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(L->r_safe.p, rs.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
@@ -251,7 +256,8 @@ static void build_level_tables(LevelHost* L) {
     d.a_c = 2.0 / dr2 + 2.0 / dz2;
     d.dr2 = dr2; d.dz2 = dz2; d.two_dr = 2.0 * L->dr; d.dr = L->dr; d.dz = L->dz;
     d.inv_a_c = 1.0 / d.a_c; d.inv_dr2 = 1.0 / dr2; d.inv_dz2 = 1.0 / dz2; d.inv_two_dr = 1.0 / d.two_dr;
-    d.a_e = L->a_e.p; d.a_w = L->a_w.p; d.r_safe = L->r_safe.p; d.r_inv = L->r_inv.p;
+    d.lo_a_c = recip_lo(d.a_c); d.lo_dr2 = recip_lo(dr2); d.lo_dz2 = recip_lo(dz2); d.lo_two_dr = recip_lo(d.two_dr);
+    d.a_e = L->a_e.p; d.a_w = L->a_w.p; d.r_safe = L->r_safe.p; d.r_inv = L->r_inv.p; d.r_inv_lo = L->r_inv_lo.p;
     L->dev = d;
 }
 
@@ -384,6 +390,7 @@ static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, doubl
     if (DEFECT || BLEND) {  // residual constants of this level
         dd.dr2 = L.dr2; dd.dz2 = L.dz2; dd.two_dr = L.two_dr; dd.inv_dr2 = L.inv_dr2; dd.inv_dz2 = L.inv_dz2;
         dd.inv_two_dr = L.inv_two_dr; dd.r_safe = L.r_safe; dd.r_inv = L.r_inv;
+        dd.lo_dr2 = L.lo_dr2; dd.lo_dz2 = L.lo_dz2; dd.lo_two_dr = L.lo_two_dr; dd.r_inv_lo = L.r_inv_lo;
     }
     if (DEFECT) {
         dd.e = dfo->e;
@@ -2551,6 +2558,27 @@ int scpn_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int
         hipLaunchKernelGGL(k_axpby, g2, BLK2D, 0, st, psiF, psiF, in, 1.0 - alpha, alpha, nz, nr, h->ld);
     }
     download(h, h->psi_slots.p, 0, psi_out);
+    API_END
+}
+
+// The device's division-by-reciprocal sequences on caller-supplied operands (the reciprocal words are formed here exactly as
+// build_level_tables forms them); lets the tests compare them with IEEE division on hard-to-round cases.
+int scpn_verify_division(const double* x, const double* d, int n, double* q5, double* q4) {
+    if (!x || !d || !q5 || !q4 || n < 1) return fail(SCPN_E_ARG, "scpn_verify_division: null buffer or n < 1");
+    API_BEGIN
+    std::vector<double> r(n), rl(n);
+    for (int i = 0; i < n; ++i) { r[i] = 1.0 / d[i]; rl[i] = std::fma(-d[i], r[i], 1.0) / d[i]; }
+    DBuf<double> dx, dd_, dr_, dl, o5, o4;
+    dx.alloc(n); dd_.alloc(n); dr_.alloc(n); dl.alloc(n); o5.alloc(n); o4.alloc(n);
+    HIP_TRY(hipMemcpy(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dd_.p, d, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dr_.p, r.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dl.p, rl.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_verify_div, dim3(cdiv(n, 256)), dim3(256), 0, nullptr, (const double*)dx.p, (const double*)dd_.p, (const double*)dr_.p,
+                       (const double*)dl.p, n, o5.p, o4.p);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(q5, o5.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(q4, o4.p, sizeof(double) * n, hipMemcpyDeviceToHost));
     API_END
 }
 
