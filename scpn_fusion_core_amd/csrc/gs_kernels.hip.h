@@ -1739,6 +1739,7 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
     double dsum = 0.0, minpsi = INFINITY;
     int bad = 0;
     VI mx{0.0, -1}, mn{0.0, -1};
+#ifdef BLEND_SERIAL_LOADS
     for (int i = tid; i < (BT_Z + 2) * (BT_R + 2); i += 256) {
         const int lz = i / (BT_R + 2), lr = i - lz * (BT_R + 2);
         const int gz = z0 + lz, gr = r0 + lr;
@@ -1760,6 +1761,46 @@ __global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld new
         }
         t[lz][lr] = v;
     }
+#else
+    // all loads of the thread's tile elements are issued before the first use (one memory round trip instead of one per element)
+    constexpr int NEL = (BT_Z + 2) * (BT_R + 2), NLD = (NEL + 255) / 256;
+    double pcv[NLD], pnv[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + 256 * k;
+        const int lz = i / (BT_R + 2), lr = i - lz * (BT_R + 2);
+        const int gz = z0 + lz, gr = r0 + lr;
+        pcv[k] = 0.0;
+        pnv[k] = 0.0;
+        if (i < NEL && gz >= 0 && gz < nz && gr >= 0 && gr < nr) {
+            const long c = (long)gz * ld + gr;
+            const bool ring = gz == 0 || gz == nz - 1 || gr == 0 || gr == nr - 1;
+            pnv[k] = ring ? bc[c] : nw[c];
+            pcv[k] = cur[c];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + 256 * k;
+        if (i >= NEL) continue;
+        const int lz = i / (BT_R + 2), lr = i - lz * (BT_R + 2);
+        const int gz = z0 + lz, gr = r0 + lr;
+        double v = 0.0;
+        if (gz >= 0 && gz < nz && gr >= 0 && gr < nr) {
+            const double pn = pnv[k], pc = pcv[k];
+            v = om_alpha * pc + alpha * pn;
+            if (lz >= 1 && lz <= BT_Z && lr >= 1 && lr <= BT_R) {  // owned point
+                if (!finite_d(pn)) bad = 1;
+                dsum += fabs(pn - pc);
+                nxt[(long)gz * ld + gr] = v;
+                const long q = (long)gz * nr + gr;
+                if (v == v) mx = vi_max(mx, VI{v, q});
+                if (finite_d(v)) minpsi = fmin(minpsi, v);
+            }
+        }
+        t[lz][lr] = v;
+    }
+#endif
     __syncthreads();
     double m = 0.0, rv[BT_Z / 4];
     const double lz_sc = lazy_nm ? st[b].jscale : 1.0;

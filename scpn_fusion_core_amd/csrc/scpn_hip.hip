@@ -943,10 +943,9 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         h->and_fb.alloc(B);
     }
     // lazy source: k_jsum keeps J_raw in the source field and the level-0 consumers (tile pre / post smoother, fused tail)
-    // apply (-mu0 R) * (J_raw * scale) on load -- the k_source pass over the fine grid disappears.  Bit-identical, but measured
-    // neutral to slightly slower on MI355X (186.0 vs 187.8 eq/s): the J_raw store costs what the source store did and the psi
-    // re-read it saves was an L2 / MALL hit.  Opt-in: SCPN_HIP_LAZYSRC=1
-    static const bool lazy_env = [] { const char* e = std::getenv("SCPN_HIP_LAZYSRC"); return e && e[0] == '1'; }();
+    // apply (-mu0 R) * (J_raw * scale) on load -- the k_source pass over the fine grid disappears (bit-identical; -1.1 % per
+    // iteration on MI355X).  SCPN_HIP_LAZYSRC=0 restores the separate source pass
+    static const bool lazy_env = [] { const char* e = std::getenv("SCPN_HIP_LAZYSRC"); return !(e && e[0] == '0'); }();
     static const bool srcgen_env0 = [] { const char* e = std::getenv("SCPN_HIP_SRCGEN"); return e && e[0] == '1'; }();
     static const bool blend_env0 = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1'; }();
     const bool lazy = lazy_env && !srcgen_env0 && !blend_env0 && h->use_fused && p->method == 0 && !p->external_profile_mode &&

@@ -16,7 +16,7 @@ SWITCHES = [
     {"SCPN_HIP_XCD": "0"},
     {"SCPN_HIP_TILE": "0,0,0"},
     {"SCPN_HIP_TILE": "2,2,2"},
-    {"SCPN_HIP_LAZYSRC": "1"},
+    {"SCPN_HIP_LAZYSRC": "0"},
     {"SCPN_HIP_SRCGEN": "1"},
     {"SCPN_HIP_BLENDFUSE": "1"},
     {"SCPN_HIP_GRAPH": "1"},
