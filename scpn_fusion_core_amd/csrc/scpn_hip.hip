@@ -138,6 +138,7 @@ struct Solver {
     Solver* partner = nullptr;  // the other stream group (exactly two groups), or nullptr
     int phase_role = 0;         // 0: leader (waits partner.seq >= seq), 1: follower (waits partner.seq >= seq + 1)
     bool phase_active = false;  // set by the Picard driver for the duration of its loop
+    int phase_mode = 1;         // 1: the fine-level (bandwidth) phases of the two groups exclude each other; 2: the coarse-level phases do
     int nr = 0, nz = 0, B = 0, ld = 0;
     long stride = 0;
     double dr = 0, dz = 0;
@@ -413,7 +414,7 @@ static void launch_tile_geo(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, d
         case 1: launch_tile<S, PROLONG, false, DEFECT, BLEND, 40, 8, TILE_WPE_V1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
         case 2: launch_tile<S, PROLONG, false, DEFECT, BLEND, 46, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
 #ifdef TILE_EXPERIMENTS
-        case 3: launch_tile<S, PROLONG, false, DEFECT, BLEND, 48, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
+        case 3: launch_tile<S, PROLONG, false, DEFECT, BLEND, 48, 8, 6>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
         case 4: launch_tile<S, PROLONG, false, DEFECT, BLEND, 56, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
         case 5: launch_tile<S, PROLONG, false, DEFECT, BLEND, 64, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
         case 6: launch_tile<S, PROLONG, false, DEFECT, BLEND, 32, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
@@ -585,7 +586,7 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
                 cur[0] = smooth(h, L0, r, bufB, src0, omega, n0 - 3, active, false, 0, nullptr, nullptr, df ? &d0 : nullptr);
             }
             defect_done0 = df;
-            if (k > 0) phase_release(h);
+            if (k > 0) { if (h->phase_mode == 2) phase_acquire(h); else phase_release(h); }
         } else {
             ProfScope ps(h, "copy", 1);
             hipLaunchKernelGGL(k_copy, grid2d(L0.nr, L0.nz, B), BLK2D, 0, h->stream, bufA, in0, L0.nz, L0.nr, L0.ld, (const int*)nullptr);
@@ -628,7 +629,7 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
         const Lvl& Lf = lv[l]->dev;
         const Lvl& Lc = lv[l + 1]->dev;
         const bool tile_post = fused && post > 0 && (long)Lf.nz * Lf.nr > SMALL_MAX;
-        if (l == 0 && tile0_done) phase_acquire(h);
+        if (l == 0 && tile0_done) { if (h->phase_mode == 2) phase_release(h); else phase_acquire(h); }
         if (tile_post) {  // prolongation fused into the post-smoother's tile load
             ProlongSrc pso;
             pso.c = cur[l + 1]; pso.nz_c = Lc.nz; pso.nr_c = Lc.nr; pso.ld_c = Lc.ld;
@@ -955,14 +956,17 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         ~LazyGuard() { h->lazy_src = nullptr; }
     } lazy_guard{h};
     if (lazy) h->lazy_src = srcF.base;
-    // phase alternation with the partner stream group (see PhaseSync).  Measured on MI355X: 177.5 vs 188.4 eq/s -- the level-0
-    // kernels are bound by workgroup residency on the CUs rather than by HBM, so chaining the groups' bandwidth phases only
-    // removes overlap.  Opt-in: SCPN_HIP_PHASE=1
+    // phase alternation with the partner stream group (see PhaseSync).  Measured on MI355X (us per iteration of the 32-member
+    // ensemble): free-running 365, fine-level phases chained (SCPN_HIP_PHASE=1) 376, coarse-level phases chained (=2) 388 -- the
+    // level-0 kernels are bound by fp64 issue / workgroup residency on the CUs rather than by HBM, so two of them share the chip
+    // without loss and any chain only removes overlap.  Opt-in.
     static const bool phase_env = [] {
         const char* e = std::getenv("SCPN_HIP_PHASE");
         const char* g = std::getenv("SCPN_HIP_GRAPH");  // (events of another stream cannot be waited on inside a capture)
-        return e && e[0] == '1' && !(g && g[0] == '1');
+        return e && (e[0] == '1' || e[0] == '2') && !(g && g[0] == '1');
     }();
+    static const int phase_mode_env = [] { const char* e = std::getenv("SCPN_HIP_PHASE"); return (e && e[0] == '2') ? 2 : 1; }();
+    h->phase_mode = phase_mode_env;
     struct PhaseGuard {
         Solver* h;
         ~PhaseGuard() {

@@ -22,6 +22,7 @@ SWITCHES = [
     {"SCPN_HIP_GRAPH": "1"},
     {"SCPN_HIP_GROUPS": "2"},
     {"SCPN_HIP_PHASE": "1", "SCPN_HIP_GROUPS": "2"},
+    {"SCPN_HIP_PHASE": "2", "SCPN_HIP_GROUPS": "2"},
     {"SCPN_HIP_DEFECT_MINLVL": "9"},
 ]
 
