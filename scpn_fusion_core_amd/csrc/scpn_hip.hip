@@ -164,6 +164,9 @@ struct Solver {
     DBuf<Member> d_st;
     DBuf<MgMember> d_mg;
     DBuf<int> d_cur, d_nxt, d_best, d_prev, d_active, d_nactive, d_pbad;
+    DBuf<int> d_scr_part, d_scr_zc, d_scr_sa, d_scr_mask;  // per-call masks of the Picard / free-boundary drivers
+    DBuf<double> d_scr_diff;
+    DBuf<Member> d_scr_st;
     DBuf<double> d_part1, d_part2, d_part3, d_jpart;  // reduction partials [B][nblk]
     DBuf<TopoPart> d_topo;
     DBuf<double> d_scal;
@@ -827,7 +830,8 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     // "all members that take part" mask for the preparation steps (active or zero-current)
     std::vector<int> part(B);
     for (int b = 0; b < B; ++b) part[b] = (member_mask ? (*member_mask)[b] : 1) && !zero_current[b];
-    DBuf<int> d_part;
+    // (per-call scratch lives in the handle: hipFree synchronises the whole device, i.e. also the other stream group)
+    DBuf<int>& d_part = h->d_scr_part;
     d_part.alloc(B);
     HIP_TRY(hipMemcpyAsync(d_part.p, part.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
 
@@ -864,7 +868,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
                                h->d_vac_i.p, (const double*)nullptr, p->mu0, 0);
         else
             hipLaunchKernelGGL(k_fill, g2, BLK2D, 0, st, WF, 0.0, nz, nr, ld, (const int*)nullptr);
-        DBuf<int> d_zc;
+        DBuf<int>& d_zc = h->d_scr_zc;
         d_zc.alloc(B);
         HIP_TRY(hipMemcpyAsync(d_zc.p, zero_current.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, curF, WF, nz, nr, ld, (const int*)d_zc.p);
@@ -894,7 +898,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         // members with |I_target| < 1e-12 keep psi untouched (their J is zero)
         std::vector<int> seed_act(B);
         for (int b = 0; b < B; ++b) seed_act[b] = part[b] && std::fabs(ms[b].i_target) >= 1e-12;
-        DBuf<int> d_sa;
+        DBuf<int>& d_sa = h->d_scr_sa;
         d_sa.alloc(B);
         HIP_TRY(hipMemcpyAsync(d_sa.p, seed_act.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_source_from_j, g2, BLK2D, 0, st, srcF, jF, nz, nr, ld, (const double*)h->d_neg_mu0R.p, (const int*)d_sa.p);
@@ -1141,7 +1145,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         bool any = false;
         for (int b = 0; b < B; ++b) { tmp[b].active = (fin[b].iterations > 0) ? 1 : 0; any |= tmp[b].active != 0; }
         if (any) {
-            DBuf<Member> d_tmp;
+            DBuf<Member>& d_tmp = h->d_scr_st;
             d_tmp.alloc(B);
             HIP_TRY(hipMemcpyAsync(d_tmp.p, tmp.data(), sizeof(Member) * B, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_source, gjs, dim3(256), 0, st, src2F, jF, 1, prevF, (const Member*)d_tmp.p, nz, nr, ld, (const double*)h->d_r.p,
@@ -1707,14 +1711,14 @@ static int S_free_boundary_solve(Solver* h, const scpn_picard_params* p, int n_c
     std::vector<int> mask(B, 1), outer_it(B, 0);
     std::vector<double> fdiff(B, INFINITY), hdiff(B);
     std::vector<scpn_picard_result> res(B), last(B);
-    DBuf<double> d_diff;
+    DBuf<double>& d_diff = h->d_scr_diff;  // (scratch in the handle: hipFree would synchronise the other stream group too)
     d_diff.alloc(B);
     const int nblk = h->nblk();
     for (int outer = 0; outer < max_outer; ++outer) {
         bool any = false;
         for (int b = 0; b < B; ++b) any |= mask[b] != 0;
         if (!any) break;
-        DBuf<int> d_mask;
+        DBuf<int>& d_mask = h->d_scr_mask;
         d_mask.alloc(B);
         HIP_TRY(hipMemcpyAsync(d_mask.p, mask.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
         Fld curF = h->slot_fld(h->d_cur.p);
