@@ -139,7 +139,7 @@ SIGNATURES = {
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile csrc/scpn_hip.hip for gfx950 into the in-tree libscpn_hip.so (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / "scpn_hip.hip", CSRC / "gs_kernels.hip.h", CSRC / "newton_kernels.hip.h", PKG_DIR.parent / "include" / "scpn_hip.h"]
+    srcs = [CSRC / "scpn_hip.hip", CSRC / "gs_kernels.hip.h", CSRC / "newton_kernels.hip.h", CSRC / "slide_kernel.hip.h", PKG_DIR.parent / "include" / "scpn_hip.h"]
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

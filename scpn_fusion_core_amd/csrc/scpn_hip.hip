@@ -22,6 +22,7 @@
 #include "../../include/scpn_hip.h"
 #include "gs_kernels.hip.h"
 #include "newton_kernels.hip.h"
+#include "slide_kernel.hip.h"
 
 using namespace gs;
 
@@ -445,6 +446,32 @@ static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
     else if (ps.c.base) launch_tile_geo<S, true, false>(h, L, out, in, src, omega, active, ps, nullptr);
     else launch_tile_geo<S, false, false>(h, L, out, in, src, omega, active, ps, nullptr);
 }
+// time-skewed smoother (slide_kernel.hip.h): 3 sweeps, optional prolongation on load; opt-in while it is being measured
+static int slide_rseg() {
+    static const int v = [] { const char* e = std::getenv("SCPN_HIP_SLIDE_RSEG"); int r = e ? std::atoi(e) : 132; return std::max(8, r & ~1); }();
+    return v;
+}
+static bool slide_enabled(const Lvl& L) {
+    static const int lv = [] { const char* e = std::getenv("SCPN_HIP_SLIDE"); return e ? std::atoi(e) : 0; }();  // 1: level 0, 2: levels 0-1, 3: all tiled levels
+    if (lv <= 0) return false;
+    const int lvl = L.nz > 300 ? 0 : (L.nz > 150 ? 1 : 2);
+    return lvl < lv;
+}
+static void launch_slide(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps) {
+    static std::once_flag once;
+    const size_t lds = (size_t)4 * SL_W * 64 * sizeof(double);
+    std::call_once(once, [&] {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_slide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_slide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    });
+    SlideArgs a{};
+    a.out = out; a.in = in; a.src = src; a.coarse = ps.c; a.nz_c = ps.nz_c; a.nr_c = ps.nr_c; a.ld_c = ps.ld_c;
+    a.active = active; a.rseg = slide_rseg(); a.omega = omega; a.om1 = 1.0 - omega;
+    if (h->lazy_src && src.base == h->lazy_src) { a.lazy_st = h->d_st.p; a.lazy_nm = h->d_neg_mu0R.p; }
+    dim3 g(cdiv(L.nr, 128 - 2 * SL_H), cdiv(L.nz, a.rseg), h->B);
+    if (ps.c.base) hipLaunchKernelGGL(k_smooth_slide<true>, g, dim3(SL_NT), lds, h->stream, a, L);
+    else hipLaunchKernelGGL(k_smooth_slide<false>, g, dim3(SL_NT), lds, h->stream, a, L);
+}
 // tiles per member of the blend-fused post-smoother (its partial arrays are indexed by tile)
 static int blend_tiles(const Lvl& L, int post) {
     const int S = ((post - 1) % 3) + 1, H = 2 * S + 2;
@@ -479,7 +506,8 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
             const bool last = left - S <= 0;
             const BlendArgs* bl = (blend && last) ? blend : nullptr;  // the last launch writes the blended iterate
             Fld dst = bl ? blend_out : b;
-            if (S == 3) launch_tile_p<3>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
+            if (S == 3 && !sgo && !dfo && !bl && slide_enabled(L)) launch_slide(h, L, dst, a, src, omega, active, pso);
+            else if (S == 3) launch_tile_p<3>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
             else if (S == 2) launch_tile_p<2>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
             else launch_tile_p<1>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
             if (bl) return dst;
