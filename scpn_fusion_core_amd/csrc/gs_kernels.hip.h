@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         by_ = (int)(t % gy);
         b = (int)(t / gy);
     }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as a scalar: row arithmetic goes to the SALU
     const int z0 = by_ * (LZ - 2 * H) - H, r0 = bx_ * (128 - 2 * H) - H;  // both even
     const int nz = L.nz, nr = L.nr, ld = L.ld;
     const double* in = inF.at(b);

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(SL_NT, 4) k_smooth_slide(SlideArgs a, Lvl L) {
         by_ = (int)(t_ % gy);
         b = (int)(t_ / gy);
     }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as a scalar: row arithmetic goes to the SALU
     const int nz = L.nz, nr = L.nr, ld = L.ld;
     const int zs = by_ * a.rseg, ze = min(zs + a.rseg, nz);  // output rows [zs, ze)
     const int z_lo = zs - SL_H;                               // even
