@@ -177,7 +177,8 @@ struct Solver {
     int n_vac = 0;
     DBuf<double> d_vac_r, d_vac_z, d_vac_i, d_fb_r, d_fb_z, d_fb_i, d_fb_t;
     std::vector<double> seed_host;
-    bool seed_user = false;
+    bool seed_user = false, seed_uploaded = false;
+    double seed_rc = NAN, seed_integral = 0.0;
     double mu0_tables = NAN;
 
     // profiling
@@ -909,18 +910,27 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     int n_part = 0;
     for (int b = 0; b < B; ++b) n_part += part[b];
     if (!p->skip_seed && n_part > 0) {
-        if (!h->seed_user) {
-            h->seed_host.assign((size_t)nz * nr, 0.0);
-            for (int iz = 0; iz < nz; ++iz)
-                for (int ir = 0; ir < nr; ++ir) {
-                    double a = h->r_axis[ir] - p->r_center;
-                    double dist_sq = a * a + h->z_axis[iz] * h->z_axis[iz];
-                    h->seed_host[(size_t)iz * nr + ir] = std::exp(-dist_sq / 2.0);
-                }
+        // the Gaussian seed and its integral depend only on the grid and r_center: built once per handle (263k exp + a 2 MB
+        // pageable upload per Picard call otherwise stall the stream for ~1 ms at 513^2)
+        const bool seed_stale = h->seed_user ? !h->seed_uploaded : !(h->seed_uploaded && h->seed_rc == p->r_center);
+        if (seed_stale) {
+            if (!h->seed_user) {
+                h->seed_host.assign((size_t)nz * nr, 0.0);
+                for (int iz = 0; iz < nz; ++iz)
+                    for (int ir = 0; ir < nr; ++ir) {
+                        double a = h->r_axis[ir] - p->r_center;
+                        double dist_sq = a * a + h->z_axis[iz] * h->z_axis[iz];
+                        h->seed_host[(size_t)iz * nr + ir] = std::exp(-dist_sq / 2.0);
+                    }
+            }
+            h->seed_integral = (np_sum(h->seed_host.data(), (long)nz * nr) * h->dr) * h->dz;
+            h->d_seed.alloc((size_t)nz * nr);
+            HIP_TRY(hipMemcpyAsync(h->d_seed.p, h->seed_host.data(), sizeof(double) * nz * nr, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            h->seed_uploaded = true;
+            h->seed_rc = p->r_center;
         }
-        double i_seed = (np_sum(h->seed_host.data(), (long)nz * nr) * h->dr) * h->dz;
-        h->d_seed.alloc((size_t)nz * nr);
-        HIP_TRY(hipMemcpyAsync(h->d_seed.p, h->seed_host.data(), sizeof(double) * nz * nr, hipMemcpyHostToDevice, st));
+        const double i_seed = h->seed_integral;
         hipLaunchKernelGGL(k_seed_j, g2, BLK2D, 0, st, jF, (const double*)h->d_seed.p, (const Member*)h->d_st.p, i_seed, nz, nr, ld,
                            (const int*)d_part.p);
         // members with |I_target| < 1e-12 keep psi untouched (their J is zero)
@@ -1661,6 +1671,7 @@ static int S_set_vacuum_coils(Solver* h, int n, const double* r, const double* z
 }
 static int S_set_seed(Solver* h, const double* seed) {
     if (!h) return fail(SCPN_E_ARG, "null handle");
+    h->seed_uploaded = false;  // the cached device copy / integral belong to the previous seed
     if (!seed) { h->seed_user = false; return SCPN_OK; }
     h->seed_host.assign(seed, seed + (size_t)h->nz * h->nr);
     h->seed_user = true;
