@@ -1707,8 +1707,11 @@ __global__ void __launch_bounds__(256) k_blend(Fld nxtF, Fld curF, Fld newF, Fld
 #ifndef BLEND_BT_Z
 #define BLEND_BT_Z 32
 #endif
+#ifndef BLEND_WPE
+#define BLEND_WPE 1  // minimum waves per SIMD the register allocation of k_blend_fused must allow
+#endif
 constexpr int BT_Z = BLEND_BT_Z, BT_R = 64;
-__global__ void __launch_bounds__(256) k_blend_fused(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
+__global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
                                                      double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
                                                      double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm) {
     __shared__ double t[BT_Z + 2][BT_R + 2 + 1];
