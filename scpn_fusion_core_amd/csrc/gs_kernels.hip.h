@@ -1565,18 +1565,29 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
         const bool two = c0 + 1 < nr;
         const double R0 = r_axis[c0], R1 = two ? r_axis[c0 + 1] : 1.0;
         const double m0 = inv_mu0R[c0], m1 = two ? inv_mu0R[c0 + 1] : 0.0;
+        // rows in batches of JS_BATCH: all loads of a batch are issued before the first J_raw store (the compiler may not move
+        // a load above a store through another pointer, so load / compute / store per row would serialise the memory round trips)
+        constexpr int JS_BATCH = 8;
 #pragma unroll
-        for (int k = 0; k < JS_ROWS / 4; ++k) {
-            const int iz = blockIdx.y * JS_ROWS + ty + 4 * k;
-            if (iz < nz) {
-                const double2 v = *reinterpret_cast<const double2*>(psi + (long)iz * ld + c0);
-                const double j0 = j_raw_at(v.x, R0, m0, pa, den, iden, pf);
-                s += j0;
-                double j1 = 0.0;
-                if (two) { j1 = j_raw_at(v.y, R1, m1, pa, den, iden, pf); s += j1; }
-                if (raw) {
-                    if (two) *reinterpret_cast<double2*>(raw + (long)iz * ld + c0) = double2{j0, j1};
-                    else raw[(long)iz * ld + c0] = j0;
+        for (int k0 = 0; k0 < JS_ROWS / 4; k0 += JS_BATCH) {
+            double2 v[JS_BATCH];
+#pragma unroll
+            for (int j = 0; j < JS_BATCH; ++j) {
+                const int iz = min(blockIdx.y * JS_ROWS + ty + 4 * (k0 + j), nz - 1);  // clamped: rows beyond nz are skipped below
+                v[j] = *reinterpret_cast<const double2*>(psi + (long)iz * ld + c0);
+            }
+#pragma unroll
+            for (int j = 0; j < JS_BATCH; ++j) {
+                const int iz = blockIdx.y * JS_ROWS + ty + 4 * (k0 + j);
+                if (k0 + j < JS_ROWS / 4 && iz < nz) {
+                    const double j0 = j_raw_at(v[j].x, R0, m0, pa, den, iden, pf);
+                    s += j0;
+                    double j1 = 0.0;
+                    if (two) { j1 = j_raw_at(v[j].y, R1, m1, pa, den, iden, pf); s += j1; }
+                    if (raw) {
+                        if (two) *reinterpret_cast<double2*>(raw + (long)iz * ld + c0) = double2{j0, j1};
+                        else raw[(long)iz * ld + c0] = j0;
+                    }
                 }
             }
         }
