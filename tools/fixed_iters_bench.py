@@ -1,5 +1,6 @@
 """Steady-state cost of one Picard iteration: 32 members, 513x513, exactly N iterations (tolerance far below reach), both
 stream groups.  usage: fixed_iters_bench.py [iters] [repeats]   (SCPN_HIP_LIB selects the library)"""
+import os
 import sys
 import time
 
@@ -20,7 +21,7 @@ with EnsembleSolver(cfg, batch=B, current_targets=ip * (1.0 + 0.1 * (2.0 * rng.r
     ts = []
     for r in range(reps + 1):
         t0 = time.perf_counter()
-        res = es.solve_equilibrium(check_every=8)
+        res = es.solve_equilibrium(check_every=int(os.environ.get("CHECK_EVERY", "8")))
         ts.append(time.perf_counter() - t0)
     assert all(x["iterations"] == iters for x in res), [x["iterations"] for x in res]
 best = min(ts[1:])
