@@ -1581,7 +1581,8 @@ int scpn_device_info(char* buf, int buflen) {
     if (scpn_device_count() <= 0) return fail(SCPN_E_DEVICE, "no HIP device");
     hipDeviceProp_t pr;
     if (hipGetDeviceProperties(&pr, g_device) != hipSuccess) return fail(SCPN_E_DEVICE, "hipGetDeviceProperties failed");
-    snprintf(buf, (size_t)buflen, "%s | %s | %d CUs | %.0f GiB | HIP", pr.name, pr.gcnArchName, pr.multiProcessorCount,
+    // (the marketing name is empty on boxes without the amdgpu.ids table)
+    snprintf(buf, (size_t)buflen, "%s | %s | %d CUs | %.0f GiB | HIP", pr.name[0] ? pr.name : "AMD GPU", pr.gcnArchName, pr.multiProcessorCount,
              (double)pr.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
     return SCPN_OK;
 }
