@@ -1725,6 +1725,20 @@ __global__ void __launch_bounds__(256) k_blend(Fld nxtF, Fld curF, Fld newF, Fld
 #define BLEND_WPE 1  // minimum waves per SIMD the register allocation of k_blend_fused must allow
 #endif
 constexpr int BT_Z = BLEND_BT_Z, BT_R = 64;
+// np.gradient + hypot inside the divertor rows (fusion_kernel.py:276-288) at tile point (LZ_, LR_) = grid point (GZ_, GR_)
+#define SCPN_BLEND_GRAD(LZ_, LR_, GZ_, GR_, P_)                                                                             \
+        if ((GZ_) < n_mask_rows) {                                                                                         \
+            double gzv, grv;                                                                                               \
+            const double ps = nan_to_num300(P_);                                                                           \
+            if ((GZ_) == 0) gzv = (nan_to_num300(t[(LZ_) + 1][LR_]) - ps) / L.dz;                                           \
+            else if ((GZ_) == nz - 1) gzv = (ps - nan_to_num300(t[(LZ_) - 1][LR_])) / L.dz;                                 \
+            else gzv = (nan_to_num300(t[(LZ_) + 1][LR_]) - nan_to_num300(t[(LZ_) - 1][LR_])) / (2.0 * L.dz);                \
+            if ((GR_) == 0) grv = (nan_to_num300(t[LZ_][(LR_) + 1]) - ps) / L.dr;                                           \
+            else if ((GR_) == nr - 1) grv = (ps - nan_to_num300(t[LZ_][(LR_) - 1])) / L.dr;                                 \
+            else grv = (nan_to_num300(t[LZ_][(LR_) + 1]) - nan_to_num300(t[LZ_][(LR_) - 1])) / (2.0 * L.dr);                \
+            const double bm = hypot(grv, gzv);                                                                             \
+            if (finite_d(bm)) mn = vi_min(mn, VI{bm, (long)(GZ_) * nr + (GR_)});                                            \
+        }
 __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
                                                      double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
                                                      double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm) {
@@ -1747,7 +1761,10 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
     const int tid = threadIdx.x;
     const int tx = tid & 63, ty = tid >> 6;
     const int nz = L.nz, nr = L.nr, ld = L.ld;
-    const int z0 = by_ * BT_Z - 1, r0 = bx_ * BT_R - 1;
+    // tile (by, bx) owns rows by*BT_Z + 1 .. by*BT_Z + BT_Z and the matching columns; the tiles of the first tile row / column
+    // also own grid row / column 0 (their halo row / column).  Grids of 2^k + 1 points are covered without sliver tiles.
+    const int z0 = by_ * BT_Z, r0 = bx_ * BT_R;
+    const int lz_min = by_ == 0 ? 0 : 1, lr_min = bx_ == 0 ? 0 : 1;
     const double* cur = curF.at(b);
     const double* nw = newF.at(b);
     const double* bc = bcF.at(b);
@@ -1767,7 +1784,7 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
             const double pn = ring ? bc[c] : nw[c];
             const double pc = cur[c];
             v = om_alpha * pc + alpha * pn;
-            if (lz >= 1 && lz <= BT_Z && lr >= 1 && lr <= BT_R) {  // owned point
+            if (lz >= lz_min && lz <= BT_Z && lr >= lr_min && lr <= BT_R) {  // owned point
                 if (!finite_d(pn)) bad = 1;
                 dsum += fabs(pn - pc);
                 nxt[c] = v;
@@ -1806,7 +1823,7 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
         if (gz >= 0 && gz < nz && gr >= 0 && gr < nr) {
             const double pn = pnv[k], pc = pcv[k];
             v = om_alpha * pc + alpha * pn;
-            if (lz >= 1 && lz <= BT_Z && lr >= 1 && lr <= BT_R) {  // owned point
+            if (lz >= lz_min && lz <= BT_Z && lr >= lr_min && lr <= BT_R) {  // owned point
                 if (!finite_d(pn)) bad = 1;
                 dsum += fabs(pn - pc);
                 nxt[(long)gz * ld + gr] = v;
@@ -1840,17 +1857,19 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
             m = fmax(m, fabs(r));
             rv[k] = r;
         }
-        if (gz < n_mask_rows) {  // np.gradient + hypot inside the divertor rows (fusion_kernel.py:276-288)
-            double gzv, grv;
-            const double ps = nan_to_num300(p);
-            if (gz == 0) gzv = (nan_to_num300(t[lz + 1][lr]) - ps) / L.dz;
-            else if (gz == nz - 1) gzv = (ps - nan_to_num300(t[lz - 1][lr])) / L.dz;
-            else gzv = (nan_to_num300(t[lz + 1][lr]) - nan_to_num300(t[lz - 1][lr])) / (2.0 * L.dz);
-            if (gr == 0) grv = (nan_to_num300(t[lz][lr + 1]) - ps) / L.dr;
-            else if (gr == nr - 1) grv = (ps - nan_to_num300(t[lz][lr - 1])) / L.dr;
-            else grv = (nan_to_num300(t[lz][lr + 1]) - nan_to_num300(t[lz][lr - 1])) / (2.0 * L.dr);
-            const double bm = hypot(grv, gzv);
-            if (finite_d(bm)) mn = vi_min(mn, VI{bm, (long)gz * nr + gr});
+        SCPN_BLEND_GRAD(lz, lr, gz, gr, p)
+    }
+    // grid row 0 / column 0 (ring points: no residual) of the first tile row / column: only the masked-gradient candidates
+    {
+        int elz = -1, elr = -1;
+        if (by_ == 0 && tid <= BT_R - lr_min) { elz = 0; elr = lr_min + tid; }                                   // row 0 (with the corner)
+        else if (bx_ == 0 && tid >= 128 && tid < 128 + BT_Z) { elz = 1 + (tid - 128); elr = 0; }                 // column 0 below the corner
+        if (elz >= 0) {
+            const int gz = z0 + elz, gr = r0 + elr;
+            if (gz < nz && gr < nr) {
+                const double p = t[elz][elr];
+                SCPN_BLEND_GRAD(elz, elr, gz, gr, p)
+            }
         }
     }
     // wave-level reductions (results in every lane), one LDS hand-over per wave
@@ -1888,6 +1907,7 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
     }
 }
 
+#undef SCPN_BLEND_GRAD
 // ---------------------------------------------------------------- Anderson mixing (a10, method "anderson")
 // core/fusion_kernel_newton_solver.py:540-550 and core/fusion_kernel_iterative_solver.py:248-314
 constexpr int AND_MAX = 8;  // max mixing depth m

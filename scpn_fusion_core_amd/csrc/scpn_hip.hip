@@ -188,7 +188,7 @@ struct Solver {
 
     int nblk() const { return std::max(cdiv((long)nz * nr, 1024), nblk2()); }  // partial-array capacity
     int nblk1() const { return cdiv((long)nz * nr, 1024); }
-    int nblk2() const { return cdiv(nr, BT_R) * cdiv(nz, BT_Z); }
+    int nblk2() const { return cdiv(nr - 1, BT_R) * cdiv(nz - 1, BT_Z); }  // tiles of k_blend_fused (first tile row / column also own row / column 0)
     int nblk_int() const { return cdiv((long)(nz - 2) * (nr - 2), 1024); }
 
     Fld slot_fld(const int* slot) { return Fld{psi_slots.p, slot, stride, B}; }
@@ -1086,7 +1086,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         } else if (h->use_fused && p->method != 3) {
             ProfScope ps(h, "blend_fused", 1);
             nb_d = nb_r = nblk2;
-            hipLaunchKernelGGL(k_blend_fused, dim3(cdiv(nr, BT_R), cdiv(nz, BT_Z), B), dim3(256), 0, st, nxtF, curF, newF, bcF, srcF,
+            hipLaunchKernelGGL(k_blend_fused, dim3(cdiv(nr - 1, BT_R), cdiv(nz - 1, BT_Z), B), dim3(256), 0, st, nxtF, curF, newF, bcF, srcF,
                                (const Member*)h->d_st.p, L0, p->alpha, om_alpha, n_mask_rows, h->d_part1.p, h->d_pbad.p, h->d_part2.p,
                                h->d_part3.p, h->d_topo.p, nblk2, lazy ? (const double*)h->d_neg_mu0R.p : (const double*)nullptr);
         } else {
