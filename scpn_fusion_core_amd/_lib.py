@@ -143,12 +143,16 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(LIB_PATH), str(CSRC / "scpn_hip.hip")]
+    # build next to the target and rename: concurrent builders (one rank per GPU) never see a half-written library
+    tmp = LIB_PATH.with_name(f".{LIB_PATH.name}.{os.getpid()}.tmp")
+    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(tmp), str(CSRC / "scpn_hip.hip")]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode:
         print(" ".join(cmd), res.stdout, res.stderr, sep="\n")
     if res.returncode:
+        tmp.unlink(missing_ok=True)
         raise RuntimeError(f"hipcc failed building {LIB_PATH.name}:\n{res.stderr[-2000:]}")
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
