@@ -31,22 +31,77 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec; the copy bandwidth measured on this very GPU is printed beside it
+
+
+# Bytes per grid point one launch of a kernel family must move (fp64, fused kernels: DESIGN.md section 5) and the SURVEY 8(d)
+# figure of the same work done as separate passes.  smooth_*_pre = 3 RB-SOR sweeps + defect + full-weight restriction
+# (psi, src in; psi out; coarse rhs + coarse e out = 2 x 8/4); smooth_*_post = prolong-add + 3 sweeps (coarse e in = 8/4).
+FAMILY_BYTES = {"smooth_pre": (28.0, 106.0), "smooth_post": (26.0, 90.0), "smooth": (24.0, 72.0),
+                "blend_fused": (32.0, 40.0), "source": (16.0, 24.0)}
+
+
+def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int) -> dict | None:
+    """Roofline object of the dominant kernel.  `fam` = per-family HIP-event times ({name: {ms, launches}}); families of one
+    role on different levels are ONE kernel symbol in a rocprofv3 trace (smooth_L{0,1,2}_pre = one template instance), and
+    the dominant kernel is the symbol with the largest summed device time, as `rocprofv3 --kernel-trace --stats` ranks it."""
+    import re
+
+    def symbol(name):
+        m = re.match(r"smooth_(?:tile|rows)_L\d+(_pre|_post)?$", name)
+        return "smooth" + (m.group(1) or "") if m else name
+
+    def level(name):
+        m = re.match(r".*_L(\d+)", name)
+        return int(m.group(1)) if m else 0
+
+    groups: dict = {}
+    for name, v in fam.items():
+        groups.setdefault(symbol(name), []).append((name, v))
+    if not groups:
+        return None
+    dom = max(groups, key=lambda k: sum(v["ms"] for _, v in groups[k]))
+    fused_pt, survey_pt = FAMILY_BYTES.get(dom, (16.0, 16.0))
+    try:
+        pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        if pmc.get("grid") != grid:
+            pmc = None
+    except (OSError, ValueError):
+        pmc = None
+    tot_ms = tot_launch = bytes_fused = bytes_survey = traffic = 0.0
+    traffic_ok = pmc is not None
+    per_level = {}
+    for name, v in groups[dom]:
+        pts = ((grid - 1) // (2 ** level(name)) + 1) ** 2 if dom.startswith("smooth") else grid * grid
+        tot_ms += v["ms"]
+        tot_launch += v["launches"]
+        bytes_fused += fused_pt * pts * members_per_launch * v["launches"]
+        bytes_survey += survey_pt * pts * members_per_launch * v["launches"]
+        per_member = (pmc["hbm_bytes_per_member_launch"].get(name) if pmc else None)
+        if per_member is None:
+            traffic_ok = False
+        else:
+            traffic += per_member * members_per_launch * v["launches"]
+        us = 1e3 * v["ms"] / v["launches"]
+        per_level[name] = {"avg_launch_us": round(us, 2), "launches": v["launches"],
+                           "achieved": round(fused_pt * pts * members_per_launch / (us * 1e-6) / 1e9, 1)}
+    ach = bytes_fused / (tot_ms * 1e-3) / 1e9
+    return {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": round(traffic / tot_launch) if traffic_ok else None,
+            "alg_bytes_per_point": fused_pt, "alg_bytes_per_launch": round(bytes_fused / tot_launch),
+            "survey_8d_equivalent": {"bytes_per_point_unfused": survey_pt,
+                                     "gbs_equivalent": round(bytes_survey / (tot_ms * 1e-3) / 1e9, 1)},
+            "avg_launch_us": round(1e3 * tot_ms / tot_launch, 2), "launches": int(tot_launch),
+            "groups": num_groups, "members_per_launch": int(members_per_launch), "isolated_kernel_timing": True,
+            "counters": "profiles/ (SQ / FETCH / WRITE passes of tools/collect_profiles.sh)",
+            "per_level": per_level, "families_ms": fam}
 
 
 def make_cfg(n: int) -> dict:
-    from tests._problems import iter_like_cfg
+    from scpn_fusion_core_amd.cases import iter_like_cfg
 
     return iter_like_cfg(n, method="multigrid", omega=1.0, tol=1e-8, max_iter=1000, alpha=0.12)
-
-
-def member_table(cfg: dict, total: int) -> tuple[np.ndarray, np.ndarray]:
-    """Coil/shape scan of BASELINE config 5: coil currents I_k*(1+0.1u) and plasma current Ip*(1+0.1u), u~U(-1,1)."""
-    base = np.array([c["current"] for c in cfg["coils"]], dtype=np.float64)
-    rng = np.random.default_rng(2026)
-    currents = base[None, :] * (1.0 + 0.1 * rng.uniform(-1.0, 1.0, size=(total, base.size)))
-    targets = cfg["physics"]["plasma_current_target"] * (1.0 + 0.1 * rng.uniform(-1.0, 1.0, size=total))
-    return currents, targets
 
 
 def main() -> int:
@@ -73,6 +128,7 @@ def main() -> int:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from scpn_fusion_core_amd import _lib
+    from scpn_fusion_core_amd.cases import member_cfg, scan_member_table
     from scpn_fusion_core_amd.ensemble import EnsembleSolver
 
     _lib.require_gpu()
@@ -81,7 +137,7 @@ def main() -> int:
     from scpn_fusion_core_amd.distributed import DevicePointer, gather_blocks_async, shard_range
 
     lo, hi = shard_range(B * world, rank, world)
-    all_currents, all_targets = member_table(cfg, B * world)
+    all_currents, all_targets = scan_member_table(cfg, B * world)
     currents, targets = all_currents[lo:hi], all_targets[lo:hi]
     es = EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, device=local_rank)
     n_pts = args.grid * args.grid
@@ -139,8 +195,12 @@ def main() -> int:
     outer = [r["outer_iterations"] for r in res]
     value = args.steps * B * world / elapsed
 
-    # ---- roofline of the dominant kernel (red-black colour pass on the 513^2 level), HIP events on
-    #      the solver stream, in a separate pass so the event records do not perturb the timed region
+    # ---- roofline of the dominant kernel: HIP events on the solver's own stream, in a separate pass (event records would
+    #      perturb the timed region); the two stream groups run one after the other while timing, so a kernel is alone on
+    #      the chip.  `achieved` = the bytes the FUSED kernel must move once per launch (psi + source in,
+    #      psi + coarse rhs + coarse e out -- what the PMC counters confirm, `traffic`) / its mean launch time.  The SURVEY
+    #      8(d) per-point figures of the UNFUSED operator sequence (3 sweeps x 24 B + residual 24 + restriction 10 = 106 B/pt)
+    #      are kept as `survey_8d_equivalent`: a statement about fusion, not about memory traffic.
     roofline = None
     if not args.no_roofline and rank == 0:
         es.fill_psi(0.0)
@@ -148,67 +208,13 @@ def main() -> int:
         es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
         fam = es.profile_report()
         es.profile(False)
-        # Families are per level and role; a KERNEL (one symbol in a rocprofv3 trace) is the set of families with the same
-        # role: smooth_tile_L*_pre is k_smooth_tile<3,false,false,true,...> on levels 0,1,2, and so on.  The dominant kernel
-        # is the symbol with the largest summed device time, as `rocprofv3 --kernel-trace --stats` ranks them.
-        import re
-
-        def symbol(name):
-            m = re.match(r"smooth_tile_L\d+(_pre|_post)?$", name)
-            return "smooth_tile" + (m.group(1) or "") if m else name
-
-        def level(name):
-            m = re.match(r".*_L(\d+)", name)
-            return int(m.group(1)) if m else 0
-
-        # ALGORITHMIC bytes per point and launch = SURVEY 8(d) per-point figures x what one launch does:
-        #   RB-SOR sweep 24 B/pt, residual 24, full-weight restriction 10, prolong-add 18, blend+norms 40, one colour pass 16.
-        #   smooth_tile_pre  = 3 sweeps + residual + restriction        -> 3*24 + 24 + 10 = 106 B/pt
-        #   smooth_tile_post = prolong-add + 3 sweeps                   -> 18 + 3*24      =  90 B/pt
-        # "fused_compulsory" = the bytes the FUSED kernel itself must move once (psi, src in; psi (+coarse rhs/e) out).
-        per_point = {"smooth_tile_pre": (106.0, 28.0), "smooth_tile_post": (90.0, 26.0), "smooth_tile": (72.0, 24.0),
-                     "blend_fused": (40.0, 32.0), "source": (24.0, 24.0)}
-        groups: dict = {}
-        for name, v in fam.items():
-            groups.setdefault(symbol(name), []).append((name, v))
-        dom = max(groups, key=lambda k: sum(v["ms"] for _, v in groups[k])) if groups else None
-        if dom:
-            per_pt, fused_pt = per_point.get(dom, (16.0, 16.0))
-            members = B / es.num_groups  # one launch covers one group's members
-            try:
-                pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-                if pmc.get("grid") != args.grid:
-                    pmc = None
-            except (OSError, ValueError):
-                pmc = None
-            tot_ms = tot_launch = 0.0
-            alg_bytes = fused_bytes = 0.0
-            traffic_bytes, traffic_ok = 0.0, pmc is not None
-            levels = {}
-            for name, v in groups[dom]:
-                lv = level(name)
-                pts = ((args.grid - 1) // (2 ** lv) + 1) ** 2 if dom.startswith("smooth_tile") else n_pts
-                tot_ms += v["ms"]
-                tot_launch += v["launches"]
-                alg_bytes += per_pt * pts * members * v["launches"]
-                fused_bytes += fused_pt * pts * members * v["launches"]
-                per_member = pmc["hbm_bytes_per_member_launch"].get(name) if pmc else None
-                if per_member is None:
-                    traffic_ok = False
-                else:
-                    traffic_bytes += per_member * members * v["launches"]
-                levels[name] = {"avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2), "launches": v["launches"],
-                                "achieved": round(per_pt * pts * members / (1e-3 * v["ms"] / v["launches"]) / 1e9, 1)}
-            ach = alg_bytes / (tot_ms * 1e-3) / 1e9
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4),
-                        "traffic": round(traffic_bytes / tot_launch) if traffic_ok else None,
-                        "alg_bytes_per_point": per_pt, "alg_bytes_per_launch": round(alg_bytes / tot_launch),
-                        "fused_compulsory_bytes_per_point": fused_pt,
-                        "achieved_fused_compulsory": round(fused_bytes / (tot_ms * 1e-3) / 1e9, 1),
-                        "avg_launch_us": round(1e3 * tot_ms / tot_launch, 2), "launches": int(tot_launch),
-                        "groups": es.num_groups, "members_per_launch": int(members), "isolated_kernel_timing": True,
-                        "per_level": levels, "families_ms": fam}
+        roofline = roofline_of(fam, args.grid, B / es.num_groups, es.num_groups)
+        try:
+            roofline["measured_copy_gbs"] = round(_lib.copy_bandwidth_probe(), 1)
+            roofline["frac_of_measured_copy"] = round(roofline["achieved"] / roofline["measured_copy_gbs"], 4)
+        except Exception as exc:  # the probe needs 2 GiB of free HBM; report, do not fail the bench line
+            roofline["measured_copy_gbs"] = None
+            roofline["copy_probe_error"] = str(exc)
 
     # ---- CPU baseline: the C oracle (port of the reference algorithm) on the host cores of this GPU's share: one full
     #      free-boundary solve per core, `cores` members solved concurrently (ctypes releases the GIL during the C call)
@@ -222,8 +228,7 @@ def main() -> int:
         cores = max(1, min(16, os.cpu_count() or 1, B))
 
         def cpu_member(m):
-            cm = {**cfg, "coils": [dict(co, current=float(currents[m, i])) for i, co in enumerate(cfg["coils"])],
-                  "physics": dict(cfg["physics"], plasma_current_target=float(targets[m]))}
+            cm = member_cfg(cfg, currents[m], targets[m])
             co = cm["coils"]
             t = time.perf_counter()
             r = orc.free_boundary_solve(cm, [c["r"] for c in co], [c["z"] for c in co], [c["current"] for c in co],

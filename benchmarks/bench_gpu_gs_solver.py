@@ -20,7 +20,7 @@ sys.path.insert(0, str(ROOT))
 
 from scpn_fusion_core_amd import gpu_tier, multi_compat  # noqa: E402
 from scpn_fusion_core_amd.ensemble import EnsembleSolver  # noqa: E402
-from tests._problems import bench_problem, iter_like_cfg  # noqa: E402
+from scpn_fusion_core_amd.cases import bench_problem, iter_like_cfg  # noqa: E402
 
 R_LEFT, R_RIGHT, Z_BOTTOM, Z_TOP, OMEGA, SWEEPS, REPEATS = 4.0, 8.0, -4.0, 4.0, 1.3, 200, 3
 

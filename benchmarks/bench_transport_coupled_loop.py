@@ -21,7 +21,7 @@ sys.path.insert(0, str(ROOT))
 
 from scpn_fusion_core_amd import transport_coupling as tc  # noqa: E402
 from scpn_fusion_core_amd.ensemble import EnsembleSolver  # noqa: E402
-from tests._problems import iter_like_cfg  # noqa: E402
+from scpn_fusion_core_amd.cases import iter_like_cfg  # noqa: E402
 
 
 def main():

@@ -17,7 +17,7 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libscpn_hip.so"
 CSRC = PKG_DIR / "csrc"
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++20"]
 
 SCPN_OK, SCPN_E_ARG, SCPN_E_DEVICE, SCPN_E_DIVERGED = 0, -1, -2, -3
 
@@ -97,6 +97,8 @@ SIGNATURES = {
     "scpn_coil_flux": (_i, [_dp, _dp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _i, _dp]),
     "scpn_green_points": (_i, [_i, _dp, _dp, _i, _dp, _dp, _dp]),
     "scpn_verify_division": (_i, [_dp, _dp, _i, _dp, _dp]),
+    "scpn_verify_lane_shift": (_i, [_dp, _dp]),
+    "scpn_copy_bandwidth_probe": (_i, [C.c_long, _i, C.POINTER(_d)]),
     "scpn_np_delta_star": (_i, [_dp, _i, _i, _dp, _d, _d, _dp]),
     "scpn_np_equation_residual": (_i, [_dp, _i, _i, _dp, _dp, _d, _d, _d, _dp]),
     "scpn_tridiag_solve": (_i, [_i, _i, _vp, _dp, _vp, _dp, _dp, _vp]),
@@ -139,7 +141,7 @@ SIGNATURES = {
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile csrc/scpn_hip.hip for gfx950 into the in-tree libscpn_hip.so (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / "scpn_hip.hip", CSRC / "gs_kernels.hip.h", CSRC / "newton_kernels.hip.h", CSRC / "slide_kernel.hip.h", PKG_DIR.parent / "include" / "scpn_hip.h"]
+    srcs = [CSRC / "scpn_hip.hip", *sorted(CSRC.glob("*.hip.h")), PKG_DIR.parent / "include" / "scpn_hip.h"]
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -208,6 +210,13 @@ def device_info() -> str | None:
     if L.scpn_device_info(buf, 256) != SCPN_OK:
         return None
     return buf.value.decode()
+
+
+def copy_bandwidth_probe(nbytes: int = 1 << 30, reps: int = 10) -> float:
+    """GB/s (read + written) of a 16-B/lane device copy of ``nbytes`` (default 1 GiB: four times the Infinity Cache)."""
+    out = _d(0.0)
+    check(require_gpu().scpn_copy_bandwidth_probe(nbytes, reps, C.byref(out)), "scpn_copy_bandwidth_probe")
+    return float(out.value)
 
 
 def last_error() -> str:

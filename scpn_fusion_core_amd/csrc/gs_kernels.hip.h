@@ -70,6 +70,18 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned lin, unsigned total)
     return k * q + (k < r ? k : r) + (lin >> 3);
 }
 
+// Scalar (SMEM) loads of wave-uniform words.  The compiler emits a VECTOR load for a uniform address whose memory it cannot
+// prove read-only, and the s_waitcnt vmcnt(0) behind it then drains every vector load in flight -- fatal for a kernel that
+// keeps a prefetch in flight.  Reading through the constant address space makes it an s_load the compiler can batch with its
+// neighbours (one lgkmcnt wait for all of them).  Only for words no kernel writes while it also reads them this way (slot
+// tables, member state written by the previous launch): the scalar cache is not coherent with vector stores of the same launch.
+__device__ __forceinline__ int sload_i32(const int* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<unsigned long>(p));
+}
+__device__ __forceinline__ double sload_f64(const double* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) double*>(reinterpret_cast<unsigned long>(p));
+}
+
 // A batched field whose member b may live in one of several ping-pong slots.
 struct Fld {
     double* base;
@@ -78,6 +90,10 @@ struct Fld {
     int nb;  // members per slot
     __device__ __forceinline__ double* at(int b) const {
         int k = slot ? slot[b] : 0;
+        return base + ((long)k * nb + b) * stride;
+    }
+    __device__ __forceinline__ double* at_scalar(int b) const {  // b wave-uniform (an SGPR): slot lookup as a scalar load
+        int k = slot ? sload_i32(slot + b) : 0;
         return base + ((long)k * nb + b) * stride;
     }
 };
@@ -244,6 +260,18 @@ __device__ __forceinline__ VI block_vi(VI x, VI* sh) {
 }
 
 // ---------------------------------------------------------------- elementwise / copies
+// device-copy bandwidth probe (bench.py: the measured denominator reported next to the nominal 8 TB/s): grid-stride copy,
+// 16 B per lane, four independent loads in flight per lane
+__global__ void __launch_bounds__(256) k_copy_probe(double2* __restrict__ dst, const double2* __restrict__ src, long n16) {
+    const long step = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * step < n16; i += 4 * step) {
+        const double2 a = src[i], b = src[i + step], c = src[i + 2 * step], d = src[i + 3 * step];
+        dst[i] = a; dst[i + step] = b; dst[i + 2 * step] = c; dst[i + 3 * step] = d;
+    }
+    for (; i < n16; i += step) dst[i] = src[i];
+}
+
 // dst <- src over the logical (nz, nr) window; grid (ceil(nr/64), ceil(nz/4), B), block (64,4)
 __global__ void k_copy(Fld dst, Fld src, int nz, int nr, int ld, const int* active) {
     int b = blockIdx.z;

@@ -22,7 +22,7 @@
 #include "../../include/scpn_hip.h"
 #include "gs_kernels.hip.h"
 #include "newton_kernels.hip.h"
-#include "slide_kernel.hip.h"
+#include "smooth_rows.hip.h"
 
 using namespace gs;
 
@@ -39,6 +39,15 @@ static int fail(int code, const std::string& msg) {
         if (e__ != hipSuccess) {                                                                        \
             throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e__));              \
         }                                                                                               \
+    } while (0)
+
+// every kernel launch is followed by hipGetLastError(): a rejected launch (dynamic LDS over budget, wrong code object, bad
+// grid) raises instead of leaving stale fields behind an SCPN_OK; API_END maps the exception to SCPN_E_DEVICE
+#define SCPN_LAUNCH(...)                                                                                 \
+    do {                                                                                                \
+        hipLaunchKernelGGL(__VA_ARGS__);                                                                \
+        hipError_t le__ = hipGetLastError();                                                            \
+        if (le__ != hipSuccess) throw std::runtime_error(std::string("kernel launch failed: ") + hipGetErrorString(le__)); \
     } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
@@ -119,27 +128,7 @@ struct ProfEntry {
     long launches;
 };
 
-// Phase alternation of two stream groups.  A Picard iteration has a bandwidth-bound phase (level-0 post-smoother, fused
-// tail, scalar tails, J sums, source, level-0 pre-smoother of the next iteration: contiguous across the iteration boundary)
-// and a latency-bound phase (levels >= 1 incl. the one-workgroup-per-member coarse kernel).  Left alone, the two groups drift
-// into phase and fight for HBM, then idle together.  With the alternation the bandwidth phases of the groups are chained
-// A(k) -> B(k) -> A(k+1) by events, so each group's latency phase runs under the other's bandwidth phase.
-// seq counts the releases (end of a bandwidth phase); an event is recorded BEFORE seq is published, and a waiter only waits
-// on events it has seen published, so every hipStreamWaitEvent refers to an already-recorded event (no cycles possible).
-struct PhaseSync {
-    static constexpr int RING = 64;
-    std::atomic<long> seq{0};
-    std::atomic<int> in_loop{0};
-    hipEvent_t ev[RING] = {};
-    bool ready = false;
-};
-
 struct Solver {
-    PhaseSync phase;
-    Solver* partner = nullptr;  // the other stream group (exactly two groups), or nullptr
-    int phase_role = 0;         // 0: leader (waits partner.seq >= seq), 1: follower (waits partner.seq >= seq + 1)
-    bool phase_active = false;  // set by the Picard driver for the duration of its loop
-    int phase_mode = 1;         // 1: the fine-level (bandwidth) phases of the two groups exclude each other; 2: the coarse-level phases do
     int nr = 0, nz = 0, B = 0, ld = 0;
     long stride = 0;
     double dr = 0, dz = 0;
@@ -198,8 +187,6 @@ struct Solver {
         for (auto& kv : hier)
             for (auto* l : kv.second.lv) delete l;
         for (auto& e : prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-        if (phase.ready)
-            for (auto& e : phase.ev) (void)hipEventDestroy(e);
         if (h_nactive) (void)hipHostFree(h_nactive);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -246,11 +233,12 @@ static void build_level_tables(LevelHost* L) {
         ri[ir] = 1.0 / r_safe;
         rl[ir] = recip_lo(r_safe);
     }
-    L->a_e.alloc(L->nr);
-    L->a_w.alloc(L->nr);
-    L->r_safe.alloc(L->nr);
-    L->r_inv.alloc(L->nr);
-    L->r_inv_lo.alloc(L->nr);
+    // (+8: the row-block smoother loads the tables as 16-B pairs (c, c+1) from a clamped even column)
+    L->a_e.alloc(L->nr + 8);
+    L->a_w.alloc(L->nr + 8);
+    L->r_safe.alloc(L->nr + 8);
+    L->r_inv.alloc(L->nr + 8);
+    L->r_inv_lo.alloc(L->nr + 8);
     HIP_TRY(hipMemcpy(L->r_inv.p, ri.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(L->r_inv_lo.p, rl.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(L->a_e.p, ae.data(), sizeof(double) * L->nr, hipMemcpyHostToDevice));
@@ -407,7 +395,7 @@ static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, doubl
     static const int xcd_env = [] { const char* e = std::getenv("SCPN_HIP_XCD"); return e ? std::atoi(e) : 1; }();
     SrcGen sgv = sg ? *sg : SrcGen{};
     if (!SRCGEN && h->lazy_src && src.base == h->lazy_src) { sgv.st = h->d_st.p; sgv.neg_mu0R = h->d_neg_mu0R.p; }
-    hipLaunchKernelGGL(kern, g, dim3(64 * NWT), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c, ld_c,
+    SCPN_LAUNCH(kern, g, dim3(64 * NWT), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c, ld_c,
                        sgv, dd, ba, xcd_env);
 }
 // the production roles (plain / +prolongation / +defect) and the blend-fused post-smoother exist in every geometry; source
@@ -418,16 +406,6 @@ static void launch_tile_geo(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, d
     switch (tile_variant_for(L)) {
         case 1: launch_tile<S, PROLONG, false, DEFECT, BLEND, 40, 8, TILE_WPE_V1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
         case 2: launch_tile<S, PROLONG, false, DEFECT, BLEND, 46, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
-#ifdef TILE_EXPERIMENTS
-        case 3: launch_tile<S, PROLONG, false, DEFECT, BLEND, 48, 8, 6>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
-        case 4: launch_tile<S, PROLONG, false, DEFECT, BLEND, 56, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
-        case 5: launch_tile<S, PROLONG, false, DEFECT, BLEND, 64, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
-        case 6: launch_tile<S, PROLONG, false, DEFECT, BLEND, 32, 8, 4>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
-        case 7: launch_tile<S, PROLONG, false, DEFECT, BLEND, 56, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
-        case 8: launch_tile<S, PROLONG, false, DEFECT, BLEND, 64, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
-        case 9: launch_tile<S, PROLONG, false, DEFECT, BLEND, 40, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
-        case 10: launch_tile<S, PROLONG, false, DEFECT, BLEND, 32, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
-#endif
         default: launch_tile<S, PROLONG, false, DEFECT, BLEND>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
     }
 }
@@ -447,35 +425,102 @@ static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
     else if (ps.c.base) launch_tile_geo<S, true, false>(h, L, out, in, src, omega, active, ps, nullptr);
     else launch_tile_geo<S, false, false>(h, L, out, in, src, omega, active, ps, nullptr);
 }
-// time-skewed smoother (slide_kernel.hip.h): 3 sweeps, optional prolongation on load; opt-in while it is being measured
-static int slide_rseg() {
-    static const int v = [] { const char* e = std::getenv("SCPN_HIP_SLIDE_RSEG"); int r = e ? std::atoi(e) : 132; return std::max(8, r & ~1); }();
-    return v;
+// register-resident row-block smoother (smooth_rows.hip.h): geometry variants (rows per wave, persistent or one tile per workgroup)
+struct RowsGeo { int rb; bool persist; };
+static int device_cus() {
+    static const int n = [] {
+        hipDeviceProp_t pr;
+        return (hipGetDeviceProperties(&pr, g_device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }();
+    return n;
 }
-static bool slide_enabled(const Lvl& L) {
-    static const int lv = [] { const char* e = std::getenv("SCPN_HIP_SLIDE"); return e ? std::atoi(e) : 0; }();  // 1: level 0, 2: levels 0-1, 3: all tiled levels
-    if (lv <= 0) return false;
+static RowsGeo rows_geo_for(const Lvl& L) {
+    // SCPN_HIP_ROWS="g0,g1,g2": geometry index for level 0, 1, 2+
+    //   0: 8 rows x 8 waves, one tile per workgroup (two workgroups per CU)      1: 10 rows x 8 waves, ditto
+    //   2: 8 x 8 persistent (one workgroup per CU, next tile prefetched)          3: 10 x 8 persistent
+    static const std::array<int, 3> cfg = [] {
+        std::array<int, 3> c{2, 0, 0};
+        if (const char* e = std::getenv("SCPN_HIP_ROWS")) {
+            int a = 0, b = 0, d = 0;
+            int n = std::sscanf(e, "%d,%d,%d", &a, &b, &d);
+            if (n >= 1) c[0] = c[1] = c[2] = a;
+            if (n >= 2) c[1] = c[2] = b;
+            if (n >= 3) c[2] = d;
+        }
+        return c;
+    }();
+    static const RowsGeo geos[4] = {{8, false}, {10, false}, {8, true}, {10, true}};
     const int lvl = L.nz > 300 ? 0 : (L.nz > 150 ? 1 : 2);
-    return lvl < lv;
+    return geos[std::min(std::max(cfg[lvl], 0), 3)];
 }
-static void launch_slide(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps) {
-    static std::once_flag once;
-    const size_t lds = (size_t)4 * SL_W * 64 * sizeof(double);
-    std::call_once(once, [&] {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_slide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_smooth_slide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    });
-    SlideArgs a{};
-    a.out = out; a.in = in; a.src = src; a.coarse = ps.c; a.nz_c = ps.nz_c; a.nr_c = ps.nr_c; a.ld_c = ps.ld_c;
-    a.active = active; a.rseg = slide_rseg(); a.omega = omega; a.om1 = 1.0 - omega;
-    if (h->lazy_src && src.base == h->lazy_src) { a.lazy_st = h->d_st.p; a.lazy_nm = h->d_neg_mu0R.p; }
-    dim3 g(cdiv(L.nr, 128 - 2 * SL_H), cdiv(L.nz, a.rseg), h->B);
-    if (ps.c.base) hipLaunchKernelGGL(k_smooth_slide<true>, g, dim3(SL_NT), lds, h->stream, a, L);
-    else hipLaunchKernelGGL(k_smooth_slide<false>, g, dim3(SL_NT), lds, h->stream, a, L);
+static bool rows_enabled() {
+    static const bool on = [] { const char* e = std::getenv("SCPN_HIP_SMOOTHER"); return !(e && std::strcmp(e, "tile") == 0); }();
+    return on;
+}
+template <int S, bool PROLONG, bool DEFECT, int RB, bool PERSIST, bool BLEND = false>
+static void launch_rows_k(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
+                          const DefectOut* dfo, const BlendArgs* bl = nullptr) {
+    constexpr int NW = 8, H = 2 * S + ((DEFECT || BLEND) ? 2 : 0), OWNZ = RB * NW - 2 * H, OWNR = 128 - 2 * H;
+    constexpr int WPE = PERSIST ? 2 : 4;  // register budget: 256 (one 8-wave workgroup per CU) / 128 (two per CU)
+    RowsArgs A{};
+    A.out = out; A.in = in; A.src = src; A.L = L; A.omega = omega; A.om1 = 1.0 - omega; A.active = active;
+    A.coarse = ps.c; A.nz_c = ps.nz_c; A.nr_c = ps.nr_c; A.ld_c = ps.ld_c;
+    if (DEFECT || BLEND) {
+        DefectDst& dd = A.dd;
+        dd.dr2 = L.dr2; dd.dz2 = L.dz2; dd.two_dr = L.two_dr; dd.inv_dr2 = L.inv_dr2; dd.inv_dz2 = L.inv_dz2;
+        dd.inv_two_dr = L.inv_two_dr; dd.r_safe = L.r_safe; dd.r_inv = L.r_inv;
+        dd.lo_dr2 = L.lo_dr2; dd.lo_dz2 = L.lo_dz2; dd.lo_two_dr = L.lo_two_dr; dd.r_inv_lo = L.r_inv_lo;
+    }
+    if (DEFECT) {
+        A.dd.e = dfo->e;
+        A.coarse = dfo->rhs; A.nz_c = dfo->nz_c; A.nr_c = dfo->nr_c; A.ld_c = dfo->ld_c;
+    }
+    static const int xcd_env = [] { const char* e = std::getenv("SCPN_HIP_XCD"); return e ? std::atoi(e) : 1; }();
+    A.xcd_remap = xcd_env;
+    A.lzs.neg_mu0R = L.a_e;  // any per-column table: loaded unconditionally, used only in lazy-source mode
+    if (h->lazy_src && src.base == h->lazy_src) { A.lzs.st = h->d_st.p; A.lzs.neg_mu0R = h->d_neg_mu0R.p; }
+    A.gx = cdiv(L.nr, OWNR); A.gy = cdiv(std::max(L.nz - 1, 1), OWNZ); A.B = h->B;
+    if (BLEND) {
+        A.ba = *bl;
+        if (A.gx * A.gy != A.ba.nblk) throw std::runtime_error("blend partial layout mismatch");
+    }
+    const long tiles = (long)A.gx * A.gy * A.B;
+    const long grid = PERSIST ? std::min<long>(tiles, device_cus()) : tiles;
+    SCPN_LAUNCH((k_smooth_rows<S, PROLONG, DEFECT, RB, NW, WPE, PERSIST, BLEND>), dim3((unsigned)grid), dim3(64 * NW), 0, h->stream, A);
+}
+// the post-smoother that also performs the Picard tail (one tile per workgroup, 8 or 10 rows per wave)
+template <int S>
+static void launch_rows_blend(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
+                              const BlendArgs* bl) {
+    const bool ten = rows_geo_for(L).rb == 10;
+    if (ps.c.base) {
+        if (ten) launch_rows_k<S, true, false, 10, false, true>(h, L, out, in, src, omega, active, ps, nullptr, bl);
+        else launch_rows_k<S, true, false, 8, false, true>(h, L, out, in, src, omega, active, ps, nullptr, bl);
+    } else {
+        if (ten) launch_rows_k<S, false, false, 10, false, true>(h, L, out, in, src, omega, active, ps, nullptr, bl);
+        else launch_rows_k<S, false, false, 8, false, true>(h, L, out, in, src, omega, active, ps, nullptr, bl);
+    }
+}
+template <int S, bool PROLONG, bool DEFECT>
+static void launch_rows_geo(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
+                            const DefectOut* dfo) {
+    const RowsGeo g = rows_geo_for(L);
+    if (g.rb == 10 && g.persist) launch_rows_k<S, PROLONG, DEFECT, 10, true>(h, L, out, in, src, omega, active, ps, dfo);
+    else if (g.rb == 10) launch_rows_k<S, PROLONG, DEFECT, 10, false>(h, L, out, in, src, omega, active, ps, dfo);
+    else if (g.persist) launch_rows_k<S, PROLONG, DEFECT, 8, true>(h, L, out, in, src, omega, active, ps, dfo);
+    else launch_rows_k<S, PROLONG, DEFECT, 8, false>(h, L, out, in, src, omega, active, ps, dfo);
+}
+template <int S>
+static void launch_rows(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
+                        const DefectOut* dfo) {
+    if (dfo) launch_rows_geo<S, false, true>(h, L, out, in, src, omega, active, ps, dfo);
+    else if (ps.c.base) launch_rows_geo<S, true, false>(h, L, out, in, src, omega, active, ps, nullptr);
+    else launch_rows_geo<S, false, false>(h, L, out, in, src, omega, active, ps, nullptr);
 }
 // tiles per member of the blend-fused post-smoother (its partial arrays are indexed by tile)
 static int blend_tiles(const Lvl& L, int post) {
     const int S = ((post - 1) % 3) + 1, H = 2 * S + 2;
+    if (rows_enabled()) return cdiv(L.nr, 128 - 2 * H) * cdiv(std::max(L.nz - 1, 1), rows_geo_for(L).rb * 8 - 2 * H);
     return cdiv(L.nr, 128 - 2 * H) * cdiv(L.nz, tile_rows_for(L) - 2 * H);
 }
 
@@ -489,7 +534,7 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
     const double om1 = 1.0 - omega;
     if (!clip && (long)L.nz * L.nr <= SMALL_MAX) {
         ProfScope ps(h, lname("small_smooth", lvl).c_str(), 1);
-        hipLaunchKernelGGL(k_small_smooth, dim3(h->B), dim3(256), 0, h->stream, in, src, L, omega, om1, n_sweeps, active);
+        SCPN_LAUNCH(k_small_smooth, dim3(h->B), dim3(256), 0, h->stream, in, src, L, omega, om1, n_sweeps, active);
         return in;
     }
     if (!clip && h->use_fused && alt.base != nullptr) {
@@ -507,8 +552,15 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
             const bool last = left - S <= 0;
             const BlendArgs* bl = (blend && last) ? blend : nullptr;  // the last launch writes the blended iterate
             Fld dst = bl ? blend_out : b;
-            if (S == 3 && !sgo && !dfo && !bl && slide_enabled(L)) launch_slide(h, L, dst, a, src, omega, active, pso);
-            else if (S == 3) launch_tile_p<3>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
+            if (rows_enabled() && !sgo && bl) {
+                if (S == 3) launch_rows_blend<3>(h, L, dst, a, src, omega, active, pso, bl);
+                else if (S == 2) launch_rows_blend<2>(h, L, dst, a, src, omega, active, pso, bl);
+                else launch_rows_blend<1>(h, L, dst, a, src, omega, active, pso, bl);
+            } else if (rows_enabled() && !sgo) {
+                if (S == 3) launch_rows<3>(h, L, dst, a, src, omega, active, pso, dfo);
+                else if (S == 2) launch_rows<2>(h, L, dst, a, src, omega, active, pso, dfo);
+                else launch_rows<1>(h, L, dst, a, src, omega, active, pso, dfo);
+            } else if (S == 3) launch_tile_p<3>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
             else if (S == 2) launch_tile_p<2>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
             else launch_tile_p<1>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
             if (bl) return dst;
@@ -524,34 +576,10 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
     dim3 g(cdiv(ncol, 64), cdiv(L.nz - 2, 4), h->B);
     for (int s = 0; s < n_sweeps; ++s)
         for (int parity = 0; parity < 2; ++parity) {
-            if (clip) hipLaunchKernelGGL(k_rb_half<true>, g, BLK2D, 0, h->stream, in, src, L, omega, om1, parity, active);
-            else hipLaunchKernelGGL(k_rb_half<false>, g, BLK2D, 0, h->stream, in, src, L, omega, om1, parity, active);
+            if (clip) SCPN_LAUNCH(k_rb_half<true>, g, BLK2D, 0, h->stream, in, src, L, omega, om1, parity, active);
+            else SCPN_LAUNCH(k_rb_half<false>, g, BLK2D, 0, h->stream, in, src, L, omega, om1, parity, active);
         }
     return in;
-}
-
-// end of this group's bandwidth phase (called after the level-0 pre-smoother has been enqueued)
-static void phase_release(Solver* h) {
-    if (!h->phase_active) return;
-    PhaseSync& ps = h->phase;
-    const long next = ps.seq.load(std::memory_order_relaxed) + 1;
-    HIP_TRY(hipEventRecord(ps.ev[next % PhaseSync::RING], h->stream));
-    ps.seq.store(next, std::memory_order_release);
-}
-// start of this group's bandwidth phase (called before the level-0 post-smoother is enqueued)
-static void phase_acquire(Solver* h) {
-    if (!h->phase_active) return;
-    PhaseSync& mine = h->phase;
-    PhaseSync& other = h->partner->phase;
-    const long target = mine.seq.load(std::memory_order_relaxed) + h->phase_role;
-    long seen = other.seq.load(std::memory_order_acquire);
-    // the partner's host thread may not have enqueued that release yet: wait for it (bounded by the partner leaving its loop)
-    while (seen < target && other.in_loop.load(std::memory_order_acquire)) {
-        std::this_thread::yield();
-        seen = other.seq.load(std::memory_order_acquire);
-    }
-    if (seen >= target && seen - target < PhaseSync::RING - 1)
-        HIP_TRY(hipStreamWaitEvent(h->stream, other.ev[target % PhaseSync::RING], 0));
 }
 
 // One V-cycle (core/multigrid_solve.py:252-335) of (in0, src0) on level 0.  in0 is left untouched; the improved
@@ -601,12 +629,11 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
         return d;
     };
     // level 0: first smoothing pass reads in0 and writes a work buffer
-    bool defect_done0 = false, tile0_done = false;
+    bool defect_done0 = false;
     {
         const Lvl& L0 = lv[0]->dev;
         const int n0 = (k == 0) ? 50 : pre;  // base case: 50 sweeps (multigrid_solve.py:292-293)
         const bool tile0 = fused && (long)L0.nz * L0.nr > SMALL_MAX && n0 > 0;
-        tile0_done = tile0 && k > 0;
         if (tile0) {
             DefectOut d0;
             const bool df = k > 0 && defect_fusable(0);
@@ -618,10 +645,9 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
                 cur[0] = smooth(h, L0, r, bufB, src0, omega, n0 - 3, active, false, 0, nullptr, nullptr, df ? &d0 : nullptr);
             }
             defect_done0 = df;
-            if (k > 0) { if (h->phase_mode == 2) phase_acquire(h); else phase_release(h); }
         } else {
             ProfScope ps(h, "copy", 1);
-            hipLaunchKernelGGL(k_copy, grid2d(L0.nr, L0.nz, B), BLK2D, 0, h->stream, bufA, in0, L0.nz, L0.nr, L0.ld, (const int*)nullptr);
+            SCPN_LAUNCH(k_copy, grid2d(L0.nr, L0.nz, B), BLK2D, 0, h->stream, bufA, in0, L0.nz, L0.nr, L0.ld, (const int*)nullptr);
             cur[0] = bufA;
             if (n0 > 0) cur[0] = smooth(h, L0, bufA, bufB, src0, omega, n0, active);
         }
@@ -641,7 +667,7 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
         if (done) continue;
         ProfScope ps(h, lname("defect_restrict", l).c_str(), 1);
         const Lvl& Lc = lv[l + 1]->dev;
-        hipLaunchKernelGGL(k_defect_restrict, grid2d(Lc.nr, Lc.nz, B), BLK2D, 0, h->stream, rhs_of(l + 1), cur[l + 1], cur[l], rhs_of(l),
+        SCPN_LAUNCH(k_defect_restrict, grid2d(Lc.nr, Lc.nz, B), BLK2D, 0, h->stream, rhs_of(l + 1), cur[l + 1], cur[l], rhs_of(l),
                            lv[l]->dev, Lc, active);
     }
     int top;  // coarsest level solved so far
@@ -651,7 +677,7 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vcycle_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         });
         ProfScope ps(h, "vcycle_coarse", 1);
-        hipLaunchKernelGGL(k_vcycle_coarse, dim3(B), dim3(1024), H.cv_lds, h->stream, cur[lc], rhs_of(lc), H.cv, omega, 1.0 - omega, pre, post, active);
+        SCPN_LAUNCH(k_vcycle_coarse, dim3(B), dim3(1024), H.cv_lds, h->stream, cur[lc], rhs_of(lc), H.cv, omega, 1.0 - omega, pre, post, active);
         top = lc;
     } else {
         cur[k] = smooth(h, lv[k]->dev, cur[k], other_of(k, cur[k]), rhs_of(k), omega, 50, active, false, k);
@@ -661,7 +687,6 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
         const Lvl& Lf = lv[l]->dev;
         const Lvl& Lc = lv[l + 1]->dev;
         const bool tile_post = fused && post > 0 && (long)Lf.nz * Lf.nr > SMALL_MAX;
-        if (l == 0 && tile0_done) { if (h->phase_mode == 2) phase_release(h); else phase_acquire(h); }
         if (tile_post) {  // prolongation fused into the post-smoother's tile load
             ProlongSrc pso;
             pso.c = cur[l + 1]; pso.nz_c = Lc.nz; pso.nr_c = Lc.nr; pso.ld_c = Lc.ld;
@@ -670,7 +695,7 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
         } else {
             {
                 ProfScope ps(h, lname("prolong_add", l).c_str(), 1);
-                hipLaunchKernelGGL(k_prolong<true>, grid2d(Lf.nr, Lf.nz, B), BLK2D, 0, h->stream, cur[l], cur[l + 1], Lf.nz, Lf.nr, Lf.ld,
+                SCPN_LAUNCH(k_prolong<true>, grid2d(Lf.nr, Lf.nz, B), BLK2D, 0, h->stream, cur[l], cur[l + 1], Lf.nz, Lf.nr, Lf.ld,
                                    Lc.nz, Lc.nr, Lc.ld, active);
             }
             cur[l] = smooth(h, Lf, cur[l], other_of(l, cur[l]), rhs_of(l), omega, post, active, false, l);
@@ -682,7 +707,7 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
 static bool same_fld(const Fld& a, const Fld& b) { return a.base == b.base && a.slot == b.slot; }
 static void copy_back(Solver* h, Fld dst, Fld res, const int* active) {
     if (same_fld(dst, res)) return;
-    hipLaunchKernelGGL(k_copy, grid2d(h->nr, h->nz, h->B), BLK2D, 0, h->stream, dst, res, h->nz, h->nr, h->ld, active);
+    SCPN_LAUNCH(k_copy, grid2d(h->nr, h->nz, h->B), BLK2D, 0, h->stream, dst, res, h->nz, h->nr, h->ld, active);
 }
 
 // ------------------------------------------------------------------------------------------ transfers
@@ -745,8 +770,8 @@ static void set_tables_mu0(Solver* h, double mu0) {
         inv[ir] = 1.0 / (mu0 * h->r_axis[ir]);  // core/fusion_kernel.py:431
         neg[ir] = (-mu0) * h->r_axis[ir];       // core/fusion_kernel_newton_solver.py:513
     }
-    h->d_inv_mu0R.alloc(h->nr);
-    h->d_neg_mu0R.alloc(h->nr);
+    h->d_inv_mu0R.alloc(h->nr + 8);
+    h->d_neg_mu0R.alloc(h->nr + 8);
     HIP_TRY(hipMemcpy(h->d_inv_mu0R.p, inv.data(), sizeof(double) * h->nr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_neg_mu0R.p, neg.data(), sizeof(double) * h->nr, hipMemcpyHostToDevice));
     h->mu0_tables = mu0;
@@ -854,7 +879,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         n_act += m.active;
     }
     HIP_TRY(hipMemcpyAsync(h->d_st.p, ms.data(), sizeof(Member) * B, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_publish_slots, dim3(cdiv(B, 64)), dim3(64), 0, st, h->d_st.p, h->d_cur.p, h->d_nxt.p, h->d_best.p,
+    SCPN_LAUNCH(k_publish_slots, dim3(cdiv(B, 64)), dim3(64), 0, st, h->d_st.p, h->d_cur.p, h->d_nxt.p, h->d_best.p,
                        h->d_prev.p, h->d_active.p, B);
     // "all members that take part" mask for the preparation steps (active or zero-current)
     std::vector<int> part(B);
@@ -879,32 +904,32 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     for (int b = 0; b < B; ++b) any_zero |= zero_current[b] != 0;
     if (need_vac) {
         if (h->n_vac > 0)
-            hipLaunchKernelGGL(k_coil_flux, g2, BLK2D, 0, st, bcF, nz, nr, ld, h->d_r.p, h->d_z.p, h->n_vac, h->d_vac_r.p, h->d_vac_z.p,
+            SCPN_LAUNCH(k_coil_flux, g2, BLK2D, 0, st, bcF, nz, nr, ld, h->d_r.p, h->d_z.p, h->n_vac, h->d_vac_r.p, h->d_vac_z.p,
                                h->d_vac_i.p, (const double*)nullptr, p->mu0, 0);
         else
-            hipLaunchKernelGGL(k_fill, g2, BLK2D, 0, st, bcF, 0.0, nz, nr, ld, (const int*)d_part.p);
+            SCPN_LAUNCH(k_fill, g2, BLK2D, 0, st, bcF, 0.0, nz, nr, ld, (const int*)d_part.p);
     } else if (!p->has_boundary_flux) {  // preserve_initial_state: the current psi is the boundary map
-        hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, bcF, curF, nz, nr, ld, (const int*)d_part.p);
+        SCPN_LAUNCH(k_copy, g2, BLK2D, 0, st, bcF, curF, nz, nr, ld, (const int*)d_part.p);
     }
     if (p->preserve_initial_state) {
-        hipLaunchKernelGGL(k_apply_bc, gring, dim3(256), 0, st, curF, bcF, nz, nr, ld, (const int*)d_part.p);
+        SCPN_LAUNCH(k_apply_bc, gring, dim3(256), 0, st, curF, bcF, nz, nr, ld, (const int*)d_part.p);
     } else {
-        hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, curF, bcF, nz, nr, ld, (const int*)d_part.p);
+        SCPN_LAUNCH(k_copy, g2, BLK2D, 0, st, curF, bcF, nz, nr, ld, (const int*)d_part.p);
     }
     if (any_zero) {  // zero-current members: psi = calculate_vacuum_field() (newton_solver.py:450)
         if (h->n_vac > 0)
-            hipLaunchKernelGGL(k_coil_flux, g2, BLK2D, 0, st, WF, nz, nr, ld, h->d_r.p, h->d_z.p, h->n_vac, h->d_vac_r.p, h->d_vac_z.p,
+            SCPN_LAUNCH(k_coil_flux, g2, BLK2D, 0, st, WF, nz, nr, ld, h->d_r.p, h->d_z.p, h->n_vac, h->d_vac_r.p, h->d_vac_z.p,
                                h->d_vac_i.p, (const double*)nullptr, p->mu0, 0);
         else
-            hipLaunchKernelGGL(k_fill, g2, BLK2D, 0, st, WF, 0.0, nz, nr, ld, (const int*)nullptr);
+            SCPN_LAUNCH(k_fill, g2, BLK2D, 0, st, WF, 0.0, nz, nr, ld, (const int*)nullptr);
         DBuf<int>& d_zc = h->d_scr_zc;
         d_zc.alloc(B);
         HIP_TRY(hipMemcpyAsync(d_zc.p, zero_current.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, curF, WF, nz, nr, ld, (const int*)d_zc.p);
+        SCPN_LAUNCH(k_copy, g2, BLK2D, 0, st, curF, WF, nz, nr, ld, (const int*)d_zc.p);
         HIP_TRY(hipStreamSynchronize(st));
     }
     // Psi_best = Psi.copy() before seeding
-    hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, bestF, curF, nz, nr, ld, (const int*)h->d_active.p);
+    SCPN_LAUNCH(k_copy, g2, BLK2D, 0, st, bestF, curF, nz, nr, ld, (const int*)h->d_active.p);
 
     // ---- _seed_plasma (iterative_solver.py:384-410)
     int n_part = 0;
@@ -931,7 +956,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             h->seed_rc = p->r_center;
         }
         const double i_seed = h->seed_integral;
-        hipLaunchKernelGGL(k_seed_j, g2, BLK2D, 0, st, jF, (const double*)h->d_seed.p, (const Member*)h->d_st.p, i_seed, nz, nr, ld,
+        SCPN_LAUNCH(k_seed_j, g2, BLK2D, 0, st, jF, (const double*)h->d_seed.p, (const Member*)h->d_st.p, i_seed, nz, nr, ld,
                            (const int*)d_part.p);
         // members with |I_target| < 1e-12 keep psi untouched (their J is zero)
         std::vector<int> seed_act(B);
@@ -939,25 +964,25 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         DBuf<int>& d_sa = h->d_scr_sa;
         d_sa.alloc(B);
         HIP_TRY(hipMemcpyAsync(d_sa.p, seed_act.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_source_from_j, g2, BLK2D, 0, st, srcF, jF, nz, nr, ld, (const double*)h->d_neg_mu0R.p, (const int*)d_sa.p);
+        SCPN_LAUNCH(k_source_from_j, g2, BLK2D, 0, st, srcF, jF, nz, nr, ld, (const double*)h->d_neg_mu0R.p, (const int*)d_sa.p);
         if (h->use_fused && nz >= 16 && nr >= 16) {  // 50 steps = 10 launches of 5 temporally blocked steps
             ProfScope ps(h, "seed_jacobi", 10);
             const dim3 gj(cdiv(nr, JT_R), cdiv(nz, JT_Z), B);
             for (int s = 0; s < 5; ++s) {
-                hipLaunchKernelGGL(k_jacobi_tile<5>, gj, dim3(256), 0, st, WF, curF, srcF, L0, (const int*)d_sa.p);
-                hipLaunchKernelGGL(k_jacobi_tile<5>, gj, dim3(256), 0, st, curF, WF, srcF, L0, (const int*)d_sa.p);
+                SCPN_LAUNCH(k_jacobi_tile<5>, gj, dim3(256), 0, st, WF, curF, srcF, L0, (const int*)d_sa.p);
+                SCPN_LAUNCH(k_jacobi_tile<5>, gj, dim3(256), 0, st, curF, WF, srcF, L0, (const int*)d_sa.p);
             }
         } else {
             ProfScope ps(h, "seed_jacobi", 50);
             for (int s = 0; s < 25; ++s) {
-                hipLaunchKernelGGL(k_jacobi, g2, BLK2D, 0, st, WF, curF, srcF, L0, (const int*)d_sa.p);
-                hipLaunchKernelGGL(k_jacobi, g2, BLK2D, 0, st, curF, WF, srcF, L0, (const int*)d_sa.p);
+                SCPN_LAUNCH(k_jacobi, g2, BLK2D, 0, st, WF, curF, srcF, L0, (const int*)d_sa.p);
+                SCPN_LAUNCH(k_jacobi, g2, BLK2D, 0, st, curF, WF, srcF, L0, (const int*)d_sa.p);
             }
         }
         HIP_TRY(hipStreamSynchronize(st));
     }
     if (p->external_profile_mode) {
-        hipLaunchKernelGGL(k_source_from_j, g2, BLK2D, 0, st, srcF, jF, nz, nr, ld, (const double*)h->d_neg_mu0R.p, (const int*)h->d_active.p);
+        SCPN_LAUNCH(k_source_from_j, g2, BLK2D, 0, st, srcF, jF, nz, nr, ld, (const double*)h->d_neg_mu0R.p, (const int*)h->d_active.p);
     }
 
     // ---- Picard loop (newton_solver.py:499-582)
@@ -990,7 +1015,8 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     // iteration on MI355X).  SCPN_HIP_LAZYSRC=0 restores the separate source pass
     static const bool lazy_env = [] { const char* e = std::getenv("SCPN_HIP_LAZYSRC"); return !(e && e[0] == '0'); }();
     static const bool srcgen_env0 = [] { const char* e = std::getenv("SCPN_HIP_SRCGEN"); return e && e[0] == '1'; }();
-    static const bool blend_env0 = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1'; }();
+    // (the LDS-tiled kernel's blend-fused variant predates the lazy source; the row-block kernel converts the source on load)
+    static const bool blend_env0 = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1' && !rows_enabled(); }();
     const bool lazy = lazy_env && !srcgen_env0 && !blend_env0 && h->use_fused && p->method == 0 && !p->external_profile_mode &&
                       vcycle_lazy_ok(h, 3, 3, 5);
     struct LazyGuard {
@@ -998,44 +1024,19 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         ~LazyGuard() { h->lazy_src = nullptr; }
     } lazy_guard{h};
     if (lazy) h->lazy_src = srcF.base;
-    // phase alternation with the partner stream group (see PhaseSync).  Measured on MI355X (us per iteration of the 32-member
-    // ensemble): free-running 365, fine-level phases chained (SCPN_HIP_PHASE=1) 376, coarse-level phases chained (=2) 388 -- the
-    // level-0 kernels are bound by fp64 issue / workgroup residency on the CUs rather than by HBM, so two of them share the chip
-    // without loss and any chain only removes overlap.  Opt-in.
-    static const bool phase_env = [] {
-        const char* e = std::getenv("SCPN_HIP_PHASE");
-        const char* g = std::getenv("SCPN_HIP_GRAPH");  // (events of another stream cannot be waited on inside a capture)
-        return e && (e[0] == '1' || e[0] == '2') && !(g && g[0] == '1');
-    }();
-    static const int phase_mode_env = [] { const char* e = std::getenv("SCPN_HIP_PHASE"); return (e && e[0] == '2') ? 2 : 1; }();
-    h->phase_mode = phase_mode_env;
-    struct PhaseGuard {
-        Solver* h;
-        ~PhaseGuard() {
-            h->phase_active = false;
-            h->phase.in_loop.store(0, std::memory_order_release);
-        }
-    } phase_guard{h};
-    if (phase_env && h->partner && h->phase.ready && h->partner->phase.ready && p->method == 0 && h->use_fused && !h->prof_on) {
-        // align the release counters (they drift when the groups run different iteration counts)
-        const long other = h->partner->phase.seq.load(std::memory_order_acquire);
-        if (other > h->phase.seq.load(std::memory_order_relaxed)) h->phase.seq.store(other, std::memory_order_release);
-        h->phase_active = true;
-        h->phase.in_loop.store(1, std::memory_order_release);
-    }
     auto iteration = [&](bool first) {
         {
             ProfScope ps(h, "topology", first || !h->use_fused || p->method == 3 || p->xpoint_saddle ? 2 : 1);
             int ntopo = topo_count;  // partial count produced by the previous iteration's fused tail
             if (first || !h->use_fused || p->method == 3 || p->xpoint_saddle) {  // later iterations get their partials from the fused blend kernel
                 ntopo = nblk1;
-                hipLaunchKernelGGL(k_topology, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, h->dr, h->dz,
+                SCPN_LAUNCH(k_topology, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, h->dr, h->dz,
                                    n_mask_rows, h->d_topo.p, nblk1);
             }
-            hipLaunchKernelGGL(k_topology_final, dim3(B), dim3(256), 0, st, curF, h->d_st.p, (const TopoPart*)h->d_topo.p, ntopo, nr, ld,
+            SCPN_LAUNCH(k_topology_final, dim3(B), dim3(256), 0, st, curF, h->d_st.p, (const TopoPart*)h->d_topo.p, ntopo, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_z.p);
             if (p->xpoint_saddle)
-                hipLaunchKernelGGL(k_xpoint_saddle, dim3(B), dim3(1024), 0, st, curF, h->d_st.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
+                SCPN_LAUNCH(k_xpoint_saddle, dim3(B), dim3(1024), 0, st, curF, h->d_st.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
                                    (const double*)h->d_r.p, (const double*)h->d_z.p);
         }
         // source generation inside the pre-smoother is implemented and bit-exact, but its 160-VGPR footprint drops the
@@ -1045,16 +1046,16 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         SrcGen sg{};
         if (!p->external_profile_mode) {
             ProfScope ps(h, "source", gen ? 1 : (lazy ? 2 : 3));
-            hipLaunchKernelGGL(k_jsum, gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
+            SCPN_LAUNCH(k_jsum, gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
                                (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, lazy ? srcF : Fld{nullptr, nullptr, 0, 0});
             if (lazy) {  // the V-cycle's level-0 tiles and the fused tail form the source from J_raw on load
-                hipLaunchKernelGGL(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
+                SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
             } else if (gen) {  // scale + source are evaluated inside the pre-smoother's tile load
                 sg.r_axis = h->d_r.p; sg.inv_mu0R = h->d_inv_mu0R.p; sg.neg_mu0R = h->d_neg_mu0R.p; sg.part = h->d_jpart.p;
                 sg.st = h->d_st.p; sg.nblk = nblkj; sg.dr = h->dr; sg.dz = h->dz; sg.pf = pf;
             } else {
-                hipLaunchKernelGGL(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
-                hipLaunchKernelGGL(k_source, gjs, dim3(256), 0, st, srcF, jF, 0, curF, (const Member*)h->d_st.p, nz, nr, ld,
+                SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
+                SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, srcF, jF, 0, curF, (const Member*)h->d_st.p, nz, nr, ld,
                                    (const double*)h->d_r.p, (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
             }
         }
@@ -1062,7 +1063,9 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         Fld newF = WF;
         // blend + norms + topology inside the post-smoother is implemented and bit-identical to k_blend_fused, but at one
         // 16-wave workgroup per CU its extra compute is not hidden (160.8 vs 172.3 eq/s measured): opt-in (SCPN_HIP_BLENDFUSE=1)
-        static const bool blend_env = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1'; }();
+        // With the row-block smoother the Picard tail is an epilogue of the level-0 post-smoother by default (psi_new stays in
+        // registers; SCPN_HIP_BLENDFUSE=0 restores the separate k_blend_fused pass)
+        static const bool blend_env = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e ? e[0] == '1' : rows_enabled(); }();
         const bool blend_in_tile = blend_env && p->method == 0 && vcycle_can_blend(h, 3, 5);
         int nb_d = nblk1, nb_r = nblk_r;
         if (p->method == 0) {
@@ -1075,29 +1078,29 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             }
             newF = vcycle(h, curF, WF, W2F, srcF, p->sor_omega, 3, 3, 5, act, gen ? &sg : nullptr, blend_in_tile ? &ba : nullptr, nxtF);
         } else if (p->method == 1 || p->method == 3 || p->method == 4) {  // "sor", "anderson" and any other method string (iterative_solver.py:376-378)
-            hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, WF, curF, nz, nr, ld);
-            hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, st, src2F, srcF, nz, nr, ld);
+            SCPN_LAUNCH(k_sanitize, g2, BLK2D, 0, st, WF, curF, nz, nr, ld);
+            SCPN_LAUNCH(k_sanitize, g2, BLK2D, 0, st, src2F, srcF, nz, nr, ld);
             smooth(h, L0, WF, Fld{nullptr, nullptr, 0, 0}, src2F, p->sor_omega, 1, act, true);
         } else {
-            hipLaunchKernelGGL(k_jacobi, g2, BLK2D, 0, st, WF, curF, srcF, L0, act);
+            SCPN_LAUNCH(k_jacobi, g2, BLK2D, 0, st, WF, curF, srcF, L0, act);
         }
         if (blend_in_tile) {
             // nothing to do: blend, norms and next-iteration topology partials came out of the post-smoother
         } else if (h->use_fused && p->method != 3) {
             ProfScope ps(h, "blend_fused", 1);
             nb_d = nb_r = nblk2;
-            hipLaunchKernelGGL(k_blend_fused, dim3(cdiv(nr - 1, BT_R), cdiv(nz - 1, BT_Z), B), dim3(256), 0, st, nxtF, curF, newF, bcF, srcF,
+            SCPN_LAUNCH(k_blend_fused, dim3(cdiv(nr - 1, BT_R), cdiv(nz - 1, BT_Z), B), dim3(256), 0, st, nxtF, curF, newF, bcF, srcF,
                                (const Member*)h->d_st.p, L0, p->alpha, om_alpha, n_mask_rows, h->d_part1.p, h->d_pbad.p, h->d_part2.p,
                                h->d_part3.p, h->d_topo.p, nblk2, lazy ? (const double*)h->d_neg_mu0R.p : (const double*)nullptr);
         } else {
             ProfScope ps(h, "blend_norms", 2);
-            hipLaunchKernelGGL(k_blend, dim3(nblk1, B), dim3(256), 0, st, nxtF, curF, newF, bcF, (const Member*)h->d_st.p, nz, nr, ld, p->alpha,
+            SCPN_LAUNCH(k_blend, dim3(nblk1, B), dim3(256), 0, st, nxtF, curF, newF, bcF, (const Member*)h->d_st.p, nz, nr, ld, p->alpha,
                                om_alpha, h->d_part1.p, h->d_pbad.p, nblk1);
             if (p->method == 3) {  // Anderson acceleration (newton_solver.py:540-550)
                 const int cap = p->anderson_m + 3;
                 const long hs = h->stride * (long)B;
                 const int slot = (and_start + and_len) % cap;
-                hipLaunchKernelGGL(k_and_push, g2, BLK2D, 0, st, h->and_psi.p + slot * hs, h->and_res.p + slot * hs, h->stride, nxtF, newF, bcF,
+                SCPN_LAUNCH(k_and_push, g2, BLK2D, 0, st, h->and_psi.p + slot * hs, h->and_res.p + slot * hs, h->stride, nxtF, newF, bcF,
                                    nz, nr, ld, act);
                 and_len += 1;
                 if (and_len >= 3 && iter_k % 3 == 0) {
@@ -1110,18 +1113,18 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
                             F.f[j] = h->and_res.p + sl * hs;
                             P.f[j] = h->and_psi.p + sl * hs;
                         }
-                        hipLaunchKernelGGL(k_and_gram, dim3(nblk1, B), dim3(256), 0, st, F, nz, nr, ld, h->and_part.p, nblk1, act);
-                        hipLaunchKernelGGL(k_and_final, dim3(cdiv(B, 64)), dim3(64), 0, st, (const double*)h->and_part.p, nblk1, mk, h->and_alpha.p,
+                        SCPN_LAUNCH(k_and_gram, dim3(nblk1, B), dim3(256), 0, st, F, nz, nr, ld, h->and_part.p, nblk1, act);
+                        SCPN_LAUNCH(k_and_final, dim3(cdiv(B, 64)), dim3(64), 0, st, (const double*)h->and_part.p, nblk1, mk, h->and_alpha.p,
                                            h->and_fb.p, B, act);
-                        hipLaunchKernelGGL(k_and_mix, g2, BLK2D, 0, st, nxtF, P, (const double*)h->and_alpha.p, (const int*)h->and_fb.p, bcF, nz, nr,
+                        SCPN_LAUNCH(k_and_mix, g2, BLK2D, 0, st, nxtF, P, (const double*)h->and_alpha.p, (const int*)h->and_fb.p, bcF, nz, nr,
                                            ld, act);
                     } else {  // mk < 2: the latest iterate with the boundary re-applied
-                        hipLaunchKernelGGL(k_apply_bc, gring, dim3(256), 0, st, nxtF, bcF, nz, nr, ld, act);
+                        SCPN_LAUNCH(k_apply_bc, gring, dim3(256), 0, st, nxtF, bcF, nz, nr, ld, act);
                     }
                 }
                 if (and_len > p->anderson_m + 2) { and_start = (and_start + 1) % cap; and_len -= 1; }
             }
-            hipLaunchKernelGGL(k_resid_norms, dim3(nblk_r, B), dim3(256), 0, st, nxtF, srcF, L0, h->d_part2.p, h->d_part3.p, nblk_r, act);
+            SCPN_LAUNCH(k_resid_norms, dim3(nblk_r, B), dim3(256), 0, st, nxtF, srcF, L0, h->d_part2.p, h->d_part3.p, nblk_r, act);
         }
         topo_count = nb_d;
         PicardCtl ctl;
@@ -1129,18 +1132,11 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         ctl.iter = 0; ctl.pad = (p->method == 4) ? 1 : 0; /* pad = keep the state on divergence (Newton warm-up) */ ctl.n_total = (long)nz * nr; ctl.n_interior = (long)(nz - 2) * (nr - 2);
         {
             ProfScope ps(h, "picard_final", 1);
-            hipLaunchKernelGGL(k_picard_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_part1.p, (const int*)h->d_pbad.p,
+            SCPN_LAUNCH(k_picard_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_part1.p, (const int*)h->d_pbad.p,
                                (const double*)h->d_part2.p, (const double*)h->d_part3.p, nb_d, nb_r, ctl, d_hist_diff.p, d_hist_gs.p,
                                d_trace.p, h->d_nactive.p, h->d_cur.p, h->d_nxt.p, h->d_best.p, h->d_prev.p, h->d_active.p);
         }
     };
-    // iteration 0 runs eagerly (it needs the stand-alone topology kernel and performs all one-time kernel attribute
-    // set-up); the steady-state body is captured once into a HIP graph and replayed: ~35 launches -> 1 per iteration
-    // (measured on MI355X: replay is ~3 % slower than eager launches for the 32-member ensemble -- the host is not the
-    // limiter and replay adds inter-node gaps -- so it is opt-in: SCPN_HIP_GRAPH=1)
-    static const bool graph_env = [] { const char* e = std::getenv("SCPN_HIP_GRAPH"); return e && e[0] == '1'; }();
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
     int k = 0;
     if (n_act > 0 && max_iter > 0) {
         iter_k = 0;
@@ -1152,16 +1148,9 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             n_act = h->h_nactive[0];
         }
     }
-    if (graph_env && p->method != 3 && !h->prof_on && n_act > 0 && k < max_iter) {
-        HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        iteration(false);
-        HIP_TRY(hipStreamEndCapture(st, &graph));
-        HIP_TRY(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
-    }
     while (n_act > 0 && k < max_iter) {
         iter_k = k;
-        if (gexec) HIP_TRY(hipGraphLaunch(gexec, st));
-        else iteration(false);
+        iteration(false);
         ++k;
         if (k % check_every == 0 || k >= max_iter) {
             HIP_TRY(hipMemcpyAsync(h->h_nactive, h->d_nactive.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1169,11 +1158,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             n_act = h->h_nactive[0];
         }
     }
-    h->phase_active = false;
-    h->phase.in_loop.store(0, std::memory_order_release);
     HIP_TRY(hipStreamSynchronize(st));
-    if (gexec) (void)hipGraphExecDestroy(gexec);
-    if (graph) (void)hipGraphDestroy(graph);
     // ---- J_phi of the last source update (recomputed from the pre-blend psi kept in slot `prev`)
     if (!p->external_profile_mode) {
         std::vector<Member> fin(B);
@@ -1186,10 +1171,10 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             DBuf<Member>& d_tmp = h->d_scr_st;
             d_tmp.alloc(B);
             HIP_TRY(hipMemcpyAsync(d_tmp.p, tmp.data(), sizeof(Member) * B, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_source, gjs, dim3(256), 0, st, src2F, jF, 1, prevF, (const Member*)d_tmp.p, nz, nr, ld, (const double*)h->d_r.p,
+            SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, src2F, jF, 1, prevF, (const Member*)d_tmp.p, nz, nr, ld, (const double*)h->d_r.p,
                                (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
             if (lazy)  // the source field held J_raw during the iterations: leave the last source in it, as the eager path does
-                hipLaunchKernelGGL(k_source, gjs, dim3(256), 0, st, srcF, jF, 0, prevF, (const Member*)d_tmp.p, nz, nr, ld, (const double*)h->d_r.p,
+                SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, srcF, jF, 0, prevF, (const Member*)d_tmp.p, nz, nr, ld, (const double*)h->d_r.p,
                                    (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
             HIP_TRY(hipStreamSynchronize(st));
         }
@@ -1313,11 +1298,11 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
     int hcnt[4] = {n_on, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(d_non, hcnt, sizeof(int) * 4, hipMemcpyHostToDevice, st));
     auto flags = [&](int op, int k = 0) {
-        hipLaunchKernelGGL(k_nt_flags, dim3(cdiv(B, 64)), dim3(64), 0, st, h->d_st.p, h->nt_st.p, h->d_active.p, B, op, o->newton_alpha, k);
+        SCPN_LAUNCH(k_nt_flags, dim3(cdiv(B, 64)), dim3(64), 0, st, h->d_st.p, h->nt_st.p, h->d_active.p, B, op, o->newton_alpha, k);
     };
     flags(3);
     if (p->external_profile_mode)
-        hipLaunchKernelGGL(k_source_from_j, g2, BLK2D, 0, st, srcF, jF, nz, nr, ld, (const double*)h->d_neg_mu0R.p, (const int*)h->d_active.p);
+        SCPN_LAUNCH(k_source_from_j, g2, BLK2D, 0, st, srcF, jF, nz, nr, ld, (const double*)h->d_neg_mu0R.p, (const int*)h->d_active.p);
 
     NtCtl ctl;
     ctl.tol = p->tol; ctl.gs_tol = p->gs_tol; ctl.require_gs = p->require_gs_residual; ctl.line_search = o->line_search;
@@ -1328,20 +1313,20 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
     auto topo_source = [&](Fld dstSrc) {
         {
             ProfScope ps(h, "topology", 2);
-            hipLaunchKernelGGL(k_topology, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, h->dr, h->dz,
+            SCPN_LAUNCH(k_topology, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, h->dr, h->dz,
                                n_mask_rows, h->d_topo.p, nblk1);
-            hipLaunchKernelGGL(k_topology_final, dim3(B), dim3(256), 0, st, curF, h->d_st.p, (const TopoPart*)h->d_topo.p, nblk1, nr, ld,
+            SCPN_LAUNCH(k_topology_final, dim3(B), dim3(256), 0, st, curF, h->d_st.p, (const TopoPart*)h->d_topo.p, nblk1, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_z.p);
             if (p->xpoint_saddle)
-                hipLaunchKernelGGL(k_xpoint_saddle, dim3(B), dim3(1024), 0, st, curF, h->d_st.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
+                SCPN_LAUNCH(k_xpoint_saddle, dim3(B), dim3(1024), 0, st, curF, h->d_st.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
                                    (const double*)h->d_r.p, (const double*)h->d_z.p);
         }
         if (!p->external_profile_mode) {
             ProfScope ps(h, "source", 3);
-            hipLaunchKernelGGL(k_jsum, gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
+            SCPN_LAUNCH(k_jsum, gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
                                (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0});
-            hipLaunchKernelGGL(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
-            hipLaunchKernelGGL(k_source, gjs, dim3(256), 0, st, dstSrc, jF, 1, curF, (const Member*)h->d_st.p, nz, nr, ld,
+            SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
+            SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, dstSrc, jF, 1, curF, (const Member*)h->d_st.p, nz, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
         }
     };
@@ -1349,8 +1334,8 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
     double* P1 = h->nt_part.p + (size_t)B * h->nt_part.n / (2 * (size_t)B);
     auto resid = [&](Fld outF, Fld sF, int mode) {
         ProfScope ps(h, "newton_resid", 2);
-        hipLaunchKernelGGL(k_nt_resid, g2, BLK2D, 0, st, outF, curF, sF, L0, (const NtMember*)h->nt_st.p, mode == 1 ? 1 : 0, P0);
-        hipLaunchKernelGGL(k_nt_resid_final, dim3(B), dim3(256), 0, st, h->d_st.p, h->nt_st.p, ctl, mode, o->line_search_c, d_hist.p, d_gs.p,
+        SCPN_LAUNCH(k_nt_resid, g2, BLK2D, 0, st, outF, curF, sF, L0, (const NtMember*)h->nt_st.p, mode == 1 ? 1 : 0, P0);
+        SCPN_LAUNCH(k_nt_resid_final, dim3(B), dim3(256), 0, st, h->d_st.p, h->nt_st.p, ctl, mode, o->line_search_c, d_hist.p, d_gs.p,
                            (const double*)P0, nb2, h->d_active.p, d_non);
     };
     auto poll = [&](int* dptr) {
@@ -1365,16 +1350,16 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         const int pe = std::max(1, o->poll_every);
         double* V = h->nt_V.p;
         auto tail = [&](int mode, const double* part, int nblk) {
-            hipLaunchKernelGGL(k_gm_tail, dim3(B), dim3(256), 0, st, h->nt_gm.p, h->nt_st.p, mode, o->gmres_atol, o->gmres_rtol, restart, precond,
+            SCPN_LAUNCH(k_gm_tail, dim3(B), dim3(256), 0, st, h->nt_gm.p, h->nt_st.p, mode, o->gmres_atol, o->gmres_rtol, restart, precond,
                                maxit, part, nblk, d_nsolve);
         };
         {
             ProfScope ps(h, "gmres_init", precond ? 4 : 2);
-            hipLaunchKernelGGL(k_gm_init, gflat, dim3(256), 0, st, buf(RHS), buf(XV), buf(RES), (const double*)buf(RK), stride, h->nt_gm.p,
+            SCPN_LAUNCH(k_gm_init, gflat, dim3(256), 0, st, buf(RHS), buf(XV), buf(RES), (const double*)buf(RK), stride, h->nt_gm.p,
                                (const NtMember*)h->nt_st.p, P0, nbf);
             tail(0, P0, nbf);
             if (precond) {
-                hipLaunchKernelGGL(k_gm_start, gflat, dim3(256), 0, st, (double*)nullptr, (const double*)buf(RHS), (const double*)buf(IVD), stride,
+                SCPN_LAUNCH(k_gm_start, gflat, dim3(256), 0, st, (double*)nullptr, (const double*)buf(RHS), (const double*)buf(IVD), stride,
                                    (const GmState*)h->nt_gm.p, 1, 1, P0, nbf);
                 tail(1, P0, nbf);
             }
@@ -1384,13 +1369,13 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         // (one workgroup per member: always for <= 65^2; up to 129^2 when there are enough members to occupy several CUs)
         const long npts = (long)nz * nr;
         if (npts <= std::min(small_max, 20000L) && (npts <= 4500 || B >= 4)) {
-            hipLaunchKernelGGL(k_gm_count, dim3(1), dim3(64), 0, st, (const GmState*)h->nt_gm.p, B, d_nsolve, d_ninner);
+            SCPN_LAUNCH(k_gm_count, dim3(1), dim3(64), 0, st, (const GmState*)h->nt_gm.p, B, d_nsolve, d_ninner);
             int left = poll(d_nsolve);
             for (int cyc = 0; cyc < maxit && left > 0; ++cyc) {
                 ProfScope ps(h, "gmres_cycle_small", 1);
                 const long nint = (long)(nz - 2) * (nr - 2);
                 auto launch = [&](auto kern) {
-                    hipLaunchKernelGGL(kern, dim3(B), dim3(1024), 0, st, V, buf(XV), buf(RES), (const double*)buf(RHS), (const double*)buf(DG),
+                    SCPN_LAUNCH(kern, dim3(B), dim3(1024), 0, st, V, buf(XV), buf(RES), (const double*)buf(RHS), (const double*)buf(DG),
                                        (const double*)buf(IVD), stride, B, L0, h->nt_gm.p, h->nt_st.p, precond, maxit, d_nsolve);
                 };
                 if (nint <= 1024L * 2) launch(k_gm_cycle_small<2>);
@@ -1401,7 +1386,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
                         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gm_cycle_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     160 * 1024 - 256));
                     });
-                    hipLaunchKernelGGL(k_gm_cycle_lds, dim3(B), dim3(1024), sizeof(double) * nint, st, V, buf(XV), buf(RES), (const double*)buf(RHS),
+                    SCPN_LAUNCH(k_gm_cycle_lds, dim3(B), dim3(1024), sizeof(double) * nint, st, V, buf(XV), buf(RES), (const double*)buf(RHS),
                                        (const double*)buf(DG), (const double*)buf(IVD), stride, B, L0, h->nt_gm.p, h->nt_st.p, precond, maxit,
                                        d_nsolve);
                 }
@@ -1410,41 +1395,41 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
             return;
         }
         for (int cyc = 0; cyc < maxit; ++cyc) {
-            hipLaunchKernelGGL(k_gm_count, dim3(1), dim3(64), 0, st, (const GmState*)h->nt_gm.p, B, d_nsolve, d_ninner);
+            SCPN_LAUNCH(k_gm_count, dim3(1), dim3(64), 0, st, (const GmState*)h->nt_gm.p, B, d_nsolve, d_ninner);
             if (poll(d_nsolve) == 0) break;
-            hipLaunchKernelGGL(k_gm_start, gflat, dim3(256), 0, st, V, (const double*)buf(RES), (const double*)buf(IVD), stride,
+            SCPN_LAUNCH(k_gm_start, gflat, dim3(256), 0, st, V, (const double*)buf(RES), (const double*)buf(IVD), stride,
                                (const GmState*)h->nt_gm.p, precond, 0, P0, nbf);
-            hipLaunchKernelGGL(k_gm_scale, gflat, dim3(256), 0, st, V, (const double*)V, stride, h->nt_gm.p, 0, (const double*)P0, nbf);
+            SCPN_LAUNCH(k_gm_scale, gflat, dim3(256), 0, st, V, (const double*)V, stride, h->nt_gm.p, 0, (const double*)P0, nbf);
             for (int col = 0; col < restart; ++col) {
                 {
                     ProfScope ps(h, "gmres_matvec", 1);
-                    hipLaunchKernelGGL(k_gm_matvec, g2, BLK2D, 0, st, buf(WV), (const double*)(V + (long)col * n), (const double*)buf(DG),
+                    SCPN_LAUNCH(k_gm_matvec, g2, BLK2D, 0, st, buf(WV), (const double*)(V + (long)col * n), (const double*)buf(DG),
                                        (const double*)buf(IVD), (const double*)buf(RHS), stride, L0, (const GmState*)h->nt_gm.p, precond, 0, P0);
                 }
                 {
                     ProfScope ps(h, "gmres_mgs", col + 3);
                     for (int k = 0; k <= col + 1; ++k)  // launch k reads the partials of the previous launch, writes the other half
-                        hipLaunchKernelGGL(k_gm_mgs, gflat, dim3(256), 0, st, buf(WV), (const double*)V, stride, B, h->nt_gm.p, col, k,
+                        SCPN_LAUNCH(k_gm_mgs, gflat, dim3(256), 0, st, buf(WV), (const double*)V, stride, B, h->nt_gm.p, col, k,
                                            (const double*)((k & 1) ? P1 : P0), k == 0 ? nb2 : nbf, (k & 1) ? P0 : P1, nbf);
-                    hipLaunchKernelGGL(k_gm_col_tail, dim3(B), dim3(256), 0, st, h->nt_gm.p, col, (const double*)(((col + 1) & 1) ? P0 : P1), nbf,
+                    SCPN_LAUNCH(k_gm_col_tail, dim3(B), dim3(256), 0, st, h->nt_gm.p, col, (const double*)(((col + 1) & 1) ? P0 : P1), nbf,
                                        d_ninner);
                 }
                 if (col + 1 < restart)
-                    hipLaunchKernelGGL(k_gm_scale, gflat, dim3(256), 0, st, V + (long)(col + 1) * n, (const double*)buf(WV), stride, h->nt_gm.p, 1,
+                    SCPN_LAUNCH(k_gm_scale, gflat, dim3(256), 0, st, V + (long)(col + 1) * n, (const double*)buf(WV), stride, h->nt_gm.p, 1,
                                        (const double*)P0, nbf);
                 if ((col + 1) % pe == 0 && col + 1 < restart && poll(d_ninner) == 0) break;
             }
             {
                 ProfScope ps(h, "gmres_update", 3);
-                hipLaunchKernelGGL(k_gm_update_x, gflat, dim3(256), 0, st, buf(XV), (const double*)V, stride, B, (const GmState*)h->nt_gm.p);
-                hipLaunchKernelGGL(k_gm_matvec, g2, BLK2D, 0, st, buf(RES), (const double*)buf(XV), (const double*)buf(DG), (const double*)buf(IVD),
+                SCPN_LAUNCH(k_gm_update_x, gflat, dim3(256), 0, st, buf(XV), (const double*)V, stride, B, (const GmState*)h->nt_gm.p);
+                SCPN_LAUNCH(k_gm_matvec, g2, BLK2D, 0, st, buf(RES), (const double*)buf(XV), (const double*)buf(DG), (const double*)buf(IVD),
                                    (const double*)buf(RHS), stride, L0, (const GmState*)h->nt_gm.p, precond, 1, P0);
                 tail(2, P0, nb2);
             }
         }
     };
     auto step_check = [&]() {
-        hipLaunchKernelGGL(k_nt_step_final, dim3(B), dim3(256), 0, st, h->d_st.p, h->nt_st.p, (const int*)h->nt_pbad.p, nb2, h->d_active.p, d_non);
+        SCPN_LAUNCH(k_nt_step_final, dim3(B), dim3(256), 0, st, h->d_st.p, h->nt_st.p, (const int*)h->nt_pbad.p, nb2, h->d_active.p, d_non);
     };
 
     // ---- phase B: Newton iterations (newton_solver.py:183-306)
@@ -1457,34 +1442,34 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         {
             ProfScope ps(h, "newton_jacobian", 2);
             if (!p->external_profile_mode)
-                hipLaunchKernelGGL(k_nt_jac_sum, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, (const NtMember*)h->nt_st.p, nz, nr,
+                SCPN_LAUNCH(k_nt_jac_sum, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, (const NtMember*)h->nt_st.p, nz, nr,
                                    ld, (const double*)h->d_r.p, P0, nblk1);
-            hipLaunchKernelGGL(k_nt_jac_diag, g2, BLK2D, 0, st, dgF, ivF, curF, jF, (const Member*)h->d_st.p, (const NtMember*)h->nt_st.p, nz, nr, ld,
+            SCPN_LAUNCH(k_nt_jac_diag, g2, BLK2D, 0, st, dgF, ivF, curF, jF, (const Member*)h->d_st.p, (const NtMember*)h->nt_st.p, nz, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_neg_mu0R.p, p->external_profile_mode, o->precond ? 1 : 0, diag_lap,
                                h->dr, h->dz, (const double*)P0, nblk1);
         }
         gmres();
         if (!o->line_search) {
-            hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, curF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 0, o->newton_alpha,
+            SCPN_LAUNCH(k_nt_step, g2, BLK2D, 0, st, curF, curF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 0, o->newton_alpha,
                                h->nt_pbad.p);
             step_check();
         } else {
-            hipLaunchKernelGGL(k_nt_copy, g2, BLK2D, 0, st, prvF, curF, (const NtMember*)h->nt_st.p, 0, nz, nr, ld);
-            hipLaunchKernelGGL(k_nt_copy, g2, BLK2D, 0, st, srtF, srcF, (const NtMember*)h->nt_st.p, 0, nz, nr, ld);
+            SCPN_LAUNCH(k_nt_copy, g2, BLK2D, 0, st, prvF, curF, (const NtMember*)h->nt_st.p, 0, nz, nr, ld);
+            SCPN_LAUNCH(k_nt_copy, g2, BLK2D, 0, st, srtF, srcF, (const NtMember*)h->nt_st.p, 0, nz, nr, ld);
             flags(0);
             for (int bt = 0; bt < o->max_backtracks; ++bt) {
-                hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, prvF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 1, 0.0, (int*)nullptr);
+                SCPN_LAUNCH(k_nt_step, g2, BLK2D, 0, st, curF, prvF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 1, 0.0, (int*)nullptr);
                 if (!p->external_profile_mode) { flags(1); topo_source(srtF); }
                 resid(Fld{nullptr, nullptr, 0, 0}, srtF, 1);
             }
             // every backtrack rejected: minimum step, J_phi refreshed, Source kept (:277-291)
-            hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, prvF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 2, 0.0, (int*)nullptr);
+            SCPN_LAUNCH(k_nt_step, g2, BLK2D, 0, st, curF, prvF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 2, 0.0, (int*)nullptr);
             if (!p->external_profile_mode) { flags(2); topo_source(src2F); }
-            hipLaunchKernelGGL(k_nt_copy, g2, BLK2D, 0, st, srcF, srtF, (const NtMember*)h->nt_st.p, 1, nz, nr, ld);
+            SCPN_LAUNCH(k_nt_copy, g2, BLK2D, 0, st, srcF, srtF, (const NtMember*)h->nt_st.p, 1, nz, nr, ld);
             flags(3);
             resid(Fld{nullptr, nullptr, 0, 0}, srcF, 2);
             // NaN / Inf check of the accepted state (alpha 0 leaves psi as it is)
-            hipLaunchKernelGGL(k_nt_step, g2, BLK2D, 0, st, curF, curF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 0, 0.0, h->nt_pbad.p);
+            SCPN_LAUNCH(k_nt_step, g2, BLK2D, 0, st, curF, curF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 0, 0.0, h->nt_pbad.p);
             step_check();
         }
         n_on = poll(d_non);
@@ -1541,13 +1526,13 @@ static void fast_sweeps(FastSolverHip* s, const double* j_host, double* psi_host
     dim3 g(cdiv(std::max(ncol, 1), 64), cdiv(std::max(nz - 2, 1), 4));
     dim3 gr(cdiv(2L * (nz + nr), 256));
     for (int it = 0; it < iterations; ++it) {
-        hipLaunchKernelGGL(k_fast_ring, gr, dim3(256), 0, st, s->psi.p, nz, nr, ld, s->boundary_value, (const int*)s->d_done.p);
+        SCPN_LAUNCH(k_fast_ring, gr, dim3(256), 0, st, s->psi.p, nz, nr, ld, s->boundary_value, (const int*)s->d_done.p);
         if (nz > 2 && nr > 2)
             for (int parity = 0; parity < 2; ++parity)
-                hipLaunchKernelGGL(k_fast_half, g, dim3(256), 0, st, s->psi.p, (const double*)s->j.p, nz, nr, ld, (const double*)s->Rtab.p,
+                SCPN_LAUNCH(k_fast_half, g, dim3(256), 0, st, s->psi.p, (const double*)s->j.p, nz, nr, ld, (const double*)s->Rtab.p,
                                    (const double*)s->c_rp.p, (const double*)s->c_rm.p, c_z, center, omega, om1, parity, s->d_bits.p,
                                    (const int*)s->d_done.p);
-        hipLaunchKernelGGL(k_fast_ctl, dim3(1), dim3(1), 0, st, s->d_bits.p, s->d_last.p, s->d_perf.p, s->d_done.p, tol, use_tol ? 1 : 0);
+        SCPN_LAUNCH(k_fast_ctl, dim3(1), dim3(1), 0, st, s->d_bits.p, s->d_last.p, s->d_perf.p, s->d_done.p, tol, use_tol ? 1 : 0);
     }
     HIP_TRY(hipMemcpy2DAsync(psi_host, sizeof(double) * nr, s->psi.p, sizeof(double) * ld, sizeof(double) * nr, nz, hipMemcpyDeviceToHost, st));
     int perf = 0;
@@ -1741,10 +1726,10 @@ static int S_free_boundary_solve(Solver* h, const scpn_picard_params* p, int n_c
     {
         ProfScope ps(h, "coil_flux", 1);
         // only the Dirichlet ring of psi_ext is consumed (free_boundary.py:652-655 and the Picard boundary map)
-        hipLaunchKernelGGL(k_coil_flux, g2, BLK2D, 0, st, extF, nz, nr, ld, h->d_r.p, h->d_z.p, n_coils, h->d_fb_r.p, h->d_fb_z.p,
+        SCPN_LAUNCH(k_coil_flux, g2, BLK2D, 0, st, extF, nz, nr, ld, h->d_r.p, h->d_z.p, n_coils, h->d_fb_r.p, h->d_fb_z.p,
                            h->d_fb_i.p, coil_turns ? (const double*)h->d_fb_t.p : (const double*)nullptr, 0.0, 1, 1);
     }
-    hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, bcF, extF, nz, nr, ld, (const int*)nullptr);
+    SCPN_LAUNCH(k_copy, g2, BLK2D, 0, st, bcF, extF, nz, nr, ld, (const int*)nullptr);
     scpn_picard_params q = *p;
     q.preserve_initial_state = 1;
     q.has_boundary_flux = 1;
@@ -1762,13 +1747,13 @@ static int S_free_boundary_solve(Solver* h, const scpn_picard_params* p, int n_c
         d_mask.alloc(B);
         HIP_TRY(hipMemcpyAsync(d_mask.p, mask.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
         Fld curF = h->slot_fld(h->d_cur.p);
-        hipLaunchKernelGGL(k_apply_bc, gring, dim3(256), 0, st, curF, extF, nz, nr, ld, (const int*)d_mask.p);
-        hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, oldF, curF, nz, nr, ld, (const int*)d_mask.p);
+        SCPN_LAUNCH(k_apply_bc, gring, dim3(256), 0, st, curF, extF, nz, nr, ld, (const int*)d_mask.p);
+        SCPN_LAUNCH(k_copy, g2, BLK2D, 0, st, oldF, curF, nz, nr, ld, (const int*)d_mask.p);
         HIP_TRY(hipStreamSynchronize(st));
         picard_solve_impl(h, &q, res.data(), nullptr, nullptr, nullptr, &mask);
         curF = h->slot_fld(h->d_cur.p);
-        hipLaunchKernelGGL(k_maxabsdiff, dim3(nblk, B), dim3(256), 0, st, curF, oldF, nz, nr, ld, h->d_part1.p, nblk);
-        hipLaunchKernelGGL(k_max_final, dim3(B), dim3(256), 0, st, d_diff.p, (const double*)h->d_part1.p, nblk);
+        SCPN_LAUNCH(k_maxabsdiff, dim3(nblk, B), dim3(256), 0, st, curF, oldF, nz, nr, ld, h->d_part1.p, nblk);
+        SCPN_LAUNCH(k_max_final, dim3(B), dim3(256), 0, st, d_diff.p, (const double*)h->d_part1.p, nblk);
         HIP_TRY(hipMemcpyAsync(hdiff.data(), d_diff.p, sizeof(double) * B, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (int b = 0; b < B; ++b) {
@@ -1817,7 +1802,7 @@ static int S_compute_b_field(Solver* h, int member, double* b_r, double* b_z) {
     DBuf<double> dbr, dbz;
     dbr.alloc(n);
     dbz.alloc(n);
-    hipLaunchKernelGGL(k_b_field, grid2d(h->nr, h->nz, nb), BLK2D, 0, h->stream, dbr.p, dbz.p, h->slot_fld(h->d_cur.p), member, h->nz, h->nr,
+    SCPN_LAUNCH(k_b_field, grid2d(h->nr, h->nz, nb), BLK2D, 0, h->stream, dbr.p, dbz.p, h->slot_fld(h->d_cur.p), member, h->nz, h->nr,
                        h->ld, h->dr, h->dz, (const double*)h->d_r.p);
     HIP_TRY(hipMemcpyAsync(b_r, dbr.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(b_z, dbz.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
@@ -1850,13 +1835,13 @@ static int S_map_profiles(Solver* h, double z_min_cfg, int n_rho, const double* 
     Fld curF = h->slot_fld(h->d_cur.p), jF = h->plain(h->jphi.p);
     {
         ProfScope ps(h, "map_profiles", 4);
-        hipLaunchKernelGGL(k_topology, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)d_ms.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
+        SCPN_LAUNCH(k_topology, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)d_ms.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
                            h->d_topo.p, nblk1);
-        hipLaunchKernelGGL(k_map_topo_final, dim3(B), dim3(256), 0, st, curF, d_ms.p, (const TopoPart*)h->d_topo.p, nblk1, nr, ld);
-        hipLaunchKernelGGL(k_map_profiles, dim3(nblk1, B), dim3(256), 0, st, jF, p2d_out ? d_p2.p : (double*)nullptr, curF, (const Member*)d_ms.p,
+        SCPN_LAUNCH(k_map_topo_final, dim3(B), dim3(256), 0, st, curF, d_ms.p, (const TopoPart*)h->d_topo.p, nblk1, nr, ld);
+        SCPN_LAUNCH(k_map_profiles, dim3(nblk1, B), dim3(256), 0, st, jF, p2d_out ? d_p2.p : (double*)nullptr, curF, (const Member*)d_ms.p,
                            nz, nr, ld, (const double*)h->d_r.p, n_rho, (const double*)d_rho.p, (const double*)d_p.p, (const double*)d_j.p, d_part.p,
                            nblk1);
-        hipLaunchKernelGGL(k_map_scale, dim3(nblk1, B), dim3(256), 0, st, jF, d_ms.p, nz, nr, ld, h->dr, h->dz, (const double*)d_part.p, nblk1);
+        SCPN_LAUNCH(k_map_scale, dim3(nblk1, B), dim3(256), 0, st, jF, d_ms.p, nz, nr, ld, h->dr, h->dz, (const double*)d_part.p, nblk1);
     }
     if (p2d_out) HIP_TRY(hipMemcpyAsync(p2d_out, d_p2.p, sizeof(double) * B * nz * nr, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(ms.data(), d_ms.p, sizeof(Member) * B, hipMemcpyDeviceToHost, st));
@@ -1872,7 +1857,7 @@ static int S_sample_psi(Solver* h, int n_pts, const double* pts_r, const double*
     dr_.alloc(n_pts); dz_.alloc(n_pts); dout.alloc((size_t)n_pts * h->B);
     HIP_TRY(hipMemcpyAsync(dr_.p, pts_r, sizeof(double) * n_pts, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(dz_.p, pts_z, sizeof(double) * n_pts, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_sample_psi, dim3(cdiv(n_pts, 128), h->B), dim3(128), 0, h->stream, dout.p, h->slot_fld(h->d_cur.p), h->nz, h->nr, h->ld,
+    SCPN_LAUNCH(k_sample_psi, dim3(cdiv(n_pts, 128), h->B), dim3(128), 0, h->stream, dout.p, h->slot_fld(h->d_cur.p), h->nz, h->nr, h->ld,
                        h->dr, h->dz, (const double*)h->d_r.p, (const double*)h->d_z.p, n_pts, (const double*)dr_.p, (const double*)dz_.p);
     HIP_TRY(hipMemcpyAsync(out, dout.p, sizeof(double) * n_pts * h->B, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1881,7 +1866,7 @@ static int S_sample_psi(Solver* h, int n_pts, const double* pts_r, const double*
 static int S_fill_psi(Solver* h, double value) {
     if (!h) return fail(SCPN_E_ARG, "null handle");
     API_BEGIN
-    hipLaunchKernelGGL(k_fill, grid2d(h->nr, h->nz, h->B), BLK2D, 0, h->stream, h->slot_fld(h->d_cur.p), value, h->nz, h->nr, h->ld,
+    SCPN_LAUNCH(k_fill, grid2d(h->nr, h->nz, h->B), BLK2D, 0, h->stream, h->slot_fld(h->d_cur.p), value, h->nz, h->nr, h->ld,
                        (const int*)nullptr);
     HIP_TRY(hipStreamSynchronize(h->stream));
     API_END
@@ -2019,16 +2004,6 @@ int scpn_gs_create(scpn_gs** out, int nr, int nz, int batch, const double* r_axi
         done += cnt;
     }
     g->off.push_back(done);
-    if (ng == 2) {
-        for (int gi = 0; gi < 2; ++gi) {
-            Solver* k = g->kids[gi];
-            for (auto& e : k->phase.ev)
-                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete g; return fail(SCPN_E_DEVICE, "hipEventCreate failed"); }
-            k->phase.ready = true;
-            k->partner = g->kids[1 - gi];
-            k->phase_role = gi;
-        }
-    }
     *out = g;
     return SCPN_OK;
 }
@@ -2232,7 +2207,7 @@ int scpn_mg_residual(const double* psi, const double* source, const double* r_ax
     upload(t.h, t.h->psi_slots.p, -1, psi);
     upload(t.h, t.h->src.p, -1, source);
     auto& lv = get_hierarchy(t.h, 1 << 30);
-    hipLaunchKernelGGL(k_residual, grid2d(nr, nz, batch), BLK2D, 0, t.h->stream, t.h->plain(t.h->W.p), t.h->slot_fld(nullptr),
+    SCPN_LAUNCH(k_residual, grid2d(nr, nz, batch), BLK2D, 0, t.h->stream, t.h->plain(t.h->W.p), t.h->slot_fld(nullptr),
                        t.h->plain(t.h->src.p), lv[0]->dev);
     download(t.h, t.h->W.p, -1, out);
     API_END
@@ -2243,7 +2218,7 @@ static void resid_norms_host(Solver* h, Fld psi, Fld src, std::vector<double>& m
     mx.assign(B, 0.0);
     ss.assign(B, 0.0);
     if (h->nz < 3 || h->nr < 3) return;
-    hipLaunchKernelGGL(k_resid_norms, dim3(nb, B), dim3(256), 0, h->stream, psi, src, lv[0]->dev, h->d_part1.p, h->d_part2.p, nb, (const int*)nullptr);
+    SCPN_LAUNCH(k_resid_norms, dim3(nb, B), dim3(256), 0, h->stream, psi, src, lv[0]->dev, h->d_part1.p, h->d_part2.p, nb, (const int*)nullptr);
     std::vector<double> pm((size_t)B * nb), ps((size_t)B * nb);
     HIP_TRY(hipMemcpyAsync(pm.data(), h->d_part1.p, sizeof(double) * B * nb, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(ps.data(), h->d_part2.p, sizeof(double) * B * nb, hipMemcpyDeviceToHost, h->stream));
@@ -2292,7 +2267,7 @@ int scpn_restrict_full_weight(const double* fine, int nz_f, int nr_f, int batch,
     df.alloc(nf * batch);
     dc.alloc(nc * batch);
     HIP_TRY(hipMemcpy(df.p, fine, sizeof(double) * nf * batch, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_restrict, grid2d(nr_c, nz_c, batch), BLK2D, 0, 0, Fld{dc.p, nullptr, (long)nc, batch},
+    SCPN_LAUNCH(k_restrict, grid2d(nr_c, nz_c, batch), BLK2D, 0, 0, Fld{dc.p, nullptr, (long)nc, batch},
                        Fld{df.p, nullptr, (long)nf, batch}, nz_f, nr_f, nr_f, nz_c, nr_c, nr_c);
     HIP_TRY(hipMemcpy(coarse, dc.p, sizeof(double) * nc * batch, hipMemcpyDeviceToHost));
     API_END
@@ -2308,7 +2283,7 @@ int scpn_prolongate_bilinear(const double* coarse, int nz_c, int nr_c, int nz_f,
     df.alloc(nf * batch);
     dc.alloc(nc * batch);
     HIP_TRY(hipMemcpy(dc.p, coarse, sizeof(double) * nc * batch, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_prolong<false>, grid2d(nr_f, nz_f, batch), BLK2D, 0, 0, Fld{df.p, nullptr, (long)nf, batch},
+    SCPN_LAUNCH(k_prolong<false>, grid2d(nr_f, nz_f, batch), BLK2D, 0, 0, Fld{df.p, nullptr, (long)nf, batch},
                        Fld{dc.p, nullptr, (long)nc, batch}, nz_f, nr_f, nr_f, nz_c, nr_c, nr_c, (const int*)nullptr);
     HIP_TRY(hipMemcpy(fine, df.p, sizeof(double) * nf * batch, hipMemcpyDeviceToHost));
     API_END
@@ -2347,7 +2322,7 @@ int scpn_multigrid_solve(const double* source, double* psi, const double* r_axis
     hipStream_t st = h->stream;
     const int B = batch;
     Fld psiF = h->slot_fld(nullptr), srcF = h->plain(h->src.p), bcF = h->plain(h->bc.p);
-    hipLaunchKernelGGL(k_copy, grid2d(nr, nz, B), BLK2D, 0, st, bcF, psiF, nz, nr, h->ld, (const int*)nullptr);
+    SCPN_LAUNCH(k_copy, grid2d(nr, nz, B), BLK2D, 0, st, bcF, psiF, nz, nr, h->ld, (const int*)nullptr);
     auto& lv0 = get_hierarchy(h, 1 << 30);
     const int nb = std::max(h->nblk_int(), 1);
     std::vector<MgMember> ms(B);
@@ -2360,9 +2335,9 @@ int scpn_multigrid_solve(const double* source, double* psi, const double* r_axis
     HIP_TRY(hipMemsetAsync(h->d_part1.p, 0, sizeof(double) * B * h->nblk(), st));
     auto norms = [&](int count_cycle) {
         if (nz >= 3 && nr >= 3)
-            hipLaunchKernelGGL(k_resid_norms, dim3(nb, B), dim3(256), 0, st, psiF, srcF, lv0[0]->dev, h->d_part1.p, h->d_part2.p, nb,
+            SCPN_LAUNCH(k_resid_norms, dim3(nb, B), dim3(256), 0, st, psiF, srcF, lv0[0]->dev, h->d_part1.p, h->d_part2.p, nb,
                                (const int*)h->d_active.p);
-        hipLaunchKernelGGL(k_mg_final, dim3(B), dim3(256), 0, st, h->d_mg.p, (const double*)h->d_part1.p, nb, tol, max_cycles, count_cycle,
+        SCPN_LAUNCH(k_mg_final, dim3(B), dim3(256), 0, st, h->d_mg.p, (const double*)h->d_part1.p, nb, tol, max_cycles, count_cycle,
                            h->d_active.p, h->d_nactive.p);
     };
     norms(0);
@@ -2374,7 +2349,7 @@ int scpn_multigrid_solve(const double* source, double* psi, const double* r_axis
         if (n_act <= 0) break;
         Fld res = vcycle(h, psiF, h->plain(h->W.p), h->plain(h->W2.p), srcF, omega, pre, post, min_grid, h->d_active.p);
         copy_back(h, psiF, res, (const int*)h->d_active.p);
-        hipLaunchKernelGGL(k_apply_bc, dim3(cdiv(2L * (nz + nr), 256), B), dim3(256), 0, st, psiF, bcF, nz, nr, h->ld, (const int*)h->d_active.p);
+        SCPN_LAUNCH(k_apply_bc, dim3(cdiv(2L * (nz + nr), 256), B), dim3(256), 0, st, psiF, bcF, nz, nr, h->ld, (const int*)h->d_active.p);
         norms(1);
     }
     HIP_TRY(hipMemcpyAsync(ms.data(), h->d_mg.p, sizeof(MgMember) * B, hipMemcpyDeviceToHost, st));
@@ -2395,7 +2370,7 @@ int scpn_jacobi_step(const double* psi, const double* source, const double* r_ax
     upload(t.h, t.h->psi_slots.p, -1, psi);
     upload(t.h, t.h->src.p, -1, source);
     auto& lv = get_hierarchy(t.h, 1 << 30);
-    hipLaunchKernelGGL(k_jacobi, grid2d(nr, nz, batch), BLK2D, 0, t.h->stream, t.h->plain(t.h->W.p), t.h->slot_fld(nullptr),
+    SCPN_LAUNCH(k_jacobi, grid2d(nr, nz, batch), BLK2D, 0, t.h->stream, t.h->plain(t.h->W.p), t.h->slot_fld(nullptr),
                        t.h->plain(t.h->src.p), lv[0]->dev, (const int*)nullptr);
     download(t.h, t.h->W.p, -1, out);
     API_END
@@ -2412,8 +2387,8 @@ int scpn_sor_step(const double* psi, const double* source, const double* r_axis,
     upload(h, h->src.p, -1, source);
     auto& lv = get_hierarchy(h, 1 << 30);
     dim3 g2 = grid2d(nr, nz, batch);
-    hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, h->stream, h->plain(h->W.p), h->slot_fld(nullptr), nz, nr, h->ld);
-    hipLaunchKernelGGL(k_sanitize, g2, BLK2D, 0, h->stream, h->plain(h->src2.p), h->plain(h->src.p), nz, nr, h->ld);
+    SCPN_LAUNCH(k_sanitize, g2, BLK2D, 0, h->stream, h->plain(h->W.p), h->slot_fld(nullptr), nz, nr, h->ld);
+    SCPN_LAUNCH(k_sanitize, g2, BLK2D, 0, h->stream, h->plain(h->src2.p), h->plain(h->src.p), nz, nr, h->ld);
     smooth(h, lv[0]->dev, h->plain(h->W.p), Fld{nullptr, nullptr, 0, 0}, h->plain(h->src2.p), omega, 1, nullptr, true);
     download(h, h->W.p, -1, out);
     API_END
@@ -2436,7 +2411,7 @@ int scpn_coil_flux(const double* r_axis, const double* z_axis, int nz, int nr, i
         HIP_TRY(hipMemcpy(ci.p, coil_i, sizeof(double) * n_coils * batch, hipMemcpyHostToDevice));
         if (coil_turns) HIP_TRY(hipMemcpy(ct.p, coil_turns, sizeof(double) * n_coils * batch, hipMemcpyHostToDevice));
     }
-    hipLaunchKernelGGL(k_coil_flux, grid2d(nr, nz, batch), BLK2D, 0, 0, Fld{dout.p, nullptr, (long)n, batch}, nz, nr, nr, (const double*)dr_.p,
+    SCPN_LAUNCH(k_coil_flux, grid2d(nr, nz, batch), BLK2D, 0, 0, Fld{dout.p, nullptr, (long)n, batch}, nz, nr, nr, (const double*)dr_.p,
                        (const double*)dz_.p, n_coils, (const double*)cr.p, (const double*)cz.p, (const double*)ci.p,
                        coil_turns ? (const double*)ct.p : (const double*)nullptr, mu0, mode);
     HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * n * batch, hipMemcpyDeviceToHost));
@@ -2460,7 +2435,7 @@ int scpn_tridiag_solve(int batch, int n, const double* dl, const double* d, cons
     }
     HIP_TRY(hipMemcpy(w.p + tot, d, sizeof(double) * tot, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(w.p + 3 * tot, b, sizeof(double) * tot, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_gtsv, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, w.p, w.p + tot, w.p + 2 * tot, w.p + 3 * tot, di.p);
+    SCPN_LAUNCH(k_gtsv, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, w.p, w.p + tot, w.p + 2 * tot, w.p + 3 * tot, di.p);
     HIP_TRY(hipMemcpy(x, w.p + 3 * tot, sizeof(double) * tot, hipMemcpyDeviceToHost));
     if (info) HIP_TRY(hipMemcpy(info, di.p, sizeof(int) * batch, hipMemcpyDeviceToHost));
     API_END
@@ -2487,7 +2462,7 @@ int scpn_current_diffusion_step(int batch, int n, const double* rho, double* psi
     CdConst c;
     const double mu0 = (4.0 * 3.141592653589793) * 1e-7;  // core/current_diffusion.py:20
     c.r0 = r0; c.a = a; c.dt = dt; c.z_eff = z_eff; c.mu0_a2 = mu0 * (a * a);
-    hipLaunchKernelGGL(k_current_diffusion, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, (const double*)drho_.p, dpsi.p, c, (const double*)dte.p,
+    SCPN_LAUNCH(k_current_diffusion, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, (const double*)drho_.p, dpsi.p, c, (const double*)dte.p,
                        (const double*)nullptr, (const double*)djb.p, (const double*)djc.p, j_ext ? (const double*)dje.p : (const double*)nullptr,
                        scratch.p, di.p);
     HIP_TRY(hipMemcpy(psi, dpsi.p, sizeof(double) * tot, hipMemcpyDeviceToHost));
@@ -2508,7 +2483,7 @@ int scpn_flux_evolution(int batch, int n, int n_steps, double dt, const double* 
     HIP_TRY(hipMemcpy(d_rate.p, rate, sizeof(double) * n1, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_src.p, source, sizeof(double) * n1, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy2D(d_psi.p, sizeof(double) * (n_steps + 1) * n, psi0, sizeof(double) * n, sizeof(double) * n, batch, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_flux_evolution, dim3(cdiv(n, 64), batch), dim3(64), 0, 0, batch, n, n_steps, dt, (const double*)d_rate.p,
+    SCPN_LAUNCH(k_flux_evolution, dim3(cdiv(n, 64), batch), dim3(64), 0, 0, batch, n, n_steps, dt, (const double*)d_rate.p,
                        (const double*)d_src.p, d_psi.p, d_inc.p, d_drop.p, d_res.p);
     HIP_TRY(hipMemcpy(psi, d_psi.p, sizeof(double) * n1, hipMemcpyDeviceToHost));
     if (inc) HIP_TRY(hipMemcpy(inc, d_inc.p, sizeof(double) * n0, hipMemcpyDeviceToHost));
@@ -2537,7 +2512,7 @@ int scpn_probe_response(int n_coils, const double* coil_r, const double* coil_z,
     bd.alloc(std::max(n_b, 1));
     if (n_b > 0) HIP_TRY(hipMemcpy(bd.p, b_dir, sizeof(int) * n_b, hipMemcpyHostToDevice));
     dout.alloc((size_t)rows * n_coils);
-    hipLaunchKernelGGL(k_probe_response, dim3(cdiv(rows, 64), n_coils), dim3(64), 0, 0, dout.p, n_coils, (const double*)cr.p, (const double*)cz.p,
+    SCPN_LAUNCH(k_probe_response, dim3(cdiv(rows, 64), n_coils), dim3(64), 0, 0, dout.p, n_coils, (const double*)cr.p, (const double*)cz.p,
                        coil_turns ? (const double*)ct.p : (const double*)nullptr, n_flux, (const double*)fr.p, (const double*)fz.p, n_b,
                        (const double*)br.p, (const double*)bz.p, (const int*)bd.p);
     HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * rows * n_coils, hipMemcpyDeviceToHost));
@@ -2554,7 +2529,7 @@ int scpn_green_points(int n_coils, const double* coil_r, const double* coil_z, i
     HIP_TRY(hipMemcpy(cz.p, coil_z, sizeof(double) * n_coils, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(pr.p, pts_r, sizeof(double) * n_pts, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(pz.p, pts_z, sizeof(double) * n_pts, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_green_points, dim3(cdiv(n_pts, 256), n_coils), dim3(256), 0, 0, dout.p, n_coils, (const double*)cr.p,
+    SCPN_LAUNCH(k_green_points, dim3(cdiv(n_pts, 256), n_coils), dim3(256), 0, 0, dout.p, n_coils, (const double*)cr.p,
                        (const double*)cz.p, n_pts, (const double*)pr.p, (const double*)pz.p);
     HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * n_coils * n_pts, hipMemcpyDeviceToHost));
     API_END
@@ -2589,20 +2564,20 @@ int scpn_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int
     dim3 g2 = grid2d(nr, nz, 1);
     const int nb = h->nblk(), nbi = std::max(h->nblk_int(), 1);
     for (int it = 0; it < n_picard; ++it) {
-        hipLaunchKernelGGL(k_max_interior, dim3(nbi, 1), dim3(256), 0, st, psiF, nz, nr, h->ld, h->d_part1.p, nbi);
-        hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, h->d_scal.p, (const double*)h->d_part1.p, nbi, 0, dr, dz, ip_target);
-        hipLaunchKernelGGL(k_np_jsum, dim3(nb, 1), dim3(256), 0, st, psiF, (const double*)h->d_scal.p, nz, nr, h->ld, (const double*)h->d_r.p, mu0,
+        SCPN_LAUNCH(k_max_interior, dim3(nbi, 1), dim3(256), 0, st, psiF, nz, nr, h->ld, h->d_part1.p, nbi);
+        SCPN_LAUNCH(k_np_final, dim3(1), dim3(256), 0, st, h->d_scal.p, (const double*)h->d_part1.p, nbi, 0, dr, dz, ip_target);
+        SCPN_LAUNCH(k_np_jsum, dim3(nb, 1), dim3(256), 0, st, psiF, (const double*)h->d_scal.p, nz, nr, h->ld, (const double*)h->d_r.p, mu0,
                            beta_mix, h->d_part2.p, nb);
-        hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, h->d_scal.p, (const double*)h->d_part2.p, nb, 1, dr, dz, ip_target);
-        hipLaunchKernelGGL(k_np_source, g2, BLK2D, 0, st, srcF, psiF, (const double*)h->d_scal.p, nz, nr, h->ld, (const double*)h->d_r.p, mu0,
+        SCPN_LAUNCH(k_np_final, dim3(1), dim3(256), 0, st, h->d_scal.p, (const double*)h->d_part2.p, nb, 1, dr, dz, ip_target);
+        SCPN_LAUNCH(k_np_source, g2, BLK2D, 0, st, srcF, psiF, (const double*)h->d_scal.p, nz, nr, h->ld, (const double*)h->d_r.p, mu0,
                            beta_mix);
-        hipLaunchKernelGGL(k_copy, g2, BLK2D, 0, st, aF, psiF, nz, nr, h->ld, (const int*)nullptr);
+        SCPN_LAUNCH(k_copy, g2, BLK2D, 0, st, aF, psiF, nz, nr, h->ld, (const int*)nullptr);
         Fld in = aF, out = bF;
         for (int j = 0; j < n_jacobi; ++j) {
-            hipLaunchKernelGGL(k_jacobi_damped, g2, BLK2D, 0, st, out, in, srcF, L, omega_j, 1.0 - omega_j);
+            SCPN_LAUNCH(k_jacobi_damped, g2, BLK2D, 0, st, out, in, srcF, L, omega_j, 1.0 - omega_j);
             std::swap(in, out);
         }
-        hipLaunchKernelGGL(k_axpby, g2, BLK2D, 0, st, psiF, psiF, in, 1.0 - alpha, alpha, nz, nr, h->ld);
+        SCPN_LAUNCH(k_axpby, g2, BLK2D, 0, st, psiF, psiF, in, 1.0 - alpha, alpha, nz, nr, h->ld);
     }
     download(h, h->psi_slots.p, 0, psi_out);
     API_END
@@ -2621,11 +2596,53 @@ int scpn_verify_division(const double* x, const double* d, int n, double* q5, do
     HIP_TRY(hipMemcpy(dd_.p, d, sizeof(double) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dr_.p, r.data(), sizeof(double) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dl.p, rl.data(), sizeof(double) * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_verify_div, dim3(cdiv(n, 256)), dim3(256), 0, nullptr, (const double*)dx.p, (const double*)dd_.p, (const double*)dr_.p,
+    SCPN_LAUNCH(k_verify_div, dim3(cdiv(n, 256)), dim3(256), 0, nullptr, (const double*)dx.p, (const double*)dd_.p, (const double*)dr_.p,
                        (const double*)dl.p, n, o5.p, o4.p);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(q5, o5.p, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(q4, o4.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    API_END
+}
+
+// direction check of the DPP wave shifts used by the row-block smoother: below[i] = value of lane i-1, above[i] = of lane i+1
+int scpn_verify_lane_shift(double* below, double* above) {
+    if (!below || !above) return fail(SCPN_E_ARG, "scpn_verify_lane_shift: null buffer");
+    API_BEGIN
+    HIP_TRY(hipSetDevice(g_device));
+    DBuf<double> a, b;
+    a.alloc(64);
+    b.alloc(64);
+    SCPN_LAUNCH(k_verify_lane_shift, dim3(1), dim3(64), 0, nullptr, a.p, b.p);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(below, a.p, sizeof(double) * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(above, b.p, sizeof(double) * 64, hipMemcpyDeviceToHost));
+    API_END
+}
+
+// device-copy bandwidth of this GPU (read + written bytes per second), HIP events around `reps` copies of `bytes`
+int scpn_copy_bandwidth_probe(long bytes, int reps, double* gb_per_s) {
+    if (!gb_per_s || bytes < (1L << 20) || reps < 1) return fail(SCPN_E_ARG, "scpn_copy_bandwidth_probe: bytes >= 1 MiB, reps >= 1");
+    API_BEGIN
+    HIP_TRY(hipSetDevice(g_device));
+    const long n16 = bytes / 16;
+    DBuf<double2> a, b;
+    a.alloc((size_t)n16);
+    b.alloc((size_t)n16);
+    HIP_TRY(hipMemset(a.p, 1, (size_t)n16 * 16));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const dim3 g(256 * 32);
+    SCPN_LAUNCH(k_copy_probe, g, dim3(256), 0, nullptr, b.p, (const double2*)a.p, n16);  // warm-up
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int r = 0; r < reps; ++r) SCPN_LAUNCH(k_copy_probe, g, dim3(256), 0, nullptr, b.p, (const double2*)a.p, n16);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gb_per_s = 2.0 * (double)n16 * 16.0 * reps / ((double)ms * 1e-3) / 1e9;
     API_END
 }
 
@@ -2638,7 +2655,7 @@ int scpn_np_delta_star(const double* psi, int nz, int nr, const double* r_axis, 
     upload(h, h->psi_slots.p, 0, psi);
     DBuf<double> d;
     d.alloc((size_t)nz * nr);
-    hipLaunchKernelGGL(k_np_delta_star, grid2d(nr, nz, 1), BLK2D, 0, h->stream, d.p, h->slot_fld(nullptr), nz, nr, h->ld, dr, dz, (const double*)h->d_r.p);
+    SCPN_LAUNCH(k_np_delta_star, grid2d(nr, nz, 1), BLK2D, 0, h->stream, d.p, h->slot_fld(nullptr), nz, nr, h->ld, dr, dz, (const double*)h->d_r.p);
     HIP_TRY(hipMemcpyAsync(out, d.p, sizeof(double) * nz * nr, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     API_END
@@ -2658,16 +2675,16 @@ int scpn_np_equation_residual(const double* psi, int nz, int nr, const double* r
     Fld psiF = h->slot_fld(nullptr), srcF = h->plain(h->src.p);
     const int nb = h->nblk(), nbi = std::max(h->nblk_int(), 1);
     // _compute_source_np (jax_gs_solver.py:88-123): psi_axis = max interior, L-mode profile, sum J renormalised to Ip
-    hipLaunchKernelGGL(k_max_interior, dim3(nbi, 1), dim3(256), 0, st, psiF, nz, nr, h->ld, h->d_part1.p, nbi);
-    hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, h->d_scal.p, (const double*)h->d_part1.p, nbi, 0, dr, dz, ip_target);
-    hipLaunchKernelGGL(k_np_jsum, dim3(nb, 1), dim3(256), 0, st, psiF, (const double*)h->d_scal.p, nz, nr, h->ld, (const double*)h->d_r.p, mu0, beta_mix,
+    SCPN_LAUNCH(k_max_interior, dim3(nbi, 1), dim3(256), 0, st, psiF, nz, nr, h->ld, h->d_part1.p, nbi);
+    SCPN_LAUNCH(k_np_final, dim3(1), dim3(256), 0, st, h->d_scal.p, (const double*)h->d_part1.p, nbi, 0, dr, dz, ip_target);
+    SCPN_LAUNCH(k_np_jsum, dim3(nb, 1), dim3(256), 0, st, psiF, (const double*)h->d_scal.p, nz, nr, h->ld, (const double*)h->d_r.p, mu0, beta_mix,
                        h->d_part2.p, nb);
-    hipLaunchKernelGGL(k_np_final, dim3(1), dim3(256), 0, st, h->d_scal.p, (const double*)h->d_part2.p, nb, 1, dr, dz, ip_target);
-    hipLaunchKernelGGL(k_np_source, grid2d(nr, nz, 1), BLK2D, 0, st, srcF, psiF, (const double*)h->d_scal.p, nz, nr, h->ld, (const double*)h->d_r.p, mu0,
+    SCPN_LAUNCH(k_np_final, dim3(1), dim3(256), 0, st, h->d_scal.p, (const double*)h->d_part2.p, nb, 1, dr, dz, ip_target);
+    SCPN_LAUNCH(k_np_source, grid2d(nr, nz, 1), BLK2D, 0, st, srcF, psiF, (const double*)h->d_scal.p, nz, nr, h->ld, (const double*)h->d_r.p, mu0,
                        beta_mix);
     DBuf<double> part;
     part.alloc((size_t)4 * nbi);
-    hipLaunchKernelGGL(k_np_eq_residual, dim3(nbi, 1), dim3(256), 0, st, psiF, srcF, L, part.p, nbi);
+    SCPN_LAUNCH(k_np_eq_residual, dim3(nbi, 1), dim3(256), 0, st, psiF, srcF, L, part.p, nbi);
     std::vector<double> hp((size_t)4 * nbi);
     HIP_TRY(hipMemcpyAsync(hp.data(), part.p, sizeof(double) * 4 * nbi, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -2720,7 +2737,7 @@ void set_boundary_dirichlet(void* solver, double v) {
     auto* s = static_cast<FastSolverHip*>(solver);
     s->boundary_value = v;
     try {
-        hipLaunchKernelGGL(k_fast_ring, dim3(cdiv(2L * (s->nz + s->nr), 256)), dim3(256), 0, s->stream, s->psi.p, s->nz, s->nr, s->ld, v,
+        SCPN_LAUNCH(k_fast_ring, dim3(cdiv(2L * (s->nz + s->nr), 256)), dim3(256), 0, s->stream, s->psi.p, s->nz, s->nr, s->ld, v,
                            (const int*)nullptr);
         HIP_TRY(hipStreamSynchronize(s->stream));
     } catch (const std::exception& e) { g_err = e.what(); }

@@ -1,24 +1,10 @@
-"""Seeded problem builders shared by the CPU and GPU parity tests (no reference import)."""
+"""Seeded problem builders shared by the CPU and GPU parity tests (no reference import).  The benchmark cases themselves
+live in the product package (scpn_fusion_core_amd/cases.py); this module adds the fixture helpers."""
 import json
 
 import numpy as np
 
-
-def grid(nz, nr, r0=4.0, r1=8.0, z0=-4.0, z1=4.0):
-    r = np.linspace(r0, r1, nr)
-    z = np.linspace(z0, z1, nz)
-    rr, zz = np.meshgrid(r, z)
-    return r, z, rr, zz
-
-
-def bench_problem(nz, nr, seed=2026):
-    """The smoother benchmark problem of the reference (benchmarks/bench_gpu_gs_solver.py:54-63)."""
-    rng = np.random.default_rng(seed)
-    r, z, rr, zz = grid(nz, nr)
-    source = -np.exp(-((rr - 6.0) ** 2 + zz**2) / 0.5)
-    psi0 = rng.normal(0.0, 1e-3, size=(nz, nr))
-    psi0[0, :] = psi0[-1, :] = psi0[:, 0] = psi0[:, -1] = 0.0
-    return psi0, source, rr, r, z
+from scpn_fusion_core_amd.cases import bench_problem, grid, iter_like_cfg, member_cfg, scan_member_table  # noqa: F401
 
 
 def operator_problem(nz, nr):
@@ -27,28 +13,6 @@ def operator_problem(nz, nr):
     zz = np.repeat(z[:, None], nr, axis=1)
     psi = psi0 + 0.01 * np.sin(rr) * np.cos(0.3 * zz)
     return psi, source, rr, float(r[1] - r[0]), float(z[1] - z[0])
-
-
-def iter_like_cfg(n, method="multigrid", omega=1.0, tol=1e-8, max_iter=1000, alpha=0.12):
-    """ITER-like case of validation/benchmark_vs_freegs.py:157,412-456 (values restated)."""
-    R0, a, kappa, Ip = 6.2, 2.0, 1.7, 15.0
-    coil_R, coil_Z = R0 + 1.5 * a, 1.2 * kappa * a
-    return {
-        "reactor_name": "ITER-like",
-        "grid_resolution": [n, n],
-        "dimensions": {"R_min": round(R0 - 2 * a, 4), "R_max": round(R0 + 2 * a, 4),
-                       "Z_min": round(-2 * kappa * a, 4), "Z_max": round(2 * kappa * a, 4)},
-        "physics": {"plasma_current_target": Ip, "vacuum_permeability": 1.0},
-        "coils": [
-            {"name": "PF1", "r": coil_R, "z": coil_Z, "current": 2.0},
-            {"name": "PF2", "r": coil_R, "z": -coil_Z, "current": 2.0},
-            {"name": "PF3", "r": R0 - 0.5 * a, "z": coil_Z * 1.1, "current": -1.0},
-            {"name": "PF4", "r": R0 - 0.5 * a, "z": -coil_Z * 1.1, "current": -1.0},
-            {"name": "CS", "r": max(R0 - 2 * a + 0.05, 0.3), "z": 0.0, "current": 0.15},
-        ],
-        "solver": {"max_iterations": max_iter, "convergence_threshold": tol, "relaxation_factor": alpha,
-                   "solver_method": method, "sor_omega": omega},
-    }
 
 
 def configs_from(npz):

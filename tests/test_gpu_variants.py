@@ -19,14 +19,9 @@ SWITCHES = [
     {"SCPN_HIP_LAZYSRC": "0"},
     {"SCPN_HIP_SRCGEN": "1"},
     {"SCPN_HIP_BLENDFUSE": "1"},
-    {"SCPN_HIP_GRAPH": "1"},
+
     {"SCPN_HIP_GROUPS": "2"},
-    {"SCPN_HIP_PHASE": "1", "SCPN_HIP_GROUPS": "2"},
-    {"SCPN_HIP_PHASE": "2", "SCPN_HIP_GROUPS": "2"},
     {"SCPN_HIP_DEFECT_MINLVL": "9"},
-    {"SCPN_HIP_SLIDE": "3"},
-    {"SCPN_HIP_SLIDE": "3", "SCPN_HIP_SLIDE_RSEG": "38"},
-    {"SCPN_HIP_SLIDE": "3", "SCPN_HIP_LAZYSRC": "0"},
 ]
 
 

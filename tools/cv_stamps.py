@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 import numpy as np
 from scpn_fusion_core_amd import _lib
 from scpn_fusion_core_amd.ensemble import EnsembleSolver
-from tests._problems import iter_like_cfg, bench_problem
+from scpn_fusion_core_amd.cases import iter_like_cfg, bench_problem
 n, B = 513, 16
 es = EnsembleSolver(iter_like_cfg(n), batch=B)
 psi0, src, rr, r, z = bench_problem(n, n)

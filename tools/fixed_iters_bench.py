@@ -7,7 +7,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, ".")
-from tests._problems import iter_like_cfg  # noqa: E402
+from scpn_fusion_core_amd.cases import iter_like_cfg  # noqa: E402
 
 from scpn_fusion_core_amd.ensemble import EnsembleSolver  # noqa: E402
 

@@ -1,7 +1,7 @@
 import sys, time, json, numpy as np
 sys.path.insert(0, '.')
 from scpn_fusion_core_amd.ensemble import EnsembleSolver
-from tests._problems import iter_like_cfg
+from scpn_fusion_core_amd.cases import iter_like_cfg
 n, B, mi = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 pre = sys.argv[4] if len(sys.argv) > 4 else "none"
 cfg = iter_like_cfg(n, method="newton", omega=1.6, tol=1e-6, max_iter=mi, alpha=0.1)

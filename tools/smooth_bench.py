@@ -8,7 +8,7 @@ sys.path.insert(0, ".")
 import numpy as np  # noqa: E402
 
 from scpn_fusion_core_amd.ensemble import EnsembleSolver  # noqa: E402
-from tests._problems import bench_problem, iter_like_cfg  # noqa: E402
+from scpn_fusion_core_amd.cases import bench_problem, iter_like_cfg  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 200

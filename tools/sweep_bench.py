@@ -3,7 +3,7 @@ import json, sys
 sys.path.insert(0, ".")
 import numpy as np
 from scpn_fusion_core_amd.ensemble import EnsembleSolver
-from tests._problems import iter_like_cfg, bench_problem
+from scpn_fusion_core_amd.cases import iter_like_cfg, bench_problem
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 513
 for B in (32, 64):
     cfg = iter_like_cfg(n)

@@ -4,21 +4,27 @@ os.environ["SCPN_HIP_GROUPS"] = "1"
 sys.path.insert(0, ".")
 import numpy as np
 from scpn_fusion_core_amd.ensemble import EnsembleSolver
-from tests._problems import iter_like_cfg, bench_problem
+from scpn_fusion_core_amd.cases import iter_like_cfg, bench_problem
 for n, B in ((513, 32),):
     es = EnsembleSolver(iter_like_cfg(n), batch=B)
     psi0, src, rr, r, z = bench_problem(n, n)
     es.set_psi(np.broadcast_to(psi0, (B, n, n)).copy()); es.set_source(np.broadcast_to(src, (B, n, n)).copy())
     mode = os.environ.get("STAMPS_MODE", "plain")
+    import time
     for _ in range(5):
         if mode == "plain": es.rb_sor(1.3, 3)
         else: es.vcycle(1.0, 3, 3, 5)
+    es.sync(); t0 = time.perf_counter()
+    for _ in range(20):
+        if mode == "plain": es.rb_sor(1.3, 3)
+        else: es.vcycle(1.0, 3, 3, 5)
+    es.sync(); print(f"{(time.perf_counter() - t0) / 20 * 1e6:.1f} us per call (stamped build)")
     L = C.CDLL(os.environ["SCPN_HIP_LIB"])
     buf = (C.c_ulonglong * 128)()
     L.scpn_debug_tile_stamps(buf)
     names = ["start", "loaded"] + [f"pass {i}" for i in range(6)] + ["stored", "defect", "end", "drain"]
     idx = (0, 1, 11, 2, 3, 4, 5, 6, 7, 10) if os.environ.get("STAMPS_DRAIN") else ((0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10) if mode == "defect" else (0, 1, 2, 3, 4, 5, 6, 7, 8, 10))
-    print(f"--- n={n} B={B}: per-phase us of 8 sampled workgroups (dispatch ids 1, 511, ...); last column = start offset")
+    print(f"--- n={n} B={B}: per-phase us (rows kernel: successive tiles of workgroup 1; tile kernel: 8 sampled workgroups); last column = start offset")
     rows = []
     for g in range(8):
         st = list(buf)[g * 16:(g + 1) * 16]

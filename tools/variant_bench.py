@@ -6,7 +6,7 @@ if len(sys.argv) > 1:
     sys.path.insert(0, ".")
     import numpy as np
     from scpn_fusion_core_amd.ensemble import EnsembleSolver
-    from tests._problems import iter_like_cfg, bench_problem
+    from scpn_fusion_core_amd.cases import iter_like_cfg, bench_problem
     out = {"lib": os.path.basename(sys.argv[1])}
     for (n, B) in ((513, 32), (513, 16), (257, 16), (129, 16)):
         es = EnsembleSolver(iter_like_cfg(n), batch=B)
