@@ -119,9 +119,6 @@ int scpn_probe_response(int n_coils, const double *coil_r, const double *coil_z,
 /* Verification hook: the two division-by-reciprocal sequences of the kernels (5 and 4 instructions, see csrc/gs_kernels.hip.h
  * divc / divc4) applied to caller-supplied x[i] / d[i]; both must equal IEEE division (NumPy's `/`) bit for bit. */
 int scpn_verify_division(const double *x, const double *d, int n, double *q5, double *q4);
-/* Verification hook: the two DPP wave shifts of the row-block smoother (csrc/smooth_rows.hip.h) executed by one 64-lane wave
- * holding lane+1: below[i] must be i (value of lane i-1; 0 for lane 0), above[i] must be i+2 (lane i+1; 0 for lane 63). */
-int scpn_verify_lane_shift(double *below, double *above);
 /* Measurement hook (bench.py, SURVEY 8d "device-copy bandwidth probe"): GB/s (read + written bytes) of a 16-B/lane device
  * copy of `bytes` bytes, HIP-event timed over `reps` launches -- the measured HBM denominator printed next to the nominal one. */
 int scpn_copy_bandwidth_probe(long bytes, int reps, double *gb_per_s);

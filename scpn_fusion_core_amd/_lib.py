@@ -97,7 +97,6 @@ SIGNATURES = {
     "scpn_coil_flux": (_i, [_dp, _dp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _i, _dp]),
     "scpn_green_points": (_i, [_i, _dp, _dp, _i, _dp, _dp, _dp]),
     "scpn_verify_division": (_i, [_dp, _dp, _i, _dp, _dp]),
-    "scpn_verify_lane_shift": (_i, [_dp, _dp]),
     "scpn_copy_bandwidth_probe": (_i, [C.c_long, _i, C.POINTER(_d)]),
     "scpn_np_delta_star": (_i, [_dp, _i, _i, _dp, _d, _d, _dp]),
     "scpn_np_equation_residual": (_i, [_dp, _i, _i, _dp, _dp, _d, _d, _d, _dp]),

@@ -70,18 +70,6 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned lin, unsigned total)
     return k * q + (k < r ? k : r) + (lin >> 3);
 }
 
-// Scalar (SMEM) loads of wave-uniform words.  The compiler emits a VECTOR load for a uniform address whose memory it cannot
-// prove read-only, and the s_waitcnt vmcnt(0) behind it then drains every vector load in flight -- fatal for a kernel that
-// keeps a prefetch in flight.  Reading through the constant address space makes it an s_load the compiler can batch with its
-// neighbours (one lgkmcnt wait for all of them).  Only for words no kernel writes while it also reads them this way (slot
-// tables, member state written by the previous launch): the scalar cache is not coherent with vector stores of the same launch.
-__device__ __forceinline__ int sload_i32(const int* p) {
-    return *reinterpret_cast<const __attribute__((address_space(4))) int*>(reinterpret_cast<unsigned long>(p));
-}
-__device__ __forceinline__ double sload_f64(const double* p) {
-    return *reinterpret_cast<const __attribute__((address_space(4))) double*>(reinterpret_cast<unsigned long>(p));
-}
-
 // A batched field whose member b may live in one of several ping-pong slots.
 struct Fld {
     double* base;
@@ -90,10 +78,6 @@ struct Fld {
     int nb;  // members per slot
     __device__ __forceinline__ double* at(int b) const {
         int k = slot ? slot[b] : 0;
-        return base + ((long)k * nb + b) * stride;
-    }
-    __device__ __forceinline__ double* at_scalar(int b) const {  // b wave-uniform (an SGPR): slot lookup as a scalar load
-        int k = slot ? sload_i32(slot + b) : 0;
         return base + ((long)k * nb + b) * stride;
     }
 };
@@ -1754,22 +1738,24 @@ __global__ void __launch_bounds__(256) k_blend(Fld nxtF, Fld curF, Fld newF, Fld
 #endif
 constexpr int BT_Z = BLEND_BT_Z, BT_R = 64;
 // np.gradient + hypot inside the divertor rows (fusion_kernel.py:276-288) at tile point (LZ_, LR_) = grid point (GZ_, GR_)
+// (the divisions by dz, 2dz, dr, 2dr use divc4 with host reciprocals: bit-identical to IEEE division, 4 instructions instead of ~30)
+struct GradRecip { double dz, inv_dz, lo_dz, two_dz, inv_two_dz, lo_two_dz, dr, inv_dr, lo_dr; };
 #define SCPN_BLEND_GRAD(LZ_, LR_, GZ_, GR_, P_)                                                                             \
         if ((GZ_) < n_mask_rows) {                                                                                         \
             double gzv, grv;                                                                                               \
             const double ps = nan_to_num300(P_);                                                                           \
-            if ((GZ_) == 0) gzv = (nan_to_num300(t[(LZ_) + 1][LR_]) - ps) / L.dz;                                           \
-            else if ((GZ_) == nz - 1) gzv = (ps - nan_to_num300(t[(LZ_) - 1][LR_])) / L.dz;                                 \
-            else gzv = (nan_to_num300(t[(LZ_) + 1][LR_]) - nan_to_num300(t[(LZ_) - 1][LR_])) / (2.0 * L.dz);                \
-            if ((GR_) == 0) grv = (nan_to_num300(t[LZ_][(LR_) + 1]) - ps) / L.dr;                                           \
-            else if ((GR_) == nr - 1) grv = (ps - nan_to_num300(t[LZ_][(LR_) - 1])) / L.dr;                                 \
-            else grv = (nan_to_num300(t[LZ_][(LR_) + 1]) - nan_to_num300(t[LZ_][(LR_) - 1])) / (2.0 * L.dr);                \
+            if ((GZ_) == 0) gzv = divc4(nan_to_num300(t[(LZ_) + 1][LR_]) - ps, gq.dz, gq.inv_dz, gq.lo_dz);                  \
+            else if ((GZ_) == nz - 1) gzv = divc4(ps - nan_to_num300(t[(LZ_) - 1][LR_]), gq.dz, gq.inv_dz, gq.lo_dz);        \
+            else gzv = divc4(nan_to_num300(t[(LZ_) + 1][LR_]) - nan_to_num300(t[(LZ_) - 1][LR_]), gq.two_dz, gq.inv_two_dz, gq.lo_two_dz); \
+            if ((GR_) == 0) grv = divc4(nan_to_num300(t[LZ_][(LR_) + 1]) - ps, gq.dr, gq.inv_dr, gq.lo_dr);                  \
+            else if ((GR_) == nr - 1) grv = divc4(ps - nan_to_num300(t[LZ_][(LR_) - 1]), gq.dr, gq.inv_dr, gq.lo_dr);        \
+            else grv = divc4(nan_to_num300(t[LZ_][(LR_) + 1]) - nan_to_num300(t[LZ_][(LR_) - 1]), L.two_dr, L.inv_two_dr, L.lo_two_dr); \
             const double bm = hypot(grv, gzv);                                                                             \
             if (finite_d(bm)) mn = vi_min(mn, VI{bm, (long)(GZ_) * nr + (GR_)});                                            \
         }
 __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
                                                      double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
-                                                     double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm) {
+                                                     double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm, GradRecip gq) {
     __shared__ double t[BT_Z + 2][BT_R + 2 + 1];
     __shared__ VI sh_mx[4], sh_mn[4];
     __shared__ double sh_dsum[4], sh_m[4], sh_minp[4], sh_s2[4];
@@ -1910,8 +1896,9 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
     const double bmax = fmax(fmax(sh_m[0], sh_m[1]), fmax(sh_m[2], sh_m[3]));
     double s2 = 0.0;
     if (bmax > 0.0) {
+        const double ib = 1.0 / bmax;  // one IEEE division per thread instead of one per point (the rescaled sum is a norm estimate)
 #pragma unroll
-        for (int k = 0; k < BT_Z / 4; ++k) { const double q = rv[k] / bmax; s2 += q * q; }
+        for (int k = 0; k < BT_Z / 4; ++k) { const double q = rv[k] * ib; s2 += q * q; }
     }
     const double w_s2 = wave_sum(s2);
     if (tx == 0) sh_s2[ty] = w_s2;

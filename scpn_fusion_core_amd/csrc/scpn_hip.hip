@@ -22,7 +22,6 @@
 #include "../../include/scpn_hip.h"
 #include "gs_kernels.hip.h"
 #include "newton_kernels.hip.h"
-#include "smooth_rows.hip.h"
 
 using namespace gs;
 
@@ -425,102 +424,9 @@ static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
     else if (ps.c.base) launch_tile_geo<S, true, false>(h, L, out, in, src, omega, active, ps, nullptr);
     else launch_tile_geo<S, false, false>(h, L, out, in, src, omega, active, ps, nullptr);
 }
-// register-resident row-block smoother (smooth_rows.hip.h): geometry variants (rows per wave, persistent or one tile per workgroup)
-struct RowsGeo { int rb; bool persist; };
-static int device_cus() {
-    static const int n = [] {
-        hipDeviceProp_t pr;
-        return (hipGetDeviceProperties(&pr, g_device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-    }();
-    return n;
-}
-static RowsGeo rows_geo_for(const Lvl& L) {
-    // SCPN_HIP_ROWS="g0,g1,g2": geometry index for level 0, 1, 2+
-    //   0: 8 rows x 8 waves, one tile per workgroup (two workgroups per CU)      1: 10 rows x 8 waves, ditto
-    //   2: 8 x 8 persistent (one workgroup per CU, next tile prefetched)          3: 10 x 8 persistent
-    static const std::array<int, 3> cfg = [] {
-        std::array<int, 3> c{2, 0, 0};
-        if (const char* e = std::getenv("SCPN_HIP_ROWS")) {
-            int a = 0, b = 0, d = 0;
-            int n = std::sscanf(e, "%d,%d,%d", &a, &b, &d);
-            if (n >= 1) c[0] = c[1] = c[2] = a;
-            if (n >= 2) c[1] = c[2] = b;
-            if (n >= 3) c[2] = d;
-        }
-        return c;
-    }();
-    static const RowsGeo geos[4] = {{8, false}, {10, false}, {8, true}, {10, true}};
-    const int lvl = L.nz > 300 ? 0 : (L.nz > 150 ? 1 : 2);
-    return geos[std::min(std::max(cfg[lvl], 0), 3)];
-}
-static bool rows_enabled() {
-    static const bool on = [] { const char* e = std::getenv("SCPN_HIP_SMOOTHER"); return !(e && std::strcmp(e, "tile") == 0); }();
-    return on;
-}
-template <int S, bool PROLONG, bool DEFECT, int RB, bool PERSIST, bool BLEND = false>
-static void launch_rows_k(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                          const DefectOut* dfo, const BlendArgs* bl = nullptr) {
-    constexpr int NW = 8, H = 2 * S + ((DEFECT || BLEND) ? 2 : 0), OWNZ = RB * NW - 2 * H, OWNR = 128 - 2 * H;
-    constexpr int WPE = PERSIST ? 2 : 4;  // register budget: 256 (one 8-wave workgroup per CU) / 128 (two per CU)
-    RowsArgs A{};
-    A.out = out; A.in = in; A.src = src; A.L = L; A.omega = omega; A.om1 = 1.0 - omega; A.active = active;
-    A.coarse = ps.c; A.nz_c = ps.nz_c; A.nr_c = ps.nr_c; A.ld_c = ps.ld_c;
-    if (DEFECT || BLEND) {
-        DefectDst& dd = A.dd;
-        dd.dr2 = L.dr2; dd.dz2 = L.dz2; dd.two_dr = L.two_dr; dd.inv_dr2 = L.inv_dr2; dd.inv_dz2 = L.inv_dz2;
-        dd.inv_two_dr = L.inv_two_dr; dd.r_safe = L.r_safe; dd.r_inv = L.r_inv;
-        dd.lo_dr2 = L.lo_dr2; dd.lo_dz2 = L.lo_dz2; dd.lo_two_dr = L.lo_two_dr; dd.r_inv_lo = L.r_inv_lo;
-    }
-    if (DEFECT) {
-        A.dd.e = dfo->e;
-        A.coarse = dfo->rhs; A.nz_c = dfo->nz_c; A.nr_c = dfo->nr_c; A.ld_c = dfo->ld_c;
-    }
-    static const int xcd_env = [] { const char* e = std::getenv("SCPN_HIP_XCD"); return e ? std::atoi(e) : 1; }();
-    A.xcd_remap = xcd_env;
-    A.lzs.neg_mu0R = L.a_e;  // any per-column table: loaded unconditionally, used only in lazy-source mode
-    if (h->lazy_src && src.base == h->lazy_src) { A.lzs.st = h->d_st.p; A.lzs.neg_mu0R = h->d_neg_mu0R.p; }
-    A.gx = cdiv(L.nr, OWNR); A.gy = cdiv(std::max(L.nz - 1, 1), OWNZ); A.B = h->B;
-    if (BLEND) {
-        A.ba = *bl;
-        if (A.gx * A.gy != A.ba.nblk) throw std::runtime_error("blend partial layout mismatch");
-    }
-    const long tiles = (long)A.gx * A.gy * A.B;
-    const long grid = PERSIST ? std::min<long>(tiles, device_cus()) : tiles;
-    SCPN_LAUNCH((k_smooth_rows<S, PROLONG, DEFECT, RB, NW, WPE, PERSIST, BLEND>), dim3((unsigned)grid), dim3(64 * NW), 0, h->stream, A);
-}
-// the post-smoother that also performs the Picard tail (one tile per workgroup, 8 or 10 rows per wave)
-template <int S>
-static void launch_rows_blend(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                              const BlendArgs* bl) {
-    const bool ten = rows_geo_for(L).rb == 10;
-    if (ps.c.base) {
-        if (ten) launch_rows_k<S, true, false, 10, false, true>(h, L, out, in, src, omega, active, ps, nullptr, bl);
-        else launch_rows_k<S, true, false, 8, false, true>(h, L, out, in, src, omega, active, ps, nullptr, bl);
-    } else {
-        if (ten) launch_rows_k<S, false, false, 10, false, true>(h, L, out, in, src, omega, active, ps, nullptr, bl);
-        else launch_rows_k<S, false, false, 8, false, true>(h, L, out, in, src, omega, active, ps, nullptr, bl);
-    }
-}
-template <int S, bool PROLONG, bool DEFECT>
-static void launch_rows_geo(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                            const DefectOut* dfo) {
-    const RowsGeo g = rows_geo_for(L);
-    if (g.rb == 10 && g.persist) launch_rows_k<S, PROLONG, DEFECT, 10, true>(h, L, out, in, src, omega, active, ps, dfo);
-    else if (g.rb == 10) launch_rows_k<S, PROLONG, DEFECT, 10, false>(h, L, out, in, src, omega, active, ps, dfo);
-    else if (g.persist) launch_rows_k<S, PROLONG, DEFECT, 8, true>(h, L, out, in, src, omega, active, ps, dfo);
-    else launch_rows_k<S, PROLONG, DEFECT, 8, false>(h, L, out, in, src, omega, active, ps, dfo);
-}
-template <int S>
-static void launch_rows(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                        const DefectOut* dfo) {
-    if (dfo) launch_rows_geo<S, false, true>(h, L, out, in, src, omega, active, ps, dfo);
-    else if (ps.c.base) launch_rows_geo<S, true, false>(h, L, out, in, src, omega, active, ps, nullptr);
-    else launch_rows_geo<S, false, false>(h, L, out, in, src, omega, active, ps, nullptr);
-}
 // tiles per member of the blend-fused post-smoother (its partial arrays are indexed by tile)
 static int blend_tiles(const Lvl& L, int post) {
     const int S = ((post - 1) % 3) + 1, H = 2 * S + 2;
-    if (rows_enabled()) return cdiv(L.nr, 128 - 2 * H) * cdiv(std::max(L.nz - 1, 1), rows_geo_for(L).rb * 8 - 2 * H);
     return cdiv(L.nr, 128 - 2 * H) * cdiv(L.nz, tile_rows_for(L) - 2 * H);
 }
 
@@ -552,15 +458,7 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
             const bool last = left - S <= 0;
             const BlendArgs* bl = (blend && last) ? blend : nullptr;  // the last launch writes the blended iterate
             Fld dst = bl ? blend_out : b;
-            if (rows_enabled() && !sgo && bl) {
-                if (S == 3) launch_rows_blend<3>(h, L, dst, a, src, omega, active, pso, bl);
-                else if (S == 2) launch_rows_blend<2>(h, L, dst, a, src, omega, active, pso, bl);
-                else launch_rows_blend<1>(h, L, dst, a, src, omega, active, pso, bl);
-            } else if (rows_enabled() && !sgo) {
-                if (S == 3) launch_rows<3>(h, L, dst, a, src, omega, active, pso, dfo);
-                else if (S == 2) launch_rows<2>(h, L, dst, a, src, omega, active, pso, dfo);
-                else launch_rows<1>(h, L, dst, a, src, omega, active, pso, dfo);
-            } else if (S == 3) launch_tile_p<3>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
+            if (S == 3) launch_tile_p<3>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
             else if (S == 2) launch_tile_p<2>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
             else launch_tile_p<1>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
             if (bl) return dst;
@@ -1015,8 +913,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     // iteration on MI355X).  SCPN_HIP_LAZYSRC=0 restores the separate source pass
     static const bool lazy_env = [] { const char* e = std::getenv("SCPN_HIP_LAZYSRC"); return !(e && e[0] == '0'); }();
     static const bool srcgen_env0 = [] { const char* e = std::getenv("SCPN_HIP_SRCGEN"); return e && e[0] == '1'; }();
-    // (the LDS-tiled kernel's blend-fused variant predates the lazy source; the row-block kernel converts the source on load)
-    static const bool blend_env0 = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1' && !rows_enabled(); }();
+    static const bool blend_env0 = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1'; }();
     const bool lazy = lazy_env && !srcgen_env0 && !blend_env0 && h->use_fused && p->method == 0 && !p->external_profile_mode &&
                       vcycle_lazy_ok(h, 3, 3, 5);
     struct LazyGuard {
@@ -1063,9 +960,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         Fld newF = WF;
         // blend + norms + topology inside the post-smoother is implemented and bit-identical to k_blend_fused, but at one
         // 16-wave workgroup per CU its extra compute is not hidden (160.8 vs 172.3 eq/s measured): opt-in (SCPN_HIP_BLENDFUSE=1)
-        // With the row-block smoother the Picard tail is an epilogue of the level-0 post-smoother by default (psi_new stays in
-        // registers; SCPN_HIP_BLENDFUSE=0 restores the separate k_blend_fused pass)
-        static const bool blend_env = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e ? e[0] == '1' : rows_enabled(); }();
+        static const bool blend_env = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1'; }();
         const bool blend_in_tile = blend_env && p->method == 0 && vcycle_can_blend(h, 3, 5);
         int nb_d = nblk1, nb_r = nblk_r;
         if (p->method == 0) {
@@ -1089,9 +984,14 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         } else if (h->use_fused && p->method != 3) {
             ProfScope ps(h, "blend_fused", 1);
             nb_d = nb_r = nblk2;
+            auto recip_lo = [](double d) { return std::fma(-d, 1.0 / d, 1.0) / d; };
+            GradRecip gq;
+            gq.dz = L0.dz; gq.inv_dz = 1.0 / L0.dz; gq.lo_dz = recip_lo(L0.dz);
+            gq.two_dz = 2.0 * L0.dz; gq.inv_two_dz = 1.0 / gq.two_dz; gq.lo_two_dz = recip_lo(gq.two_dz);
+            gq.dr = L0.dr; gq.inv_dr = 1.0 / L0.dr; gq.lo_dr = recip_lo(L0.dr);
             SCPN_LAUNCH(k_blend_fused, dim3(cdiv(nr - 1, BT_R), cdiv(nz - 1, BT_Z), B), dim3(256), 0, st, nxtF, curF, newF, bcF, srcF,
                                (const Member*)h->d_st.p, L0, p->alpha, om_alpha, n_mask_rows, h->d_part1.p, h->d_pbad.p, h->d_part2.p,
-                               h->d_part3.p, h->d_topo.p, nblk2, lazy ? (const double*)h->d_neg_mu0R.p : (const double*)nullptr);
+                               h->d_part3.p, h->d_topo.p, nblk2, lazy ? (const double*)h->d_neg_mu0R.p : (const double*)nullptr, gq);
         } else {
             ProfScope ps(h, "blend_norms", 2);
             SCPN_LAUNCH(k_blend, dim3(nblk1, B), dim3(256), 0, st, nxtF, curF, newF, bcF, (const Member*)h->d_st.p, nz, nr, ld, p->alpha,
@@ -2601,21 +2501,6 @@ int scpn_verify_division(const double* x, const double* d, int n, double* q5, do
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(q5, o5.p, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(q4, o4.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-    API_END
-}
-
-// direction check of the DPP wave shifts used by the row-block smoother: below[i] = value of lane i-1, above[i] = of lane i+1
-int scpn_verify_lane_shift(double* below, double* above) {
-    if (!below || !above) return fail(SCPN_E_ARG, "scpn_verify_lane_shift: null buffer");
-    API_BEGIN
-    HIP_TRY(hipSetDevice(g_device));
-    DBuf<double> a, b;
-    a.alloc(64);
-    b.alloc(64);
-    SCPN_LAUNCH(k_verify_lane_shift, dim3(1), dim3(64), 0, nullptr, a.p, b.p);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(below, a.p, sizeof(double) * 64, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(above, b.p, sizeof(double) * 64, hipMemcpyDeviceToHost));
     API_END
 }
 

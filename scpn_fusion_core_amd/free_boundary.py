@@ -74,13 +74,16 @@ def green_points(coil_r, coil_z, pts_r, pts_z):
     return out
 
 
+def _require(ok: bool, message: str) -> None:
+    if not ok:
+        raise ValueError(message)
+
+
 def green_function(R_src: float, Z_src: float, R_obs: float, Z_obs: float) -> float:
-    """core/fusion_kernel_free_boundary.py:31-55."""
-    values = np.asarray([R_src, Z_src, R_obs, Z_obs], dtype=np.float64)
-    if not np.all(np.isfinite(values)):
-        raise ValueError("Green's-function coordinates must be finite.")
-    if R_src <= 0.0 or R_obs <= 0.0:
-        raise ValueError("Green's-function radii must be positive.")
+    """Flux at (R_obs, Z_obs) of a unit-current filament at (R_src, Z_src), core/fusion_kernel_free_boundary.py:31-55 --
+    one point through the device kernel."""
+    _require(bool(np.isfinite([R_src, Z_src, R_obs, Z_obs]).all()), "Green's-function coordinates must be finite.")
+    _require(min(R_src, R_obs) > 0.0, "Green's-function radii must be positive.")
     return float(green_points([R_src], [Z_src], [R_obs], [Z_obs])[0, 0])
 
 
@@ -103,38 +106,38 @@ def build_mutual_inductance_matrix(kernel: Any, coils: CoilSet, obs_points) -> n
     return coils.turns_array()[:, None] * G
 
 
-def _as_finite_vector(value, *, name: str, length: int | None = None) -> np.ndarray:
-    arr = np.asarray(value, dtype=np.float64).reshape(-1)
-    if length is not None and arr.shape != (length,):
-        raise ValueError(f"{name} must have length {length}.")
-    if not np.all(np.isfinite(arr)):
-        raise ValueError(f"{name} must contain finite values only.")
+def _finite_array(value, name: str, *, pairs: bool = False, length: int | None = None) -> np.ndarray:
+    """float64 view of a caller-supplied vector (``pairs=False``, optionally of a fixed length) or (n, 2) point list, finite."""
+    arr = np.asarray(value, dtype=np.float64)
+    if pairs:
+        _require(arr.ndim == 2 and arr.shape[1] == 2 and arr.shape[0] >= 1, f"{name} must have shape (n_points, 2) with n_points > 0.")
+    else:
+        arr = arr.reshape(-1)
+        _require(length is None or arr.shape == (length,), f"{name} must have length {length}.")
+    _require(bool(np.all(np.isfinite(arr))), f"{name} must contain finite values only.")
     return arr
+
+
+def _as_finite_vector(value, *, name: str, length: int | None = None) -> np.ndarray:
+    return _finite_array(value, name, length=length)
 
 
 def _as_finite_points(value, *, name: str) -> np.ndarray:
-    arr = np.asarray(value, dtype=np.float64)
-    if arr.ndim != 2 or arr.shape[1] != 2 or arr.shape[0] < 1:
-        raise ValueError(f"{name} must have shape (n_points, 2) with n_points > 0.")
-    if not np.all(np.isfinite(arr)):
-        raise ValueError(f"{name} must contain finite values only.")
-    return arr
+    return _finite_array(value, name, pairs=True)
 
 
 def _points_inside_polygon(points, polygon) -> np.ndarray:
-    """Even-odd containment mask (core/fusion_kernel_free_boundary.py:114-134)."""
-    pts = _as_finite_points(points, name="points")
-    poly = _as_finite_points(polygon, name="polygon")
-    if poly.shape[0] < 3:
-        raise ValueError("polygon must contain at least three points.")
-    x, y = pts[:, 0], pts[:, 1]
-    x0, y0 = poly[:, 0], poly[:, 1]
-    x1, y1 = np.roll(x0, -1), np.roll(y0, -1)
-    inside = np.zeros(pts.shape[0], dtype=bool)
-    for xa, ya, xb, yb in zip(x0, y0, x1, y1):
-        intersects = ((ya > y) != (yb > y)) & (x < (xb - xa) * (y - ya) / max(abs(yb - ya), 1.0e-300) + xa)
-        inside ^= intersects
-    return inside
+    """Even-odd containment mask (core/fusion_kernel_free_boundary.py:114-134), all edges at once: a point is inside when the
+    ray towards +R crosses an odd number of edges (edge k runs from vertex k to vertex k+1, the last one closes the contour)."""
+    pts = _finite_array(points, "points", pairs=True)
+    ring = _finite_array(polygon, "polygon", pairs=True)
+    _require(ring.shape[0] >= 3, "polygon must contain at least three points.")
+    head, tail = ring, np.roll(ring, -1, axis=0)
+    pr, pz = pts[:, 0][:, None], pts[:, 1][:, None]                # (n_pts, 1) against (n_edges,)
+    straddles = (head[:, 1] > pz) != (tail[:, 1] > pz)
+    rise = np.maximum(np.abs(tail[:, 1] - head[:, 1]), 1.0e-300)
+    crossing_r = (tail[:, 0] - head[:, 0]) * (pz - head[:, 1]) / rise + head[:, 0]
+    return (np.count_nonzero(straddles & (pr < crossing_r), axis=1) % 2).astype(bool)
 
 
 def sample_flux_at_points(kernel: Any, points) -> np.ndarray:
@@ -163,12 +166,10 @@ def sample_psi_grid(psi, r_axis, z_axis, points) -> np.ndarray:
 
 
 def _validate_probe_directions(directions, *, length: int) -> list[str]:
-    if len(directions) != length:
-        raise ValueError("b_probe_directions must have one entry per b_probe_point.")
-    out = [str(direction).upper() for direction in directions]
-    if [d for d in out if d not in {"R", "Z"}]:
-        raise ValueError("b_probe_directions entries must be 'R' or 'Z'.")
-    return out
+    _require(len(directions) == length, "b_probe_directions must have one entry per b_probe_point.")
+    axes = [str(d).upper() for d in directions]
+    _require(set(axes) <= {"R", "Z"}, "b_probe_directions entries must be 'R' or 'Z'.")
+    return axes
 
 
 def build_magnetic_probe_response_matrix(kernel: Any, coils: CoilSet, *, flux_points=None, b_probe_points=None,
@@ -176,18 +177,14 @@ def build_magnetic_probe_response_matrix(kernel: Any, coils: CoilSet, *, flux_po
     """Diagnostic response matrix, rows = flux loops then B probes, columns = coils
     (core/fusion_kernel_free_boundary.py:315-373); every entry is evaluated by one device kernel."""
     del kernel
-    if len(coils.positions) < 1:
-        raise ValueError("CoilSet.positions must contain at least one coil.")
-    if len(coils.currents) != len(coils.positions):
-        raise ValueError("CoilSet.currents length must match number of coil positions.")
-    flux_obs = None if flux_points is None else _as_finite_points(flux_points, name="flux_points")
-    b_obs = None if b_probe_points is None else _as_finite_points(b_probe_points, name="b_probe_points")
-    if flux_obs is None and b_obs is None:
-        raise ValueError("At least one flux point or B probe point must be provided.")
+    _require(len(coils.positions) >= 1, "CoilSet.positions must contain at least one coil.")
+    _require(len(coils.currents) == len(coils.positions), "CoilSet.currents length must match number of coil positions.")
+    flux_obs = _finite_array(flux_points, "flux_points", pairs=True) if flux_points is not None else None
+    b_obs = _finite_array(b_probe_points, "b_probe_points", pairs=True) if b_probe_points is not None else None
+    _require(flux_obs is not None or b_obs is not None, "At least one flux point or B probe point must be provided.")
     directions: list[str] = []
     if b_obs is not None:
-        if b_probe_directions is None:
-            raise ValueError("b_probe_directions must be provided with b_probe_points.")
+        _require(b_probe_directions is not None, "b_probe_directions must be provided with b_probe_points.")
         directions = _validate_probe_directions(b_probe_directions, length=int(b_obs.shape[0]))
     pos = np.array(coils.positions, dtype=np.float64).reshape(-1, 2)
     if not np.all(np.isfinite(pos)) or np.any(pos[:, 0] <= 0.0):
@@ -216,55 +213,83 @@ def build_magnetic_probe_response_matrix(kernel: Any, coils: CoilSet, *, flux_po
 def reconstruct_boundary_flux_from_coils(kernel: Any, coils: CoilSet, *, boundary_points, limiter_points=None, axis_point=None,
                                          x_points=None, target_flux=None) -> dict[str, Any]:
     """Forward free-boundary vacuum contract (core/fusion_kernel_free_boundary.py:162-270): coil Green's-function flux on the
-    boundary / limiter / axis / X-point sets plus residual diagnostics.  Responses come from the device kernel."""
-    obs = _as_finite_points(boundary_points, name="boundary_points")
-    if len(coils.positions) < 1:
-        raise ValueError("CoilSet.positions must contain at least one coil.")
-    currents = _as_finite_vector(coils.currents, name="currents", length=len(coils.positions))
-    response = build_mutual_inductance_matrix(kernel, coils, obs)
-    reconstructed = response.T @ currents
-    if not np.all(np.isfinite(reconstructed)):
-        raise ValueError("reconstructed boundary flux contains non-finite values.")
-    diagnostics: dict[str, Any] = {
-        "boundary_points": obs, "reconstructed_flux": reconstructed, "response_matrix": response,
-        "response_rank": int(np.linalg.matrix_rank(response)), "point_count": int(obs.shape[0]),
-        "coil_count": int(len(coils.positions)), "limiter_point_count": 0, "limiter_flux": np.array([], dtype=np.float64),
-        "min_limiter_distance_m": None, "axis_point": None, "axis_flux": None, "x_point_count": 0,
-        "x_point_flux": np.array([], dtype=np.float64), "x_point_flux_span": None, "x_point_pair_symmetry_abs_error": None,
-    }
+    boundary / limiter / axis / X-point sets plus residual diagnostics.  All point sets go through ONE device evaluation of the
+    Green's functions; the per-set fluxes are products of the matching column blocks with the coil currents."""
+    named = {"boundary": _finite_array(boundary_points, "boundary_points", pairs=True)}
     if limiter_points is not None:
-        limiter_obs = _as_finite_points(limiter_points, name="limiter_points")
-        limiter_flux = build_mutual_inductance_matrix(kernel, coils, limiter_obs).T @ currents
-        distances = np.linalg.norm(limiter_obs[:, None, :] - obs[None, :, :], axis=2)
-        mask = _points_inside_polygon(obs, limiter_obs)
-        frac = float(np.mean(mask)) if mask.size else 0.0
-        diagnostics.update({"limiter_points": limiter_obs, "limiter_flux": limiter_flux, "limiter_point_count": int(limiter_obs.shape[0]),
-                            "min_limiter_distance_m": float(np.min(distances)), "boundary_containment_fraction": frac,
-                            "boundary_containment_pass": bool(frac >= 1.0)})
+        named["limiter"] = _finite_array(limiter_points, "limiter_points", pairs=True)
     if axis_point is not None:
-        axis_obs = _as_finite_points(np.asarray(axis_point, dtype=np.float64).reshape(1, 2), name="axis_point")
-        axis_response = build_mutual_inductance_matrix(kernel, coils, axis_obs)
-        diagnostics.update({"axis_point": axis_obs[0], "axis_flux": float((axis_response.T @ currents)[0])})
+        named["axis"] = _finite_array(np.asarray(axis_point, dtype=np.float64).reshape(1, 2), "axis_point", pairs=True)
     if x_points is not None:
-        x_obs = _as_finite_points(x_points, name="x_points")
-        x_flux = build_mutual_inductance_matrix(kernel, coils, x_obs).T @ currents
-        span = float(np.max(x_flux) - np.min(x_flux)) if x_flux.size else None
-        sym = None
-        ax = diagnostics.get("axis_point")
-        if ax is not None and x_obs.shape[0] == 2:
-            same_r = abs(float(x_obs[0, 0] - x_obs[1, 0])) <= 1.0e-9
-            mirrored = abs(float(x_obs[0, 1] + x_obs[1, 1] - 2.0 * ax[1])) <= 1.0e-9
-            if same_r and mirrored:
-                sym = float(abs(x_flux[0] - x_flux[1]))
-        diagnostics.update({"x_points": x_obs, "x_point_flux": x_flux, "x_point_count": int(x_obs.shape[0]), "x_point_flux_span": span,
-                            "x_point_pair_symmetry_abs_error": sym})
+        named["x"] = _finite_array(x_points, "x_points", pairs=True)
+    n_coils = len(coils.positions)
+    _require(n_coils >= 1, "CoilSet.positions must contain at least one coil.")
+    currents = _finite_array(coils.currents, "currents", length=n_coils)
+    every = build_mutual_inductance_matrix(kernel, coils, np.vstack(list(named.values())))
+    blocks, start = {}, 0
+    for key, pts in named.items():  # column blocks, contiguous copies (same matrix shapes as a per-set evaluation)
+        blocks[key] = np.ascontiguousarray(every[:, start:start + pts.shape[0]])
+        start += pts.shape[0]
+    flux = {key: blk.T @ currents for key, blk in blocks.items()}
+    obs, response, reconstructed = named["boundary"], blocks["boundary"], flux["boundary"]
+    _require(bool(np.all(np.isfinite(reconstructed))), "reconstructed boundary flux contains non-finite values.")
+    no_flux = np.array([], dtype=np.float64)
+    report: dict[str, Any] = dict(
+        boundary_points=obs, reconstructed_flux=reconstructed, response_matrix=response,
+        response_rank=int(np.linalg.matrix_rank(response)), point_count=int(obs.shape[0]), coil_count=int(n_coils),
+        limiter_point_count=0, limiter_flux=no_flux, min_limiter_distance_m=None, axis_point=None, axis_flux=None,
+        x_point_count=0, x_point_flux=no_flux.copy(), x_point_flux_span=None, x_point_pair_symmetry_abs_error=None)
+    if "limiter" in named:
+        wall = named["limiter"]
+        gap = np.linalg.norm(wall[:, None, :] - obs[None, :, :], axis=2)
+        contained = _points_inside_polygon(obs, wall)
+        share = float(np.mean(contained)) if contained.size else 0.0
+        report.update(limiter_points=wall, limiter_flux=flux["limiter"], limiter_point_count=int(wall.shape[0]),
+                      min_limiter_distance_m=float(np.min(gap)), boundary_containment_fraction=share,
+                      boundary_containment_pass=bool(share >= 1.0))
+    if "axis" in named:
+        report.update(axis_point=named["axis"][0], axis_flux=float(flux["axis"][0]))
+    if "x" in named:
+        xp, xf = named["x"], flux["x"]
+        pair_error = None
+        axis = report["axis_point"]
+        if axis is not None and xp.shape[0] == 2:  # an up-down mirrored X-point pair at one major radius must see the same flux
+            aligned = abs(float(xp[0, 0] - xp[1, 0])) <= 1.0e-9 and abs(float(xp[0, 1] + xp[1, 1] - 2.0 * axis[1])) <= 1.0e-9
+            if aligned:
+                pair_error = float(abs(xf[0] - xf[1]))
+        report.update(x_points=xp, x_point_flux=xf, x_point_count=int(xp.shape[0]),
+                      x_point_flux_span=float(np.max(xf) - np.min(xf)) if xf.size else None, x_point_pair_symmetry_abs_error=pair_error)
     if target_flux is not None:
-        target = _as_finite_vector(target_flux, name="target_flux", length=int(obs.shape[0]))
-        residual = reconstructed - target
-        diagnostics.update({"target_flux": target, "residual": residual,
-                            "rmse": float(np.sqrt(np.mean(residual**2))) if residual.size else 0.0,
-                            "max_abs_error": float(np.max(np.abs(residual))) if residual.size else 0.0})
-    return diagnostics
+        wanted = _finite_array(target_flux, "target_flux", length=int(obs.shape[0]))
+        miss = reconstructed - wanted
+        report.update(target_flux=wanted, residual=miss, rmse=float(np.sqrt(np.mean(miss**2))) if miss.size else 0.0,
+                      max_abs_error=float(np.max(np.abs(miss))) if miss.size else 0.0)
+    return report
+
+
+def _current_bounds(coils: CoilSet, n_coils: int, *, strictly_positive: bool) -> tuple[np.ndarray, np.ndarray]:
+    """Box bounds (-|limit|, +|limit|) of the coil currents; unbounded without ``current_limits``.  ``strictly_positive`` is the
+    probe-inversion contract (core/fusion_kernel_free_boundary.py:452-455), finiteness + length the shape-fit one (:531-536)."""
+    if coils.current_limits is None:
+        return np.full(n_coils, -np.inf), np.full(n_coils, np.inf)
+    if strictly_positive:
+        limits = _as_finite_vector(coils.current_limits, name="current_limits", length=n_coils)
+        _require(not np.any(limits <= 0.0), "current_limits must contain finite positive values only.")
+    else:
+        limits = np.asarray(coils.current_limits, dtype=np.float64).reshape(-1)
+        _require(limits.shape[0] == n_coils, "current_limits must have one entry per coil.")
+        _require(bool(np.all(np.isfinite(limits))), "current_limits must contain finite values only.")
+    mag = np.abs(limits)
+    return -mag, mag
+
+
+def _ridge_system(rows: np.ndarray, rhs: np.ndarray, alpha: float, prior: np.ndarray | None) -> tuple[np.ndarray, np.ndarray]:
+    """Augmented least-squares system of a Tikhonov fit: ``rows`` stacked on sqrt(alpha)*I, ``rhs`` on sqrt(alpha)*prior (zeros
+    when the regulariser pulls towards zero current)."""
+    n = rows.shape[1]
+    damp = np.sqrt(alpha)
+    anchor = np.zeros(n) if prior is None else damp * prior
+    return np.vstack([rows, damp * np.eye(n, dtype=np.float64)]), np.concatenate([rhs, anchor])
 
 
 def reconstruct_coil_currents_from_magnetic_probes(kernel: Any, coils: CoilSet, *, flux_points=None, flux_measurements=None,
@@ -275,156 +300,156 @@ def reconstruct_coil_currents_from_magnetic_probes(kernel: Any, coils: CoilSet, 
     (rows + n_coils) x n_coils ``lsq_linear`` stays on the host as in the reference."""
     response = build_magnetic_probe_response_matrix(kernel, coils, flux_points=flux_points, b_probe_points=b_probe_points,
                                                     b_probe_directions=b_probe_directions)
-    targets = []
-    if flux_points is not None:
-        if flux_measurements is None:
-            raise ValueError("flux_measurements must be provided with flux_points.")
-        n_flux = _as_finite_points(flux_points, name="flux_points").shape[0]
-        targets.append(_as_finite_vector(flux_measurements, name="flux_measurements", length=n_flux))
-    elif flux_measurements is not None:
-        raise ValueError("flux_points must be provided with flux_measurements.")
-    if b_probe_points is not None:
-        if b_probe_measurements is None:
-            raise ValueError("b_probe_measurements must be provided with b_probe_points.")
-        n_probe = _as_finite_points(b_probe_points, name="b_probe_points").shape[0]
-        targets.append(_as_finite_vector(b_probe_measurements, name="b_probe_measurements", length=n_probe))
-    elif b_probe_measurements is not None:
-        raise ValueError("b_probe_points must be provided with b_probe_measurements.")
-    if not targets:
-        raise ValueError("At least one measurement vector must be provided.")
-    target = np.concatenate(targets).astype(np.float64, copy=False)
-    if target.shape != (response.shape[0],):
-        raise ValueError("measurement vector length must match response rows.")
-    weights = np.ones(response.shape[0], dtype=np.float64)
+    # one measurement block per diagnostic kind, in response-row order; a block needs both its geometry and its readings
+    blocks = (("flux_points", flux_points, "flux_measurements", flux_measurements),
+              ("b_probe_points", b_probe_points, "b_probe_measurements", b_probe_measurements))
+    readings = []
+    for geo_name, geo, val_name, val in blocks:
+        if geo is None:
+            _require(val is None, f"{geo_name} must be provided with {val_name}.")
+            continue
+        _require(val is not None, f"{val_name} must be provided with {geo_name}.")
+        readings.append(_as_finite_vector(val, name=val_name, length=_as_finite_points(geo, name=geo_name).shape[0]))
+    _require(bool(readings), "At least one measurement vector must be provided.")
+    target = np.concatenate(readings).astype(np.float64, copy=False)
+    n_rows, n_coils = response.shape[0], len(coils.positions)
+    _require(target.shape == (n_rows,), "measurement vector length must match response rows.")
+    weights = np.ones(n_rows, dtype=np.float64)
     if measurement_sigma is not None:
-        sigma = _as_finite_vector(measurement_sigma, name="measurement_sigma", length=response.shape[0])
-        if np.any(sigma <= 0.0):
-            raise ValueError("measurement_sigma must contain finite positive values only.")
+        sigma = _as_finite_vector(measurement_sigma, name="measurement_sigma", length=n_rows)
+        _require(not np.any(sigma <= 0.0), "measurement_sigma must contain finite positive values only.")
         weights = 1.0 / sigma
     alpha = float(tikhonov_alpha)
-    if not np.isfinite(alpha) or alpha < 0.0:
-        raise ValueError("tikhonov_alpha must be finite and non-negative.")
-    n_coils = len(coils.positions)
-    weighted_response = response * weights[:, None]
-    weighted_target = target * weights
+    _require(bool(np.isfinite(alpha)) and alpha >= 0.0, "tikhonov_alpha must be finite and non-negative.")
     prior = np.asarray(coils.currents, dtype=np.float64).reshape(-1)
-    if prior.shape != (n_coils,) or not np.all(np.isfinite(prior)):
-        raise ValueError("CoilSet.currents must be finite with one entry per coil.")
+    _require(prior.shape == (n_coils,) and bool(np.all(np.isfinite(prior))), "CoilSet.currents must be finite with one entry per coil.")
+    A, b = response * weights[:, None], target * weights
     if alpha > 0.0:
-        A = np.vstack([weighted_response, np.sqrt(alpha) * np.eye(n_coils, dtype=np.float64)])
-        b = np.concatenate([weighted_target, np.sqrt(alpha) * prior])
-    else:
-        A, b = weighted_response, weighted_target
-    if coils.current_limits is not None:
-        limits = _as_finite_vector(coils.current_limits, name="current_limits", length=n_coils)
-        if np.any(limits <= 0.0):
-            raise ValueError("current_limits must contain finite positive values only.")
-        lb, ub = -np.abs(limits), np.abs(limits)
-    else:
-        lb, ub = -np.inf * np.ones(n_coils), np.inf * np.ones(n_coils)
+        A, b = _ridge_system(A, b, alpha, prior)
+    lb, ub = _current_bounds(coils, n_coils, strictly_positive=True)
     from scipy.optimize import lsq_linear
 
-    result = lsq_linear(A, b, bounds=(lb, ub), method="trf")
-    if not bool(getattr(result, "success", False)) or not np.all(np.isfinite(result.x)):
-        raise RuntimeError(f"Magnetic probe inverse reconstruction failed: {getattr(result, 'message', '')}")
-    currents = np.asarray(result.x, dtype=np.float64)
-    residual = response @ currents - target
-    weighted_residual = residual * weights
+    fit = lsq_linear(A, b, bounds=(lb, ub), method="trf")
+    if not bool(getattr(fit, "success", False)) or not np.all(np.isfinite(fit.x)):
+        raise RuntimeError(f"Magnetic probe inverse reconstruction failed: {getattr(fit, 'message', '')}")
+    currents = np.asarray(fit.x, dtype=np.float64)
+    misfit = response @ currents - target
+    rms = lambda v: float(np.sqrt(np.mean(v**2))) if v.size else 0.0  # noqa: E731
     return {
-        "coil_currents": currents, "residual": residual, "weighted_residual": weighted_residual,
-        "residual_rms": float(np.sqrt(np.mean(residual**2))) if residual.size else 0.0,
-        "weighted_residual_rms": float(np.sqrt(np.mean(weighted_residual**2))) if weighted_residual.size else 0.0,
+        "coil_currents": currents, "residual": misfit, "weighted_residual": misfit * weights,
+        "residual_rms": rms(misfit), "weighted_residual_rms": rms(misfit * weights),
         "response_rank": int(np.linalg.matrix_rank(response)),
         "response_condition": float(np.linalg.cond(response)) if response.size else float("inf"),
         "active_bounds": int(np.count_nonzero(np.isclose(currents, lb) | np.isclose(currents, ub))),
     }
 
 
+def _bilinear_psi(kernel: Any, points: np.ndarray) -> np.ndarray:
+    """Bilinear samples of ``kernel.Psi`` at ``points[:, (R, Z)]`` (cell index from the sorted axes, offsets clamped to the cell;
+    the four corner terms are added in the order SW, SE, NW, NE as core/fusion_kernel_free_boundary.py:562-580 does)."""
+    pts = np.asarray(points, dtype=np.float64).reshape(-1, 2)
+    cell_r = np.clip(np.searchsorted(kernel.R, pts[:, 0]) - 1, 0, kernel.NR - 2)
+    cell_z = np.clip(np.searchsorted(kernel.Z, pts[:, 1]) - 1, 0, kernel.NZ - 2)
+    fr = np.clip((pts[:, 0] - np.asarray(kernel.R)[cell_r]) / kernel.dR, 0.0, 1.0)
+    fz = np.clip((pts[:, 1] - np.asarray(kernel.Z)[cell_z]) / kernel.dZ, 0.0, 1.0)
+    psi = np.asarray(kernel.Psi)
+    out = (1 - fr) * (1 - fz) * psi[cell_z, cell_r]
+    out = out + fr * (1 - fz) * psi[cell_z, cell_r + 1]
+    out = out + (1 - fr) * fz * psi[cell_z + 1, cell_r]
+    return out + fr * fz * psi[cell_z + 1, cell_r + 1]
+
+
 def interp_psi(kernel: Any, R_pt: float, Z_pt: float) -> float:
-    """Bilinear sample of kernel.Psi (core/fusion_kernel_free_boundary.py:562-580) -- host-side, 4 points."""
-    ir = int(np.searchsorted(kernel.R, R_pt)) - 1
-    iz = int(np.searchsorted(kernel.Z, Z_pt)) - 1
-    ir = max(0, min(ir, kernel.NR - 2))
-    iz = max(0, min(iz, kernel.NZ - 2))
-    t_r = max(0.0, min(1.0, (R_pt - kernel.R[ir]) / kernel.dR))
-    t_z = max(0.0, min(1.0, (Z_pt - kernel.Z[iz]) / kernel.dZ))
-    P = kernel.Psi
-    return float((1 - t_r) * (1 - t_z) * P[iz, ir] + t_r * (1 - t_z) * P[iz, ir + 1] + (1 - t_r) * t_z * P[iz + 1, ir]
-                 + t_r * t_z * P[iz + 1, ir + 1])
+    """Bilinear sample of kernel.Psi at one point (core/fusion_kernel_free_boundary.py:562-580) -- host-side, 4 grid values."""
+    return float(_bilinear_psi(kernel, np.array([[R_pt, Z_pt]], dtype=np.float64))[0])
+
+
+def _control_points(coils: CoilSet, purpose: str) -> np.ndarray:
+    """The isoflux control points of a CoilSet as an (n, 2) array (n > 0)."""
+    _require(coils.target_flux_points is not None, f"CoilSet.target_flux_points must be set for {purpose}.")
+    pts = np.asarray(coils.target_flux_points, dtype=np.float64)
+    _require(pts.ndim == 2 and pts.shape[1] == 2 and pts.shape[0] > 0, "target_flux_points must have shape (n_points, 2) with n_points > 0.")
+    return pts
 
 
 def resolve_shape_target_flux(kernel: Any, coils: CoilSet) -> np.ndarray:
     """core/fusion_kernel_free_boundary.py:583-605: explicit target values, or the isoflux mean of bilinear psi samples."""
-    if coils.target_flux_points is None:
-        raise ValueError("CoilSet.target_flux_points must be set for shape optimisation.")
-    obs = np.asarray(coils.target_flux_points, dtype=np.float64)
-    n_pts = int(obs.shape[0])
-    if obs.ndim != 2 or obs.shape[1] != 2 or n_pts == 0:
-        raise ValueError("target_flux_points must have shape (n_points, 2) with n_points > 0.")
-    if coils.target_flux_values is not None:
-        target = np.asarray(coils.target_flux_values, dtype=np.float64).reshape(-1)
-        if target.shape[0] != n_pts:
-            raise ValueError("target_flux_values must have the same length as target_flux_points.")
-        if not np.all(np.isfinite(target)):
-            raise ValueError("target_flux_values must contain finite values only.")
-        return target
-    samples = np.array([float(interp_psi(kernel, R_t, Z_t)) for R_t, Z_t in obs], dtype=np.float64)
-    return np.full(n_pts, float(np.mean(samples)), dtype=np.float64)
+    pts = _control_points(coils, "shape optimisation")
+    if coils.target_flux_values is None:
+        return np.full(pts.shape[0], float(np.mean(_bilinear_psi(kernel, pts))), dtype=np.float64)
+    explicit = np.asarray(coils.target_flux_values, dtype=np.float64).reshape(-1)
+    _require(explicit.shape[0] == pts.shape[0], "target_flux_values must have the same length as target_flux_points.")
+    _require(bool(np.all(np.isfinite(explicit))), "target_flux_values must contain finite values only.")
+    return explicit
 
 
 def optimize_coil_currents(kernel: Any, coils: CoilSet, target_flux, tikhonov_alpha: float = 1e-4) -> np.ndarray:
     """Bounded Tikhonov least squares for the coil currents (core/fusion_kernel_free_boundary.py:491-559).  The response
-    matrix comes from the device Green's-function kernel; the (n_pts + n_coils) x n_coils ``lsq_linear`` stays on the host."""
+    matrix comes from the device Green's-function kernel; the (n_pts + n_coils) x n_coils ``lsq_linear`` stays on the host.
+    A failed fit falls back to the prior currents clipped into the bounds, as the reference does."""
+    pts = _control_points(coils, "optimisation")
+    _require(len(coils.positions) > 0, "CoilSet.positions must contain at least one coil.")
+    _require(len(coils.currents) == len(coils.positions), "CoilSet.currents length must match number of coil positions.")
+    _require(bool(np.isfinite(tikhonov_alpha)) and tikhonov_alpha >= 0.0, "tikhonov_alpha must be finite and non-negative.")
+    _require(bool(np.all(np.isfinite(pts))), "target_flux_points must contain finite values only.")
+    wanted = np.asarray(target_flux, dtype=np.float64).reshape(-1)
+    _require(wanted.shape[0] == pts.shape[0], "target_flux must have the same length as target_flux_points.")
+    _require(bool(np.all(np.isfinite(wanted))), "target_flux must contain finite values only.")
+    mutual = build_mutual_inductance_matrix(kernel, coils, pts)  # (n_coils, n_pts), device Green's functions
+    _require(bool(np.all(np.isfinite(mutual))), "Mutual inductance matrix contains non-finite entries.")
+    A, b = _ridge_system(mutual.T, wanted, float(tikhonov_alpha), None)
+    lb, ub = _current_bounds(coils, mutual.shape[0], strictly_positive=False)
     from scipy.optimize import lsq_linear
 
-    if coils.target_flux_points is None:
-        raise ValueError("CoilSet.target_flux_points must be set for optimisation.")
-    if len(coils.positions) == 0:
-        raise ValueError("CoilSet.positions must contain at least one coil.")
-    if len(coils.currents) != len(coils.positions):
-        raise ValueError("CoilSet.currents length must match number of coil positions.")
-    if not np.isfinite(tikhonov_alpha) or tikhonov_alpha < 0.0:
-        raise ValueError("tikhonov_alpha must be finite and non-negative.")
-    obs = np.asarray(coils.target_flux_points, dtype=np.float64)
-    if obs.ndim != 2 or obs.shape[1] != 2 or obs.shape[0] == 0:
-        raise ValueError("target_flux_points must have shape (n_points, 2) with n_points > 0.")
-    target = np.asarray(target_flux, dtype=np.float64).reshape(-1)
-    if target.shape[0] != obs.shape[0]:
-        raise ValueError("target_flux must have the same length as target_flux_points.")
-    if not np.all(np.isfinite(target)):
-        raise ValueError("target_flux must contain finite values only.")
-    M = build_mutual_inductance_matrix(kernel, coils, obs)
-    if not np.all(np.isfinite(M)):
-        raise ValueError("Mutual inductance matrix contains non-finite entries.")
-    n_coils = M.shape[0]
-    A = np.vstack([M.T, np.sqrt(tikhonov_alpha) * np.eye(n_coils)])
-    rhs = np.concatenate([target, np.zeros(n_coils)])
-    if coils.current_limits is not None:
-        limits = np.asarray(coils.current_limits, dtype=np.float64).reshape(-1)
-        if limits.shape[0] != n_coils:
-            raise ValueError("current_limits must have one entry per coil.")
-        lb, ub = -np.abs(limits), np.abs(limits)
-    else:
-        lb, ub = -np.inf * np.ones(n_coils), np.inf * np.ones(n_coils)
-    result = lsq_linear(A, rhs, bounds=(lb, ub), method="trf")
-    if not bool(getattr(result, "success", False)) or not np.all(np.isfinite(result.x)):
-        return np.clip(np.asarray(coils.currents, dtype=np.float64).copy(), lb, ub)
-    return np.asarray(result.x, dtype=np.float64)
+    fit = lsq_linear(A, b, bounds=(lb, ub), method="trf")
+    if bool(getattr(fit, "success", False)) and np.all(np.isfinite(fit.x)):
+        return np.asarray(fit.x, dtype=np.float64)
+    return np.clip(np.asarray(coils.currents, dtype=np.float64), lb, ub).astype(np.float64)
+
+
+def _perimeter_indices(nz: int, nr: int) -> tuple[np.ndarray, np.ndarray]:
+    """(iz, ir) of every computational-boundary node once, walking bottom row -> right column -> top row backwards -> left column
+    backwards (the order of core/fusion_kernel_free_boundary.py:608-620 and :716-723)."""
+    iz = np.concatenate([np.zeros(nr, int), np.arange(1, nz), np.full(nr - 1, nz - 1), np.arange(nz - 2, 0, -1)])
+    ir = np.concatenate([np.arange(nr), np.full(nz - 1, nr - 1), np.arange(nr - 2, -1, -1), np.zeros(nz - 2, int)])
+    return iz, ir
 
 
 def _kernel_boundary_points(kernel: Any) -> np.ndarray:
-    """Unique computational-boundary points in (R, Z) order: bottom row, right column, top row reversed, left column reversed
-    (core/fusion_kernel_free_boundary.py:608-620)."""
+    """Unique computational-boundary points as (R, Z) rows in perimeter order."""
     r, z = np.asarray(kernel.R, dtype=np.float64), np.asarray(kernel.Z, dtype=np.float64)
-    if r.ndim != 1 or z.ndim != 1 or r.size < 2 or z.size < 2:
-        raise ValueError("kernel R/Z axes must be one-dimensional with at least two points.")
-    if not np.all(np.isfinite(r)) or not np.all(np.isfinite(z)):
-        raise ValueError("kernel R/Z axes must contain finite values only.")
-    bottom = np.column_stack([r, np.full(r.shape, z[0])])
-    right = np.column_stack([np.full(z[1:].shape, r[-1]), z[1:]])
-    top = np.column_stack([r[-2::-1], np.full(r[-2::-1].shape, z[-1])])
-    left = np.column_stack([np.full(z[-2:0:-1].shape, r[0]), z[-2:0:-1]])
-    return np.vstack([bottom, right, top, left]).astype(np.float64, copy=False)
+    _require(r.ndim == 1 and z.ndim == 1 and r.size >= 2 and z.size >= 2, "kernel R/Z axes must be one-dimensional with at least two points.")
+    _require(bool(np.all(np.isfinite(r)) and np.all(np.isfinite(z))), "kernel R/Z axes must contain finite values only.")
+    iz, ir = _perimeter_indices(z.size, r.size)
+    return np.column_stack([r[ir], z[iz]])
+
+
+def _shape_step(kernel: Any, coils: CoilSet, tikhonov_alpha: float) -> dict[str, Any]:
+    """One shape-control update inside the free-boundary outer loop (core/fusion_kernel_free_boundary.py:663-706): isoflux
+    target from the fresh psi, bounded least-squares currents (a ``kernel.optimize_coil_currents`` hook wins over the module
+    function), the achieved-flux report, and the new currents written into ``coils``."""
+    wanted = resolve_shape_target_flux(kernel, coils)
+    gain = build_mutual_inductance_matrix(kernel, coils, coils.target_flux_points).T  # (n_points, n_coils)
+    hook = getattr(kernel, "optimize_coil_currents", None)
+    fitted = hook(coils, wanted, tikhonov_alpha=tikhonov_alpha) if hook is not None else optimize_coil_currents(
+        kernel, coils, wanted, tikhonov_alpha=tikhonov_alpha)
+    fitted = np.asarray(fitted, dtype=np.float64).reshape(-1)
+    n_coils = len(coils.positions)
+    _require(fitted.shape == (n_coils,), "optimised coil current vector length must match coil count.")
+    _require(bool(np.all(np.isfinite(fitted))), "optimised coil currents must contain finite values only.")
+    got = gain @ fitted
+    miss = got - wanted
+    rmse = float(np.sqrt(np.mean(miss**2)))
+    at_bound = 0
+    if coils.current_limits is not None:
+        caps = _finite_array(coils.current_limits, "current_limits", length=n_coils)
+        at_bound = int(np.count_nonzero(np.isclose(np.abs(fitted), caps, rtol=0.0)))
+    coils.currents = fitted
+    return dict(solver_mode="free_boundary_solver_shape_current_optimization", target_point_count=int(wanted.shape[0]),
+                coil_count=int(n_coils), response_rank=int(np.linalg.matrix_rank(gain)), response_condition=float(np.linalg.cond(gain)),
+                flux_rmse=rmse, flux_relative_rmse=float(rmse / max(float(np.sqrt(np.mean(wanted**2))), 1.0)),
+                max_abs_flux_residual=float(np.max(np.abs(miss))), active_current_bounds=at_bound,
+                target_flux=wanted.copy(), achieved_flux=got.astype(np.float64, copy=False))
 
 
 def solve_free_boundary(kernel: Any, coils: CoilSet, max_outer_iter: int = 20, tol: float = 1e-4,
@@ -448,46 +473,21 @@ def solve_free_boundary(kernel: Any, coils: CoilSet, max_outer_iter: int = 20, t
         psi_ext = compute_external_flux(kernel, coils)
     else:
         psi_ext = compute_external_flux(kernel, coils)
-        diff, outer = float("inf"), 0
-        for outer in range(max_outer_iter):
-            kernel.Psi[0, :], kernel.Psi[-1, :] = psi_ext[0, :], psi_ext[-1, :]
-            kernel.Psi[:, 0], kernel.Psi[:, -1] = psi_ext[:, 0], psi_ext[:, -1]
-            psi_old = kernel.Psi.copy()
+        ring = _perimeter_indices(*np.shape(psi_ext))
+        reshape = optimize_shape and coils.target_flux_points is not None
+        diff, outer_iterations = float("inf"), 0
+        while outer_iterations < max_outer_iter:
+            outer_iterations += 1
+            kernel.Psi[ring] = psi_ext[ring]  # Dirichlet data of this pass
+            before = kernel.Psi.copy()
             kernel.solve_equilibrium(preserve_initial_state=True, boundary_flux=psi_ext)
-            if optimize_shape and coils.target_flux_points is not None:
-                target_psi = resolve_shape_target_flux(kernel, coils)
-                response = build_mutual_inductance_matrix(kernel, coils, coils.target_flux_points)
-                optimise = getattr(kernel, "optimize_coil_currents", None)  # kernel method first: keeps caller hooks working
-                new_currents = (optimise(coils, target_psi, tikhonov_alpha=tikhonov_alpha) if optimise is not None
-                                else optimize_coil_currents(kernel, coils, target_psi, tikhonov_alpha=tikhonov_alpha))
-                new_currents = np.asarray(new_currents, dtype=np.float64).reshape(-1)
-                if new_currents.shape != (len(coils.positions),):
-                    raise ValueError("optimised coil current vector length must match coil count.")
-                if not np.all(np.isfinite(new_currents)):
-                    raise ValueError("optimised coil currents must contain finite values only.")
-                achieved = response.T @ new_currents
-                residual = achieved - target_psi
-                flux_rmse = float(np.sqrt(np.mean(residual**2)))
-                active_bounds = 0
-                if coils.current_limits is not None:
-                    limits = _as_finite_vector(coils.current_limits, name="current_limits", length=len(coils.positions))
-                    active_bounds = int(np.count_nonzero(np.isclose(np.abs(new_currents), limits, rtol=0.0)))
-                shape_optimization = {
-                    "solver_mode": "free_boundary_solver_shape_current_optimization",
-                    "target_point_count": int(target_psi.shape[0]), "coil_count": int(len(coils.positions)),
-                    "response_rank": int(np.linalg.matrix_rank(response.T)), "response_condition": float(np.linalg.cond(response.T)),
-                    "flux_rmse": flux_rmse,
-                    "flux_relative_rmse": float(flux_rmse / max(float(np.sqrt(np.mean(target_psi**2))), 1.0)),
-                    "max_abs_flux_residual": float(np.max(np.abs(residual))), "active_current_bounds": active_bounds,
-                    "target_flux": target_psi.copy(), "achieved_flux": achieved.astype(np.float64, copy=False),
-                }
-                coils.currents = new_currents
+            if reshape:
+                shape_optimization = _shape_step(kernel, coils, tikhonov_alpha)
                 psi_ext = compute_external_flux(kernel, coils)
-            diff = float(np.max(np.abs(kernel.Psi - psi_old)))
+            diff = float(np.max(np.abs(kernel.Psi - before)))
             if diff < tol:
                 break
-        outer_iterations = outer + 1
-    boundary_target = np.concatenate([psi_ext[0, :], psi_ext[1:, -1], psi_ext[-1, -2::-1], psi_ext[-2:0:-1, 0]]).astype(np.float64)
+    boundary_target = np.asarray(psi_ext, dtype=np.float64)[_perimeter_indices(*np.shape(psi_ext))]
     boundary_reconstruction = reconstruct_boundary_flux_from_coils(
         kernel, coils, boundary_points=_kernel_boundary_points(kernel), limiter_points=limiter_points, axis_point=axis_point,
         x_points=x_points, target_flux=boundary_target)

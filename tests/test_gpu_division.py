@@ -54,16 +54,3 @@ def test_division_sequences_are_correctly_rounded():
     # the cases are hard: the uncorrected product x * RN(1/d) misses some of them
     assert np.count_nonzero(x * (1.0 / d) != ref) > 0
 
-
-def test_wave_shift_directions():
-    """The row-block smoother takes its E/W neighbours from lane-1 / lane+1 over DPP wave shifts: pin their direction and the
-    zero fill at the wave ends on this device."""
-    from scpn_fusion_core_amd import _lib
-    from scpn_fusion_core_amd._lib import check
-
-    L = _lib.require_gpu()
-    below, above = np.empty(64), np.empty(64)
-    check(L.scpn_verify_lane_shift(below, above))
-    lanes = np.arange(64, dtype=np.float64)
-    assert np.array_equal(below, lanes)  # lane i sees lane i-1 (value i), lane 0 sees 0
-    assert np.array_equal(above, np.where(lanes < 63, lanes + 2.0, 0.0))
