@@ -210,7 +210,8 @@ def main() -> int:
         es.profile(False)
         roofline = roofline_of(fam, args.grid, B / es.num_groups, es.num_groups)
         try:
-            roofline["measured_copy_gbs"] = round(_lib.copy_bandwidth_probe(), 1)
+            roofline["measured_copy_gbs"] = round(_lib.copy_bandwidth_probe(mode=0), 1)
+            roofline["measured_read_gbs"] = round(_lib.copy_bandwidth_probe(mode=1), 1)
             roofline["frac_of_measured_copy"] = round(roofline["achieved"] / roofline["measured_copy_gbs"], 4)
         except Exception as exc:  # the probe needs 2 GiB of free HBM; report, do not fail the bench line
             roofline["measured_copy_gbs"] = None
@@ -247,9 +248,58 @@ def main() -> int:
                          f"{dt0:.1f} s on its core; wall {dt:.1f} s) by oracle/gs_oracle.c",
                "single_core_value": round(1.0 / min(o[1] for o in outs), 5),
                "picard_iterations": ref["picard_iterations"]}
+        # second CPU lane: the NumPy restatement (oracle/numpy_lane.py, bit-exact vs the reference fixtures), one core,
+        # bounded sample of Picard iterations on the converged state of member 0, extrapolated with that member's iteration count
+        try:
+            from oracle import numpy_lane as npl
+
+            d = cfg["dimensions"]
+            r1 = np.linspace(d["R_min"], d["R_max"], args.grid)
+            z1 = np.linspace(d["Z_min"], d["Z_max"], args.grid)
+            rr, zz = np.meshgrid(r1, z1)
+            state, n_it = np.array(ref["psi"], dtype=np.float64), 8
+            tn = time.perf_counter()
+            for _ in range(n_it):
+                state, _diff = npl.picard_iteration(state, ref["psi"], rr, zz, float(r1[1] - r1[0]), float(z1[1] - z1[0]),
+                                                    i_target=float(targets[0]), mu0=cfg["physics"]["vacuum_permeability"],
+                                                    z_min_cfg=d["Z_min"], alpha=cfg["solver"]["relaxation_factor"],
+                                                    omega=cfg["solver"]["sor_omega"])
+            per_it = (time.perf_counter() - tn) / n_it
+            cpu["numpy_lane"] = {"seconds_per_picard_iteration": round(per_it, 5), "iterations_timed": n_it, "cores": 1,
+                                 "equilibria_per_s_equivalent": round(1.0 / (per_it * sum(ref["picard_iterations"])), 5),
+                                 "sample": f"{n_it} Picard iterations (axis/X-point, L-mode source, one V-cycle, blend) at {args.grid}x{args.grid} "
+                                           "by oracle/numpy_lane.py, extrapolated to member 0's iteration count"}
+        except Exception as exc:  # the baseline line must not be lost to the optional lane
+            cpu["numpy_lane"] = {"error": str(exc)}
         if psi0 is not None:  # the oracle's psi of member 0 against the device's (same inputs, full size)
             cpu["psi_rel_linf_vs_gpu"] = float(np.abs(psi0 - ref["psi"]).max() / np.abs(ref["psi"]).max())
             cpu["picard_iterations_gpu_member0"] = picard_gpu0
+
+    # ---- strict-parity gate (outside the timed region): the HIP free-boundary solve of the DIII-D-like case at 129^2 against the
+    #      reference's own NumPy-lane flux map (fixture generated from the imported reference, tests/golden/freegs.npz), with the
+    #      metrics and thresholds of validation/benchmark_freegs_public_example_reconstruction.py:491-497
+    parity = None
+    if rank == 0:
+        try:
+            from scpn_fusion_core_amd.parity_gate import strict_parity_metrics
+
+            g = np.load(ROOT / "tests" / "golden" / "freegs.npz")
+            gcfg = json.loads(str(g["_configs"]))["d3d129"]
+            with EnsembleSolver(gcfg, batch=2, device=local_rank) as ges:
+                ges.solve_free_boundary(max_outer_iter=20, tol=1e-4)
+                gpsi = ges.get_psi(0)
+            gd, gax = gcfg["dimensions"], g["d3d129_axis_x"]
+            m = strict_parity_metrics(gpsi, g["d3d129_psi"], np.linspace(gd["R_min"], gd["R_max"], 129),
+                                      np.linspace(gd["Z_min"], gd["Z_max"], 129), x_points=[(gax[2], gax[3])])
+            parity = {"case": "DIII-D-like free-boundary 129x129 (validation/diiid_config.json) vs the reference NumPy lane",
+                      "psi_rmse_wb": m["psi_rmse"], "psi_n_rmse": m["psi_n_rmse"], "axis_error_m": m["axis_error_m"],
+                      "boundary_max_abs_error_wb": m["boundary_max_abs_error_wb"], "xpoint_psi_n_error_max": m["xpoint_psi_n_error_max"],
+                      "thresholds": {"psi_n_rmse": 0.05, "axis_error_m": 0.025, "boundary_max_abs_error_wb": 1e-10, "xpoint_psi_n_error": 0.05},
+                      "pass": m["pass"],
+                      "freegs": "live FreeGS absent (unpinned); FreeGS 0.8.2 vacuum-psi samples held by the reference reproduced by the "
+                                "device Green's function to 2e-9 Wb (tests/test_gpu_freegs_gate.py)"}
+        except Exception as exc:  # the gate must not cost the bench line
+            parity = {"error": str(exc)}
 
     if rank == 0:
         line = {
@@ -268,6 +318,8 @@ def main() -> int:
             line["roofline"] = roofline
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if parity is not None:
+            line["parity"] = parity
         print(json.dumps(line))
     es.close()
     if dist is not None:

@@ -98,6 +98,7 @@ SIGNATURES = {
     "scpn_green_points": (_i, [_i, _dp, _dp, _i, _dp, _dp, _dp]),
     "scpn_verify_division": (_i, [_dp, _dp, _i, _dp, _dp]),
     "scpn_copy_bandwidth_probe": (_i, [C.c_long, _i, C.POINTER(_d)]),
+    "scpn_bandwidth_probe": (_i, [_i, C.c_long, _i, C.POINTER(_d)]),
     "scpn_np_delta_star": (_i, [_dp, _i, _i, _dp, _d, _d, _dp]),
     "scpn_np_equation_residual": (_i, [_dp, _i, _i, _dp, _dp, _d, _d, _d, _dp]),
     "scpn_tridiag_solve": (_i, [_i, _i, _vp, _dp, _vp, _dp, _dp, _vp]),
@@ -211,10 +212,11 @@ def device_info() -> str | None:
     return buf.value.decode()
 
 
-def copy_bandwidth_probe(nbytes: int = 1 << 30, reps: int = 10) -> float:
-    """GB/s (read + written) of a 16-B/lane device copy of ``nbytes`` (default 1 GiB: four times the Infinity Cache)."""
+def copy_bandwidth_probe(nbytes: int = 1 << 30, reps: int = 10, mode: int = 0) -> float:
+    """GB/s of a 16-B/lane device copy (mode 0: read + written bytes) or read-only sum (mode 1) of ``nbytes`` (default 1 GiB:
+    four times the Infinity Cache), best of three grid sizes."""
     out = _d(0.0)
-    check(require_gpu().scpn_copy_bandwidth_probe(nbytes, reps, C.byref(out)), "scpn_copy_bandwidth_probe")
+    check(require_gpu().scpn_bandwidth_probe(mode, nbytes, reps, C.byref(out)), "scpn_bandwidth_probe")
     return float(out.value)
 
 

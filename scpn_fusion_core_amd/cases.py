@@ -58,6 +58,6 @@ def scan_member_table(cfg: dict, total: int, seed: int = 2026) -> tuple[np.ndarr
 
 
 def member_cfg(cfg: dict, currents_row, target) -> dict:
-    """The config of one scan member (what the CPU oracle / the reference would be handed for it)."""
+    """The config of one scan member on its own (what a single-equilibrium solver would be handed for it)."""
     return {**cfg, "coils": [dict(co, current=float(currents_row[i])) for i, co in enumerate(cfg["coils"])],
             "physics": dict(cfg["physics"], plasma_current_target=float(target))}

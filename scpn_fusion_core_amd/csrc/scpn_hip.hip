@@ -2504,30 +2504,40 @@ int scpn_verify_division(const double* x, const double* d, int n, double* q5, do
     API_END
 }
 
-// device-copy bandwidth of this GPU (read + written bytes per second), HIP events around `reps` copies of `bytes`
-int scpn_copy_bandwidth_probe(long bytes, int reps, double* gb_per_s) {
-    if (!gb_per_s || bytes < (1L << 20) || reps < 1) return fail(SCPN_E_ARG, "scpn_copy_bandwidth_probe: bytes >= 1 MiB, reps >= 1");
+// device bandwidth of this GPU, HIP events around `reps` launches on `bytes` of HBM: mode 0 = copy (read + written bytes per
+// second, best of three grid sizes), mode 1 = read-only sum
+int scpn_copy_bandwidth_probe(long bytes, int reps, double* gb_per_s) { return scpn_bandwidth_probe(0, bytes, reps, gb_per_s); }
+int scpn_bandwidth_probe(int mode, long bytes, int reps, double* gb_per_s) {
+    if (!gb_per_s || bytes < (1L << 20) || reps < 1 || mode < 0 || mode > 1) return fail(SCPN_E_ARG, "scpn_bandwidth_probe: mode 0|1, bytes >= 1 MiB, reps >= 1");
     API_BEGIN
     HIP_TRY(hipSetDevice(g_device));
     const long n16 = bytes / 16;
     DBuf<double2> a, b;
     a.alloc((size_t)n16);
-    b.alloc((size_t)n16);
+    if (mode == 0) b.alloc((size_t)n16); else b.alloc(16);
     HIP_TRY(hipMemset(a.p, 1, (size_t)n16 * 16));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    const dim3 g(256 * 32);
-    SCPN_LAUNCH(k_copy_probe, g, dim3(256), 0, nullptr, b.p, (const double2*)a.p, n16);  // warm-up
-    HIP_TRY(hipEventRecord(e0, nullptr));
-    for (int r = 0; r < reps; ++r) SCPN_LAUNCH(k_copy_probe, g, dim3(256), 0, nullptr, b.p, (const double2*)a.p, n16);
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    double best = 0.0;
+    for (int wg_per_cu : {8, 16, 32}) {
+        const dim3 g(256 * wg_per_cu);
+        auto launch = [&] {
+            if (mode == 0) SCPN_LAUNCH(k_copy_probe, g, dim3(256), 0, nullptr, b.p, (const double2*)a.p, n16);
+            else SCPN_LAUNCH(k_read_probe, g, dim3(256), 0, nullptr, reinterpret_cast<double*>(b.p), (const double2*)a.p, n16);
+        };
+        launch();  // warm-up
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        for (int r = 0; r < reps; ++r) launch();
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        best = std::max(best, (mode == 0 ? 2.0 : 1.0) * (double)n16 * 16.0 * reps / ((double)ms * 1e-3) / 1e9);
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    *gb_per_s = 2.0 * (double)n16 * 16.0 * reps / ((double)ms * 1e-3) / 1e9;
+    *gb_per_s = best;
     API_END
 }
 

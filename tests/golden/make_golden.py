@@ -706,8 +706,50 @@ def gen_newton():
     save("newton.npz", **out)
 
 
+# ── FreeGS pin + strict-parity gate fixtures ───────────────────────────────────────────────────────────────────
+# validation/benchmark_freegs_public_example_reconstruction.py:248-270,491-523 and the tracked artifact
+# validation/reference_data/full_fidelity_public_artifacts/freegs_public_example_reconstruction_attempt.json
+def gen_freegs():
+    """(1) The FreeGS 0.8.2 vacuum-psi samples the reference holds (9 points x 2 machines, data only) with the sample points of
+    ``_sample_points`` (:248-259), the coil records and the acceptance thresholds stored beside them.  (2) The gate thresholds
+    of ``_native_same_case_profile_source_comparison`` (:491-497).  (3) psi of the reference's own NumPy lane
+    (``FusionKernel.solve_free_boundary``) for the DIII-D-like config (validation/diiid_config.json) at 65^2 and 129^2: what the
+    HIP free-boundary solve is gated against (tests/test_gpu_freegs_gate.py, bench.py ``psi_rmse``)."""
+    art = json.loads((REF / "validation" / "reference_data" / "full_fidelity_public_artifacts"
+                      / "freegs_public_example_reconstruction_attempt.json").read_text())
+    out = {"freegs_version": np.array(art["freegs_version"])}
+    for case in art["cases"]:
+        cid, dom, vac = case["case_id"], case["domain"], case["vacuum_green_function_comparison"]
+        quarter = lambda lo, hi: np.linspace(lo + 0.25 * (hi - lo), hi - 0.25 * (hi - lo), 3)  # noqa: E731
+        pts = np.asarray([(float(r), float(z)) for z in quarter(dom["z_min"], dom["z_max"]) for r in quarter(dom["r_min"], dom["r_max"])])
+        out[f"{cid}_points"] = pts
+        out[f"{cid}_freegs_vacuum_psi"] = np.asarray(vac["freegs_vacuum_psi_sample"], dtype=float)
+        out[f"{cid}_native_vacuum_psi"] = np.asarray(vac["native_vacuum_psi_sample"], dtype=float)
+        out[f"{cid}_thresholds"] = np.array([vac["thresholds"]["max_abs_error_wb"], vac["thresholds"]["nrmse"]])
+        out[f"{cid}_coils"] = np.array(json.dumps(vac["coils"]))
+        out[f"{cid}_source_contract"] = np.array(json.dumps(case["source_contract"]))
+        gate = case["nonlinear_solve_attempt"]["native_same_case_profile_source_comparison"]["thresholds"]
+        out["gate_thresholds"] = np.array(json.dumps(gate))
+    cfgs = {}
+    for n in (65, 129):
+        cfg = d3d_cfg(n)
+        k = make_kernel(cfg)
+        coils = CoilSet(positions=[(c["r"], c["z"]) for c in cfg["coils"]],
+                        currents=np.array([c["current"] for c in cfg["coils"]], dtype=float), turns=[1] * len(cfg["coils"]))
+        r = k.solve_free_boundary(coils, max_outer_iter=20, tol=1e-4, optimize_shape=False)
+        (xr, xz), psi_x = k.find_x_point(k.Psi)
+        iz, ir = np.unravel_index(int(np.argmax(k.Psi)), k.Psi.shape)
+        cfgs[f"d3d{n}"] = cfg
+        out[f"d3d{n}_psi"] = k.Psi
+        out[f"d3d{n}_axis_x"] = np.array([k.R[ir], k.Z[iz], xr, xz, psi_x])
+        out[f"d3d{n}_stats"] = np.array([r["outer_iterations"], r["final_diff"]])
+        print("native lane", n, r["outer_iterations"], r["final_diff"], (k.R[ir], k.Z[iz]), (xr, xz))
+    out["_configs"] = np.array(json.dumps(cfgs))
+    save("freegs.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["smooth", "operators", "mgsolve", "polyglot", "picard", "pieces", "green",
-                             "free_boundary", "fastsolver", "anderson", "shape", "eqdsk", "newton", "products", "transport", "saddle"]
+                             "free_boundary", "fastsolver", "anderson", "shape", "eqdsk", "newton", "products", "transport", "saddle", "freegs"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -153,6 +153,38 @@ def test_gs_transport_outer_step(hip, orc):
         assert resid[b] == pytest.approx(np.linalg.norm(ref["psi"] - psi0[b]) / np.linalg.norm(psi0[b]), rel=1e-6)
 
 
+def test_config4_coupled_step_513(hip, orc):
+    """BASELINE config 4 at full size: one coupled transport step (map_profiles_to_2d -> external-profile re-solve -> relative
+    flux change -> current-diffusion step) on the 513x513 ITER-like grid for 2 members, against the same sequence on the CPU
+    oracle (core/integrated_transport_solver_coupling.py:114-146; ~10 s of oracle time)."""
+    from scpn_fusion_core_amd import transport_coupling as tc
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    n = 513
+    cfg = iter_like_cfg(n, tol=1e-8, max_iter=1000)
+    rho = np.linspace(0, 1, 64)
+    p1 = np.stack([5.0 * (1 - rho**2) ** 1.5, 5.05 * (1 - rho**2) ** 1.5])  # the benchmark's stub profile and its 1 % drift
+    jb = np.stack([1e-3 * rho * (1 - rho), 1.01e-3 * rho * (1 - rho)])
+    te = np.stack([8.0 * (1 - 0.9 * rho**2), 8.1 * (1 - 0.9 * rho**2)])
+    ne, jcd = 5.0 * (1 - 0.5 * rho**2), np.zeros_like(rho)
+    with EnsembleSolver(cfg, batch=2) as es:
+        es.solve_equilibrium()
+        psi0 = es.get_psi()
+        resid, res = tc.gs_transport_outer_step(es, rho, p1, jb)
+        psi1 = es.get_psi()
+    cd = tc.CurrentDiffusionSolver(rho, R0=6.2, a=2.0, B0=5.3, batch=2)
+    cd_psi0 = cd.psi.copy()
+    psi_cd = cd.step(0.5, te, ne, 1.7, jb, jcd)
+    ref = orc.picard_solve(cfg, external_profile_mode=True)  # the reference's seed overrides the mapped J (SURVEY 9.15)
+    assert ref["converged"]
+    for b in range(2):
+        assert res[b]["iterations"] == ref["iterations"] and res[b]["converged"] == ref["converged"], b
+        assert np.abs(psi1[b] - ref["psi"]).max() <= 1e-10 * np.abs(ref["psi"]).max(), b
+        assert resid[b] == pytest.approx(np.linalg.norm(ref["psi"] - psi0[b]) / np.linalg.norm(psi0[b]), rel=1e-6)
+        p_ref, _info = orc.current_diffusion_step(rho, cd_psi0[b], 6.2, 2.0, 5.3, 0.5, te[b], ne, 1.7, jb[b], jcd)
+        assert np.abs(psi_cd[b] - p_ref).max() <= 1e-13 * np.abs(p_ref).max(), b
+
+
 def test_flux_evolution_nonadiabatic_golden(hip, golden, orc):
     """solve_flux_evolution_nonadiabatic (core/current_diffusion.py:55-172) with the reference benchmark's drive functions
     (benchmarks/bench_current_diffusion_nonadiabatic.py:43-72), an undamped case (tau = inf) and a rho-dependent tau.  One exp per

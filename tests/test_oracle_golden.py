@@ -369,3 +369,93 @@ def test_flux_evolution_nonadiabatic_oracle(golden):
         else:
             assert np.abs(psi - g[f"fx_{tag}_psi"]).max() <= 1e-14 * np.abs(psi).max()
         assert np.array_equal(resid, g[f"fx_{tag}_resid"])
+
+
+# ---- the NumPy lane (oracle/numpy_lane.py, the second CPU baseline of bench.py) against the same reference fixtures
+def test_numpy_lane_smoother_bit_exact(golden):
+    from oracle import numpy_lane as npl
+
+    g = golden("smooth.npz")
+    for nz, nr, omega, sweeps in g["cases"]:
+        nz, nr, sweeps = int(nz), int(nr), int(sweeps)
+        psi0, source, rr, r, z = bench_problem(nz, nr)
+        out = npl.rb_sor_sweeps(psi0.copy(), source, rr, 4.0 / (nr - 1), 8.0 / (nz - 1), float(omega), sweeps)
+        assert np.array_equal(out, g[f"out_{nz}x{nr}_w{omega}_s{sweeps}"]), (nz, nr, omega, sweeps)
+    with pytest.raises(ValueError):
+        npl.rb_sor_sweeps(psi0.copy(), source, rr, 0.5, 1.0, 2.0, 1)
+
+
+def test_numpy_lane_operators_bit_exact(golden):
+    from oracle import numpy_lane as npl
+
+    g = golden("operators.npz")
+    for nz, nr in g["shapes"]:
+        nz, nr = int(nz), int(nr)
+        tag = f"{nz}x{nr}"
+        psi, source, rr, dr, dz = operator_problem(nz, nr)
+        assert np.array_equal(npl.gs_residual(psi, source, rr, dr, dz), g[f"res_{tag}"]), tag
+        c = npl.restrict_fw(g[f"fine_{tag}"])
+        assert np.array_equal(c, g[f"restrict_{tag}"]), tag
+        assert np.array_equal(npl.restrict_fw(rr), g[f"restrict_r_{tag}"]), tag
+        assert np.array_equal(npl.prolong_bilinear(c, nz, nr), g[f"prolong_{tag}"]), tag
+        if min(nz, nr) >= 5:
+            for omega in (1.0, 1.6):
+                assert np.array_equal(npl.vcycle(psi, source, rr, dr, dz, omega=omega), g[f"vcycle_{tag}_w{omega}"]), (tag, omega)
+
+
+def test_numpy_lane_picard_iteration_matches_the_c_oracle():
+    """One L-mode multigrid Picard iteration of the NumPy lane against the C restatement (same seeded ITER-like state)."""
+    from oracle import numpy_lane as npl
+    from tests._problems import iter_like_cfg
+
+    cfg = iter_like_cfg(65, tol=1e-30, max_iter=6)
+    ref6 = orc.picard_solve(cfg)
+    cfg5 = iter_like_cfg(65, tol=1e-30, max_iter=5)
+    ref5 = orc.picard_solve(cfg5)
+    d = cfg["dimensions"]
+    r, z = np.linspace(d["R_min"], d["R_max"], 65), np.linspace(d["Z_min"], d["Z_max"], 65)
+    rr, zz = np.meshgrid(r, z)
+    bc = ref5["psi"].copy()
+    nxt, diff = npl.picard_iteration(ref5["psi"], bc, rr, zz, float(r[1] - r[0]), float(z[1] - z[0]),
+                                     i_target=cfg["physics"]["plasma_current_target"], mu0=cfg["physics"]["vacuum_permeability"],
+                                     z_min_cfg=d["Z_min"], alpha=cfg["solver"]["relaxation_factor"], omega=cfg["solver"]["sor_omega"])
+    assert np.abs(nxt - ref6["psi"]).max() <= 1e-12 * np.abs(ref6["psi"]).max()
+
+
+# ---- FreeGS pin (tests/golden/freegs.npz: the FreeGS 0.8.2 vacuum-psi samples the reference holds) and the gate metrics
+def test_green_function_against_freegs_vacuum_samples(golden):
+    import json
+
+    from tests._freegs_machines import tokamak_filaments
+
+    g = golden("freegs.npz")
+    assert str(g["freegs_version"]) == "0.8.2"
+    cid = "freegs_01_test_tokamak_freeboundary"
+    coils = {c["name"]: c["effective_current_a_turns"] for c in json.loads(str(g[f"{cid}_coils"]))}
+    fil = tokamak_filaments(coils)
+    assert fil.shape == (26, 3)  # the artifact's filament_count
+    psi = np.array([sum(i * orc.green_function(rc, zc, r, z) for rc, zc, i in fil) for r, z in g[f"{cid}_points"]])
+    want = g[f"{cid}_freegs_vacuum_psi"]
+    assert np.abs(psi - want).max() <= 2e-9  # restated FreeGS quadrature, see tests/_freegs_machines.py
+    for case in (cid, "freegs_16_diiid_public_example"):  # the reference's own acceptance, on the data it stores
+        assert np.abs(g[f"{case}_native_vacuum_psi"] - g[f"{case}_freegs_vacuum_psi"]).max() <= float(g[f"{case}_thresholds"][0])
+
+
+def test_parity_gate_metrics_host_logic(golden):
+    from scpn_fusion_core_amd.parity_gate import strict_parity_metrics
+
+    g = golden("freegs.npz")
+    psi = g["d3d65_psi"]
+    r, z = np.linspace(0.8, 2.6, 65), np.linspace(-1.8, 1.8, 65)
+    same = strict_parity_metrics(psi, psi, r, z, x_points=[(0.8, -1.8)])
+    assert same["pass"] and same["psi_n_rmse"] == 0.0 and same["axis_error_m"] == 0.0
+    ax = g["d3d65_axis_x"]
+    assert (same["psi_rmse"], ax[0], ax[1]) == (0.0, 1.925, 0.0)
+    off = psi.copy()
+    off[0, :] += 1e-9  # a boundary error above 1e-10 Wb must fail the gate
+    assert not strict_parity_metrics(off, psi, r, z)["pass"]
+    shifted = np.roll(psi, 3, axis=1)  # axis moved by 3 cells = 8.4 cm > 2.5 cm
+    bad = strict_parity_metrics(shifted, psi, r, z)
+    assert not bad["checks"]["axis_error_m"] and bad["axis_error_m"] == pytest.approx(3 * (r[1] - r[0]))
+    with pytest.raises(ValueError):
+        strict_parity_metrics(psi[:-1], psi, r, z)
