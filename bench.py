@@ -12,7 +12,8 @@ x ~240 Picard iterations of one V-cycle each, all on the device).  Inputs (coil 
 resident in HBM before the timed region; results stay in HBM (the RCCL gather for N>1 is inside).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (torchrun is only the process launcher:
+    bench.py and the package import no torch; ranks meet over TCP and gather over RCCL through the C ABI)
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timed on the
 solver's own stream) and "cpu_baseline" (the CPU oracle on the host cores, rank 0, N=1 only).
@@ -119,13 +120,11 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
+    comm = None
     if world > 1 or os.environ.get("SCPN_BENCH_FORCE_DIST") == "1":  # (the override exercises the RCCL path on one rank)
-        import torch
-        import torch.distributed as dist  # rendezvous + RCCL gather only; the solver itself is torch-free
+        from scpn_fusion_core_amd.distributed import EnsembleComm
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        comm = EnsembleComm.from_env()  # TCP rendezvous of the RCCL id, then ncclCommInitRank on this rank's GPU
 
     from scpn_fusion_core_amd import _lib
     from scpn_fusion_core_amd.cases import member_cfg, scan_member_table
@@ -134,7 +133,7 @@ def main() -> int:
     _lib.require_gpu()
     cfg = make_cfg(args.grid)
     B = args.batch
-    from scpn_fusion_core_amd.distributed import DevicePointer, gather_blocks_async, shard_range
+    from scpn_fusion_core_amd.distributed import shard_range
 
     lo, hi = shard_range(B * world, rank, world)
     all_currents, all_targets = scan_member_table(cfg, B * world)
@@ -142,34 +141,18 @@ def main() -> int:
     es = EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, device=local_rank)
     n_pts = args.grid * args.grid
 
-    pending = {"work": None, "out": None}  # the psi gather of the previous step, overlapping the current solve
-
-    def finish_gather():
-        if pending["work"] is not None:
-            import torch
-
-            pending["work"].wait()
-            torch.cuda.current_stream().synchronize()
-            pending["work"] = None
-
     def barrier():
         es.sync()
-        if dist is not None:
-            import torch
-
-            finish_gather()
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm is not None:
+            comm.wait()     # the gather of the last step
+            comm.barrier()  # RCCL all-reduce on the communicator's stream, waited for
 
     def step():
         es.fill_psi(0.0)
         res = es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
-        if dist is not None:  # ensemble gather of the psi blocks over RCCL/xGMI (the path's only exchange step): launched
-            import torch      # asynchronously, it runs while the next step solves; every gather ends inside the timed region
-
-            finish_gather()  # the previous gather still reads the packed buffer
-            send = torch.as_tensor(DevicePointer(es.pack_psi_device(), (B, args.grid, args.grid)), device=f"cuda:{local_rank}")
-            pending["work"], pending["out"] = gather_blocks_async(send, B * world, out=pending["out"])
+        if comm is not None:  # ensemble gather of the psi blocks over RCCL/xGMI (the path's only exchange step): launched
+            comm.wait()       # asynchronously, it runs while the next step solves; every gather ends inside the timed region
+            comm.allgather_psi(es)
         return res
 
     for _ in range(args.warmup):
@@ -180,12 +163,8 @@ def main() -> int:
         res = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        elapsed = comm.allreduce_max(elapsed)
 
     # member 0 of the last timed solve, kept for the full-size parity figure reported with the CPU baseline
     psi_gpu0 = es.get_psi(0) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
@@ -310,7 +289,7 @@ def main() -> int:
             "config": {"workload": f"ensemble of {B} ITER-like free-boundary equilibria per GPU, {args.grid}x{args.grid}, "
                                    "PF-coil Green's-function boundary, Picard+V-cycle tol 1e-8 (BASELINE configs[2]/[4])",
                        "grid": args.grid, "members_per_gpu": B, "global_members": B * world,
-                       "parallelism": f"ensemble-sharded x{world}",
+                       "parallelism": f"ensemble-sharded x{world}", "rccl": comm.info() if comm is not None else None,
                        "converged_members_rank0": n_conv, "outer_iterations": [min(outer), max(outer)],
                        "picard_iterations_per_member": [min(picard_total), max(picard_total)]},
         }
@@ -322,8 +301,8 @@ def main() -> int:
             line["parity"] = parity
         print(json.dumps(line))
     es.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.close()
     return 0
 
 

@@ -304,6 +304,27 @@ int scpn_gs_sync(scpn_gs *h);
  * group overlap bandwidth-bound fine-level kernels of another */
 int scpn_gs_num_groups(scpn_gs *h);
 
+/* ------------------------------------------------------------------------------------------
+ * 4. Ensemble gather over RCCL / xGMI (one process per GPU).  The path shards across members, so the only
+ *    collective is the all-gather of the dense psi blocks; librccl is dlopen'ed at the first call.  Rendezvous: rank 0 calls
+ *    scpn_comm_unique_id and the host passes the 128 bytes to the other ranks (scpn_fusion_core_amd/distributed.py: TCP on
+ *    MASTER_ADDR:MASTER_PORT), every rank then calls scpn_comm_init.  The reference has no counterpart to replace (its only
+ *    multi-device code is the domain-decomposition prototype scpn-fusion-rs/crates/fusion-core/src/mpi_domain.rs:741-770).
+ * ---------------------------------------------------------------------------------------- */
+#define SCPN_COMM_ID_BYTES 128
+int scpn_comm_unique_id(char *id128);
+int scpn_comm_init(int rank, int world, const char *id128, int device); /* selects `device` for this process */
+int scpn_comm_info(int *rank, int *world, int *rccl_version);           /* as RCCL sees them */
+/* pack + ncclAllGather of psi: recv_device = [world][batch][nz][nr] doubles on this GPU; asynchronous on the communicator's
+ * stream (overlaps the next solve) -- scpn_comm_wait() before the buffer is read or the next gather is issued */
+int scpn_comm_allgather_psi(scpn_gs *h, void *recv_device);
+int scpn_comm_wait(void);
+int scpn_comm_allreduce_max(double *value); /* in place, blocking: the max-over-ranks of a timing and the barrier */
+int scpn_comm_finalize(void);
+int scpn_device_alloc(long bytes, void **ptr);
+int scpn_device_free(void *ptr);
+int scpn_device_download(void *host, const void *device_ptr, long bytes);
+
 #ifdef __cplusplus
 }
 #endif

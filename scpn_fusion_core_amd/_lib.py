@@ -17,7 +17,7 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libscpn_hip.so"
 CSRC = PKG_DIR / "csrc"
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++20"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++20", "-ldl"]
 
 SCPN_OK, SCPN_E_ARG, SCPN_E_DEVICE, SCPN_E_DIVERGED = 0, -1, -2, -3
 
@@ -136,6 +136,17 @@ SIGNATURES = {
     "scpn_gs_profile_names": (_i, [_vp, C.c_char_p, _i]),
     "scpn_gs_sync": (_i, [_vp]),
     "scpn_gs_num_groups": (_i, [_vp]),
+    # ensemble gather over RCCL
+    "scpn_comm_unique_id": (_i, [C.c_char_p]),
+    "scpn_comm_init": (_i, [_i, _i, C.c_char_p, _i]),
+    "scpn_comm_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "scpn_comm_allgather_psi": (_i, [_vp, _vp]),
+    "scpn_comm_wait": (_i, []),
+    "scpn_comm_allreduce_max": (_i, [C.POINTER(_d)]),
+    "scpn_comm_finalize": (_i, []),
+    "scpn_device_alloc": (_i, [C.c_long, C.POINTER(_vp)]),
+    "scpn_device_free": (_i, [_vp]),
+    "scpn_device_download": (_i, [_vp, _vp, C.c_long]),
 }
 
 

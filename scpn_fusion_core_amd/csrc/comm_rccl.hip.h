@@ -1,0 +1,64 @@
+// comm_rccl.hip.h -- the ensemble gather over RCCL / xGMI behind the C ABI (no PyTorch anywhere on the path).
+//
+// The hot path shards across ensemble members (one process per GPU, no data-path collective); the only exchange step is the
+// all-gather of the dense psi blocks at the end of a solve (the reference's only multi-device prototype is the
+// additive-Schwarz sketch scpn-fusion-rs/crates/fusion-core/src/mpi_domain.rs:741-770, which this deliberately does not copy).
+// librccl is loaded with dlopen at the first scpn_comm_* call, so single-GPU users never need it.  Rendezvous: rank 0 creates
+// the 128-byte ncclUniqueId (scpn_comm_unique_id) and the host side passes it to the other ranks over a TCP socket on
+// MASTER_ADDR:MASTER_PORT (scpn_fusion_core_amd/distributed.py) -- before any rank touches its GPU.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and enums only: every entry point is resolved through dlsym
+
+namespace comm {
+
+struct Api {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+struct State {
+    Api api;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    int rank = -1, world = 0, device = 0;
+    double* d_scalar = nullptr;  // one device double for the scalar all-reduce / barrier
+};
+inline State& state() {
+    static State s;
+    return s;
+}
+
+inline const char* load(Api& a) {  // nullptr on success, else what is missing
+    if (a.lib) return nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (a.lib) break;
+    }
+    if (!a.lib) return "librccl.so not found (dlopen)";
+#define SCPN_RCCL_SYM(field, sym)                                   \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, sym)); \
+    if (!a.field) return "librccl.so lacks " sym;
+    SCPN_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+    SCPN_RCCL_SYM(CommInitRank, "ncclCommInitRank")
+    SCPN_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    SCPN_RCCL_SYM(CommCount, "ncclCommCount")
+    SCPN_RCCL_SYM(CommUserRank, "ncclCommUserRank")
+    SCPN_RCCL_SYM(GetVersion, "ncclGetVersion")
+    SCPN_RCCL_SYM(AllGather, "ncclAllGather")
+    SCPN_RCCL_SYM(AllReduce, "ncclAllReduce")
+    SCPN_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef SCPN_RCCL_SYM
+    return nullptr;
+}
+
+}  // namespace comm

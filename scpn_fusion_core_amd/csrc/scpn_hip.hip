@@ -22,6 +22,7 @@
 #include "../../include/scpn_hip.h"
 #include "gs_kernels.hip.h"
 #include "newton_kernels.hip.h"
+#include "comm_rccl.hip.h"
 
 using namespace gs;
 
@@ -2035,6 +2036,115 @@ int scpn_gs_pack_psi_device(scpn_gs* g, void** device_ptr) {
     *device_ptr = g->dense.p;
     return SCPN_OK;
 }
+// ------------------------------------------------------------------------------------------ ensemble gather over RCCL
+#define RCCL_TRY(expr)                                                                                              \
+    do {                                                                                                            \
+        ncclResult_t r__ = (expr);                                                                                  \
+        if (r__ != ncclSuccess)                                                                                     \
+            throw std::runtime_error(std::string(#expr) + ": " + (comm::state().api.GetErrorString ? comm::state().api.GetErrorString(r__) : "rccl error")); \
+    } while (0)
+
+int scpn_comm_unique_id(char* id128) {
+    if (!id128) return fail(SCPN_E_ARG, "scpn_comm_unique_id: null buffer");
+    API_BEGIN
+    comm::State& c = comm::state();
+    if (const char* miss = comm::load(c.api)) throw std::runtime_error(miss);
+    ncclUniqueId id;
+    static_assert(sizeof(id) == SCPN_COMM_ID_BYTES, "ncclUniqueId size");
+    RCCL_TRY(c.api.GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    API_END
+}
+int scpn_comm_init(int rank, int world, const char* id128, int device) {
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(SCPN_E_ARG, "scpn_comm_init: need 0 <= rank < world and an id");
+    API_BEGIN
+    comm::State& c = comm::state();
+    if (c.comm) throw std::runtime_error("scpn_comm_init: communicator already initialised");
+    if (const char* miss = comm::load(c.api)) throw std::runtime_error(miss);
+    HIP_TRY(hipSetDevice(device));
+    g_device = device;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    RCCL_TRY(c.api.CommInitRank(&c.comm, world, id, rank));
+    HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&c.d_scalar, 2 * sizeof(double)));
+    c.rank = rank; c.world = world; c.device = device;
+    API_END
+}
+int scpn_comm_info(int* rank, int* world, int* rccl_version) {
+    API_BEGIN
+    comm::State& c = comm::state();
+    if (!c.comm) throw std::runtime_error("communicator not initialised");
+    int r = -1, w = 0, v = 0;
+    RCCL_TRY(c.api.CommUserRank(c.comm, &r));
+    RCCL_TRY(c.api.CommCount(c.comm, &w));
+    RCCL_TRY(c.api.GetVersion(&v));
+    if (rank) *rank = r;
+    if (world) *world = w;
+    if (rccl_version) *rccl_version = v;
+    API_END
+}
+// pack the local members' psi densely and all-gather the blocks of all ranks into recv_device ([world][batch][nz][nr] doubles);
+// the collective runs on the communicator's own stream and is NOT waited for: it overlaps the next solve (scpn_comm_wait)
+int scpn_comm_allgather_psi(scpn_gs* g, void* recv_device) {
+    if (!g || !recv_device) return fail(SCPN_E_ARG, "scpn_comm_allgather_psi: null handle / buffer");
+    void* send = nullptr;
+    int rc = scpn_gs_pack_psi_device(g, &send);  // (synchronises the solver streams: psi is final)
+    if (rc) return rc;
+    API_BEGIN
+    comm::State& c = comm::state();
+    if (!c.comm) throw std::runtime_error("communicator not initialised");
+    RCCL_TRY(c.api.AllGather(send, recv_device, (size_t)g->B * g->nz * g->nr, ncclDouble, c.comm, c.stream));
+    API_END
+}
+int scpn_comm_wait(void) {
+    API_BEGIN
+    comm::State& c = comm::state();
+    if (c.stream) HIP_TRY(hipStreamSynchronize(c.stream));
+    API_END
+}
+// in-place all-reduce (max) of one host double over the ranks; doubles as the barrier of the timed region
+int scpn_comm_allreduce_max(double* value) {
+    if (!value) return fail(SCPN_E_ARG, "scpn_comm_allreduce_max: null value");
+    API_BEGIN
+    comm::State& c = comm::state();
+    if (!c.comm) throw std::runtime_error("communicator not initialised");
+    HIP_TRY(hipMemcpyAsync(c.d_scalar, value, sizeof(double), hipMemcpyHostToDevice, c.stream));
+    RCCL_TRY(c.api.AllReduce(c.d_scalar, c.d_scalar + 1, 1, ncclDouble, ncclMax, c.comm, c.stream));
+    HIP_TRY(hipMemcpyAsync(value, c.d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    API_END
+}
+int scpn_comm_finalize(void) {
+    API_BEGIN
+    comm::State& c = comm::state();
+    if (c.stream) { (void)hipStreamSynchronize(c.stream); }
+    if (c.comm) { (void)c.api.CommDestroy(c.comm); c.comm = nullptr; }
+    if (c.d_scalar) { (void)hipFree(c.d_scalar); c.d_scalar = nullptr; }
+    if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
+    c.rank = -1; c.world = 0;
+    API_END
+}
+// plain device buffers for the gathered ensemble (the caller owns them)
+int scpn_device_alloc(long bytes, void** ptr) {
+    if (!ptr || bytes < 0) return fail(SCPN_E_ARG, "scpn_device_alloc: bad arguments");
+    API_BEGIN
+    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipMalloc(ptr, (size_t)std::max<long>(bytes, 1)));
+    API_END
+}
+int scpn_device_free(void* ptr) {
+    API_BEGIN
+    if (ptr) HIP_TRY(hipFree(ptr));
+    API_END
+}
+int scpn_device_download(void* host, const void* device_ptr, long bytes) {
+    if (!host || !device_ptr || bytes < 0) return fail(SCPN_E_ARG, "scpn_device_download: bad arguments");
+    API_BEGIN
+    HIP_TRY(hipMemcpy(host, device_ptr, (size_t)bytes, hipMemcpyDeviceToHost));
+    API_END
+}
+
 int scpn_gs_sync(scpn_gs* g) {
     if (!g) return fail(SCPN_E_ARG, "null handle");
     return each_group(g, [&](int, Solver* k) { return S_sync(k); });

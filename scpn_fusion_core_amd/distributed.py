@@ -1,15 +1,28 @@
-"""Ensemble sharding across the GPUs of one node: one process per GPU, no data-path collective.
+"""Ensemble sharding across the GPUs of one node: one process per GPU, no data-path collective, no PyTorch.
 
-The equilibria of an ensemble (coil / shape scan, shot replay) are independent units, so the path shards across
-members: rank r owns a contiguous block of ``ceil(total / world)`` members, solves it with its resident
-:class:`~scpn_fusion_core_amd.ensemble.EnsembleSolver` and the only exchange step is the final gather of the psi
-blocks and the per-member scalar table (``torch.distributed`` all_gather: RCCL over xGMI with backend "nccl", gloo
-in the CPU tests).  torch is imported lazily -- it is plumbing for the rendezvous / collective only.
+The equilibria of an ensemble (coil / shape scan, shot replay) are independent units, so the path shards across members:
+rank r owns a contiguous block of ``ceil(total / world)`` members, solves it with its resident
+:class:`~scpn_fusion_core_amd.ensemble.EnsembleSolver`, and the only exchange step is the final all-gather of the dense psi
+blocks -- RCCL over xGMI, bound through the C ABI (``scpn_comm_*`` in include/scpn_hip.h, librccl dlopen'ed by the library).
+
+Rendezvous (before any rank touches its GPU): rank 0 creates the 128-byte RCCL unique id and serves it on a TCP socket at
+``MASTER_ADDR:port``; the other ranks connect and read it.  ``port`` is ``MASTER_PORT``, or ``MASTER_PORT + 1`` under
+``torchrun`` / ``python -m torch.distributed.run`` (which is only the process launcher here: its agent keeps its own store on
+``MASTER_PORT``); ``SCPN_RDZV_PORT`` overrides.  The small per-member result table (converged, iterations, residual, axis ...)
+travels over the same kind of socket (:func:`gather_rows`): host data, a few hundred bytes per rank.
 """
 
 from __future__ import annotations
 
+import ctypes as C
+import os
+import socket
+import struct
+import time
+
 import numpy as np
+
+ID_BYTES = 128
 
 
 def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
@@ -25,60 +38,174 @@ def shard_sizes(total: int, world: int) -> list[int]:
     return [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
 
 
-class DevicePointer:
-    """Wraps a raw device address as a ``__cuda_array_interface__`` object so torch can alias it without a copy."""
-
-    def __init__(self, ptr: int, shape: tuple[int, ...], typestr: str = "<f8"):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 3,
-                                         "strides": None}
-
-
-def gather_blocks(local, total: int, group=None):
-    """All-gather equally-padded member blocks; returns the (total, ...) array on every rank.
-
-    ``local`` is a torch tensor (CPU for gloo, device for nccl) or a numpy array of shape (n_local, ...).
-    Blocks are padded to ceil(total/world) members so a single all_gather_into_tensor suffices.
-    """
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    was_numpy = isinstance(local, np.ndarray)
-    t = torch.from_numpy(np.ascontiguousarray(local)) if was_numpy else local
-    per = -(-total // world)
-    start, stop = shard_range(total, rank, world)
-    if t.shape[0] != stop - start:
-        raise ValueError(f"rank {rank} holds {t.shape[0]} members, expected {stop - start}")
-    if t.shape[0] < per:  # pad the last rank(s)
-        pad = torch.zeros((per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        t = torch.cat([t, pad], dim=0)
-    out = torch.empty((world * per,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
-    out = out[:total]
-    return out.numpy() if was_numpy else out
+# ------------------------------------------------------------------------------------------------- TCP plumbing (host data)
+def rendezvous_port(env=None) -> int:
+    env = os.environ if env is None else env
+    if env.get("SCPN_RDZV_PORT"):
+        return int(env["SCPN_RDZV_PORT"])
+    port = int(env.get("MASTER_PORT", "29400"))
+    return port + 1 if env.get("TORCHELASTIC_RUN_ID") else port
 
 
-def gather_blocks_async(local, total: int, out=None, group=None):
-    """Non-blocking form of :func:`gather_blocks` for torch tensors: launches the all-gather and returns ``(work, out)``
-    immediately so the collective (RCCL over xGMI) overlaps the next solve.  ``work.wait()`` followed by a synchronisation of
-    the current torch stream must precede any reuse of ``local``'s storage or of ``out`` (pass the previous ``out`` back in
-    to reuse its allocation).  Members are padded per rank exactly as in :func:`gather_blocks`; ``out[:total]`` is the result."""
-    import torch
-    import torch.distributed as dist
+def _recv_exact(conn: socket.socket, n: int) -> bytes:
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = conn.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the rendezvous socket early")
+        buf += chunk
+    return bytes(buf)
 
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    per = -(-total // world)
-    start, stop = shard_range(total, rank, world)
-    t = local
-    if t.shape[0] != stop - start:
-        raise ValueError(f"rank {rank} holds {t.shape[0]} members, expected {stop - start}")
-    if t.shape[0] < per:
-        pad = torch.zeros((per - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        t = torch.cat([t, pad], dim=0)
-    shape = (world * per,) + tuple(t.shape[1:])
-    if out is None or tuple(out.shape) != shape or out.dtype != t.dtype or out.device != t.device:
-        out = torch.empty(shape, dtype=t.dtype, device=t.device)
-    work = dist.all_gather_into_tensor(out, t.contiguous(), group=group, async_op=True)
-    return work, out
+
+def _connect(addr: str, port: int, timeout: float) -> socket.socket:
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            return socket.create_connection((addr, port), timeout=5.0)
+        except OSError:
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"no rendezvous server at {addr}:{port} after {timeout:.0f} s")
+            time.sleep(0.05)
+
+
+def exchange(rank: int, world: int, payload: bytes, *, addr: str, port: int, timeout: float = 120.0) -> list[bytes]:
+    """All ranks contribute ``payload`` (any length) and all receive the list of the ``world`` payloads in rank order.
+    Rank 0 is the server: it accepts world-1 connections, reads (rank, length, bytes) from each, then sends everybody the
+    whole table.  One round trip, used for the unique id (only rank 0's entry is non-empty) and for result tables."""
+    if world == 1:
+        return [payload]
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        table: list[bytes | None] = [None] * world
+        table[0] = payload
+        conns = []
+        try:
+            for _ in range(world - 1):
+                conn, _peer = srv.accept()
+                conn.settimeout(timeout)
+                r, n = struct.unpack("!ii", _recv_exact(conn, 8))
+                if not (0 < r < world) or table[r] is not None:
+                    raise ConnectionError(f"unexpected rank {r} at the rendezvous")
+                table[r] = _recv_exact(conn, n)
+                conns.append(conn)
+            blob = b"".join(struct.pack("!i", len(p)) + p for p in table)  # type: ignore[arg-type]
+            for conn in conns:
+                conn.sendall(blob)
+        finally:
+            for conn in conns:
+                conn.close()
+            srv.close()
+        return list(table)  # type: ignore[arg-type]
+    deadline = time.monotonic() + timeout
+    while True:  # a connection that lands in the backlog of the PREVIOUS round's closing server is reset: try again
+        conn = _connect(addr, port, timeout)
+        try:
+            conn.settimeout(timeout)
+            conn.sendall(struct.pack("!ii", rank, len(payload)) + payload)
+            out = []
+            for _ in range(world):
+                (n,) = struct.unpack("!i", _recv_exact(conn, 4))
+                out.append(_recv_exact(conn, n))
+            return out
+        except (ConnectionError, socket.timeout):
+            if time.monotonic() > deadline:
+                raise
+            time.sleep(0.05)
+        finally:
+            conn.close()
+
+
+def gather_rows(rank: int, world: int, rows: np.ndarray, total: int, *, addr: str, port: int) -> np.ndarray:
+    """Assemble the (total, k) float64 table of per-member result rows from the ranks' (n_local, k) blocks (on every rank)."""
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    lo, hi = shard_range(total, rank, world)
+    if rows.ndim != 2 or rows.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} holds {rows.shape[0] if rows.ndim == 2 else '?'} rows, expected {hi - lo}")
+    parts = exchange(rank, world, rows.tobytes(), addr=addr, port=port)
+    k = rows.shape[1]
+    blocks = [np.frombuffer(p, dtype=np.float64).reshape(-1, k) for p in parts]
+    for r, blk in enumerate(blocks):
+        if blk.shape[0] != shard_sizes(total, world)[r]:
+            raise ValueError(f"rank {r} sent {blk.shape[0]} rows")
+    return np.concatenate(blocks, axis=0)
+
+
+# ------------------------------------------------------------------------------------------------- RCCL communicator
+class EnsembleComm:
+    """The RCCL communicator of one rank (``scpn_comm_*``).  Create with :meth:`from_env` BEFORE the first device call of the
+    process: the unique id travels over TCP first, ``scpn_comm_init`` then selects this rank's GPU."""
+
+    def __init__(self, rank: int, world: int, device: int, *, addr: str, port: int):
+        from . import _lib
+
+        self._lib = _lib
+        self.rank, self.world, self.device, self.addr, self.port = rank, world, device, addr, port
+        L = _lib.lib()
+        ident = C.create_string_buffer(ID_BYTES)
+        if rank == 0:
+            _lib.check(L.scpn_comm_unique_id(ident), "scpn_comm_unique_id")
+        got = exchange(rank, world, ident.raw if rank == 0 else b"", addr=addr, port=port)[0]
+        if len(got) != ID_BYTES:
+            raise ConnectionError("rendezvous delivered a malformed RCCL id")
+        _lib.check(L.scpn_comm_init(rank, world, got, device), "scpn_comm_init")
+        self._recv = None
+        self._recv_bytes = 0
+
+    @classmethod
+    def from_env(cls, env=None) -> "EnsembleComm":
+        env = os.environ if env is None else env
+        return cls(int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1")), int(env.get("LOCAL_RANK", "0")),
+                   addr=env.get("MASTER_ADDR", "127.0.0.1"), port=rendezvous_port(env))
+
+    def info(self) -> dict:
+        r, w, v = C.c_int(), C.c_int(), C.c_int()
+        self._lib.check(self._lib.lib().scpn_comm_info(C.byref(r), C.byref(w), C.byref(v)), "scpn_comm_info")
+        return {"rank": r.value, "world": w.value, "rccl_version": v.value}
+
+    def allgather_psi(self, es) -> int:
+        """Launch the all-gather of ``es``'s psi blocks (asynchronous); returns the device address of the gathered
+        [world][batch][nz][nr] buffer, valid after :meth:`wait`."""
+        need = self.world * es.batch * es.NZ * es.NR * 8
+        L = self._lib.lib()
+        if self._recv is None or self._recv_bytes != need:
+            self.wait()
+            if self._recv is not None:
+                self._lib.check(L.scpn_device_free(self._recv), "scpn_device_free")
+            p = C.c_void_p()
+            self._lib.check(L.scpn_device_alloc(need, C.byref(p)), "scpn_device_alloc")
+            self._recv, self._recv_bytes = p, need
+        self._lib.check(L.scpn_comm_allgather_psi(es._h, self._recv), "scpn_comm_allgather_psi")
+        return int(self._recv.value)
+
+    def wait(self) -> None:
+        self._lib.check(self._lib.lib().scpn_comm_wait(), "scpn_comm_wait")
+
+    def download(self, shape: tuple[int, ...]) -> np.ndarray:
+        """The gathered buffer as a host array (after :meth:`wait`)."""
+        out = np.empty(shape, dtype=np.float64)
+        if out.nbytes != self._recv_bytes:
+            raise ValueError("shape does not match the gathered buffer")
+        self.wait()
+        self._lib.check(self._lib.lib().scpn_device_download(out.ctypes.data, self._recv, out.nbytes), "scpn_device_download")
+        return out
+
+    def allreduce_max(self, value: float) -> float:
+        """Max over the ranks (blocking): the per-run time of the slowest rank, and the barrier of the timed region."""
+        v = C.c_double(float(value))
+        self._lib.check(self._lib.lib().scpn_comm_allreduce_max(C.byref(v)), "scpn_comm_allreduce_max")
+        return float(v.value)
+
+    def barrier(self) -> None:
+        self.allreduce_max(0.0)
+
+    def close(self) -> None:
+        L = self._lib.lib()
+        self.wait()
+        if self._recv is not None:
+            L.scpn_device_free(self._recv)
+            self._recv = None
+        L.scpn_comm_finalize()

@@ -16,6 +16,15 @@ from tests._problems import configs_from
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def hip():
+    import scpn_fusion_core_amd as pkg
+    from scpn_fusion_core_amd import _lib
+
+    _lib.require_gpu()  # fail loudly: no fallback path exists
+    return pkg
+
+
 def test_device_green_function_reproduces_freegs_vacuum_flux(hip, golden):
     from scpn_fusion_core_amd.free_boundary import green_points
 
