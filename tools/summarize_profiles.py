@@ -18,7 +18,7 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01g"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02b"
 grid = int(sys.argv[2]) if len(sys.argv) > 2 else 513
 members = int(sys.argv[3]) if len(sys.argv) > 3 else 32  # PMC passes run with SCPN_HIP_GROUPS=1: a launch covers all members
 src = ROOT / "gpurun_out" / f"prof_{tag}"
@@ -81,6 +81,12 @@ for fam, sub in (("blend_fused", "k_blend_fused"), ("vcycle_coarse", "k_vcycle_c
     v = hbm_bytes(sub, None)
     if v:
         traffic[fam] = round(v, 1)
+# ---- SQ / GRBM counters (tools/sq_summary.py)
+import subprocess  # noqa: E402
+
+if (src / "s1" / "s1_counter_collection.csv").exists():
+    subprocess.run([sys.executable, str(ROOT / "tools" / "sq_summary.py"), str(src), str(out / f"{tag}_sq_by_kernel.csv")], check=True)
+
 (out / "pmc_traffic.json").write_text(json.dumps({
     "source": f"profiles/{tag}_pmc_fetch_write_by_kernel.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
               f"SCPN_HIP_GROUPS=1, {members} members per launch)",
