@@ -115,6 +115,7 @@ def main() -> int:
     ap.add_argument("--check-every", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-newton", action="store_true", help="skip the Newton-lane figure reported beside the metric")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -254,6 +255,36 @@ def main() -> int:
             cpu["psi_rel_linf_vs_gpu"] = float(np.abs(psi0 - ref["psi"]).max() / np.abs(ref["psi"]).max())
             cpu["picard_iterations_gpu_member0"] = picard_gpu0
 
+    # ---- beside the Picard figure: the same ensemble with the Newton inner solver of this package (finite-difference Jacobian
+    #      action, V-cycle-preconditioned GMRES, full steps).  Not the metric -- the metric is the reference's
+    #      Picard iteration -- but the same converged equilibria (psi compared below) per second
+    newton = None
+    if rank == 0 and world == 1 and not args.no_newton:
+        try:
+            ncfg = {**cfg, "solver": {**cfg["solver"], "solver_method": "newton", "gmres_preconditioner": "multigrid",
+                                      "newton_jacobian": "finite_difference", "newton_damping": 1.0, "max_iterations": 60}}
+            psi_picard = es.get_psi()
+            with EnsembleSolver(ncfg, batch=B, coil_currents=currents, current_targets=targets, device=local_rank) as nes:
+                def nstep():
+                    nes.fill_psi(0.0)
+                    return nes.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
+                nres = nstep()
+                nes.sync()
+                tn = time.perf_counter()
+                for _ in range(args.steps):
+                    nres = nstep()
+                nes.sync()
+                dtn = (time.perf_counter() - tn) / args.steps
+                psi_newton = nes.get_psi()
+            inner = [sum(r["picard_iterations"]) for r in nres]
+            newton = {"value": round(B / dtn, 3), "unit": "equilibria/s", "ms_per_step": round(dtn * 1e3, 2),
+                      "converged_members": sum(int(r["converged"]) for r in nres), "outer_iterations": [min(o_ for o_ in [r["outer_iterations"] for r in nres]), max(r["outer_iterations"] for r in nres)],
+                      "inner_iterations_per_member": [min(inner), max(inner)],
+                      "psi_rel_linf_vs_picard": float(np.abs(psi_newton - psi_picard).max() / np.abs(psi_picard).max()),
+                      "method": "15 Picard warm-up steps + Newton steps, J v by finite difference of the source map, GMRES(12) left-preconditioned by one V-cycle(3,3), full steps; inside the same device free-boundary loop"}
+        except Exception as exc:
+            newton = {"error": str(exc)}
+
     # ---- strict-parity gate (outside the timed region): the HIP free-boundary solve of the DIII-D-like case at 129^2 against the
     #      reference's own NumPy-lane flux map (fixture generated from the imported reference, tests/golden/freegs.npz), with the
     #      metrics and thresholds of validation/benchmark_freegs_public_example_reconstruction.py:491-497
@@ -299,6 +330,8 @@ def main() -> int:
             line["cpu_baseline"] = cpu
         if parity is not None:
             line["parity"] = parity
+        if newton is not None:
+            line["newton_fd_mg"] = newton
         print(json.dumps(line))
     es.close()
     if comm is not None:

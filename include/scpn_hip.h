@@ -228,7 +228,8 @@ int scpn_gs_picard_solve(scpn_gs *h, const scpn_picard_params *p, scpn_picard_re
  * preconditioner none | diagonal; "ilu" is not available on the device), psi += 0.5*delta or the
  * Armijo backtracking line search (:246-294).  p->method is ignored (the warm-up is the SOR branch). */
 typedef struct scpn_newton_opts {
-    int precond;            /* 0 none, 1 diagonal (solver.gmres_preconditioner) */
+    int precond;            /* 0 none, 1 diagonal (solver.gmres_preconditioner), 2 one geometric V-cycle of the GS* operator
+                             * (extension: the reference's JAX lane has this preconditioner, core/jax_multigrid_precond.py:208-276) */
     int line_search;        /* solver.newton_line_search */
     double line_search_c;   /* solver.newton_line_search_c (1e-4) */
     int max_backtracks;     /* solver.newton_line_search_max_backtracks (6) */
@@ -239,7 +240,8 @@ typedef struct scpn_newton_opts {
     double gmres_atol;      /* 1e-8 */
     double gmres_rtol;      /* 1e-6 */
     int poll_every;         /* host polls the device "inner loop finished" word every this many columns (>=1) */
-    int reserved;
+    int reserved;           /* Jacobian action: 0 = the reference's profile Jacobian (diagonal dS/dpsi term); 1 = finite difference of the
+                             * full source map (axis / X-point / I_p renormalisation included) -- extension, use with newton_alpha 1 */
 } scpn_newton_opts;
 
 typedef struct scpn_newton_result {
@@ -268,6 +270,13 @@ int scpn_gs_free_boundary_solve(scpn_gs *h, const scpn_picard_params *p, int n_c
                                 const double *coil_turns, int max_outer, double tol,
                                 int *outer_iterations, double *final_diff, int *picard_iters,
                                 scpn_picard_result *results);
+/* the same outer loop with the Newton-Kantorovich solve as the inner solver (solver_method = "newton" inside
+ * FusionKernel.solve_free_boundary, core/fusion_kernel_free_boundary.py:659-662 -> newton_solver.py:435-439); `inner_iters`
+ * receives the inner solver's iteration count (warm-up + Newton steps) per outer iteration */
+int scpn_gs_free_boundary_solve_newton(scpn_gs *h, const scpn_picard_params *p, const scpn_newton_opts *o, int n_coils,
+                                       const double *coil_r, const double *coil_z, const double *coil_i, const double *coil_turns,
+                                       int max_outer, double tol, int *outer_iterations, double *final_diff, int *inner_iters,
+                                       scpn_picard_result *results);
 
 /* resident smoother / V-cycle on the handle state (psi, source): the zero-copy path the
  * smoother benchmark's roofline figure is taken on */

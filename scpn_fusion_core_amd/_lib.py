@@ -124,6 +124,8 @@ SIGNATURES = {
     "scpn_gs_newton_solve": (_i, [_vp, C.POINTER(PicardParams), C.POINTER(NewtonOpts), C.POINTER(NewtonResult), _vp, _vp]),
     "scpn_gs_free_boundary_solve": (_i, [_vp, C.POINTER(PicardParams), _i, _vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp,
                                          C.POINTER(PicardResult)]),
+    "scpn_gs_free_boundary_solve_newton": (_i, [_vp, C.POINTER(PicardParams), C.POINTER(NewtonOpts), _i, _vp, _vp, _vp, _vp, _i, _d, _vp,
+                                                _vp, _vp, C.POINTER(PicardResult)]),
     "scpn_gs_rb_sor": (_i, [_vp, _d, _i]),
     "scpn_gs_vcycle": (_i, [_vp, _d, _i, _i, _i]),
     "scpn_gs_compute_b_field": (_i, [_vp, _i, _dp, _dp]),

@@ -491,6 +491,61 @@ __global__ void __launch_bounds__(256) k_gm_matvec(double* out, const double* vi
     double bs = block_sum_flat(v * v, sh);
     if (threadIdx.x == 0 && threadIdx.y == 0) part[(long)b * nblk + by_ * gridDim.x + bx_] = bs;
 }
+// ---- finite-difference Jacobian action (opt-in, solver.newton_jacobian = "finite_difference"): the reference's profile
+// Jacobian (k_nt_jac_diag) drops the non-local terms of dS/dpsi -- the dependence of psi_axis / psi_bnd and of the I_p
+// renormalisation on psi -- so its Newton step needs the fixed 0.5 damping and converges linearly (rate 0.5).  With
+//   J v = L*v - (S(psi + eps v) - S(psi)) / eps
+// the step is a true Newton step.  eps_b = 1e-7 * sqrt(n_interior) * max(|psi_axis|, 1e-6) / ||v||_2 keeps eps*v at 1e-7 of psi.
+__global__ void __launch_bounds__(256) k_fd_eps(double* eps, const double* part, int nblk, const Member* st, double n_interior,
+                                                const GmState* gm) {
+    __shared__ double sh[4];
+    const int b = blockIdx.x;
+    if (!gm[b].solve_on) return;
+    const double tot = sum_partials(part + (long)b * nblk, nblk, sh);
+    if (threadIdx.x == 0) eps[b] = tot > 0.0 ? 1e-7 * sqrt(n_interior) * fmax(fabs(st[b].psi_axis), 1e-6) / sqrt(tot) : 0.0;
+}
+// out = psi + eps_b * v over the whole member stride (v has a zero ring: the Dirichlet data are untouched)
+__global__ void __launch_bounds__(256) k_fd_perturb(Fld outF, Fld psiF, const double* v, long stride, const double* eps, const GmState* gm) {
+    const int b = blockIdx.y;
+    if (!gm[b].solve_on) return;
+    const double e = eps[b];
+    const double* p = psiF.at(b);
+    double* o = outF.at(b);
+    const double* vb = v + (long)b * stride;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2; i < stride; i += (long)gridDim.x * 512) {
+        const double2 a = *reinterpret_cast<const double2*>(p + i), c = *reinterpret_cast<const double2*>(vb + i);
+        *reinterpret_cast<double2*>(o + i) = double2{a.x + e * c.x, a.y + e * c.y};
+    }
+}
+// out = L*v - (S_pert - S_0)/eps (resid_mode: rhs - that) + per-block sum of squares; grid / block as k_gm_matvec
+__global__ void __launch_bounds__(256) k_gm_matvec_fd(double* out, const double* vin, Fld spF, Fld s0F, const double* eps, const double* rhs,
+                                                      long stride, Lvl L, const GmState* gm, int resid_mode, double* part) {
+    __shared__ double sh[4];
+    int bx_, by_, b;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        const unsigned lin = xcd_contiguous(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+        bx_ = (int)(lin % gx);
+        by_ = (int)((lin / gx) % gy);
+        b = (int)(lin / (gx * gy));
+    }
+    if (!gm[b].solve_on) return;
+    if (!resid_mode && !gm[b].inner_on) return;
+    const long off = (long)b * stride;
+    const int ir = bx_ * 64 + threadIdx.x, iz = by_ * 4 + threadIdx.y;
+    double v = 0.0;
+    if (iz > 0 && iz < L.nz - 1 && ir > 0 && ir < L.nr - 1) {
+        const long c = (long)iz * L.ld + ir;
+        const double e = eps[b];
+        const double ds = e != 0.0 ? (spF.at(b)[c] - s0F.at(b)[c]) / e : 0.0;
+        const double av = lop_at(vin + off, L, iz, ir) - ds;
+        v = resid_mode ? rhs[off + c] - av : av;
+        out[off + c] = v;
+    }
+    const int nblk = gridDim.x * gridDim.y;
+    double bs = block_sum_flat(v * v, sh);
+    if (threadIdx.x == 0 && threadIdx.y == 0) part[(long)b * nblk + by_ * gridDim.x + bx_] = bs;
+}
 // one modified Gram-Schmidt step of column `col` (scipy gmres: "for k in range(col+1): tmp = dot(v[k], w); w -= tmp*v[k]"):
 //   every block first finishes the PREVIOUS launch's reduction from `part_in` (k == 0: h0 = ||w||, else h[col][k-1] = <v[k-1], w>),
 //   block 0 stores it in the member state;

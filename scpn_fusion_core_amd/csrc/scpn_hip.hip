@@ -1111,7 +1111,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
 // ------------------------------------------------------------------------------------------ Newton-Kantorovich + GMRES
 // core/fusion_kernel_newton_solver.py:104-372.  Phase A = picard_solve_impl in warm-up mode (method 4); phase B below.
 static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn_newton_opts* o, scpn_newton_result* results,
-                              double* hist_out, double* gs_hist_out) {
+                              double* hist_out, double* gs_hist_out, const std::vector<int>* member_mask = nullptr) {
     const int B = h->B, nz = h->nz, nr = h->nr, ld = h->ld;
     const long stride = h->stride;
     const int max_iter = std::max(p->max_iter, 0);
@@ -1126,12 +1126,12 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
     pa.skip_seed = 0;
     std::vector<scpn_picard_result> ra(B);
     std::vector<double> hd((size_t)B * std::max(warmup, 1), 0.0), hg((size_t)B * std::max(warmup, 1), 0.0);
-    picard_solve_impl(h, &pa, ra.data(), warmup > 0 ? hd.data() : nullptr, warmup > 0 ? hg.data() : nullptr, nullptr, nullptr);
+    picard_solve_impl(h, &pa, ra.data(), warmup > 0 ? hd.data() : nullptr, warmup > 0 ? hg.data() : nullptr, nullptr, member_mask);
 
     // ---- workspace
     const long n = stride * B;
     const int restart = std::max(1, std::min({o->gmres_restart > 0 ? o->gmres_restart : GM_R, GM_R, (nz - 2) * (nr - 2)}));
-    enum { RK = 0, RHS, RES, WV, XV, DG, IVD, SRT, PRV, NBUF };
+    enum { RK = 0, RHS, RES, WV, XV, DG, IVD, SRT, PRV, ZERO, TMPV, PSIP, NBUF };  // ZERO / TMPV: multigrid preconditioner; PSIP: psi + eps v
     if (!h->nt_ws.p) {
         h->nt_ws.alloc((size_t)n * NBUF);
         HIP_TRY(hipMemsetAsync(h->nt_ws.p, 0, sizeof(double) * n * NBUF, st));
@@ -1187,7 +1187,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         m.gs_best = pushed > 0 ? ra[b].gs_residual_best : INFINITY;
         m.converged = ra[b].converged;
         m.iterations = warmup > 0 ? ra[b].iterations : 1;
-        m.on = (!m.converged && warmup < max_iter) ? 1 : 0;
+        m.on = (!m.converged && warmup < max_iter && !(member_mask && !(*member_mask)[b])) ? 1 : 0;
         n_on += m.on;
     }
     HIP_TRY(hipMemcpyAsync(h->nt_st.p, nm.data(), sizeof(NtMember) * B, hipMemcpyHostToDevice, st));
@@ -1244,24 +1244,71 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         HIP_TRY(hipStreamSynchronize(st));
         return h->h_nactive[0];
     };
-    // restarted GMRES on (L - diag) x = -r_k for the members that are `on` (scipy gmres, see newton_kernels.hip.h)
+    // restarted GMRES on (L - diag) x = -r_k for the members that are `on` (scipy gmres, see newton_kernels.hip.h).
+    // Preconditioner modes: 0 none, 1 diagonal (the reference's), 2 multigrid: z = M^-1 v is ONE V-cycle(3,3) of the GS* operator
+    // from a zero start with v as right-hand side on the zero-ring Krylov grid -- M^-1 (L - D) = I - M^-1 D, the Jacobian's
+    // profile term is a bounded perturbation, so the Krylov space needs a handful of vectors instead of thousands.
     auto gmres = [&]() {
-        const int precond = o->precond ? 1 : 0;
+        const int mg = o->precond == 2 ? 1 : 0;
+        const int precond = (o->precond && !mg) ? 1 : 0;   // what the kernels apply themselves (the diagonal scaling)
+        const int pflag = o->precond ? 1 : 0;              // what the tolerance logic sees (a preconditioned norm exists)
         const int maxit = o->gmres_maxiter > 0 ? o->gmres_maxiter : 100;
         const int pe = std::max(1, o->poll_every);
         double* V = h->nt_V.p;
+        Fld zeroF = h->plain(buf(ZERO)), tmpF = h->plain(buf(TMPV)), WbufF = h->plain(h->W.p), W2bufF = h->plain(h->W2.p);
+        // dst <- M^-1 src (multigrid): returns the device pointer that holds the result (one of the two work buffers)
+        auto apply_mg = [&](const double* src_field) -> const double* {
+            ProfScope ps(h, "gmres_mg_precond", 1);
+            Fld srcv = h->plain(const_cast<double*>(src_field));
+            Fld z = vcycle(h, zeroF, WbufF, W2bufF, srcv, 1.0, 3, 3, 5, nullptr);
+            return z.base;
+        };
+        // A v (resid_mode 0, into `out`, with the partial sums of |out|^2 in P0) or rhs - A x (resid_mode 1)
+        const bool fd = o->reserved == 1 && !p->external_profile_mode;
+        auto matvec = [&](double* out, const double* vin, int resid_mode) {
+            if (!fd) {
+                SCPN_LAUNCH(k_gm_matvec, g2, BLK2D, 0, st, out, vin, (const double*)buf(DG), (const double*)buf(IVD), (const double*)buf(RHS), stride,
+                                   L0, (const GmState*)h->nt_gm.p, precond, resid_mode, P0);
+                return;
+            }
+            // finite-difference Jacobian action: ||v|| -> eps, psi + eps v, topology + source of the perturbed state on a scratch
+            // copy of the member table, then L v - (S_pert - S_0) / eps
+            Fld pF = h->plain(buf(PSIP));
+            DBuf<Member>& scr = h->d_scr_st;
+            scr.alloc(B);
+            h->d_scr_diff.alloc(B);
+            SCPN_LAUNCH(k_gm_start, gflat, dim3(256), 0, st, (double*)nullptr, vin, (const double*)buf(IVD), stride, (const GmState*)h->nt_gm.p, 0, 1,
+                               P1, nbf);
+            SCPN_LAUNCH(k_fd_eps, dim3(B), dim3(256), 0, st, h->d_scr_diff.p, (const double*)P1, nbf, (const Member*)h->d_st.p,
+                               (double)((long)(nz - 2) * (nr - 2)), (const GmState*)h->nt_gm.p);
+            SCPN_LAUNCH(k_fd_perturb, dim3(std::min(cdiv(stride, 512), 1024), B), dim3(256), 0, st, pF, curF, vin, stride,
+                               (const double*)h->d_scr_diff.p, (const GmState*)h->nt_gm.p);
+            HIP_TRY(hipMemcpyAsync(scr.p, h->d_st.p, sizeof(Member) * B, hipMemcpyDeviceToDevice, st));
+            SCPN_LAUNCH(k_topology, dim3(nblk1, B), dim3(256), 0, st, pF, (const Member*)scr.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
+                               h->d_topo.p, nblk1);
+            SCPN_LAUNCH(k_topology_final, dim3(B), dim3(256), 0, st, pF, scr.p, (const TopoPart*)h->d_topo.p, nblk1, nr, ld,
+                               (const double*)h->d_r.p, (const double*)h->d_z.p);
+            SCPN_LAUNCH(k_jsum, gjs, dim3(256), 0, st, pF, (const Member*)scr.p, nz, nr, ld, (const double*)h->d_r.p,
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0});
+            SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, scr.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
+            SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, src2F, jF, 0, pF, (const Member*)scr.p, nz, nr, ld, (const double*)h->d_r.p,
+                               (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
+            SCPN_LAUNCH(k_gm_matvec_fd, g2, BLK2D, 0, st, out, vin, src2F, srcF, (const double*)h->d_scr_diff.p, (const double*)buf(RHS), stride, L0,
+                               (const GmState*)h->nt_gm.p, resid_mode, P0);
+        };
         auto tail = [&](int mode, const double* part, int nblk) {
-            SCPN_LAUNCH(k_gm_tail, dim3(B), dim3(256), 0, st, h->nt_gm.p, h->nt_st.p, mode, o->gmres_atol, o->gmres_rtol, restart, precond,
+            SCPN_LAUNCH(k_gm_tail, dim3(B), dim3(256), 0, st, h->nt_gm.p, h->nt_st.p, mode, o->gmres_atol, o->gmres_rtol, restart, pflag,
                                maxit, part, nblk, d_nsolve);
         };
         {
-            ProfScope ps(h, "gmres_init", precond ? 4 : 2);
+            ProfScope ps(h, "gmres_init", pflag ? 4 : 2);
             SCPN_LAUNCH(k_gm_init, gflat, dim3(256), 0, st, buf(RHS), buf(XV), buf(RES), (const double*)buf(RK), stride, h->nt_gm.p,
                                (const NtMember*)h->nt_st.p, P0, nbf);
             tail(0, P0, nbf);
-            if (precond) {
-                SCPN_LAUNCH(k_gm_start, gflat, dim3(256), 0, st, (double*)nullptr, (const double*)buf(RHS), (const double*)buf(IVD), stride,
-                                   (const GmState*)h->nt_gm.p, 1, 1, P0, nbf);
+            if (pflag) {  // norm of the preconditioned right-hand side
+                const double* pb = mg ? apply_mg(buf(RHS)) : (const double*)buf(RHS);
+                SCPN_LAUNCH(k_gm_start, gflat, dim3(256), 0, st, (double*)nullptr, pb, (const double*)buf(IVD), stride,
+                                   (const GmState*)h->nt_gm.p, precond, 1, P0, nbf);
                 tail(1, P0, nbf);
             }
         }
@@ -1269,7 +1316,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         static const long small_max = [] { const char* e = std::getenv("SCPN_HIP_GMRES_SMALL"); return e ? std::atol(e) : 20000L; }();
         // (one workgroup per member: always for <= 65^2; up to 129^2 when there are enough members to occupy several CUs)
         const long npts = (long)nz * nr;
-        if (npts <= std::min(small_max, 20000L) && (npts <= 4500 || B >= 4)) {
+        if (!mg && !fd && npts <= std::min(small_max, 20000L) && (npts <= 4500 || B >= 4)) {
             SCPN_LAUNCH(k_gm_count, dim3(1), dim3(64), 0, st, (const GmState*)h->nt_gm.p, B, d_nsolve, d_ninner);
             int left = poll(d_nsolve);
             for (int cyc = 0; cyc < maxit && left > 0; ++cyc) {
@@ -1295,36 +1342,45 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
             }
             return;
         }
+        const int pe_mg = mg ? 1 : pe;  // a preconditioned solve takes a handful of columns: look at the inner flag after every one
         for (int cyc = 0; cyc < maxit; ++cyc) {
             SCPN_LAUNCH(k_gm_count, dim3(1), dim3(64), 0, st, (const GmState*)h->nt_gm.p, B, d_nsolve, d_ninner);
             if (poll(d_nsolve) == 0) break;
-            SCPN_LAUNCH(k_gm_start, gflat, dim3(256), 0, st, V, (const double*)buf(RES), (const double*)buf(IVD), stride,
-                               (const GmState*)h->nt_gm.p, precond, 0, P0, nbf);
+            {
+                const double* pr = mg ? apply_mg(buf(RES)) : (const double*)buf(RES);
+                SCPN_LAUNCH(k_gm_start, gflat, dim3(256), 0, st, V, pr, (const double*)buf(IVD), stride,
+                                   (const GmState*)h->nt_gm.p, precond, 0, P0, nbf);
+            }
             SCPN_LAUNCH(k_gm_scale, gflat, dim3(256), 0, st, V, (const double*)V, stride, h->nt_gm.p, 0, (const double*)P0, nbf);
             for (int col = 0; col < restart; ++col) {
+                int nb_first = nb2;  // number of partial sums of |w|^2 the first MGS launch reads
                 {
                     ProfScope ps(h, "gmres_matvec", 1);
-                    SCPN_LAUNCH(k_gm_matvec, g2, BLK2D, 0, st, buf(WV), (const double*)(V + (long)col * n), (const double*)buf(DG),
-                                       (const double*)buf(IVD), (const double*)buf(RHS), stride, L0, (const GmState*)h->nt_gm.p, precond, 0, P0);
+                    matvec(mg ? buf(TMPV) : buf(WV), (const double*)(V + (long)col * n), 0);
+                }
+                if (mg) {  // w = M^-1 (A v): V-cycle, then the copy into w together with the partial sums of |w|^2
+                    const double* z = apply_mg(buf(TMPV));
+                    SCPN_LAUNCH(k_gm_start, gflat, dim3(256), 0, st, buf(WV), z, (const double*)buf(IVD), stride, (const GmState*)h->nt_gm.p, 0, 0,
+                                       P0, nbf);
+                    nb_first = nbf;
                 }
                 {
                     ProfScope ps(h, "gmres_mgs", col + 3);
                     for (int k = 0; k <= col + 1; ++k)  // launch k reads the partials of the previous launch, writes the other half
                         SCPN_LAUNCH(k_gm_mgs, gflat, dim3(256), 0, st, buf(WV), (const double*)V, stride, B, h->nt_gm.p, col, k,
-                                           (const double*)((k & 1) ? P1 : P0), k == 0 ? nb2 : nbf, (k & 1) ? P0 : P1, nbf);
+                                           (const double*)((k & 1) ? P1 : P0), k == 0 ? nb_first : nbf, (k & 1) ? P0 : P1, nbf);
                     SCPN_LAUNCH(k_gm_col_tail, dim3(B), dim3(256), 0, st, h->nt_gm.p, col, (const double*)(((col + 1) & 1) ? P0 : P1), nbf,
                                        d_ninner);
                 }
                 if (col + 1 < restart)
                     SCPN_LAUNCH(k_gm_scale, gflat, dim3(256), 0, st, V + (long)(col + 1) * n, (const double*)buf(WV), stride, h->nt_gm.p, 1,
                                        (const double*)P0, nbf);
-                if ((col + 1) % pe == 0 && col + 1 < restart && poll(d_ninner) == 0) break;
+                if ((col + 1) % pe_mg == 0 && col + 1 < restart && poll(d_ninner) == 0) break;
             }
             {
                 ProfScope ps(h, "gmres_update", 3);
                 SCPN_LAUNCH(k_gm_update_x, gflat, dim3(256), 0, st, buf(XV), (const double*)V, stride, B, (const GmState*)h->nt_gm.p);
-                SCPN_LAUNCH(k_gm_matvec, g2, BLK2D, 0, st, buf(RES), (const double*)buf(XV), (const double*)buf(DG), (const double*)buf(IVD),
-                                   (const double*)buf(RHS), stride, L0, (const GmState*)h->nt_gm.p, precond, 1, P0);
+                matvec(buf(RES), (const double*)buf(XV), 1);
                 tail(2, P0, nb2);
             }
         }
@@ -1346,7 +1402,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
                 SCPN_LAUNCH(k_nt_jac_sum, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, (const NtMember*)h->nt_st.p, nz, nr,
                                    ld, (const double*)h->d_r.p, P0, nblk1);
             SCPN_LAUNCH(k_nt_jac_diag, g2, BLK2D, 0, st, dgF, ivF, curF, jF, (const Member*)h->d_st.p, (const NtMember*)h->nt_st.p, nz, nr, ld,
-                               (const double*)h->d_r.p, (const double*)h->d_neg_mu0R.p, p->external_profile_mode, o->precond ? 1 : 0, diag_lap,
+                               (const double*)h->d_r.p, (const double*)h->d_neg_mu0R.p, p->external_profile_mode, o->precond == 1 ? 1 : 0, diag_lap,
                                h->dr, h->dz, (const double*)P0, nblk1);
         }
         gmres();
@@ -1586,7 +1642,8 @@ static int S_newton_solve(Solver* h, const scpn_picard_params* p, const scpn_new
     if (!h || !p || !o) return fail(SCPN_E_ARG, "null handle / params");
     if (!omega_ok(p->sor_omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");
     if (p->require_gs_residual && !(p->gs_tol > 0.0)) return fail(SCPN_E_ARG, "solver.gs_residual_threshold must be > 0");
-    if (o->precond < 0 || o->precond > 1) return fail(SCPN_E_ARG, "solver.gmres_preconditioner must be none or diagonal on the device");
+    if (o->reserved < 0 || o->reserved > 1) return fail(SCPN_E_ARG, "solver.newton_jacobian must be profile or finite_difference");
+    if (o->precond < 0 || o->precond > 2) return fail(SCPN_E_ARG, "solver.gmres_preconditioner must be none, diagonal or multigrid on the device");
     if (o->line_search && (!(o->line_search_c > 0.0) || !(o->line_search_c < 1.0)))
         return fail(SCPN_E_ARG, "solver.newton_line_search_c must be finite and in (0, 1)");
     if (o->line_search && o->max_backtracks <= 0) return fail(SCPN_E_ARG, "solver.newton_line_search_max_backtracks must be >= 1");
@@ -1602,7 +1659,7 @@ static int S_newton_solve(Solver* h, const scpn_picard_params* p, const scpn_new
 
 static int S_free_boundary_solve(Solver* h, const scpn_picard_params* p, int n_coils, const double* coil_r, const double* coil_z,
                                 const double* coil_i, const double* coil_turns, int max_outer, double tol, int* outer_iterations,
-                                double* final_diff, int* picard_iters, scpn_picard_result* results) {
+                                double* final_diff, int* picard_iters, scpn_picard_result* results, const scpn_newton_opts* newton = nullptr) {
     if (!h || !p) return fail(SCPN_E_ARG, "null handle / params");
     if (max_outer < 1) return fail(SCPN_E_ARG, "max_outer_iter must be >= 1.");
     if (!std::isfinite(tol) || tol < 0.0) return fail(SCPN_E_ARG, "tol must be finite and >= 0.");
@@ -1651,7 +1708,17 @@ static int S_free_boundary_solve(Solver* h, const scpn_picard_params* p, int n_c
         SCPN_LAUNCH(k_apply_bc, gring, dim3(256), 0, st, curF, extF, nz, nr, ld, (const int*)d_mask.p);
         SCPN_LAUNCH(k_copy, g2, BLK2D, 0, st, oldF, curF, nz, nr, ld, (const int*)d_mask.p);
         HIP_TRY(hipStreamSynchronize(st));
-        picard_solve_impl(h, &q, res.data(), nullptr, nullptr, nullptr, &mask);
+        if (newton) {  // inner solve = Newton-Kantorovich (solver_method "newton"): same outer loop, same Dirichlet data
+            std::vector<scpn_newton_result> nres(B);
+            newton_solve_impl(h, &q, newton, nres.data(), nullptr, nullptr, &mask);
+            for (int b = 0; b < B; ++b) {
+                std::memset(&res[b], 0, sizeof(res[b]));
+                res[b].converged = nres[b].converged; res[b].iterations = nres[b].iterations; res[b].diverged = nres[b].diverged;
+                res[b].residual = nres[b].residual; res[b].gs_residual = nres[b].gs_residual; res[b].gs_residual_best = nres[b].gs_residual_best;
+            }
+        } else {
+            picard_solve_impl(h, &q, res.data(), nullptr, nullptr, nullptr, &mask);
+        }
         curF = h->slot_fld(h->d_cur.p);
         SCPN_LAUNCH(k_maxabsdiff, dim3(nblk, B), dim3(256), 0, st, curF, oldF, nz, nr, ld, h->d_part1.p, nblk);
         SCPN_LAUNCH(k_max_final, dim3(B), dim3(256), 0, st, d_diff.p, (const double*)h->d_part1.p, nblk);
@@ -1978,6 +2045,20 @@ int scpn_gs_free_boundary_solve(scpn_gs* g, const scpn_picard_params* p, int n_c
                                      coil_i ? coil_i + oc : nullptr, coil_turns ? coil_turns + oc : nullptr, max_outer, tol,
                                      outer_iterations ? outer_iterations + o : nullptr, final_diff ? final_diff + o : nullptr,
                                      picard_iters ? picard_iters + o * max_outer : nullptr, results ? results + o : nullptr);
+    });
+}
+int scpn_gs_free_boundary_solve_newton(scpn_gs* g, const scpn_picard_params* p, const scpn_newton_opts* o, int n_coils, const double* coil_r,
+                                       const double* coil_z, const double* coil_i, const double* coil_turns, int max_outer, double tol,
+                                       int* outer_iterations, double* final_diff, int* inner_iters, scpn_picard_result* results) {
+    if (!g || !p || !o) return fail(SCPN_E_ARG, "null handle / params");
+    if (max_outer < 1) return fail(SCPN_E_ARG, "max_outer_iter must be >= 1.");
+    if (o->precond < 0 || o->precond > 2 || o->reserved < 0 || o->reserved > 1) return fail(SCPN_E_ARG, "bad Newton options");
+    return run_groups(g, [&](int gi, Solver* k) {
+        const size_t of = (size_t)g->off[gi], oc = of * (size_t)std::max(n_coils, 0);
+        return S_free_boundary_solve(k, p, n_coils, coil_r ? coil_r + oc : nullptr, coil_z ? coil_z + oc : nullptr,
+                                     coil_i ? coil_i + oc : nullptr, coil_turns ? coil_turns + oc : nullptr, max_outer, tol,
+                                     outer_iterations ? outer_iterations + of : nullptr, final_diff ? final_diff + of : nullptr,
+                                     inner_iters ? inner_iters + of * max_outer : nullptr, results ? results + of : nullptr, o);
     });
 }
 int scpn_gs_rb_sor(scpn_gs* g, double omega, int n_sweeps) {

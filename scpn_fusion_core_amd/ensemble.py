@@ -11,6 +11,7 @@ NumPy ensemble driver; the per-member semantics are exact
 from __future__ import annotations
 
 import ctypes as C
+import logging
 from typing import Any, Sequence
 
 import numpy as np
@@ -75,10 +76,14 @@ def newton_opts_from_cfg(cfg: dict, *, poll_every: int = 10) -> NewtonOpts:
         mode = "none"
     if mode == "none" and bool(sol.get("gmres_diagonal_preconditioner", False)):
         mode = "diagonal"
-    if mode not in {"none", "diagonal", "ilu"}:
-        raise ValueError("solver.gmres_preconditioner must be one of {'none', 'diagonal', 'ilu'}")
+    if mode not in {"none", "diagonal", "ilu", "multigrid"}:
+        raise ValueError("solver.gmres_preconditioner must be one of {'none', 'diagonal', 'ilu', 'multigrid'}")
     if mode == "ilu":
-        raise NotImplementedError("gmres_preconditioner='ilu' (SuperLU spilu) is not on the HIP path; use 'none' or 'diagonal'")
+        # the reference degrades to the diagonal preconditioner when SuperLU's spilu is unavailable
+        # (core/fusion_kernel_solver_runtime.py:289-293); there is no incomplete LU on the device, so this is that path
+        logging.getLogger(__name__).warning("ILU preconditioner unavailable on the HIP path (%s); falling back to diagonal.",
+                                            "no device spilu")
+        mode = "diagonal"
     drop, fill = float(sol.get("gmres_ilu_drop_tol", 1e-4)), float(sol.get("gmres_ilu_fill_factor", 8.0))
     if (not np.isfinite(drop)) or drop <= 0.0:
         raise ValueError("solver.gmres_ilu_drop_tol must be finite and > 0")
@@ -88,14 +93,29 @@ def newton_opts_from_cfg(cfg: dict, *, poll_every: int = 10) -> NewtonOpts:
     if budget is not None and (isinstance(budget, bool) or int(budget) < 0):
         raise ValueError("solver.gmres_nonconverged_budget must be an int >= 0")
     o = NewtonOpts()
-    o.precond = 1 if mode == "diagonal" else 0
+    o.precond = {"none": 0, "diagonal": 1, "multigrid": 2}[mode]  # 2: one V-cycle of the GS* operator (extension of this package)
     o.line_search = int(bool(sol.get("newton_line_search", False)))
     o.line_search_c = c
     o.max_backtracks = mb
     o.warmup_steps = -1
-    o.newton_alpha = 0.5
-    o.gmres_restart, o.gmres_maxiter, o.gmres_atol, o.gmres_rtol = 50, 100, 1e-8, 1e-6
+    # the reference applies psi += 0.5 * delta (core/fusion_kernel_newton_solver.py:297); ``solver.newton_damping`` is this
+    # package's opt-in for the full Newton step, useful once the linear solves are accurate (multigrid-preconditioned GMRES)
+    damping = float(sol.get("newton_damping", 0.5))
+    if (not np.isfinite(damping)) or damping <= 0.0 or damping > 1.0:
+        raise ValueError("solver.newton_damping must be finite and in (0, 1]")
+    o.newton_alpha = damping
+    o.gmres_restart, o.gmres_maxiter, o.gmres_atol, o.gmres_rtol = 50, 100, 1e-8, 1e-6  # the reference's call (solver_runtime.py:296-312)
+    if mode == "multigrid":
+        # inexact Newton: a V-cycle-preconditioned solve reaches rtol 1e-6 in ~6 columns; a step whose Jacobian action is at its
+        # finite-difference noise floor must not spin through 100 x 50 columns, so the Krylov space is capped (overridable)
+        o.gmres_restart, o.gmres_maxiter = int(sol.get("gmres_restart", 12)), int(sol.get("gmres_maxiter", 1))
+        if o.gmres_restart < 1 or o.gmres_maxiter < 1:
+            raise ValueError("solver.gmres_restart and solver.gmres_maxiter must be >= 1")
     o.poll_every = int(poll_every)
+    jac = str(sol.get("newton_jacobian", "profile")).strip().lower()
+    if jac not in {"profile", "finite_difference"}:
+        raise ValueError("solver.newton_jacobian must be 'profile' (the reference's) or 'finite_difference'")
+    o.reserved = 1 if jac == "finite_difference" else 0
     return o
 
 
@@ -311,9 +331,7 @@ class EnsembleSolver:
             raise ValueError("max_outer_iter must be >= 1.")
         if not np.isfinite(tol) or tol < 0.0:
             raise ValueError("tol must be finite and >= 0.")
-        if self.cfg.get("solver", {}).get("solver_method", "multigrid") == "newton":
-            raise NotImplementedError("the resident free-boundary loop drives the Picard methods; with solver_method='newton' use "
-                                      "free_boundary.solve_free_boundary(FusionKernel, ...) (outer loop on the host, Newton on the device)")
+        newton = self.cfg.get("solver", {}).get("solver_method", "multigrid") == "newton"
 
         def bc(a, default):
             a = default if a is None else as_f64(a)
@@ -333,8 +351,13 @@ class EnsembleSolver:
         outer = np.zeros(self.batch, dtype=np.int32)
         fdiff = np.zeros(self.batch)
         pits = np.zeros((self.batch, max_outer_iter), dtype=np.int32)
-        check(self._L.scpn_gs_free_boundary_solve(self._h, C.byref(p), n, ptr(cr), ptr(cz), ptr(ci), ptr(ct), int(max_outer_iter),
-                                                  float(tol), ptr(outer), ptr(fdiff), ptr(pits), res))
+        if newton:  # the same outer loop, Newton-Kantorovich as the inner solver (picard_iterations = its iteration counts)
+            o = newton_opts_from_cfg(self.cfg)
+            check(self._L.scpn_gs_free_boundary_solve_newton(self._h, C.byref(p), C.byref(o), n, ptr(cr), ptr(cz), ptr(ci), ptr(ct),
+                                                             int(max_outer_iter), float(tol), ptr(outer), ptr(fdiff), ptr(pits), res))
+        else:
+            check(self._L.scpn_gs_free_boundary_solve(self._h, C.byref(p), n, ptr(cr), ptr(cz), ptr(ci), ptr(ct), int(max_outer_iter),
+                                                      float(tol), ptr(outer), ptr(fdiff), ptr(pits), res))
         out = []
         for b in range(self.batch):
             d = _result_dict(res[b])
