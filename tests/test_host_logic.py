@@ -135,8 +135,14 @@ def test_config_contract_and_param_block():
                 {"gmres_nonconverged_budget": -1}, {"gmres_ilu_drop_tol": 0.0}):  # tests/test_newton_equilibrium.py:176-230
         with pytest.raises(ValueError):
             newton_opts_from_cfg({**cfg, "solver": {**cfg["solver"], **bad}})
-    with pytest.raises(NotImplementedError):
-        newton_opts_from_cfg({**cfg, "solver": {**cfg["solver"], "gmres_preconditioner": "ilu"}})
+    # "ilu" degrades to the diagonal preconditioner (the reference's fallback when spilu is unavailable, solver_runtime.py:289-293)
+    assert newton_opts_from_cfg({**cfg, "solver": {**cfg["solver"], "gmres_preconditioner": "ilu"}}).precond == 1
+    mgo = newton_opts_from_cfg({**cfg, "solver": {**cfg["solver"], "gmres_preconditioner": "multigrid", "newton_jacobian": "finite_difference",
+                                                  "newton_damping": 1.0}})
+    assert (mgo.precond, mgo.reserved, mgo.newton_alpha, mgo.gmres_restart, mgo.gmres_maxiter) == (2, 1, 1.0, 12, 1)
+    for bad in ({"newton_jacobian": "exact"}, {"newton_damping": 0.0}, {"newton_damping": 1.5}):
+        with pytest.raises(ValueError):
+            newton_opts_from_cfg({**cfg, "solver": {**cfg["solver"], **bad}})
     for k in ("gmres_preconditioner", "newton_line_search", "newton_line_search_max_backtracks"):
         cfg["solver"].pop(k)
     cfg["solver"].update(solver_method="multigrid", require_gs_residual=True, gs_residual_threshold=0.0)
