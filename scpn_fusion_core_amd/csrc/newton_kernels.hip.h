@@ -349,15 +349,27 @@ __global__ void __launch_bounds__(256) k_gm_init(double* rhs, double* x, double*
 // scalar tails of the GMRES driver; one block per member.
 // mode 0 (after k_gm_init): ||b||, atol, solve_on                      mode 1 (after k_gm_norm): Mb = ||M^-1 b||, first ptol
 // mode 2 (after the end-of-cycle residual): rnorm, restart / exit logic, inner-tolerance adaptation, telemetry
+// mode 3 (multigrid-preconditioned capped solve, last cycle): exit without the true residual
 __global__ void __launch_bounds__(256) k_gm_tail(GmState* gm, NtMember* nt, int mode, double atol_in, double rtol, int restart,
                                                  int precond, int maxiter, const double* part, int nblk, int* n_solve) {
     __shared__ double sh[4];
     const int b = blockIdx.x;
     if (mode == 0 ? !nt[b].on : !gm[b].solve_on) return;
-    const double tot = sum_partials(part + (long)b * nblk, nblk, sh);
+    const double tot = mode == 3 ? 0.0 : sum_partials(part + (long)b * nblk, nblk, sh);
     if (threadIdx.x != 0) return;
     GmState& g = gm[b];
     const double eps = 2.220446049250313e-16;
+    if (mode == 3) {  // final cycle of a capped (inexact-Newton) solve: judged on the Arnoldi estimate of the preconditioned residual
+        g.cycles += 1;
+        g.solve_on = 0;
+        g.info = (g.presid <= g.ptol || g.breakdown) ? 0 : maxiter;
+        NtMember& m = nt[b];
+        m.gm_last_info = g.info;
+        if (g.info > 0) m.gm_nonconv += 1;
+        m.gm_inner += g.inner_total;
+        atomicSub(n_solve, 1);
+        return;
+    }
     if (mode == 0) {
         g.bnrm2 = sqrt(tot);
         g.atol = fmax(atol_in, rtol * g.bnrm2);

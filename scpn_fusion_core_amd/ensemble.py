@@ -97,7 +97,11 @@ def newton_opts_from_cfg(cfg: dict, *, poll_every: int = 10) -> NewtonOpts:
     o.line_search = int(bool(sol.get("newton_line_search", False)))
     o.line_search_c = c
     o.max_backtracks = mb
-    o.warmup_steps = -1
+    # the reference always warms up with min(15, max_iter // 2) Picard iterations (fusion_kernel_newton_runtime.py:92) = -1 here;
+    # ``solver.newton_warmup_steps`` overrides it (the finite-difference / multigrid lane needs far fewer)
+    o.warmup_steps = int(sol.get("newton_warmup_steps", -1))
+    if o.warmup_steps < -1:
+        raise ValueError("solver.newton_warmup_steps must be >= 0 (or -1 for the reference's rule)")
     # the reference applies psi += 0.5 * delta (core/fusion_kernel_newton_solver.py:297); ``solver.newton_damping`` is this
     # package's opt-in for the full Newton step, useful once the linear solves are accurate (multigrid-preconditioned GMRES)
     damping = float(sol.get("newton_damping", 0.5))
@@ -106,11 +110,17 @@ def newton_opts_from_cfg(cfg: dict, *, poll_every: int = 10) -> NewtonOpts:
     o.newton_alpha = damping
     o.gmres_restart, o.gmres_maxiter, o.gmres_atol, o.gmres_rtol = 50, 100, 1e-8, 1e-6  # the reference's call (solver_runtime.py:296-312)
     if mode == "multigrid":
-        # inexact Newton: a V-cycle-preconditioned solve reaches rtol 1e-6 in ~6 columns; a step whose Jacobian action is at its
-        # finite-difference noise floor must not spin through 100 x 50 columns, so the Krylov space is capped (overridable)
-        o.gmres_restart, o.gmres_maxiter = int(sol.get("gmres_restart", 12)), int(sol.get("gmres_maxiter", 1))
+        # inexact Newton: a V-cycle-preconditioned solve gains about a decade per column, and a forcing term of 1e-3 keeps the
+        # outer iteration superlinear at a third of the columns of rtol 1e-6 (measured: tools/newton_fb_sweep.py); a step whose
+        # Jacobian action is at its finite-difference noise floor must not spin through 100 x 50 columns, so the Krylov space
+        # is capped.  All four are overridable (solver.gmres_restart / gmres_maxiter / gmres_rtol / gmres_atol).
+        o.gmres_restart, o.gmres_maxiter = int(sol.get("gmres_restart", 8)), int(sol.get("gmres_maxiter", 1))
+        o.gmres_rtol = 1e-3
         if o.gmres_restart < 1 or o.gmres_maxiter < 1:
             raise ValueError("solver.gmres_restart and solver.gmres_maxiter must be >= 1")
+        o.gmres_rtol, o.gmres_atol = float(sol.get("gmres_rtol", o.gmres_rtol)), float(sol.get("gmres_atol", o.gmres_atol))
+        if not (np.isfinite(o.gmres_rtol) and o.gmres_rtol > 0.0 and np.isfinite(o.gmres_atol) and o.gmres_atol >= 0.0):
+            raise ValueError("solver.gmres_rtol must be finite and > 0, solver.gmres_atol finite and >= 0")
     o.poll_every = int(poll_every)
     jac = str(sol.get("newton_jacobian", "profile")).strip().lower()
     if jac not in {"profile", "finite_difference"}:

@@ -282,3 +282,27 @@ def test_free_boundary_ensemble_with_newton_inner_solver(hip):
         assert rn[b]["converged"] and rn[b]["outer_iterations"] == rp[b]["outer_iterations"] == 2
         assert sum(rn[b]["picard_iterations"]) * 8 < sum(rp[b]["picard_iterations"])
         assert np.abs(psi_n[b] - psi_p[b]).max() <= 1e-8 * np.abs(psi_p[b]).max(), b
+
+
+@pytest.mark.parametrize("n,B", [(257, 64), (513, 32)])
+def test_newton_lane_short_warmup_over_the_scan_table(hip, n, B):
+    """The setting bench.py reports (2 warm-up steps, forcing term 1e-3, Krylov cap 8) over a +-10 % coil / I_p scan: every member
+    converges to the Picard solution of the same member."""
+    from scpn_fusion_core_amd.cases import scan_member_table
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    cfg = iter_like_cfg(n, tol=1e-8, max_iter=1000)
+    currents, targets = scan_member_table(cfg, B)
+    with EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets) as es:
+        rp = es.solve_free_boundary(max_outer_iter=20, tol=1e-4)
+        psi_p = es.get_psi()
+    c = {**cfg, "solver": {**cfg["solver"], "solver_method": "newton", "gmres_preconditioner": "multigrid", "newton_jacobian": "finite_difference",
+                           "newton_damping": 1.0, "max_iterations": 60, "newton_warmup_steps": 2}}
+    with EnsembleSolver(c, batch=B, coil_currents=currents, current_targets=targets) as es:
+        rn = es.solve_free_boundary(max_outer_iter=20, tol=1e-4)
+        psi_n = es.get_psi()
+    assert all(r["converged"] for r in rp) and all(r["converged"] for r in rn)
+    assert [r["outer_iterations"] for r in rn] == [r["outer_iterations"] for r in rp]
+    scale = np.abs(psi_p).max(axis=(1, 2))
+    assert (np.abs(psi_n - psi_p).max(axis=(1, 2)) <= 2e-8 * scale).all()
+    assert max(sum(r["picard_iterations"]) for r in rn) <= 40

@@ -139,8 +139,13 @@ def test_config_contract_and_param_block():
     assert newton_opts_from_cfg({**cfg, "solver": {**cfg["solver"], "gmres_preconditioner": "ilu"}}).precond == 1
     mgo = newton_opts_from_cfg({**cfg, "solver": {**cfg["solver"], "gmres_preconditioner": "multigrid", "newton_jacobian": "finite_difference",
                                                   "newton_damping": 1.0}})
-    assert (mgo.precond, mgo.reserved, mgo.newton_alpha, mgo.gmres_restart, mgo.gmres_maxiter) == (2, 1, 1.0, 12, 1)
-    for bad in ({"newton_jacobian": "exact"}, {"newton_damping": 0.0}, {"newton_damping": 1.5}):
+    assert (mgo.precond, mgo.reserved, mgo.newton_alpha, mgo.gmres_restart, mgo.gmres_maxiter) == (2, 1, 1.0, 8, 1)
+    assert (mgo.gmres_rtol, mgo.gmres_atol, mgo.warmup_steps) == (1e-3, 1e-8, -1)  # inexact-Newton forcing term; the reference's warm-up rule
+    tuned = newton_opts_from_cfg({**cfg, "solver": {**cfg["solver"], "gmres_preconditioner": "multigrid", "gmres_restart": 4, "gmres_rtol": 1e-2,
+                                                    "gmres_atol": 0.0, "newton_warmup_steps": 2}})
+    assert (tuned.gmres_restart, tuned.gmres_rtol, tuned.gmres_atol, tuned.warmup_steps) == (4, 1e-2, 0.0, 2)
+    for bad in ({"newton_jacobian": "exact"}, {"newton_damping": 0.0}, {"newton_damping": 1.5}, {"newton_warmup_steps": -2},
+                {"gmres_preconditioner": "multigrid", "gmres_rtol": 0.0}, {"gmres_preconditioner": "multigrid", "gmres_restart": 0}):
         with pytest.raises(ValueError):
             newton_opts_from_cfg({**cfg, "solver": {**cfg["solver"], **bad}})
     for k in ("gmres_preconditioner", "newton_line_search", "newton_line_search_max_backtracks"):
