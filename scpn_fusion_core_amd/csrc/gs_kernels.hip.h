@@ -642,6 +642,9 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         return;
     }
     TILE_STAMP(0);
+#if defined(TILE_SKIP) && (TILE_SKIP & 16)
+    if (nz > 0) return;
+#endif
     const double* src = srcF.at(b);
     // lazy-source mode (!SRCGEN && sg.st): srcF holds J_raw of k_jsum; Source = (-mu0 R) * (J_raw * scale) is formed on load
     // with the expression of k_source, so the separate source pass over the fine grid disappears.  Otherwise scale = nm = 1.
@@ -700,9 +703,14 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             const int i = g0 + j, lz = w + NW * i;
             const int gzc = min(max(z0 + min(lz, LZ - 1), 0), nz - 1);
             const long o = (long)gzc * ld + cc;
+#if defined(TILE_SKIP) && (TILE_SKIP & 1)
+            pv[j] = double2{(double)(o & 1023), 1.0};
+            sv2[j] = double2{1.0, (double)(o & 255)};
+#else
             pv[j] = *reinterpret_cast<const double2*>(in + o);
             if (!SRCGEN) sv2[j] = *reinterpret_cast<const double2*>(src + o);
             else sv2[j] = double2{0.0, 0.0};
+#endif
             if (PROLONG) {
                 const int ic = gzc >> 1, icc = min(ic, nz_c - 1), icc1 = (gzc & 1) ? min(ic + 1, nz_c - 1) : icc;
                 ca0[j] = ccp[(long)icc * ld_c + jcc];
@@ -813,6 +821,9 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             }
         }
     };
+#if defined(TILE_SKIP) && (TILE_SKIP & 2)
+    if (nz < 0)
+#endif
 #pragma unroll 1
     for (int sw = 0; sw < S; ++sw) {
         half_sweep(std::integral_constant<int, 0>{}, 2 * sw);
@@ -822,6 +833,9 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         __syncthreads();
         TILE_STAMP(3 + 2 * sw);
     }
+#if defined(TILE_SKIP) && (TILE_SKIP & 8)
+    if (nz < 0)
+#endif
     if (!BLEND)
 #pragma unroll
     for (int i = 0; i < NROWS; ++i) {
@@ -847,7 +861,11 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         }
     }
     TILE_STAMP(8);
+#if defined(TILE_SKIP) && (TILE_SKIP & 4)
+    if (DEFECT && nz < 0) {
+#else
     if (DEFECT) {
+#endif
         // (1) defect d = -(L*psi - src) of this wave's rows, both colours, into the source registers
         double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0;  // r_safe / its reciprocal (two words) of the lane's even / odd column
         if (c0 >= 1 && c0 <= nr - 2) { rs0 = dd.r_safe[c0]; ri0 = dd.r_inv[c0]; rl0 = dd.r_inv_lo[c0]; }
@@ -1068,6 +1086,7 @@ struct CoarseV {
     int n;                 // number of levels held (last one is the base case)
     int nz[CV_MAX], nr[CV_MAX];
     int off_psi[CV_MAX], off_rhs[CV_MAX], off_tab[CV_MAX];  // LDS offsets (doubles); tab = a_e, a_w, r_safe, r_inv (4*nr)
+    int off_scr;           // scratch of nz[0]*nr[0] doubles: the defect field between its evaluation and its restriction
     double a_ns[CV_MAX], a_c[CV_MAX], dr2[CV_MAX], dz2[CV_MAX], two_dr[CV_MAX];
     double inv_a_c[CV_MAX], inv_dr2[CV_MAX], inv_dz2[CV_MAX], inv_two_dr[CV_MAX];
     const double* r_inv[CV_MAX];
@@ -1126,8 +1145,54 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
         __syncthreads();
         return;
     }
+    // Up to 2 column pairs per thread (65x65 on 1024 threads): the pair's coefficients, right-hand sides and OWN values stay in
+    // registers for all passes.  A pass updates one column of the pair, whose E or W neighbour is the thread's other column, so
+    // an update costs three LDS reads (S, N and the neighbour outside the pair) and one write instead of eight reads and a write
+    // -- the level is bound by the CU's LDS bandwidth and the pass-to-pass latency, not by arithmetic.
+    if (tot <= 2 * (int)blockDim.x) {
+        constexpr int NJ = 2;
+        int c0[NJ], fl[NJ];
+        bool ok0[NJ], ok1[NJ];
+        double ae0[NJ], ae1[NJ], aw0[NJ], aw1[NJ], s0[NJ], s1[NJ], v0[NJ], v1[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int t = threadIdx.x + j * blockDim.x;
+            ok0[j] = t < tot;
+            const int iz = ok0[j] ? 1 + t / hw : 1, k = ok0[j] ? t - (iz - 1) * hw : 0, col = 1 + 2 * k;
+            ok1[j] = ok0[j] && col + 1 <= nr - 2;
+            c0[j] = iz * nr + col;
+            fl[j] = (iz + 1) & 1;
+            ae0[j] = ok0[j] ? a_e[col] : 0.0; aw0[j] = ok0[j] ? a_w[col] : 0.0;
+            ae1[j] = ok1[j] ? a_e[col + 1] : 0.0; aw1[j] = ok1[j] ? a_w[col + 1] : 0.0;
+            s0[j] = ok0[j] ? rhs[c0[j]] : 0.0; s1[j] = ok1[j] ? rhs[c0[j] + 1] : 0.0;
+            v0[j] = ok0[j] ? psi[c0[j]] : 0.0; v1[j] = ok0[j] ? psi[c0[j] + 1] : 0.0;  // (col + 1 <= nr - 1: ring or interior)
+        }
+        const int njs = tot <= (int)blockDim.x ? 1 : NJ;
+        for (int s = 0; s < 2 * n_sweeps; ++s) {
+            const int parity = s & 1;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (j < njs) {
+                    const int e = fl[j] ^ parity;
+                    if (e ? ok1[j] : ok0[j]) {
+                        const int c = c0[j] + e;
+                        const double oth = psi[e ? c + 1 : c - 1];
+                        const double Sv = psi[c - nr], Nv = psi[c + nr];
+                        const double E = e ? oth : v1[j], W = e ? v0[j] : oth, C = e ? v1[j] : v0[j];
+                        const double gs = divc((e ? ae1[j] : ae0[j]) * E + (e ? aw1[j] : aw0[j]) * W + a_ns * Sv + a_ns * Nv - (e ? s1[j] : s0[j]),
+                                               a_c, inv_a_c);
+                        const double nw = om1 * C + omega * gs;
+                        if (e) v1[j] = nw; else v0[j] = nw;
+                        psi[c] = nw;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     // thread -> point mapping is the same in every pass: hoist the integer division out of the pass loop
-    constexpr int MAXIT = 4;  // 65x65 with 1024 threads needs 2
+    constexpr int MAXIT = 4;
     int cbase[MAXIT], flag[MAXIT], kcol[MAXIT];
 #pragma unroll
     for (int j = 0; j < MAXIT; ++j) {
@@ -1190,6 +1255,9 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
     if (active && !active[b]) return;
+#if defined(TILE_SKIP) && (TILE_SKIP & 128)
+    if (pre >= 0) return;
+#endif
     CV_STAMP(0);
     // stage the coefficient tables of every level and the top-level rhs
     for (int l = 0; l < V.n; ++l) {
@@ -1202,14 +1270,25 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
         }
     }
     {
+        // top-level rhs: batches of 5 loads per thread in flight (one round trip to memory for 65x65 instead of five)
         const double* g = rhsF.at(b);
         double* rhs = lds + V.off_rhs[0];
         double* psi = lds + V.off_psi[0];
         const int nz = V.nz[0], nr = V.nr[0], n = nz * nr;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            int iz = i / nr, ir = i - iz * nr;
-            rhs[i] = g[(long)iz * V.ld0 + ir];
-            psi[i] = 0.0;
+        constexpr int RB = 5;
+        for (int i0 = threadIdx.x; i0 < n; i0 += RB * blockDim.x) {
+            double tmp[RB];
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const int i = min(i0 + k * (int)blockDim.x, n - 1);
+                const int iz = i / nr, ir = i - iz * nr;
+                tmp[k] = g[(long)iz * V.ld0 + ir];
+            }
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const int i = i0 + k * (int)blockDim.x;
+                if (i < n) { rhs[i] = tmp[k]; psi[i] = 0.0; }
+            }
         }
     }
     __syncthreads();
@@ -1225,21 +1304,31 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
         double* pc = lds + V.off_psi[l + 1];
         const int nzc = V.nz[l + 1], nrc = V.nr[l + 1], nrf = V.nr[l], nc = nzc * nrc;
         const double* rs = tab + 2 * nrf;
-        for (int i = threadIdx.x; i < nc; i += blockDim.x) {
-            int ic = i / nrc, jc = i - ic * nrc;
-            double v = -0.0;
-            if (jc > 0 && jc < nrc - 1 && ic > 0 && ic < nzc - 1) {
-                int ii = 2 * ic, jj = 2 * jc;
-                const CvC kk{V.dr2[l], V.dz2[l], V.two_dr[l], V.inv_dr2[l], V.inv_dz2[l], V.inv_two_dr[l]};
-                double c = -cv_resid(psi, rhs, rs, nrf, kk, ii, jj);
-                double up = -cv_resid(psi, rhs, rs, nrf, kk, ii - 1, jj), dn = -cv_resid(psi, rhs, rs, nrf, kk, ii + 1, jj);
-                double lf = -cv_resid(psi, rhs, rs, nrf, kk, ii, jj - 1), rt = -cv_resid(psi, rhs, rs, nrf, kk, ii, jj + 1);
-                double ul = -cv_resid(psi, rhs, rs, nrf, kk, ii - 1, jj - 1), ur = -cv_resid(psi, rhs, rs, nrf, kk, ii - 1, jj + 1);
-                double dl = -cv_resid(psi, rhs, rs, nrf, kk, ii + 1, jj - 1), dr_ = -cv_resid(psi, rhs, rs, nrf, kk, ii + 1, jj + 1);
-                v = fw9(c, up, dn, lf, rt, ul, ur, dl, dr_);
+        // (1) the defect -(L*psi - rhs) of every fine interior point, once, into the scratch field (the restriction stencils of
+        //     neighbouring coarse points overlap: evaluating it per coarse point costs 2.25x the arithmetic and LDS reads)
+        double* scr = lds + V.off_scr;
+        {
+            const CvC kk{V.dr2[l], V.dz2[l], V.two_dr[l], V.inv_dr2[l], V.inv_dz2[l], V.inv_two_dr[l]};
+            const int wi = nrf - 2, ni = (V.nz[l] - 2) * wi;
+            for (int i = threadIdx.x; i < ni; i += blockDim.x) {
+                const int iz = 1 + i / wi, ir = 1 + (i - (iz - 1) * wi);
+                scr[iz * nrf + ir] = -cv_resid(psi, rhs, rs, nrf, kk, iz, ir);
             }
-            rc[i] = v;
-            pc[i] = 0.0;
+        }
+        __syncthreads();
+        // (2) full weighting on the coarse interior (one point per thread up to 33x33), -0.0 on the coarse ring, coarse e = 0
+        {
+            const int wi = nrc - 2, ni = (nzc - 2) * wi;
+            for (int i = threadIdx.x; i < ni; i += blockDim.x) {
+                const int ic = 1 + i / wi, jc = 1 + (i - (ic - 1) * wi);
+                const double* d = scr + (2 * ic) * nrf + 2 * jc;
+                rc[ic * nrc + jc] = fw9(d[0], d[-nrf], d[nrf], d[-1], d[1], d[-nrf - 1], d[-nrf + 1], d[nrf - 1], d[nrf + 1]);
+            }
+            for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+                const int ic = i / nrc, jc = i - ic * nrc;
+                if (!(jc > 0 && jc < nrc - 1 && ic > 0 && ic < nzc - 1)) rc[i] = -0.0;
+                pc[i] = 0.0;
+            }
         }
         __syncthreads();
         CV_STAMP(3 + 2 * l);
@@ -1580,6 +1669,9 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
     __shared__ double sh[4];
     int b = blockIdx.z;
     if (!st[b].active) return;
+#if defined(TILE_SKIP) && (TILE_SKIP & 64)
+    if (nz > 0) return;
+#endif
     const double* psi = psiF.at(b);
     double* raw = rawF.base ? rawF.at(b) : nullptr;  // lazy-source mode: J_raw is kept, consumers apply scale and -mu0 R
     const double pa = st[b].psi_axis, den = st[b].denom, iden = st[b].inv_denom;
@@ -1773,6 +1865,9 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
     __shared__ VI sh_mx[4], sh_mn[4];
     __shared__ double sh_dsum[4], sh_m[4], sh_minp[4], sh_s2[4];
     __shared__ int sh_bad[4];
+#if defined(TILE_SKIP) && (TILE_SKIP & 32)
+    if (nblk > 0) return;
+#endif
     // XCD-aware tile order (see k_smooth_tile): XCD k gets a contiguous run of tiles so halo rows are re-read from its own L2
     int bx_, by_, b;
     {

@@ -307,7 +307,7 @@ static Hier& get_hier(Solver* h, int min_grid) {
         auto need = [&](int from) {
             size_t tot = 0;
             for (int l = from; l <= k; ++l) tot += 2 * (size_t)v[l]->nz * v[l]->nr + 4 * (size_t)v[l]->nr + 8;
-            return tot;
+            return tot + (size_t)v[from]->nz * v[from]->nr + 2;  // + the defect scratch of the top level
         };
         while (lc - 1 >= 1 && (k - (lc - 1) + 1) <= CV_MAX && need(lc - 1) <= budget) --lc;
         if (need(lc) <= budget && (k - lc + 1) <= CV_MAX) {
@@ -326,6 +326,7 @@ static Hier& get_hier(Solver* h, int min_grid) {
                 V.inv_a_c[i] = L->dev.inv_a_c; V.inv_dr2[i] = L->dev.inv_dr2; V.inv_dz2[i] = L->dev.inv_dz2; V.inv_two_dr[i] = L->dev.inv_two_dr;
                 V.a_e[i] = L->dev.a_e; V.a_w[i] = L->dev.a_w; V.r_safe[i] = L->dev.r_safe; V.r_inv[i] = L->dev.r_inv;
             }
+            V.off_scr = al(v[lc]->nz * v[lc]->nr);
             V.ld0 = v[lc]->ld;
             V.stride0 = v[lc]->stride;
             H.cv_lds = (size_t)off * sizeof(double);
