@@ -241,3 +241,28 @@ def test_resident_smoother_matches_operator_path():
         es.vcycle(omega=1.0)
         ref2 = multigrid_vcycle(ref, np.stack([source, source, 3 * source]), r, es.dR, es.dZ, omega=1.0)
         assert np.array_equal(es.get_psi(), ref2)
+
+
+def test_rccl_ensemble_gather_through_the_c_abi_on_one_rank():
+    """The exchange step of the multi-GPU path (include/scpn_hip.h section 4) with world_size 1: librccl is loaded by the library,
+    the communicator is initialised from a unique id, the all-gather of the resident psi blocks lands in a device buffer that
+    equals the solver's psi, and the max-reduction returns its input.  (More ranks need more GPUs than a test box has.)"""
+    from scpn_fusion_core_amd.distributed import EnsembleComm
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    comm = EnsembleComm(0, 1, 0, addr="127.0.0.1", port=0)  # world 1: no socket is opened
+    try:
+        info = comm.info()
+        assert (info["rank"], info["world"]) == (0, 1) and info["rccl_version"] > 20000
+        cfg = iter_like_cfg(65, tol=1e-6, max_iter=40)
+        with EnsembleSolver(cfg, batch=3, current_targets=np.array([15.0, 14.0, 16.0])) as es:
+            es.solve_equilibrium()
+            comm.allgather_psi(es)
+            got = comm.download((1, 3, 65, 65))
+            assert np.array_equal(got[0], es.get_psi())
+            comm.allgather_psi(es)  # a second gather reuses the receive buffer
+            comm.wait()
+        assert comm.allreduce_max(3.25) == 3.25
+        comm.barrier()
+    finally:
+        comm.close()
