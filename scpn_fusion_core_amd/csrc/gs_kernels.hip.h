@@ -1088,7 +1088,7 @@ struct CoarseV {
     int off_psi[CV_MAX], off_rhs[CV_MAX], off_tab[CV_MAX];  // LDS offsets (doubles); tab = a_e, a_w, r_safe, r_inv (4*nr)
     int off_scr;           // scratch of nz[0]*nr[0] doubles: the defect field between its evaluation and its restriction
     double a_ns[CV_MAX], a_c[CV_MAX], dr2[CV_MAX], dz2[CV_MAX], two_dr[CV_MAX];
-    double inv_a_c[CV_MAX], inv_dr2[CV_MAX], inv_dz2[CV_MAX], inv_two_dr[CV_MAX];
+    double inv_a_c[CV_MAX], inv_dr2[CV_MAX], inv_dz2[CV_MAX], inv_two_dr[CV_MAX], lo_a_c[CV_MAX];
     const double* r_inv[CV_MAX];
     const double* a_e[CV_MAX];
     const double* a_w[CV_MAX];
@@ -1096,95 +1096,125 @@ struct CoarseV {
     int ld0;       // pitch of the global level-lc arrays
     long stride0;
 };
+// a double moved along its 16-lane DPP row (CTRL 0x101+n-1: row_shl:n = value of lane+n; 0x111+n-1: row_shr:n = value of lane-n;
+// lanes whose source is outside the row receive 0)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const double* tab, int nz, int nr, double a_ns,
-                                          double a_c, double inv_a_c, double omega, double om1, int n_sweeps) {
+                                          double a_c, double inv_a_c, double lo_a_c, double omega, double om1, int n_sweeps) {
     const int hw = (nr - 2 + 1) / 2, tot = (nz - 2) * hw;
     const double* a_e = tab;
     const double* a_w = tab + nr;
-    if (nz * nr <= 64) {
-        // the whole level fits one wave (the 5x5 / 4x4 base case: 50 sweeps): one grid point per lane, value in a
-        // register, neighbours by wave shuffles -- no LDS round trip and no barrier per colour pass
+    const int wi = nr - 2, hi_ = nz - 2;  // interior width / height
+    if (wi <= 0 || hi_ <= 0) { __syncthreads(); return; }
+    if (wi * hi_ <= 64) {
+        // The interior fits one wave (9x9 level, 5x5 base case with its 50 sweeps): one interior point per lane, its value in
+        // a register for all passes, the four neighbours from the neighbouring lanes, ring neighbours as per-lane constants --
+        // no LDS round trip and no barrier per colour pass.  Interiors of at most 4x4 points sit in one 16-lane DPP row
+        // (lane = 4 * row + column): the neighbours come by row_shr / row_shl moves instead of ds_bpermute.
         if (threadIdx.x < 64) {
-            const int lane = threadIdx.x, n = nz * nr;
-            const int iz = lane / nr, ir = lane - iz * nr;
-            const bool in = lane < n, interior = in && iz >= 1 && iz <= nz - 2 && ir >= 1 && ir <= nr - 2;
-            double v = in ? psi[lane] : 0.0;
-            const double ae = interior ? a_e[ir] : 0.0, aw = interior ? a_w[ir] : 0.0, sv = interior ? rhs[lane] : 0.0;
+            const int lane = threadIdx.x;
+            const bool dpp = wi <= 4 && hi_ <= 4;
+            const int lw = dpp ? 4 : wi;  // lanes per interior row
+            const int rz = lane / lw, rr = lane - rz * lw;
+            const bool in = rz < hi_ && rr < wi;
+            const int iz = in ? rz + 1 : 1, ir = in ? rr + 1 : 1, c = iz * nr + ir;
+            double v = in ? psi[c] : 0.0;
+            const double ae = in ? a_e[ir] : 0.0, aw = in ? a_w[ir] : 0.0, sv = in ? rhs[c] : 0.0;
+            const bool hasE = in && ir < nr - 2, hasW = in && ir > 1, hasN = in && iz < nz - 2, hasS = in && iz > 1;
+            const double rE = (in && !hasE) ? psi[c + 1] : 0.0, rW = (in && !hasW) ? psi[c - 1] : 0.0;
+            const double rN = (in && !hasN) ? psi[c + nr] : 0.0, rS = (in && !hasS) ? psi[c - nr] : 0.0;
             const int par = (iz + ir) & 1;
-            for (int s = 0; s < 2 * n_sweeps; ++s) {
-                const double E = __shfl(v, lane + 1, 64), W = __shfl(v, lane - 1, 64);
-                const double S = __shfl(v, lane - nr, 64), N = __shfl(v, lane + nr, 64);
-                const double gs = divc(ae * E + aw * W + a_ns * S + a_ns * N - sv, a_c, inv_a_c);
-                const double nw = om1 * v + omega * gs;
-                if (interior && par == (s & 1)) v = nw;
-            }
-            if (in) psi[lane] = v;
-        }
-        __syncthreads();
-        return;
-    }
-    if (tot <= 64) {
-        // tiny level (9x9): one wave does every colour pass; LDS accesses of a single wave execute in order, so
-        // a wave-local fence replaces the 16-wave workgroup barrier of each pass
-        if (threadIdx.x < 64) {
-            for (int s = 0; s < 2 * n_sweeps; ++s) {
-                const int parity = s & 1;
-                for (int t = threadIdx.x; t < tot; t += 64) {
-                    int iz = 1 + t / hw, k = t - (iz - 1) * hw;
-                    int ir = 1 + ((iz + 1 + parity) & 1) + 2 * k;
-                    if (ir <= nr - 2) {
-                        int c = iz * nr + ir;
-                        double gs = divc(a_e[ir] * psi[c + 1] + a_w[ir] * psi[c - 1] + a_ns * psi[c - nr] + a_ns * psi[c + nr] - rhs[c], a_c, inv_a_c);
-                        psi[c] = om1 * psi[c] + omega * gs;
-                    }
+            if (dpp) {
+                for (int s = 0; s < 2 * n_sweeps; ++s) {
+                    // (the moves run with every lane enabled: a DPP read from a disabled lane returns 0)
+                    const double Ed = dpp_f64<0x101>(v), Wd = dpp_f64<0x111>(v);  // row_shl:1 / row_shr:1
+                    const double Nd = dpp_f64<0x104>(v), Sd = dpp_f64<0x114>(v);  // row_shl:4 / row_shr:4
+                    const double E = hasE ? Ed : rE, W = hasW ? Wd : rW, N = hasN ? Nd : rN, S = hasS ? Sd : rS;
+                    const double gs = divc4(ae * E + aw * W + a_ns * S + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
+                    const double nw = om1 * v + omega * gs;
+                    if (in && par == (s & 1)) v = nw;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+            } else {
+                for (int s = 0; s < 2 * n_sweeps; ++s) {
+                    const double Es = __shfl(v, lane + 1, 64), Ws = __shfl(v, lane - 1, 64);
+                    const double Ns = __shfl(v, lane + lw, 64), Ss = __shfl(v, lane - lw, 64);
+                    const double E = hasE ? Es : rE, W = hasW ? Ws : rW, N = hasN ? Ns : rN, S = hasS ? Ss : rS;
+                    const double gs = divc4(ae * E + aw * W + a_ns * S + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
+                    const double nw = om1 * v + omega * gs;
+                    if (in && par == (s & 1)) v = nw;
+                }
             }
+            if (in) psi[c] = v;
         }
         __syncthreads();
         return;
     }
     // Up to 2 column pairs per thread (65x65 on 1024 threads): the pair's coefficients, right-hand sides and OWN values stay in
     // registers for all passes.  A pass updates one column of the pair, whose E or W neighbour is the thread's other column, so
-    // an update costs three LDS reads (S, N and the neighbour outside the pair) and one write instead of eight reads and a write
-    // -- the level is bound by the CU's LDS bandwidth and the pass-to-pass latency, not by arithmetic.
+    // an update costs three LDS reads (S, N and the neighbour outside the pair) and one write.  Rows are dealt to the threads
+    // odd rows first, then even rows: the column a lane updates in a pass (e = row parity ^ pass parity) is then the same
+    // for a whole wave (for 2^k+1 grids even for the whole workgroup) and the update is compiled for e = 0 and e = 1 without
+    // per-lane selects; a wave that straddles the odd / even boundary of an odd-sized grid takes the select form.
     if (tot <= 2 * (int)blockDim.x) {
         constexpr int NJ = 2;
-        int c0[NJ], fl[NJ];
+        const int n_odd = (nz - 2 + 1) / 2;  // interior rows 1, 3, 5, ...
         bool ok0[NJ], ok1[NJ];
+        int fl[NJ];
         double ae0[NJ], ae1[NJ], aw0[NJ], aw1[NJ], s0[NJ], s1[NJ], v0[NJ], v1[NJ];
+        double* pc[NJ];  // &psi[row][col] of the pair's first column
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int t = threadIdx.x + j * blockDim.x;
             ok0[j] = t < tot;
-            const int iz = ok0[j] ? 1 + t / hw : 1, k = ok0[j] ? t - (iz - 1) * hw : 0, col = 1 + 2 * k;
+            const int rs = ok0[j] ? t / hw : 0, k = ok0[j] ? t - rs * hw : 0, col = 1 + 2 * k;
+            const int iz = rs < n_odd ? 1 + 2 * rs : 2 + 2 * (rs - n_odd);
             ok1[j] = ok0[j] && col + 1 <= nr - 2;
-            c0[j] = iz * nr + col;
+            const int c0 = iz * nr + col;
+            pc[j] = psi + c0;
             fl[j] = (iz + 1) & 1;
             ae0[j] = ok0[j] ? a_e[col] : 0.0; aw0[j] = ok0[j] ? a_w[col] : 0.0;
             ae1[j] = ok1[j] ? a_e[col + 1] : 0.0; aw1[j] = ok1[j] ? a_w[col + 1] : 0.0;
-            s0[j] = ok0[j] ? rhs[c0[j]] : 0.0; s1[j] = ok1[j] ? rhs[c0[j] + 1] : 0.0;
-            v0[j] = ok0[j] ? psi[c0[j]] : 0.0; v1[j] = ok0[j] ? psi[c0[j] + 1] : 0.0;  // (col + 1 <= nr - 1: ring or interior)
+            s0[j] = ok0[j] ? rhs[c0] : 0.0; s1[j] = ok1[j] ? rhs[c0 + 1] : 0.0;
+            v0[j] = ok0[j] ? psi[c0] : 0.0; v1[j] = ok0[j] ? psi[c0 + 1] : 0.0;  // (col + 1 <= nr - 1: ring or interior)
         }
         const int njs = tot <= (int)blockDim.x ? 1 : NJ;
         for (int s = 0; s < 2 * n_sweeps; ++s) {
             const int parity = s & 1;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if (j < njs) {
-                    const int e = fl[j] ^ parity;
-                    if (e ? ok1[j] : ok0[j]) {
-                        const int c = c0[j] + e;
-                        const double oth = psi[e ? c + 1 : c - 1];
-                        const double Sv = psi[c - nr], Nv = psi[c + nr];
-                        const double E = e ? oth : v1[j], W = e ? v0[j] : oth, C = e ? v1[j] : v0[j];
-                        const double gs = divc((e ? ae1[j] : ae0[j]) * E + (e ? aw1[j] : aw0[j]) * W + a_ns * Sv + a_ns * Nv - (e ? s1[j] : s0[j]),
-                                               a_c, inv_a_c);
-                        const double nw = om1 * C + omega * gs;
-                        if (e) v1[j] = nw; else v0[j] = nw;
-                        psi[c] = nw;
+                if (j >= njs) continue;
+                const int e = fl[j] ^ parity;
+                const unsigned long long mv = __ballot(ok0[j]), m1 = __ballot(ok0[j] && e);
+                double* const p = pc[j];
+                if (m1 == 0) {  // the wave updates the first column of its pairs: E is the lane's own second column
+                    if (ok0[j]) {
+                        const double gs = divc4(ae0[j] * v1[j] + aw0[j] * p[-1] + a_ns * p[-nr] + a_ns * p[nr] - s0[j], a_c, inv_a_c, lo_a_c);
+                        const double nw = om1 * v0[j] + omega * gs;
+                        v0[j] = nw;
+                        p[0] = nw;
                     }
+                } else if (m1 == mv) {  // the second column: W is the lane's own first column
+                    if (ok1[j]) {
+                        const double gs = divc4(ae1[j] * p[2] + aw1[j] * v0[j] + a_ns * p[1 - nr] + a_ns * p[1 + nr] - s1[j], a_c, inv_a_c, lo_a_c);
+                        const double nw = om1 * v1[j] + omega * gs;
+                        v1[j] = nw;
+                        p[1] = nw;
+                    }
+                } else if (e ? ok1[j] : ok0[j]) {  // mixed wave (odd-sized grids only)
+                    const double oth = p[e ? 2 : -1];
+                    const double Sv = p[e - nr], Nv = p[e + nr];
+                    const double E = e ? oth : v1[j], W = e ? v0[j] : oth, C = e ? v1[j] : v0[j];
+                    const double gs = divc4((e ? ae1[j] : ae0[j]) * E + (e ? aw1[j] : aw0[j]) * W + a_ns * Sv + a_ns * Nv - (e ? s1[j] : s0[j]),
+                                            a_c, inv_a_c, lo_a_c);
+                    const double nw = om1 * C + omega * gs;
+                    if (e) v1[j] = nw; else v0[j] = nw;
+                    p[e] = nw;
                 }
             }
             __syncthreads();
@@ -1259,36 +1289,39 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
     if (pre >= 0) return;
 #endif
     CV_STAMP(0);
-    // stage the coefficient tables of every level and the top-level rhs
-    for (int l = 0; l < V.n; ++l) {
-        double* tab = lds + V.off_tab[l];
-        for (int i = threadIdx.x; i < V.nr[l]; i += blockDim.x) {
-            tab[i] = V.a_e[l][i];
-            tab[V.nr[l] + i] = V.a_w[l][i];
-            tab[2 * V.nr[l] + i] = V.r_safe[l][i];
-            tab[3 * V.nr[l] + i] = V.r_inv[l][i];
-        }
-    }
+    // stage the top-level rhs and the coefficient tables of every level.  The first five rhs values of a thread (all of a 65x65
+    // level) are requested before the table loops run, so their round trip to memory overlaps the tables'
     {
-        // top-level rhs: batches of 5 loads per thread in flight (one round trip to memory for 65x65 instead of five)
         const double* g = rhsF.at(b);
         double* rhs = lds + V.off_rhs[0];
         double* psi = lds + V.off_psi[0];
         const int nz = V.nz[0], nr = V.nr[0], n = nz * nr;
         constexpr int RB = 5;
-        for (int i0 = threadIdx.x; i0 < n; i0 += RB * blockDim.x) {
-            double tmp[RB];
+        double tmp[RB];
 #pragma unroll
-            for (int k = 0; k < RB; ++k) {
-                const int i = min(i0 + k * (int)blockDim.x, n - 1);
-                const int iz = i / nr, ir = i - iz * nr;
-                tmp[k] = g[(long)iz * V.ld0 + ir];
+        for (int k = 0; k < RB; ++k) {
+            const int i = min((int)threadIdx.x + k * (int)blockDim.x, n - 1);
+            const int iz = i / nr, ir = i - iz * nr;
+            tmp[k] = g[(long)iz * V.ld0 + ir];
+        }
+        for (int l = 0; l < V.n; ++l) {
+            double* tab = lds + V.off_tab[l];
+            for (int i = threadIdx.x; i < V.nr[l]; i += blockDim.x) {
+                tab[i] = V.a_e[l][i];
+                tab[V.nr[l] + i] = V.a_w[l][i];
+                tab[2 * V.nr[l] + i] = V.r_safe[l][i];
+                tab[3 * V.nr[l] + i] = V.r_inv[l][i];
             }
+        }
 #pragma unroll
-            for (int k = 0; k < RB; ++k) {
-                const int i = i0 + k * (int)blockDim.x;
-                if (i < n) { rhs[i] = tmp[k]; psi[i] = 0.0; }
-            }
+        for (int k = 0; k < RB; ++k) {
+            const int i = threadIdx.x + k * (int)blockDim.x;
+            if (i < n) { rhs[i] = tmp[k]; psi[i] = 0.0; }
+        }
+        for (int i = threadIdx.x + RB * blockDim.x; i < n; i += blockDim.x) {  // levels beyond 5120 points
+            const int iz = i / nr, ir = i - iz * nr;
+            rhs[i] = g[(long)iz * V.ld0 + ir];
+            psi[i] = 0.0;
         }
     }
     __syncthreads();
@@ -1297,7 +1330,7 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
         double* psi = lds + V.off_psi[l];
         const double* rhs = lds + V.off_rhs[l];
         const double* tab = lds + V.off_tab[l];
-        cv_smooth(psi, rhs, tab, V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], omega, om1, pre);
+        cv_smooth(psi, rhs, tab, V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, pre);
         CV_STAMP(2 + 2 * l);
         // coarse rhs = restrict_full_weight(-(L*psi - rhs)); coarse e = 0
         double* rc = lds + V.off_rhs[l + 1];
@@ -1335,20 +1368,35 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
     }
     {
         const int l = V.n - 1;  // base case: 50 sweeps (multigrid_solve.py:293)
-        cv_smooth(lds + V.off_psi[l], lds + V.off_rhs[l], lds + V.off_tab[l], V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], omega, om1, 50);
+        cv_smooth(lds + V.off_psi[l], lds + V.off_rhs[l], lds + V.off_tab[l], V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, 50);
         CV_STAMP(20);
     }
     for (int l = V.n - 2; l >= 0; --l) {
         double* psi = lds + V.off_psi[l];
         const double* pc = lds + V.off_psi[l + 1];
         const int nzf = V.nz[l], nrf = V.nr[l], nzc = V.nz[l + 1], nrc = V.nr[l + 1], n = nzf * nrf;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            int iz = i / nrf, ir = i - iz * nrf;
-            psi[i] = psi[i] + prolong_at(pc, nrc, nzc, nrc, nzf, nrf, iz, ir);
+        // psi += P e, one thread per coarse cell: its four coarse corners are read once and serve the coincident fine point, the
+        // two edge midpoints and the cell centre (expressions and zero fill of prolong_at, core/multigrid_solve.py:117-143)
+        (void)n;
+        {
+            const int h_end = min(2 * (nrc - 1), nrf - 1), v_end = min(2 * (nzc - 1), nzf - 1);
+            for (int i = threadIdx.x; i < nzc * nrc; i += blockDim.x) {
+                const int ic = i / nrc, jc = i - ic * nrc;
+                const int fi = 2 * ic, fj = 2 * jc;
+                const bool jn = jc + 1 < nrc, in_ = ic + 1 < nzc;
+                const double c00 = pc[i], c01 = jn ? pc[i + 1] : 0.0, c10 = in_ ? pc[i + nrc] : 0.0, c11 = (jn && in_) ? pc[i + nrc + 1] : 0.0;
+                double* f = psi + fi * nrf + fj;
+                f[0] = f[0] + c00;
+                if (fj + 1 < nrf) f[1] = f[1] + ((fj + 1 >= h_end) ? 0.0 : 0.5 * (c00 + c01));
+                if (fi + 1 < nzf) {
+                    f[nrf] = f[nrf] + ((fi + 1 >= v_end) ? 0.0 : 0.5 * (c00 + c10));
+                    if (fj + 1 < nrf) f[nrf + 1] = f[nrf + 1] + ((fi + 1 >= v_end || fj + 1 >= h_end) ? 0.0 : 0.25 * (c00 + c10 + c01 + c11));
+                }
+            }
         }
         __syncthreads();
         CV_STAMP(21 + 2 * l);
-        cv_smooth(psi, lds + V.off_rhs[l], lds + V.off_tab[l], nzf, nrf, V.a_ns[l], V.a_c[l], V.inv_a_c[l], omega, om1, post);
+        cv_smooth(psi, lds + V.off_rhs[l], lds + V.off_tab[l], nzf, nrf, V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, post);
         CV_STAMP(22 + 2 * l);
     }
     {

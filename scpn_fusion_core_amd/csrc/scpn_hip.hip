@@ -323,7 +323,7 @@ static Hier& get_hier(Solver* h, int min_grid) {
                 V.off_rhs[i] = al(L->nz * L->nr);
                 V.off_tab[i] = al(4 * L->nr);
                 V.a_ns[i] = L->dev.a_ns; V.a_c[i] = L->dev.a_c; V.dr2[i] = L->dev.dr2; V.dz2[i] = L->dev.dz2; V.two_dr[i] = L->dev.two_dr;
-                V.inv_a_c[i] = L->dev.inv_a_c; V.inv_dr2[i] = L->dev.inv_dr2; V.inv_dz2[i] = L->dev.inv_dz2; V.inv_two_dr[i] = L->dev.inv_two_dr;
+                V.inv_a_c[i] = L->dev.inv_a_c; V.lo_a_c[i] = L->dev.lo_a_c; V.inv_dr2[i] = L->dev.inv_dr2; V.inv_dz2[i] = L->dev.inv_dz2; V.inv_two_dr[i] = L->dev.inv_two_dr;
                 V.a_e[i] = L->dev.a_e; V.a_w[i] = L->dev.a_w; V.r_safe[i] = L->dev.r_safe; V.r_inv[i] = L->dev.r_inv;
             }
             V.off_scr = al(v[lc]->nz * v[lc]->nr);
