@@ -1598,22 +1598,41 @@ __global__ void __launch_bounds__(256) k_topology(Fld psiF, const Member* st, in
 __global__ void __launch_bounds__(256) k_topology_final(Fld psiF, Member* st, const TopoPart* part, int nblk,
                                                         int nr, int ld, const double* r_axis,
                                                         const double* z_axis) {
-    __shared__ VI shv[4];
+    // One block per member on the dependent chain of every Picard iteration: the activity flag and the partials are requested
+    // together (one round trip), the three reductions share one barrier (same combination order as block_vi / block_max).
+    __shared__ VI shx[4], shn[4];
     __shared__ double shd[4];
-    int b = blockIdx.x;
-    if (!st[b].active) return;
+    const int b = blockIdx.x;
+    const int act = st[b].active;
     VI mx{0.0, -1}, mn{0.0, -1};
     double minpsi = INFINITY;
-    for (int i = threadIdx.x; i < nblk; i += 256) {
-        TopoPart t = part[(long)b * nblk + i];
+    if ((int)threadIdx.x < nblk) {
+        const TopoPart t = part[(long)b * nblk + threadIdx.x];
+        mx = VI{t.maxv, t.maxi};
+        mn = VI{t.minb, t.mini};
+        minpsi = t.minpsi;
+        if (mx.i < 0) mx = VI{0.0, -1};  // (what vi_max / vi_min against the empty start value would keep)
+        if (mn.i < 0) mn = VI{0.0, -1};
+    }
+    if (!act) return;
+    for (int i = threadIdx.x + 256; i < nblk; i += 256) {
+        const TopoPart t = part[(long)b * nblk + i];
         mx = vi_max(mx, VI{t.maxv, t.maxi});
         mn = vi_min(mn, VI{t.minb, t.mini});
         minpsi = fmin(minpsi, t.minpsi);
     }
-    VI rmx = block_vi<true, 256>(mx, shv);
-    VI rmn = block_vi<false, 256>(mn, shv);
-    double rmp = -block_max<256>(-minpsi, shd);
+    mx = wave_vi<true>(mx);
+    mn = wave_vi<false>(mn);
+    const double wmp = wave_max(-minpsi);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { shx[w] = mx; shn[w] = mn; shd[w] = wmp; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        VI rmx = shx[0], rmn = shn[0];
+        double rmp = shd[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) { rmx = vi_max(rmx, shx[i]); rmn = vi_min(rmn, shn[i]); rmp = fmax(rmp, shd[i]); }
+        rmp = -rmp;
         Member& m = st[b];
         const double* psi = psiF.at(b);
         double pa = rmx.i >= 0 ? rmx.v : 0.0;
@@ -1622,9 +1641,9 @@ __global__ void __launch_bounds__(256) k_topology_final(Fld psiF, Member* st, co
         if (rmn.i >= 0) {
             int iz = (int)(rmn.i / nr), ir = (int)(rmn.i - (long)iz * nr);
             pb = psi[(long)iz * ld + ir];
-            if (!finite_d(pb)) pb = nan_to_num300(pb);
-            xr = r_axis[ir];
+            xr = r_axis[ir];  // (the three loads are independent: one more round trip, not three)
             xz = z_axis[iz];
+            if (!finite_d(pb)) pb = nan_to_num300(pb);
         } else {
             pb = rmp;
         }
@@ -1763,15 +1782,18 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
 __global__ void __launch_bounds__(256) k_jsum_final(Member* st, const double* part, int nblk, double dr,
                                                     double dz) {
     __shared__ double sh[4];
-    int b = blockIdx.x;
-    if (!st[b].active) return;
+    const int b = blockIdx.x;
+    const int act = st[b].active;           // requested together with the partials and the target current: one round trip
+    const double itg = st[b].i_target;
     double s = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 256) s += part[(long)b * nblk + i];
+    if ((int)threadIdx.x < nblk) s += part[(long)b * nblk + threadIdx.x];
+    if (!act) return;
+    for (int i = threadIdx.x + 256; i < nblk; i += 256) s += part[(long)b * nblk + i];
     double tot = block_sum<256>(s, sh);
     if (threadIdx.x == 0) {
         double ic = (tot * dr) * dz;  // core/fusion_kernel.py:436
         st[b].i_current = ic;
-        st[b].jscale = fabs(ic) > 1e-9 ? st[b].i_target / ic : 0.0;
+        st[b].jscale = fabs(ic) > 1e-9 ? itg / ic : 0.0;
     }
 }
 // Source = (-mu0*R) * (J_raw * scale)  (core/fusion_kernel.py:440, newton_solver.py:513); optionally stores J_phi.
@@ -2212,43 +2234,74 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
                                                       int nblk_r, PicardCtl ctl, double* hist_diff,
                                                       double* hist_gs, double* trace, int* n_active, int* f_cur, int* f_nxt,
                                                       int* f_best, int* f_prev, int* f_active) {
-    __shared__ double sh[4];
-    __shared__ int shbad;
-    int b = blockIdx.x;
-    if (!st[b].active) return;
-    if (threadIdx.x == 0) shbad = 0;
-    __syncthreads();
-    double s = 0.0, rs = 0.0, rm = 0.0;
+    __shared__ double sh[4], sh2[4];
+    __shared__ int shbad[4];
+    const int b = blockIdx.x;
+    // everything the block reads is requested before the first wait: activity, the member record (thread 0 updates it below)
+    // and the partials -- one round trip; the (max, sum) residual partials stay in registers for the rescaling pass
+    const int act = st[b].active;
+    const int m_it = st[b].iterations, m_cur = st[b].cur, m_nxt = st[b].nxt, m_best = st[b].best, m_prev = st[b].prev;
+    const double m_gs_best = st[b].gs_best, m_diff_best = st[b].diff_best;
+    double s = 0.0, rs = 0.0, rm = 0.0, rm0 = 0.0, rq0 = 0.0;
     int bad = 0;
-    for (int i = threadIdx.x; i < nblk; i += 256) {
+    if ((int)threadIdx.x < nblk) {
+        s += psum[(long)b * nblk + threadIdx.x];
+        bad |= pbad[(long)b * nblk + threadIdx.x];
+    }
+    if ((int)threadIdx.x < nblk_r) {
+        rm0 = rmax[(long)b * nblk_r + threadIdx.x];
+        rq0 = rsum[(long)b * nblk_r + threadIdx.x];
+        rm = fmax(rm, rm0);
+    }
+    if (!act) return;
+    for (int i = threadIdx.x + 256; i < nblk; i += 256) {
         s += psum[(long)b * nblk + i];
         bad |= pbad[(long)b * nblk + i];
     }
-    for (int i = threadIdx.x; i < nblk_r; i += 256) rm = fmax(rm, rmax[(long)b * nblk_r + i]);
-    if (bad) atomicOr(&shbad, 1);
-    const double rmx_all = block_max_all<256>(rm, sh);  // M = max_b m_b
-    if (rmx_all > 0.0)
-        for (int i = threadIdx.x; i < nblk_r; i += 256) {
+    for (int i = threadIdx.x + 256; i < nblk_r; i += 256) rm = fmax(rm, rmax[(long)b * nblk_r + i]);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wbad = __any(bad) ? 1 : 0;
+    if (lane == 0) shbad[w] = wbad;
+    const double rmx_all = block_max_all<256>(rm, sh);  // M = max_b m_b  (its barriers also publish shbad)
+    if (rmx_all > 0.0) {
+        if ((int)threadIdx.x < nblk_r) {
+            const double f = rm0 / rmx_all;
+            rs += rq0 * (f * f);
+        }
+        for (int i = threadIdx.x + 256; i < nblk_r; i += 256) {
             const double f = rmax[(long)b * nblk_r + i] / rmx_all;
             rs += rsum[(long)b * nblk_r + i] * (f * f);
         }
+    }
+    // the two sums share one barrier (block_sum's combination order: wave totals added 0..3 by thread 0)
+    s = wave_sum(s);
+    rs = wave_sum(rs);
+    __syncthreads();  // (sh is still being read by block_max_all above)
+    if (lane == 0) { sh[w] = s; sh2[w] = rs; }
     __syncthreads();
-    double tot = block_sum<256>(s, sh);
-    double rtot = block_sum<256>(rs, sh);
+    double tot = 0.0, rtot = 0.0;
+    int anybad = 0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { tot += sh[i]; rtot += sh2[i]; anybad |= shbad[i]; }
+    }
     double rmx = rmx_all;
     if (threadIdx.x == 0) {
         Member& m = st[b];
-        const int it = m.iterations;  // iteration index lives on the device: kernel arguments stay constant (HIP graph replay)
+        const int it = m_it;  // iteration index lives on the device: kernel arguments stay constant
         m.iterations = it + 1;
-        if (shbad) {  // diverged: revert to best, stop (newton_solver.py:518-532); the Newton warm-up keeps Psi (:163-166)
+        if (anybad) {  // diverged: revert to best, stop (newton_solver.py:518-532); the Newton warm-up keeps Psi (:163-166)
+            int cur = m_cur, prev = m_prev;
             if (!ctl.pad) {
-                m.prev = m.cur;
-                m.cur = m.best;
+                prev = m_cur;
+                cur = m_best;
+                m.prev = prev;
+                m.cur = cur;
             }
             m.diverged = 1;
             m.active = 0;
             atomicSub(n_active, 1);
-            f_cur[b] = m.cur; f_nxt[b] = m.nxt; f_best[b] = m.best; f_prev[b] = m.prev; f_active[b] = 0;
+            f_cur[b] = cur; f_nxt[b] = m_nxt; f_best[b] = m_best; f_prev[b] = prev; f_active[b] = 0;
             return;
         }
         double diff = tot / (double)ctl.n_total;
@@ -2256,13 +2309,14 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
         double gs = rmx <= 0.0 ? 0.0 : rmx * sqrt(rtot / (double)ctl.n_interior);
         m.diff = diff;
         m.gs = gs;
-        if (gs < m.gs_best) m.gs_best = gs;
-        int old = m.cur;
-        m.prev = old;
-        m.cur = m.nxt;
-        if (diff < m.diff_best) { m.diff_best = diff; m.best = m.cur; }
+        if (gs < m_gs_best) m.gs_best = gs;
+        const int prev = m_cur, cur = m_nxt;
+        int best = m_best;
+        m.prev = prev;
+        m.cur = cur;
+        if (diff < m_diff_best) { m.diff_best = diff; best = cur; m.best = best; }
         int nx = 0;
-        for (int k = 0; k < 3; ++k) if (k != m.cur && k != m.best) { nx = k; break; }
+        for (int k = 0; k < 3; ++k) if (k != cur && k != best) { nx = k; break; }
         m.nxt = nx;
         if (hist_diff) hist_diff[(long)b * ctl.max_iter + it] = diff;
         if (hist_gs) hist_gs[(long)b * ctl.max_iter + it] = gs;
@@ -2272,10 +2326,12 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
         }
         bool upd = diff < ctl.tol;
         bool gsc = (!ctl.require_gs) || (gs < ctl.gs_tol);
-        if (upd && gsc) { m.converged = 1; m.active = 0; atomicSub(n_active, 1); }
-        else if (it + 1 >= ctl.max_iter) { m.active = 0; atomicSub(n_active, 1); }
+        int active = 1;
+        if (upd && gsc) { m.converged = 1; active = 0; }
+        else if (it + 1 >= ctl.max_iter) active = 0;
+        if (!active) { m.active = 0; atomicSub(n_active, 1); }
         // publish the slot indices / activity the field kernels index (was a separate k_publish_slots launch)
-        f_cur[b] = m.cur; f_nxt[b] = m.nxt; f_best[b] = m.best; f_prev[b] = m.prev; f_active[b] = m.active;
+        f_cur[b] = cur; f_nxt[b] = nx; f_best[b] = best; f_prev[b] = prev; f_active[b] = active;
     }
 }
 // copies the per-member slot indices into flat int arrays the kernels index (cur/nxt/best/prev/active)
