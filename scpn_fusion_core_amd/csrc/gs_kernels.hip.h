@@ -2233,10 +2233,25 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
                                                       const double* rmax, const double* rsum, int nblk,
                                                       int nblk_r, PicardCtl ctl, double* hist_diff,
                                                       double* hist_gs, double* trace, int* n_active, int* f_cur, int* f_nxt,
-                                                      int* f_best, int* f_prev, int* f_active) {
+                                                      int* f_best, int* f_prev, int* f_active, const TopoPart* topo, int ntopo,
+                                                      Fld psiF, int nr, int ld, const double* r_axis, const double* z_axis) {
+    // topo != nullptr: the kernel also finishes the axis / X-point search of the NEXT iteration (the work of k_topology_final on
+    // the partials the fused tail just produced) for the members that stay active -- one launch less on the dependent chain
     __shared__ double sh[4], sh2[4];
     __shared__ int shbad[4];
+    __shared__ VI shx[4], shn[4];
+    __shared__ double shd[4];
     const int b = blockIdx.x;
+    VI tmx{0.0, -1}, tmn{0.0, -1};
+    double tminpsi = INFINITY;
+    if (topo && (int)threadIdx.x < ntopo) {
+        const TopoPart t = topo[(long)b * ntopo + threadIdx.x];
+        tmx = VI{t.maxv, t.maxi};
+        tmn = VI{t.minb, t.mini};
+        tminpsi = t.minpsi;
+        if (tmx.i < 0) tmx = VI{0.0, -1};
+        if (tmn.i < 0) tmn = VI{0.0, -1};
+    }
     // everything the block reads is requested before the first wait: activity, the member record (thread 0 updates it below)
     // and the partials -- one round trip; the (max, sum) residual partials stay in registers for the rescaling pass
     const int act = st[b].active;
@@ -2273,11 +2288,22 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
             rs += rsum[(long)b * nblk_r + i] * (f * f);
         }
     }
-    // the two sums share one barrier (block_sum's combination order: wave totals added 0..3 by thread 0)
+    if (topo) {
+        for (int i = threadIdx.x + 256; i < ntopo; i += 256) {
+            const TopoPart t = topo[(long)b * ntopo + i];
+            tmx = vi_max(tmx, VI{t.maxv, t.maxi});
+            tmn = vi_min(tmn, VI{t.minb, t.mini});
+            tminpsi = fmin(tminpsi, t.minpsi);
+        }
+        tmx = wave_vi<true>(tmx);
+        tmn = wave_vi<false>(tmn);
+        tminpsi = wave_max(-tminpsi);
+    }
+    // the sums (and the topology candidates) share one barrier (block_sum's combination order: wave totals added 0..3 by thread 0)
     s = wave_sum(s);
     rs = wave_sum(rs);
     __syncthreads();  // (sh is still being read by block_max_all above)
-    if (lane == 0) { sh[w] = s; sh2[w] = rs; }
+    if (lane == 0) { sh[w] = s; sh2[w] = rs; shx[w] = tmx; shn[w] = tmn; shd[w] = tminpsi; }
     __syncthreads();
     double tot = 0.0, rtot = 0.0;
     int anybad = 0;
@@ -2332,6 +2358,30 @@ __global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* 
         if (!active) { m.active = 0; atomicSub(n_active, 1); }
         // publish the slot indices / activity the field kernels index (was a separate k_publish_slots launch)
         f_cur[b] = cur; f_nxt[b] = nx; f_best[b] = best; f_prev[b] = prev; f_active[b] = active;
+        if (topo && active) {  // k_topology_final for the next iteration, on the new current iterate
+            VI rmx = shx[0], rmn = shn[0];
+            double rmp = shd[0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) { rmx = vi_max(rmx, shx[i]); rmn = vi_min(rmn, shn[i]); rmp = fmax(rmp, shd[i]); }
+            rmp = -rmp;
+            const double* psi = psiF.base + ((long)cur * psiF.nb + b) * psiF.stride;
+            double pa = rmx.i >= 0 ? rmx.v : 0.0;
+            if (fabs(pa) < 1e-6) pa = 1e-6;
+            double pb, xr = 0.0, xz = 0.0;
+            if (rmn.i >= 0) {
+                int iz = (int)(rmn.i / nr), ir = (int)(rmn.i - (long)iz * nr);
+                pb = psi[(long)iz * ld + ir];
+                xr = r_axis[ir];
+                xz = z_axis[iz];
+                if (!finite_d(pb)) pb = nan_to_num300(pb);
+            } else {
+                pb = rmp;
+            }
+            if (fabs(pa - pb) < 0.1) pb = pa * 0.1;
+            double denom = pb - pa;  // core/fusion_kernel.py:415-417
+            if (fabs(denom) < 1e-9) denom = 1e-9;
+            m.psi_axis = pa; m.psi_bnd = pb; m.denom = denom; m.inv_denom = 1.0 / denom; m.x_idx = rmn.i; m.x_r = xr; m.x_z = xz;
+        }
     }
 }
 // copies the per-member slot indices into flat int arrays the kernels index (cur/nxt/best/prev/active)

@@ -928,8 +928,11 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         ~LazyGuard() { h->lazy_src = nullptr; }
     } lazy_guard{h};
     if (lazy) h->lazy_src = srcF.base;
+    // the fused tail (k_blend_fused) leaves the topology partials of the next iterate, and k_picard_final finishes them for the
+    // members that stay active: from the second iteration on there is no topology launch at all
+    const bool topo_in_final = h->use_fused && p->method != 3 && !p->xpoint_saddle;
     auto iteration = [&](bool first) {
-        {
+        if (first || !topo_in_final) {
             ProfScope ps(h, "topology", first || !h->use_fused || p->method == 3 || p->xpoint_saddle ? 2 : 1);
             int ntopo = topo_count;  // partial count produced by the previous iteration's fused tail
             if (first || !h->use_fused || p->method == 3 || p->xpoint_saddle) {  // later iterations get their partials from the fused blend kernel
@@ -1041,7 +1044,9 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             ProfScope ps(h, "picard_final", 1);
             SCPN_LAUNCH(k_picard_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_part1.p, (const int*)h->d_pbad.p,
                                (const double*)h->d_part2.p, (const double*)h->d_part3.p, nb_d, nb_r, ctl, d_hist_diff.p, d_hist_gs.p,
-                               d_trace.p, h->d_nactive.p, h->d_cur.p, h->d_nxt.p, h->d_best.p, h->d_prev.p, h->d_active.p);
+                               d_trace.p, h->d_nactive.p, h->d_cur.p, h->d_nxt.p, h->d_best.p, h->d_prev.p, h->d_active.p,
+                               topo_in_final ? (const TopoPart*)h->d_topo.p : (const TopoPart*)nullptr, nb_d, curF, nr, ld,
+                               (const double*)h->d_r.p, (const double*)h->d_z.p);
         }
     };
     int k = 0;
