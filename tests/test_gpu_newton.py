@@ -306,3 +306,29 @@ def test_newton_lane_short_warmup_over_the_scan_table(hip, n, B):
     scale = np.abs(psi_p).max(axis=(1, 2))
     assert (np.abs(psi_n - psi_p).max(axis=(1, 2)) <= 2e-8 * scale).all()
     assert max(sum(r["picard_iterations"]) for r in rn) <= 40
+
+
+@pytest.mark.parametrize("n", [129, 257])
+def test_newton_lane_h_mode_profiles(hip, n):
+    """mtanh pedestal profiles (core/fusion_kernel.py:376-440): the finite-difference Jacobian needs no profile derivative, the
+    multigrid-preconditioned lane converges to the Picard solution in a handful of Newton steps with and without line search."""
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    cfg = iter_like_cfg(n, tol=1e-8, max_iter=2000)
+    cfg["physics"]["profiles"] = {"mode": "h-mode", "p_prime": {"ped_top": 0.9, "ped_width": 0.05, "ped_height": 1.0, "core_alpha": 0.4},
+                                  "ff_prime": {"ped_top": 0.9, "ped_width": 0.05, "ped_height": 0.8, "core_alpha": 0.3}}
+    targets = np.array([15.0, 13.5])
+    with EnsembleSolver(cfg, batch=2, current_targets=targets) as es:
+        rp = es.solve_equilibrium()
+        psi_p = es.get_psi()
+    assert all(r["converged"] for r in rp)
+    for extra in ({"newton_warmup_steps": 2}, {"newton_line_search": True}):
+        c = {**cfg, "solver": {**cfg["solver"], "solver_method": "newton", "gmres_preconditioner": "multigrid", "newton_jacobian": "finite_difference",
+                               "newton_damping": 1.0, "max_iterations": 80, **extra}}
+        with EnsembleSolver(c, batch=2, current_targets=targets) as es:
+            rn = es.solve_equilibrium()
+            psi_n = es.get_psi()
+        warm = extra.get("newton_warmup_steps", 15)
+        for b in range(2):
+            assert rn[b]["converged"] and rn[b]["iterations"] <= warm + 12, (extra, b, rn[b]["iterations"])
+            assert np.abs(psi_n[b] - psi_p[b]).max() <= 2e-8 * np.abs(psi_p[b]).max(), (extra, b)
