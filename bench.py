@@ -122,10 +122,15 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     comm = None
+    comm_error = None
+    host_sync = None
     if world > 1 or os.environ.get("SCPN_BENCH_FORCE_DIST") == "1":  # (the override exercises the RCCL path on one rank)
         from scpn_fusion_core_amd.distributed import EnsembleComm
 
-        comm = EnsembleComm.from_env()  # TCP rendezvous of the RCCL id, then ncclCommInitRank on this rank's GPU
+        try:
+            comm = EnsembleComm.from_env()  # TCP rendezvous of the RCCL id, then ncclCommInitRank on this rank's GPU
+        except Exception as exc:  # no RCCL on this node: the ranks still solve their shards; the line says the gather did not run
+            comm_error = f"{type(exc).__name__}: {exc}"
 
     from scpn_fusion_core_amd import _lib
     from scpn_fusion_core_amd.cases import member_cfg, scan_member_table
@@ -142,11 +147,18 @@ def main() -> int:
     es = EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, device=local_rank)
     n_pts = args.grid * args.grid
 
+    if comm is None and world > 1:
+        from scpn_fusion_core_amd.distributed import HostSync
+
+        host_sync = HostSync.from_env()  # timing barrier over the rendezvous sockets only
+
     def barrier():
         es.sync()
         if comm is not None:
             comm.wait()     # the gather of the last step
             comm.barrier()  # RCCL all-reduce on the communicator's stream, waited for
+        elif host_sync is not None:
+            host_sync.barrier()
 
     def step():
         es.fill_psi(0.0)
@@ -166,6 +178,8 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
     if comm is not None:
         elapsed = comm.allreduce_max(elapsed)
+    elif host_sync is not None:
+        elapsed = host_sync.allreduce_max(elapsed)
 
     # member 0 of the last timed solve, kept for the full-size parity figure reported with the CPU baseline
     psi_gpu0 = es.get_psi(0) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
@@ -322,7 +336,7 @@ def main() -> int:
             "config": {"workload": f"ensemble of {B} ITER-like free-boundary equilibria per GPU, {args.grid}x{args.grid}, "
                                    "PF-coil Green's-function boundary, Picard+V-cycle tol 1e-8 (BASELINE configs[2]/[4])",
                        "grid": args.grid, "members_per_gpu": B, "global_members": B * world,
-                       "parallelism": f"ensemble-sharded x{world}", "rccl": comm.info() if comm is not None else None,
+                       "parallelism": f"ensemble-sharded x{world}", "rccl": comm.info() if comm is not None else ({"error": comm_error, "gather": "not run"} if comm_error else None),
                        "converged_members_rank0": n_conv, "outer_iterations": [min(outer), max(outer)],
                        "picard_iterations_per_member": [min(picard_total), max(picard_total)]},
         }

@@ -134,6 +134,27 @@ def gather_rows(rank: int, world: int, rows: np.ndarray, total: int, *, addr: st
     return np.concatenate(blocks, axis=0)
 
 
+class HostSync:
+    """Barrier / max-reduction over the rendezvous sockets alone (no device, no RCCL): what a launcher script or a benchmark falls
+    back to for its TIMING when the RCCL communicator cannot be created -- never a substitute for the psi gather."""
+
+    def __init__(self, rank: int, world: int, *, addr: str, port: int):
+        self.rank, self.world, self.addr, self.port = rank, world, addr, port
+
+    @classmethod
+    def from_env(cls, env=None) -> "HostSync":
+        env = os.environ if env is None else env
+        return cls(int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1")), addr=env.get("MASTER_ADDR", "127.0.0.1"),
+                   port=rendezvous_port(env))
+
+    def allreduce_max(self, value: float) -> float:
+        parts = exchange(self.rank, self.world, struct.pack("!d", float(value)), addr=self.addr, port=self.port)
+        return max(struct.unpack("!d", p)[0] for p in parts)
+
+    def barrier(self) -> None:
+        self.allreduce_max(0.0)
+
+
 # ------------------------------------------------------------------------------------------------- RCCL communicator
 class EnsembleComm:
     """The RCCL communicator of one rank (``scpn_comm_*``).  Create with :meth:`from_env` BEFORE the first device call of the
@@ -146,11 +167,18 @@ class EnsembleComm:
         self.rank, self.world, self.device, self.addr, self.port = rank, world, device, addr, port
         L = _lib.lib()
         ident = C.create_string_buffer(ID_BYTES)
+        payload = b""
         if rank == 0:
-            _lib.check(L.scpn_comm_unique_id(ident), "scpn_comm_unique_id")
-        got = exchange(rank, world, ident.raw if rank == 0 else b"", addr=addr, port=port)[0]
+            # a failure to create the id (no librccl on the node) is shipped to the other ranks in place of the id, so that every
+            # rank leaves the rendezvous with the same verdict instead of waiting for a server that never comes
+            try:
+                _lib.check(L.scpn_comm_unique_id(ident), "scpn_comm_unique_id")
+                payload = ident.raw
+            except Exception as exc:
+                payload = b"ERR " + str(exc).encode()[:200]
+        got = exchange(rank, world, payload, addr=addr, port=port)[0]
         if len(got) != ID_BYTES:
-            raise ConnectionError("rendezvous delivered a malformed RCCL id")
+            raise ConnectionError("no RCCL unique id from rank 0: " + (got[4:].decode(errors="replace") if got[:4] == b"ERR " else "malformed"))
         _lib.check(L.scpn_comm_init(rank, world, got, device), "scpn_comm_init")
         self._recv = None
         self._recv_bytes = 0

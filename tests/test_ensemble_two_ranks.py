@@ -46,7 +46,13 @@ def _worker(rank, world, port, out_dir):
     psi, table = solve_block(a, b)
     all_tab = gather_rows(rank, world, table, TOTAL, addr="127.0.0.1", port=port)
     all_psi = gather_rows(rank, world, psi.reshape(b - a, -1), TOTAL, addr="127.0.0.1", port=port).reshape(TOTAL, 17, 17)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), psi=all_psi, table=all_tab, ident=np.frombuffer(got, dtype=np.uint8))
+    # (3) the timing barrier / max-reduction a launcher falls back to when no RCCL communicator can be created
+    from scpn_fusion_core_amd.distributed import HostSync
+
+    hs = HostSync(rank, world, addr="127.0.0.1", port=port)
+    hs.barrier()
+    tmax = hs.allreduce_max(1.5 + rank)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), psi=all_psi, table=all_tab, ident=np.frombuffer(got, dtype=np.uint8), tmax=tmax)
 
 
 def test_two_rank_sharded_ensemble_matches_serial(tmp_path):
@@ -68,6 +74,7 @@ def test_two_rank_sharded_ensemble_matches_serial(tmp_path):
         assert got["psi"].shape == (TOTAL, 17, 17)
         assert np.array_equal(got["psi"], psi_ref) and np.array_equal(got["table"], tab_ref)
         assert np.array_equal(got["ident"], want_id)
+        assert float(got["tmax"]) == 2.5
 
 
 def test_gather_rows_rejects_wrong_block_size():
