@@ -96,6 +96,9 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
             "avg_launch_us": round(1e3 * tot_ms / tot_launch, 2), "launches": int(tot_launch),
             "groups": num_groups, "members_per_launch": int(members_per_launch), "isolated_kernel_timing": True,
             "counters": "profiles/ (SQ / FETCH / WRITE passes of tools/collect_profiles.sh)",
+            "limiter": "not HBM: counter traffic equals the compulsory bytes; fp64 VALU 57 % busy, LDS 46 %, colour passes at the "
+                       "CU's LDS bandwidth, load / sweep / defect phases of the resident workgroups only partly overlapped "
+                       "(DESIGN.md section 6, profiles/r02d_sq_by_kernel.csv, profiles/r02c_phase_costs.md)",
             "per_level": per_level, "families_ms": fam}
 
 
