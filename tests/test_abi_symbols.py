@@ -60,3 +60,20 @@ def test_product_package_never_imports_the_oracle():
     for f in list(pkg.glob("*.py")) + [q for q in (pkg / "csrc").glob("*") if q.is_file()]:
         src = f.read_text(errors="ignore")
         assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_scpn_fusion_rs_stand_in_exports_the_gpu_tier_surface(monkeypatch):
+    """integration/scpn_fusion_rs: the names benchmarks/bench_gpu_gs_solver.py:82-113 and the dispatcher's GPU tier import."""
+    import importlib
+    import sys
+    from pathlib import Path
+
+    monkeypatch.syspath_prepend(str(Path(__file__).resolve().parents[1] / "integration"))
+    sys.modules.pop("scpn_fusion_rs", None)
+    mod = importlib.import_module("scpn_fusion_rs")
+    try:
+        for name in ("PyGpuSolver", "py_gpu_available", "py_gpu_info", "multigrid_vcycle"):
+            assert hasattr(mod, name), name
+        assert isinstance(mod.py_gpu_available(), bool)
+    finally:
+        sys.modules.pop("scpn_fusion_rs", None)
