@@ -225,8 +225,12 @@ int scpn_gs_picard_solve(scpn_gs *h, const scpn_picard_params *p, scpn_picard_re
  * Picard warm-up (min(15, max_iter/2) SOR-step iterations), then Newton steps, each solving
  * (L - diag) delta = -r with restarted GMRES exactly as scipy.sparse.linalg.gmres (SciPy 1.15.3) runs
  * for core/fusion_kernel_solver_runtime.py:206-315 (restart 50, maxiter 100, atol 1e-8, rtol 1e-6;
- * preconditioner none | diagonal; "ilu" is not available on the device), psi += 0.5*delta or the
- * Armijo backtracking line search (:246-294).  p->method is ignored (the warm-up is the SOR branch). */
+ * preconditioner none | diagonal; "ilu": no incomplete LU on the device -- the host mirror takes the reference's
+ * own fallback to diagonal, solver_runtime.py:289-293), psi += 0.5*delta or the Armijo backtracking line search
+ * (:246-294).  p->method is ignored (the warm-up is the SOR branch).
+ * Extension lane of this library (opt-in): precond = 2 (one V-cycle(3,3) as left preconditioner;
+ * the first Krylov vector is the preconditioned right-hand side, a solve capped at gmres_restart x gmres_maxiter columns
+ * exits its last cycle on the Arnoldi estimate), reserved = 1 (finite-difference Jacobian action), newton_alpha = 1. */
 typedef struct scpn_newton_opts {
     int precond;            /* 0 none, 1 diagonal (solver.gmres_preconditioner), 2 one geometric V-cycle of the GS* operator
                              * (extension: the reference's JAX lane has this preconditioner, core/jax_multigrid_precond.py:208-276) */
