@@ -213,6 +213,37 @@ def main() -> int:
         except Exception as exc:  # the probe needs 2 GiB of free HBM; report, do not fail the bench line
             roofline["measured_copy_gbs"] = None
             roofline["copy_probe_error"] = str(exc)
+        # the same kernels with the chip filled by ONE launch: all members of this GPU in one stream group (the production run
+        # reaches this fill by overlapping its two groups).  HIP events again; the rocprofv3 durations of this configuration are
+        # profiles/*_isolated_kernel_times.csv (tools/isolated_kernel_times.sh), ~6 us per launch shorter (event pair + dispatch)
+        try:
+            old_groups = os.environ.get("SCPN_HIP_GROUPS")
+            os.environ["SCPN_HIP_GROUPS"] = "1"
+            try:
+                with EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, device=local_rank) as one:
+                    one.fill_psi(0.0)
+                    one.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
+                    one.fill_psi(0.0)
+                    one.profile(True)
+                    one.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
+                    fam1 = one.profile_report()
+                    one.profile(False)
+            finally:
+                if old_groups is None:
+                    os.environ.pop("SCPN_HIP_GROUPS", None)
+                else:
+                    os.environ["SCPN_HIP_GROUPS"] = old_groups
+            full = {}
+            for name, (key, bpp) in {"smooth_tile_L0_pre": ("smooth_pre", 28.0), "smooth_tile_L0_post": ("smooth_post", 26.0),
+                                     "blend_fused": ("blend_fused", 32.0)}.items():
+                if name in fam1 and fam1[name]["launches"]:
+                    us = 1e3 * fam1[name]["ms"] / fam1[name]["launches"]
+                    gbs = bpp * n_pts * B / us / 1e3
+                    full[name] = {"avg_launch_us": round(us, 2), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                  "frac_of_measured_copy": round(gbs / roofline["measured_copy_gbs"], 4) if roofline.get("measured_copy_gbs") else None}
+            roofline["one_group_all_members"] = {"members_per_launch": B, "timing": "HIP events", "kernels": full}
+        except Exception as exc:
+            roofline["one_group_all_members"] = {"error": str(exc)}
 
     # ---- CPU baseline: the C oracle (port of the reference algorithm) on the host cores of this GPU's share: one full
     #      free-boundary solve per core, `cores` members solved concurrently (ctypes releases the GIL during the C call)
