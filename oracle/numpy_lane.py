@@ -70,10 +70,10 @@ def restrict_fw(fine: np.ndarray) -> np.ndarray:
     c = lambda dz, dr: fine[2 + dz : 2 + dz + 2 * (nz_c - 2) : 2, 2 + dr : 2 + dr + 2 * (nr_c - 2) : 2]  # noqa: E731
     coarse[1:-1, 1:-1] = (4.0 * c(0, 0) + 2.0 * (c(-1, 0) + c(1, 0) + c(0, -1) + c(0, 1))
                           + (c(-1, -1) + c(-1, 1) + c(1, -1) + c(1, 1))) / 16.0
-    coarse[0, :] = fine[0, ::2][:nr_c]
-    coarse[-1, :] = fine[-1, ::2][:nr_c]
-    coarse[:, 0] = fine[::2, 0][:nz_c]
-    coarse[:, -1] = fine[::2, -1][:nz_c]
+    # ring: injection of every second fine ring value (first / last fine row and column)
+    for edge in (0, -1):
+        coarse[edge, :] = fine[edge, ::2][:nr_c]
+        coarse[:, edge] = fine[::2, edge][:nz_c]
     return coarse
 
 
