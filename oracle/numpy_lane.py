@@ -71,8 +71,10 @@ def restrict_fw(fine: np.ndarray) -> np.ndarray:
     coarse[1:-1, 1:-1] = (4.0 * c(0, 0) + 2.0 * (c(-1, 0) + c(1, 0) + c(0, -1) + c(0, 1))
                           + (c(-1, -1) + c(-1, 1) + c(1, -1) + c(1, 1))) / 16.0
     # ring: injection of every second fine ring value (first / last fine row and column)
+    # (rows first, then columns: for even fine sizes the corners take the column's value)
     for edge in (0, -1):
         coarse[edge, :] = fine[edge, ::2][:nr_c]
+    for edge in (0, -1):
         coarse[:, edge] = fine[::2, edge][:nz_c]
     return coarse
 
