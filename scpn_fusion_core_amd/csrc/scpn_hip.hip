@@ -921,7 +921,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     static const bool lazy_env = [] { const char* e = std::getenv("SCPN_HIP_LAZYSRC"); return !(e && e[0] == '0'); }();
     static const bool srcgen_env0 = [] { const char* e = std::getenv("SCPN_HIP_SRCGEN"); return e && e[0] == '1'; }();
     static const bool blend_env0 = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1'; }();
-    const bool lazy = lazy_env && !srcgen_env0 && !blend_env0 && h->use_fused && p->method == 0 && !p->external_profile_mode &&
+    const bool lazy = lazy_env && !srcgen_env0 && h->use_fused && p->method == 0 && !p->external_profile_mode &&
                       vcycle_lazy_ok(h, 3, 3, 5);
     struct LazyGuard {
         Solver* h;
@@ -969,7 +969,11 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         // _elliptic_solve (iterative_solver.py:361-380)
         Fld newF = WF;
         // blend + norms + topology inside the post-smoother is implemented and bit-identical to k_blend_fused, but at one
-        // 16-wave workgroup per CU its extra compute is not hidden (160.8 vs 172.3 eq/s measured): opt-in (SCPN_HIP_BLENDFUSE=1)
+        // 16-wave workgroup per CU its extra compute is not hidden (160.8 vs 172.3 eq/s measured): opt-in (SCPN_HIP_BLENDFUSE=1).
+        // Round 2, 40-row tiles + lazy source: 344.5 vs 353-357 us per iteration (-2.7 %), but its residual sum squares r
+        // unscaled (overflow above |r| ~ 1e154, where k_blend_fused stays finite) and making it safe (power-of-two scaling by the
+        // previous residual) costs the gain back (347-350 vs 351-353): the kernel sits at its 80-VGPR cap with 36 B of scratch and
+        // every added live value shows.  Still opt-in.
         static const bool blend_env = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1'; }();
         const bool blend_in_tile = blend_env && p->method == 0 && vcycle_can_blend(h, 3, 5);
         int nb_d = nblk1, nb_r = nblk_r;
