@@ -508,12 +508,15 @@ __global__ void __launch_bounds__(256) k_gm_matvec(double* out, const double* vi
 // renormalisation on psi -- so its Newton step needs the fixed 0.5 damping and converges linearly (rate 0.5).  With
 //   J v = L*v - (S(psi + eps v) - S(psi)) / eps
 // the step is a true Newton step.  eps_b = 1e-7 * sqrt(n_interior) * max(|psi_axis|, 1e-6) / ||v||_2 keeps eps*v at 1e-7 of psi.
+// part == nullptr: v is a Krylov basis vector (unit 2-norm by construction), no norm pass was run.  The kernel also copies the
+// member record into the scratch table the perturbed topology / current sum are written to (was a device-to-device memcpy).
 __global__ void __launch_bounds__(256) k_fd_eps(double* eps, const double* part, int nblk, const Member* st, double n_interior,
-                                                const GmState* gm) {
+                                                const GmState* gm, Member* scratch) {
     __shared__ double sh[4];
     const int b = blockIdx.x;
+    if (scratch && threadIdx.x == 64) scratch[b] = st[b];
     if (!gm[b].solve_on) return;
-    const double tot = sum_partials(part + (long)b * nblk, nblk, sh);
+    const double tot = part ? sum_partials(part + (long)b * nblk, nblk, sh) : 1.0;
     if (threadIdx.x == 0) eps[b] = tot > 0.0 ? 1e-7 * sqrt(n_interior) * fmax(fabs(st[b].psi_axis), 1e-6) / sqrt(tot) : 0.0;
 }
 // out = psi + eps_b * v over the whole member stride (v has a zero ring: the Dirichlet data are untouched)

@@ -1280,7 +1280,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         };
         // A v (resid_mode 0, into `out`, with the partial sums of |out|^2 in P0) or rhs - A x (resid_mode 1)
         const bool fd = o->reserved == 1 && !p->external_profile_mode;
-        auto matvec = [&](double* out, const double* vin, int resid_mode) {
+        auto matvec = [&](double* out, const double* vin, int resid_mode, bool unit_norm = false) {
             if (!fd) {
                 SCPN_LAUNCH(k_gm_matvec, g2, BLK2D, 0, st, out, vin, (const double*)buf(DG), (const double*)buf(IVD), (const double*)buf(RHS), stride,
                                    L0, (const GmState*)h->nt_gm.p, precond, resid_mode, P0);
@@ -1292,13 +1292,13 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
             DBuf<Member>& scr = h->d_scr_st;
             scr.alloc(B);
             h->d_scr_diff.alloc(B);
-            SCPN_LAUNCH(k_gm_start, gflat, dim3(256), 0, st, (double*)nullptr, vin, (const double*)buf(IVD), stride, (const GmState*)h->nt_gm.p, 0, 1,
-                               P1, nbf);
-            SCPN_LAUNCH(k_fd_eps, dim3(B), dim3(256), 0, st, h->d_scr_diff.p, (const double*)P1, nbf, (const Member*)h->d_st.p,
-                               (double)((long)(nz - 2) * (nr - 2)), (const GmState*)h->nt_gm.p);
+            if (!unit_norm)  // (Krylov basis vectors have unit norm: no pass over v for them)
+                SCPN_LAUNCH(k_gm_start, gflat, dim3(256), 0, st, (double*)nullptr, vin, (const double*)buf(IVD), stride, (const GmState*)h->nt_gm.p,
+                                   0, 1, P1, nbf);
+            SCPN_LAUNCH(k_fd_eps, dim3(B), dim3(256), 0, st, h->d_scr_diff.p, unit_norm ? (const double*)nullptr : (const double*)P1, nbf,
+                               (const Member*)h->d_st.p, (double)((long)(nz - 2) * (nr - 2)), (const GmState*)h->nt_gm.p, scr.p);
             SCPN_LAUNCH(k_fd_perturb, dim3(std::min(cdiv(stride, 512), 1024), B), dim3(256), 0, st, pF, curF, vin, stride,
                                (const double*)h->d_scr_diff.p, (const GmState*)h->nt_gm.p);
-            HIP_TRY(hipMemcpyAsync(scr.p, h->d_st.p, sizeof(Member) * B, hipMemcpyDeviceToDevice, st));
             SCPN_LAUNCH(k_topology, dim3(nblk1, B), dim3(256), 0, st, pF, (const Member*)scr.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
                                h->d_topo.p, nblk1);
             SCPN_LAUNCH(k_topology_final, dim3(B), dim3(256), 0, st, pF, scr.p, (const TopoPart*)h->d_topo.p, nblk1, nr, ld,
@@ -1372,7 +1372,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
                 int nb_first = nb2;  // number of partial sums of |w|^2 the first MGS launch reads
                 {
                     ProfScope ps(h, "gmres_matvec", 1);
-                    matvec(mg ? buf(TMPV) : buf(WV), (const double*)(V + (long)col * n), 0);
+                    matvec(mg ? buf(TMPV) : buf(WV), (const double*)(V + (long)col * n), 0, true);
                 }
                 if (mg) {  // w = M^-1 (A v): V-cycle, then the copy into w together with the partial sums of |w|^2
                     const double* z = apply_mg(buf(TMPV));
