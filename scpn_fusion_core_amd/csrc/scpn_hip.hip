@@ -1416,7 +1416,8 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         resid(rkF, srcF, 0);
         n_on = poll(d_non);
         if (n_on == 0) break;
-        {
+        // (finite-difference operator + multigrid preconditioner: neither the profile-Jacobian diagonal nor its inverse is read)
+        if (!(o->precond == 2 && o->reserved == 1 && !p->external_profile_mode)) {
             ProfScope ps(h, "newton_jacobian", 2);
             if (!p->external_profile_mode)
                 SCPN_LAUNCH(k_nt_jac_sum, dim3(nblk1, B), dim3(256), 0, st, curF, (const Member*)h->d_st.p, (const NtMember*)h->nt_st.p, nz, nr,
