@@ -1361,7 +1361,8 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         const int pe_mg = mg ? 1 : pe;  // a preconditioned solve takes a handful of columns: look at the inner flag after every one
         for (int cyc = 0; cyc < maxit; ++cyc) {
             SCPN_LAUNCH(k_gm_count, dim3(1), dim3(64), 0, st, (const GmState*)h->nt_gm.p, B, d_nsolve, d_ninner);
-            if (poll(d_nsolve) == 0) break;
+            // (multigrid lane, first cycle: no host round trip -- members with nothing to solve are masked on the device anyway)
+            if (!(mg && cyc == 0) && poll(d_nsolve) == 0) break;
             if (!(mg && cyc == 0)) {  // (multigrid, cycle 0: V[0] and its partial sums are already there from the prologue)
                 const double* pr = mg ? apply_mg(buf(RES)) : (const double*)buf(RES);
                 SCPN_LAUNCH(k_gm_start, gflat, dim3(256), 0, st, V, pr, (const double*)buf(IVD), stride,
@@ -1450,7 +1451,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
             SCPN_LAUNCH(k_nt_step, g2, BLK2D, 0, st, curF, curF, dxF, bcF, (const NtMember*)h->nt_st.p, nz, nr, ld, 0, 0.0, h->nt_pbad.p);
             step_check();
         }
-        n_on = poll(d_non);
+        // (no poll here: the one after the next iteration's residual sees the members this step switched off)
     }
     HIP_TRY(hipStreamSynchronize(st));
 
