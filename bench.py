@@ -124,6 +124,8 @@ def main() -> int:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SCPN_BENCH_DEVICE") is not None:  # rehearsal of the N>1 launch on a one-GPU box: every rank on this device
+        local_rank = int(os.environ["SCPN_BENCH_DEVICE"])
     comm = None
     comm_error = None
     host_sync = None
@@ -131,7 +133,7 @@ def main() -> int:
         from scpn_fusion_core_amd.distributed import EnsembleComm
 
         try:
-            comm = EnsembleComm.from_env()  # TCP rendezvous of the RCCL id, then ncclCommInitRank on this rank's GPU
+            comm = EnsembleComm.from_env({**os.environ, "LOCAL_RANK": str(local_rank)})  # TCP rendezvous of the RCCL id, then ncclCommInitRank on this rank's GPU
         except Exception as exc:  # no RCCL on this node: the ranks still solve their shards; the line says the gather did not run
             comm_error = f"{type(exc).__name__}: {exc}"
 
