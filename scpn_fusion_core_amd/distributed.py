@@ -18,6 +18,7 @@ import ctypes as C
 import os
 import socket
 import struct
+import sys
 import time
 
 import numpy as np
@@ -179,7 +180,22 @@ class EnsembleComm:
         got = exchange(rank, world, payload, addr=addr, port=port)[0]
         if len(got) != ID_BYTES:
             raise ConnectionError("no RCCL unique id from rank 0: " + (got[4:].decode(errors="replace") if got[:4] == b"ERR " else "malformed"))
-        _lib.check(L.scpn_comm_init(rank, world, got, device), "scpn_comm_init")
+        # RCCL prints a version banner on the C stdout of rank 0 while it initialises; callers of this module own stdout (bench.py
+        # prints exactly one JSON line there), so fd 1 points at stderr for the duration of the call and C stdio is flushed
+        # before it is restored
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            rc = L.scpn_comm_init(rank, world, got, device)
+            try:
+                C.CDLL(None).fflush(None)
+            except Exception:
+                pass
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        _lib.check(rc, "scpn_comm_init")
         self._recv = None
         self._recv_bytes = 0
 
