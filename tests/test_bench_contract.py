@@ -35,6 +35,15 @@ def test_roofline_and_cpu_baseline_objects():
     assert r["alg_bytes_per_launch"] > r["alg_bytes_per_point"] * 513 * 513 * r["members_per_launch"] / 3
     # the HBM fraction is a statement about bytes really moved: it can never exceed the peak
     assert r["frac"] <= 1.0 and all(v["achieved"] <= r["peak"] for v in r["per_level"].values())
+    # measured bandwidth beside the nominal peak, and the full-fill launches (all members in one launch) beside the 16-member ones
+    assert 1000.0 < r["measured_copy_gbs"] < r["peak"] and r["measured_read_gbs"] > 1000.0
+    full = r["one_group_all_members"]
+    assert full["members_per_launch"] == d["config"]["members_per_gpu"]
+    for k in full["kernels"].values():
+        assert 0.0 < k["frac"] <= 1.0 and abs(k["frac"] - k["achieved"] / r["peak"]) < 1e-3
+    assert isinstance(r["limiter"], str) and r["limiter"]
+    n = d["newton_fd_mg"]  # the Newton lane beside the metric: same ensemble, same converged equilibria
+    assert n["converged_members"] == d["config"]["members_per_gpu"] and n["psi_rel_linf_vs_picard"] < 1e-7 and n["value"] > d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
 
