@@ -126,6 +126,20 @@ def test_vcycle_vs_oracle_bit_exact(mgs, orc, shape):
     assert mgs.residual_linf(out, source, rr, dr, dz) == orc.residual_linf(ref, source, rr, dr, dz)
 
 
+def test_vcycle_random_shapes_vs_oracle_bit_exact(mgs, orc):
+    """48 seeded shapes between 9 and 150 points per side (odd, even, non-square), omega 1.0 / 1.25 / 1.6: every branch of the in-LDS
+    coarse kernel (register smoother with wave-uniform and mixed column choice, one-point-per-lane levels with wave shuffles or DPP
+    row moves, scratch-field defect, per-cell prolongation) and of the tile path is visited by some shape."""
+    rng = np.random.default_rng(20260410)
+    shapes = [(int(a), int(b)) for a, b in rng.integers(9, 151, size=(40, 2))] + [(9, 9), (10, 10), (11, 12), (12, 37), (33, 65), (65, 33), (17, 150), (150, 17)]
+    for k, (nz, nr) in enumerate(shapes):
+        psi, source, rr, dr, dz = operator_problem(nz, nr)
+        omega = (1.0, 1.25, 1.6)[k % 3]
+        ref = orc.multigrid_vcycle(psi, source, rr, dr, dz, omega=omega)
+        out = mgs.multigrid_vcycle(psi, source, rr, dr, dz, omega=omega)
+        assert np.array_equal(out, ref), (nz, nr, omega)
+
+
 def test_vcycle_batched_with_frozen_members_matches_oracle(mgs, orc):
     # multigrid_solve with members that converge at different cycles exercises the pass-through of frozen members
     n = 129
