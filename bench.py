@@ -121,9 +121,37 @@ def main() -> int:
     ap.add_argument("--no-newton", action="store_true", help="skip the Newton-lane figure reported beside the metric")
     args = ap.parse_args()
 
+    # ---- `python bench.py --gpus N` with nobody having started the ranks: this process becomes the launcher.  It has not
+    #      touched a GPU (nothing of the package is imported yet); it starts N fresh children of itself, one rank per GPU, with
+    #      RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, forwards rank 0's JSON line and fails if any rank fails
+    #      or if the line does not say n_gpus == N.  Under `python -m torch.distributed.run` WORLD_SIZE is already set.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        from scpn_fusion_core_amd.distributed import spawn_ranks
+
+        rc, out = spawn_ranks([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], args.gpus)
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        for ln in out.splitlines():
+            if not ln.startswith("{"):
+                print(ln, file=sys.stderr)
+        if not lines:
+            print(f"bench.py: rank 0 printed no result line (exit code {rc})", file=sys.stderr)
+            return rc or 1
+        print(lines[-1])
+        if json.loads(lines[-1]).get("n_gpus") != args.gpus:
+            print(f"bench.py: the result line does not report n_gpus == {args.gpus}", file=sys.stderr)
+            return rc or 1
+        return rc
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (or drop WORLD_SIZE and let "
+              "bench.py start them)", file=sys.stderr)
+        return 2
+    # two stream groups per resident handle + a second handle alive during the Newton lane: ask the HIP runtime for 8 hardware
+    # queues (default 4) before this process's first device call -- the library itself never touches the environment
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if os.environ.get("SCPN_BENCH_DEVICE") is not None:  # rehearsal of the N>1 launch on a one-GPU box: every rank on this device
         local_rank = int(os.environ["SCPN_BENCH_DEVICE"])
     comm = None
@@ -134,8 +162,8 @@ def main() -> int:
 
         try:
             comm = EnsembleComm.from_env({**os.environ, "LOCAL_RANK": str(local_rank)})  # TCP rendezvous of the RCCL id, then ncclCommInitRank on this rank's GPU
-        except Exception as exc:  # no RCCL on this node: the ranks still solve their shards; the line says the gather did not run
-            comm_error = f"{type(exc).__name__}: {exc}"
+        except Exception as exc:  # no communicator (EVERY rank gets the same verdict: EnsembleComm exchanges it): the ranks still
+            comm_error = f"{type(exc).__name__}: {exc}"  # solve their shards, the line says the gather did not run and is marked invalid
 
     from scpn_fusion_core_amd import _lib
     from scpn_fusion_core_amd.cases import member_cfg, scan_member_table
@@ -170,7 +198,7 @@ def main() -> int:
         res = es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
         if comm is not None:  # ensemble gather of the psi blocks over RCCL/xGMI (the path's only exchange step): launched
             comm.wait()       # asynchronously, it runs while the next step solves; every gather ends inside the timed region
-            comm.allgather_psi(es)
+            comm.allgather_psi(es, total=B * world)
         return res
 
     for _ in range(args.warmup):
@@ -207,11 +235,12 @@ def main() -> int:
         es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
         fam = es.profile_report()
         es.profile(False)
-        roofline = roofline_of(fam, args.grid, B / es.num_groups, es.num_groups)
+        roofline = roofline_of(fam, args.grid, B / es.num_groups, es.num_groups) or {"error": "empty profile report"}
         try:
             roofline["measured_copy_gbs"] = round(_lib.copy_bandwidth_probe(mode=0), 1)
             roofline["measured_read_gbs"] = round(_lib.copy_bandwidth_probe(mode=1), 1)
-            roofline["frac_of_measured_copy"] = round(roofline["achieved"] / roofline["measured_copy_gbs"], 4)
+            if "achieved" in roofline:
+                roofline["frac_of_measured_copy"] = round(roofline["achieved"] / roofline["measured_copy_gbs"], 4)
         except Exception as exc:  # the probe needs 2 GiB of free HBM; report, do not fail the bench line
             roofline["measured_copy_gbs"] = None
             roofline["copy_probe_error"] = str(exc)
@@ -384,11 +413,14 @@ def main() -> int:
             line["parity"] = parity
         if newton is not None:
             line["newton_fd_mg"] = newton
+        if world > 1 and comm is None:  # the N>1 metric includes the ensemble gather: without it the line is not a scaling point
+            line["valid"] = False
+            line["n_gpus_gathered"] = 0
         print(json.dumps(line))
     es.close()
     if comm is not None:
         comm.close()
-    return 0
+    return 3 if (world > 1 and comm is None) else 0
 
 
 if __name__ == "__main__":

@@ -328,9 +328,11 @@ int scpn_gs_num_groups(scpn_gs *h);
 int scpn_comm_unique_id(char *id128);
 int scpn_comm_init(int rank, int world, const char *id128, int device); /* selects `device` for this process */
 int scpn_comm_info(int *rank, int *world, int *rccl_version);           /* as RCCL sees them */
-/* pack + ncclAllGather of psi: recv_device = [world][batch][nz][nr] doubles on this GPU; asynchronous on the communicator's
- * stream (overlaps the next solve) -- scpn_comm_wait() before the buffer is read or the next gather is issued */
-int scpn_comm_allgather_psi(scpn_gs *h, void *recv_device);
+/* pack + ncclAllGather of psi: every rank sends a block of `per_rank_members` members (>= its own batch; the rank that owns the
+ * short last block of an uneven ensemble is padded with zeros, so all ranks issue the same count), recv_device =
+ * [world][per_rank_members][nz][nr] doubles on this GPU; asynchronous on the communicator's stream, ordered behind the solver
+ * streams by events (overlaps the next solve) -- scpn_comm_wait() before the buffer is read or the next gather is issued */
+int scpn_comm_allgather_psi(scpn_gs *h, int per_rank_members, void *recv_device);
 int scpn_comm_wait(void);
 int scpn_comm_allreduce_max(double *value); /* in place, blocking: the max-over-ranks of a timing and the barrier */
 int scpn_comm_finalize(void);

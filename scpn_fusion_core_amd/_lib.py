@@ -142,7 +142,7 @@ SIGNATURES = {
     "scpn_comm_unique_id": (_i, [C.c_char_p]),
     "scpn_comm_init": (_i, [_i, _i, C.c_char_p, _i]),
     "scpn_comm_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
-    "scpn_comm_allgather_psi": (_i, [_vp, _vp]),
+    "scpn_comm_allgather_psi": (_i, [_vp, _i, _vp]),
     "scpn_comm_wait": (_i, []),
     "scpn_comm_allreduce_max": (_i, [C.POINTER(_d)]),
     "scpn_comm_finalize": (_i, []),

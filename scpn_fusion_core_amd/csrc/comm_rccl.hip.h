@@ -9,7 +9,22 @@
 #pragma once
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>  // types and enums only: every entry point is resolved through dlsym
+#include <vector>
+
+// The handful of RCCL / NCCL ABI types this file needs, declared here so that the library (single-GPU solver included) builds on a
+// ROCm install without the RCCL development headers; every entry point is resolved through dlsym at the first scpn_comm_* call.
+// The values are NCCL's stable public ABI (nccl.h 2.x == rccl.h): ncclUniqueId = 128 opaque bytes passed BY VALUE to
+// ncclCommInitRank, ncclSuccess = 0, ncclFloat64 = 8, ncclMax = 2.  scpn_comm_init checks ncclGetVersion() >= 2.0 at run time.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+}
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclDouble = 8;
+constexpr ncclRedOp_t ncclMax = 2;
 
 namespace comm {
 
@@ -32,6 +47,7 @@ struct State {
     hipStream_t stream = nullptr;
     int rank = -1, world = 0, device = 0;
     double* d_scalar = nullptr;  // one device double for the scalar all-reduce / barrier
+    std::vector<hipEvent_t> ready;  // one per solver group: "this group's psi is packed" (the gather waits on them, not the host)
 };
 inline State& state() {
     static State s;

@@ -31,9 +31,9 @@ static thread_local std::string g_err;
 static int g_device = 0;
 // Every resident handle owns two streams (one per member group) and the HIP runtime multiplexes streams onto 4 hardware queues by
 // default: with a second handle alive in the process two group streams land on one queue and stop overlapping (measured: the
-// Newton lane 37.5 -> 50.7 ms per ensemble solve).  Ask for 8 queues unless the user has chosen a value; the runtime reads the
-// variable when it initialises, which is after this library's load.
-__attribute__((constructor)) static void scpn_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// Newton lane 37.5 -> 50.7 ms per ensemble solve).  GPU_MAX_HW_QUEUES=8 avoids that, but it is a process-wide setting read when the
+// HIP runtime initialises, so this library does NOT touch the environment of its host application: bench.py sets the variable itself
+// before its first device call, and INTEGRATION.md tells an embedding application to do the same.
 static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
@@ -1861,7 +1861,7 @@ static int S_fill_psi(Solver* h, double value) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     API_END
 }
-static int S_pack_psi_into(Solver* h, double* dst) {  // dst: device buffer [B][nz][nr] (dense)
+static int S_pack_psi_into(Solver* h, double* dst, bool wait = true) {  // dst: device buffer [B][nz][nr] (dense)
     if (!h || !dst) return fail(SCPN_E_ARG, "bad arguments");
     API_BEGIN
     size_t n = (size_t)h->nz * h->nr;
@@ -1869,7 +1869,7 @@ static int S_pack_psi_into(Solver* h, double* dst) {  // dst: device buffer [B][
     for (int b = 0; b < h->B; ++b)
         HIP_TRY(hipMemcpy2DAsync(dst + n * b, sizeof(double) * h->nr, psi_member_ptr(h, cur, b), sizeof(double) * h->ld,
                                  sizeof(double) * h->nr, h->nz, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (wait) HIP_TRY(hipStreamSynchronize(h->stream));  // (otherwise the caller orders its consumer behind h->stream with an event)
     API_END
 }
 static int S_sync(Solver* h) {
@@ -2168,6 +2168,9 @@ int scpn_comm_init(int rank, int world, const char* id128, int device) {
     g_device = device;
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
+    int ver = 0;
+    RCCL_TRY(c.api.GetVersion(&ver));
+    if (ver < 20000) throw std::runtime_error("librccl reports version " + std::to_string(ver) + ": the NCCL 2.x ABI is required");
     RCCL_TRY(c.api.CommInitRank(&c.comm, world, id, rank));
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void**)&c.d_scalar, 2 * sizeof(double)));
@@ -2187,17 +2190,31 @@ int scpn_comm_info(int* rank, int* world, int* rccl_version) {
     if (rccl_version) *rccl_version = v;
     API_END
 }
-// pack the local members' psi densely and all-gather the blocks of all ranks into recv_device ([world][batch][nz][nr] doubles);
-// the collective runs on the communicator's own stream and is NOT waited for: it overlaps the next solve (scpn_comm_wait)
-int scpn_comm_allgather_psi(scpn_gs* g, void* recv_device) {
+// pack the local members' psi densely and all-gather the blocks of all ranks into recv_device ([world][per][nz][nr] doubles).
+// `per` (>= this handle's batch) is the block size EVERY rank sends: a rank that owns fewer members (the short last block of an
+// uneven ensemble) pads with zeros, so the collective counts agree on all ranks and recv_device holds `world` whole blocks.
+// The pack copies run on the solver groups' streams and the collective on the communicator's own stream, ordered behind them by
+// events; nothing here waits on the host, so the gather overlaps the next solve (scpn_comm_wait).
+int scpn_comm_allgather_psi(scpn_gs* g, int per, void* recv_device) {
     if (!g || !recv_device) return fail(SCPN_E_ARG, "scpn_comm_allgather_psi: null handle / buffer");
-    void* send = nullptr;
-    int rc = scpn_gs_pack_psi_device(g, &send);  // (synchronises the solver streams: psi is final)
-    if (rc) return rc;
+    if (per < g->B) return fail(SCPN_E_ARG, "scpn_comm_allgather_psi: the common block is smaller than this rank's batch");
     API_BEGIN
     comm::State& c = comm::state();
     if (!c.comm) throw std::runtime_error("communicator not initialised");
-    RCCL_TRY(c.api.AllGather(send, recv_device, (size_t)g->B * g->nz * g->nr, ncclDouble, c.comm, c.stream));
+    const size_t n = (size_t)g->nz * g->nr;
+    g->dense.alloc((size_t)per * n);
+    while (c.ready.size() < g->kids.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c.ready.push_back(e);
+    }
+    if (per > g->B) HIP_TRY(hipMemsetAsync(g->dense.p + (size_t)g->B * n, 0, sizeof(double) * (per - g->B) * n, c.stream));
+    for (size_t gi = 0; gi < g->kids.size(); ++gi) {
+        if (int rc = S_pack_psi_into(g->kids[gi], g->dense.p + (size_t)g->off[gi] * n, false)) return rc;
+        HIP_TRY(hipEventRecord(c.ready[gi], g->kids[gi]->stream));
+        HIP_TRY(hipStreamWaitEvent(c.stream, c.ready[gi], 0));
+    }
+    RCCL_TRY(c.api.AllGather(g->dense.p, recv_device, (size_t)per * n, ncclDouble, c.comm, c.stream));
     API_END
 }
 int scpn_comm_wait(void) {
@@ -2224,6 +2241,8 @@ int scpn_comm_finalize(void) {
     if (c.stream) { (void)hipStreamSynchronize(c.stream); }
     if (c.comm) { (void)c.api.CommDestroy(c.comm); c.comm = nullptr; }
     if (c.d_scalar) { (void)hipFree(c.d_scalar); c.d_scalar = nullptr; }
+    for (hipEvent_t e : c.ready) (void)hipEventDestroy(e);
+    c.ready.clear();
     if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
     c.rank = -1; c.world = 0;
     API_END

@@ -135,6 +135,94 @@ def gather_rows(rank: int, world: int, rows: np.ndarray, total: int, *, addr: st
     return np.concatenate(blocks, axis=0)
 
 
+def free_port(addr: str = "127.0.0.1") -> int:
+    """A TCP port that is free now AND whose successor is free (the rendezvous may use ``port + 1``)."""
+    for _ in range(64):
+        with socket.socket() as a:
+            a.bind((addr, 0))
+            port = a.getsockname()[1]
+            try:
+                with socket.socket() as b:
+                    b.bind((addr, port + 1))
+            except OSError:
+                continue
+        return port
+    raise OSError("no pair of free rendezvous ports")
+
+
+def spawn_ranks(argv: list[str], n: int, *, env=None, addr: str = "127.0.0.1", timeout: float | None = None) -> tuple[int, str]:
+    """Start ``n`` fresh child processes of ``argv`` -- one rank per GPU -- and wait for them.
+
+    The launcher a ``--gpus N`` command line uses when nobody has set ``WORLD_SIZE``: each child gets
+    ``RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT``; rank 0's stdout is captured and returned (the one JSON line),
+    every other stream is passed through to this process's stderr.  The parent must not have touched a GPU: it only forks
+    children (no exec of a process that has initialised HIP).  Returns ``(exit code, rank-0 stdout)``; the exit code is the
+    first non-zero child code (a rank killed by a signal counts as 128 + signal), and when one rank fails the others are
+    terminated instead of being left to wait at a rendezvous that will never complete."""
+    import subprocess
+
+    if n < 1:
+        raise ValueError("need at least one rank")
+    base = dict(os.environ if env is None else env)
+    port = free_port(addr)
+    procs = []
+    for r in range(n):
+        e = {**base, "RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+             "MASTER_ADDR": addr, "MASTER_PORT": str(port)}
+        e.pop("TORCHELASTIC_RUN_ID", None)
+        procs.append(subprocess.Popen(argv, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    out0, rc = "", 0
+    pending = set(range(n))
+    try:
+        while pending:
+            for r in sorted(pending):
+                p = procs[r]
+                if r == 0 and p.poll() is None:
+                    try:  # keep rank 0's pipe drained while it runs
+                        o, _ = p.communicate(timeout=0.2)
+                        out0 += o or ""
+                    except subprocess.TimeoutExpired:
+                        continue
+                code = p.poll()
+                if code is None:
+                    continue
+                if r == 0 and p.stdout is not None and not p.stdout.closed:
+                    out0 += p.stdout.read() or ""
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+            if rc != 0 or (deadline is not None and time.monotonic() > deadline):
+                if rc == 0:
+                    rc = 124
+                break
+            if pending and 0 not in pending:
+                time.sleep(0.05)
+    finally:
+        for r in pending:  # exact PIDs this function started
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    return rc, out0
+
+
+class CommUnavailable(RuntimeError):
+    """The RCCL communicator could not be created on at least one rank; EVERY rank raises this (same verdict everywhere)."""
+
+
+def common_verdict(rank: int, world: int, error: bytes, *, addr: str, port: int) -> None:
+    """One verdict for the whole job: a rank whose ``ncclCommInitRank`` failed must not fall back alone while its peers wait
+    inside a collective for it.  Every rank ships ``b""`` (ok) or its error text over the rendezvous socket; if any rank
+    failed, every rank raises the same :class:`CommUnavailable` (and the caller tears its own communicator down)."""
+    verdicts = exchange(rank, world, error, addr=addr, port=port)
+    bad = [(r, v.decode(errors="replace")) for r, v in enumerate(verdicts) if v]
+    if bad:
+        raise CommUnavailable("; ".join(f"rank {r}: {m}" for r, m in bad))
+
+
 class HostSync:
     """Barrier / max-reduction over the rendezvous sockets alone (no device, no RCCL): what a launcher script or a benchmark falls
     back to for its TIMING when the RCCL communicator cannot be created -- never a substitute for the psi gather."""
@@ -195,9 +283,16 @@ class EnsembleComm:
         finally:
             os.dup2(saved, 1)
             os.close(saved)
-        _lib.check(rc, "scpn_comm_init")
+        err = b"" if rc == _lib.SCPN_OK else (_lib.last_error() or "scpn_comm_init failed").encode()[:300]
+        try:
+            common_verdict(rank, world, err, addr=addr, port=port)
+        except CommUnavailable:
+            if rc == _lib.SCPN_OK:
+                L.scpn_comm_finalize()
+            raise
         self._recv = None
         self._recv_bytes = 0
+        self._per_checked: set[int] = set()
 
     @classmethod
     def from_env(cls, env=None) -> "EnsembleComm":
@@ -210,10 +305,22 @@ class EnsembleComm:
         self._lib.check(self._lib.lib().scpn_comm_info(C.byref(r), C.byref(w), C.byref(v)), "scpn_comm_info")
         return {"rank": r.value, "world": w.value, "rccl_version": v.value}
 
-    def allgather_psi(self, es) -> int:
+    def allgather_psi(self, es, total: int | None = None) -> int:
         """Launch the all-gather of ``es``'s psi blocks (asynchronous); returns the device address of the gathered
-        [world][batch][nz][nr] buffer, valid after :meth:`wait`."""
-        need = self.world * es.batch * es.NZ * es.NR * 8
+        ``[world][per][nz][nr]`` buffer, valid after :meth:`wait`.  ``per = ceil(total / world)`` is the block EVERY rank sends:
+        a rank that owns fewer members (the last block of an uneven ``total``, see :func:`shard_range`) pads its block with
+        zeros, so all ranks issue the collective with the same count and the receive buffer holds ``world`` whole blocks.
+        Without ``total`` the block is this rank's batch, which then has to be the same on every rank -- checked once per
+        block size over the rendezvous socket before the first collective, a mismatch raises on every rank."""
+        per = es.batch if total is None else -(-int(total) // self.world)
+        if per < es.batch:
+            raise ValueError(f"rank {self.rank} holds {es.batch} members but the common block is {per}")
+        if per not in self._per_checked:
+            seen = {struct.unpack("!i", p)[0] for p in exchange(self.rank, self.world, struct.pack("!i", per), addr=self.addr, port=self.port)}
+            if len(seen) != 1:
+                raise ValueError(f"ranks disagree on the all-gather block size: {sorted(seen)} members")
+            self._per_checked.add(per)
+        need = self.world * per * es.NZ * es.NR * 8
         L = self._lib.lib()
         if self._recv is None or self._recv_bytes != need:
             self.wait()
@@ -222,8 +329,15 @@ class EnsembleComm:
             p = C.c_void_p()
             self._lib.check(L.scpn_device_alloc(need, C.byref(p)), "scpn_device_alloc")
             self._recv, self._recv_bytes = p, need
-        self._lib.check(L.scpn_comm_allgather_psi(es._h, self._recv), "scpn_comm_allgather_psi")
+        self._lib.check(L.scpn_comm_allgather_psi(es._h, per, self._recv), "scpn_comm_allgather_psi")
         return int(self._recv.value)
+
+    @staticmethod
+    def unpad(gathered: np.ndarray, total: int) -> np.ndarray:
+        """``[world][per][nz][nr]`` (as gathered) -> ``[total][nz][nr]`` in member order, padding dropped."""
+        world, per = gathered.shape[:2]
+        sizes = shard_sizes(total, world)
+        return np.concatenate([gathered[r, :sizes[r]] for r in range(world)], axis=0)
 
     def wait(self) -> None:
         self._lib.check(self._lib.lib().scpn_comm_wait(), "scpn_comm_wait")

@@ -52,7 +52,29 @@ def _worker(rank, world, port, out_dir):
     hs = HostSync(rank, world, addr="127.0.0.1", port=port)
     hs.barrier()
     tmax = hs.allreduce_max(1.5 + rank)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), psi=all_psi, table=all_tab, ident=np.frombuffer(got, dtype=np.uint8), tmax=tmax)
+    # (4) the psi all-gather with an uneven total: every rank sends a block padded to ceil(TOTAL / world) members (what
+    #     EnsembleComm.allgather_psi does on the device), the ranks agree on the block size first, the padding is dropped after
+    from scpn_fusion_core_amd.distributed import CommUnavailable, EnsembleComm, common_verdict
+    import struct
+
+    per = -(-TOTAL // world)
+    seen = {struct.unpack("!i", p)[0] for p in exchange(rank, world, struct.pack("!i", per), addr="127.0.0.1", port=port)}
+    assert seen == {per}
+    block = np.zeros((per, 17, 17))
+    block[: b - a] = psi
+    parts = exchange(rank, world, block.tobytes(), addr="127.0.0.1", port=port)
+    assert len({len(p) for p in parts}) == 1  # equal counts on every rank: the condition ncclAllGather needs
+    gathered = np.stack([np.frombuffer(p, dtype=np.float64).reshape(per, 17, 17) for p in parts])
+    padded_psi = EnsembleComm.unpad(gathered, TOTAL)
+    # (5) one verdict for the whole job: rank 1 "fails" its communicator, BOTH ranks must raise
+    raised = ""
+    try:
+        common_verdict(rank, world, b"ncclCommInitRank: invalid usage" if rank == 1 else b"", addr="127.0.0.1", port=port)
+    except CommUnavailable as exc:
+        raised = str(exc)
+    common_verdict(rank, world, b"", addr="127.0.0.1", port=port)  # and all-ok passes on both
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), psi=all_psi, table=all_tab, ident=np.frombuffer(got, dtype=np.uint8), tmax=tmax,
+             padded_psi=padded_psi, raised=np.array(raised))
 
 
 def test_two_rank_sharded_ensemble_matches_serial(tmp_path):
@@ -75,6 +97,8 @@ def test_two_rank_sharded_ensemble_matches_serial(tmp_path):
         assert np.array_equal(got["psi"], psi_ref) and np.array_equal(got["table"], tab_ref)
         assert np.array_equal(got["ident"], want_id)
         assert float(got["tmax"]) == 2.5
+        assert np.array_equal(got["padded_psi"], psi_ref)
+        assert "rank 1: ncclCommInitRank" in str(got["raised"])
 
 
 def test_gather_rows_rejects_wrong_block_size():
@@ -85,3 +109,57 @@ def test_gather_rows_rejects_wrong_block_size():
     with pytest.raises(ValueError):
         gather_rows(0, 1, np.zeros((2, 4)), 3, addr="127.0.0.1", port=1)
     assert gather_rows(0, 1, np.ones((3, 2)), 3, addr="127.0.0.1", port=1).shape == (3, 2)
+
+
+# ------------------------------------------------------------------------------------------------- `bench.py --gpus N` launcher
+_STUB = """
+import json, os, sys
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+assert "TORCHELASTIC_RUN_ID" not in os.environ
+sys.path.insert(0, {root!r})
+from scpn_fusion_core_amd.distributed import HostSync
+t = HostSync.from_env().allreduce_max(float(r))          # the ranks really meet on the port they were given
+print("chatter from rank", r)                            # non-JSON stdout of rank 0 must not become the result line
+if r == {fail_rank}:
+    sys.exit(7)
+if r == 0:
+    print(json.dumps({{"n_gpus": w, "tmax": t, "argv": sys.argv[1:]}}))
+"""
+
+
+def _run_stub(tmp_path, n, fail_rank=-1):
+    import json
+    import sys
+
+    from scpn_fusion_core_amd.distributed import spawn_ranks
+    from tests.conftest import ROOT
+
+    stub = tmp_path / "stub_rank.py"
+    stub.write_text(_STUB.format(root=str(ROOT), fail_rank=fail_rank))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    rc, out = spawn_ranks([sys.executable, str(stub), "--gpus", str(n)], n, env=env, timeout=120)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    return rc, [json.loads(ln) for ln in lines]
+
+
+def test_spawner_starts_one_rank_per_gpu_and_forwards_rank0(tmp_path):
+    rc, lines = _run_stub(tmp_path, 3)
+    assert rc == 0 and len(lines) == 1
+    assert lines[0] == {"n_gpus": 3, "tmax": 2.0, "argv": ["--gpus", "3"]}
+
+
+def test_spawner_reports_a_failed_rank(tmp_path):
+    rc, _lines = _run_stub(tmp_path, 2, fail_rank=1)
+    assert rc == 7
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus(tmp_path):
+    import subprocess
+    import sys
+
+    from tests.conftest import ROOT
+
+    env = {**os.environ, "WORLD_SIZE": "1", "RANK": "0"}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()

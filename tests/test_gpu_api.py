@@ -262,6 +262,13 @@ def test_rccl_ensemble_gather_through_the_c_abi_on_one_rank():
             assert np.array_equal(got[0], es.get_psi())
             comm.allgather_psi(es)  # a second gather reuses the receive buffer
             comm.wait()
+            # the padded block of an uneven ensemble: this rank owns 3 members of a common block of 5 -> two zero members behind
+            comm.allgather_psi(es, total=5)
+            padded = comm.download((1, 5, 65, 65))
+            assert np.array_equal(padded[0, :3], es.get_psi()) and not padded[0, 3:].any()
+            assert np.array_equal(EnsembleComm.unpad(padded, 3), es.get_psi())
+            with pytest.raises(ValueError):
+                comm.allgather_psi(es, total=2)  # a common block smaller than this rank's batch
         assert comm.allreduce_max(3.25) == 3.25
         comm.barrier()
     finally:
