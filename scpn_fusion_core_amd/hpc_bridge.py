@@ -22,71 +22,105 @@ import numpy as np
 from . import _lib
 
 _SOLVER_LIB_ENV = "SCPN_SOLVER_LIB"
+_HEX = frozenset("0123456789abcdef")
 
 
-def _sha256_file(path: Path) -> str:
-    h = hashlib.sha256()
-    with open(path, "rb") as f:
-        for chunk in iter(lambda: f.read(1 << 20), b""):
-            h.update(chunk)
-    return h.hexdigest()
+class LibraryTrust:
+    """The trust rule of hpc/_hpc_native_trust.py:186-221 for an explicitly named solver library, as one object.
 
+    ``LibraryTrust(path)`` validates the path (absolute, no symlink, existing regular file) and ``.verify()`` compares the
+    file's SHA-256 with the FIRST pinned digest found in this order: ``SCPN_SOLVER_LIB_SHA256``, the JSON manifest named by
+    ``SCPN_SOLVER_TRUST_MANIFEST`` (flat ``{path-or-name: digest}`` or under ``"libraries"``), the ``<lib>.sha256`` sidecar.
+    Environment-variable names and error texts are the reference's (its tests match on them); the structure is not."""
 
-def _normalise_sha256(value: str) -> str:
-    token = value.strip().split()[0].lower() if value.strip() else ""
-    if len(token) != 64 or any(c not in "0123456789abcdef" for c in token):
-        raise ValueError("SHA-256 digest must be 64 hexadecimal characters")
-    return token
+    # (test on the candidate path / its resolution, error text) -- evaluated in order, first failure raises
+    _PATH_RULES = (
+        (lambda raw, res: raw.is_absolute(), lambda raw, res: f"{_SOLVER_LIB_ENV}/lib_path must be an absolute path"),
+        (lambda raw, res: not raw.is_symlink(), lambda raw, res: f"explicit native solver library must not be a symlink: {raw}"),
+        (lambda raw, res: res.exists(), lambda raw, res: f"explicit native solver library does not exist: {res}"),
+        (lambda raw, res: res.is_file(), lambda raw, res: f"explicit native solver library must be a regular file: {res}"),
+    )
 
+    def __init__(self, path) -> None:
+        raw = Path(path).expanduser()
+        resolved = raw.resolve(strict=False) if raw.is_absolute() else raw
+        for ok, message in self._PATH_RULES:
+            if not ok(raw, resolved):
+                raise ValueError(message(raw, resolved))
+        self.path = resolved
 
-def _expected_library_digest(path: Path) -> str | None:
-    env = os.environ.get("SCPN_SOLVER_LIB_SHA256")
-    if env:
-        return _normalise_sha256(env)
-    manifest_path = os.environ.get("SCPN_SOLVER_TRUST_MANIFEST")
-    if manifest_path:
-        manifest = json.loads(Path(manifest_path).read_text(encoding="utf-8"))
-        if isinstance(manifest, dict) and "libraries" in manifest:
-            manifest = manifest["libraries"]
-        if not isinstance(manifest, dict):
+    # ---- digests
+    @staticmethod
+    def parse_digest(text: str) -> str:
+        """First whitespace-separated token of ``text`` as a lower-case SHA-256 (the ``sha256sum`` line format)."""
+        token = (text.split() or [""])[0].lower()
+        if len(token) != 64 or not set(token) <= _HEX:
+            raise ValueError("SHA-256 digest must be 64 hexadecimal characters")
+        return token
+
+    def actual_digest(self) -> str:
+        h = hashlib.sha256()
+        with open(self.path, "rb") as f:
+            while chunk := f.read(1 << 20):
+                h.update(chunk)
+        return h.hexdigest()
+
+    def _from_env(self):
+        return os.environ.get("SCPN_SOLVER_LIB_SHA256") or None
+
+    def _from_manifest(self):
+        where = os.environ.get("SCPN_SOLVER_TRUST_MANIFEST")
+        if not where:
+            return None
+        table = json.loads(Path(where).read_text(encoding="utf-8"))
+        table = table.get("libraries", table) if isinstance(table, dict) else table
+        if not isinstance(table, dict):
             raise ValueError("native library trust manifest must be a JSON object")
-        for key in (str(path), str(path.resolve()), path.name):
-            if key in manifest:
-                return _normalise_sha256(manifest[key])
-    sidecar = path.with_suffix(path.suffix + ".sha256")
-    if sidecar.exists():
-        return _normalise_sha256(sidecar.read_text(encoding="utf-8"))
-    return None
+        hit = next((table[k] for k in (str(self.path), str(self.path.resolve()), self.path.name) if k in table), None)
+        if hit is not None and not isinstance(hit, str):
+            raise ValueError("native library trust manifest digest must be a string")
+        return hit
 
+    def _from_sidecar(self):
+        side = self.sidecar_path(self.path)
+        return side.read_text(encoding="utf-8") if side.exists() else None
 
-def verify_native_library_trust(path: Path) -> str:
-    digest = _sha256_file(path)
-    expected = _expected_library_digest(path)
-    if expected is None:
-        raise ValueError("native solver library trust metadata is required; provide SCPN_SOLVER_LIB_SHA256, "
-                         "SCPN_SOLVER_TRUST_MANIFEST, or a .sha256 sidecar")
-    if not hmac.compare_digest(digest, expected):
-        raise ValueError("native solver library SHA-256 does not match trusted metadata")
-    return digest
+    def pinned_digest(self) -> str | None:
+        for source in (self._from_env, self._from_manifest, self._from_sidecar):
+            text = source()
+            if text:
+                return self.parse_digest(text)
+        return None
+
+    def verify(self) -> str:
+        pinned = self.pinned_digest()
+        if pinned is None:
+            raise ValueError("native solver library trust metadata is required; provide SCPN_SOLVER_LIB_SHA256, "
+                             "SCPN_SOLVER_TRUST_MANIFEST, or a .sha256 sidecar")
+        actual = self.actual_digest()
+        if not hmac.compare_digest(actual, pinned):
+            raise ValueError("native solver library SHA-256 does not match trusted metadata")
+        return actual
+
+    @staticmethod
+    def sidecar_path(path: Path) -> Path:
+        return path.with_name(path.name + ".sha256")
 
 
 def require_explicit_library_path(path) -> Path:
-    lib_path = Path(path).expanduser()
-    if not lib_path.is_absolute():
-        raise ValueError(f"{_SOLVER_LIB_ENV}/lib_path must be an absolute path")
-    if lib_path.is_symlink():
-        raise ValueError(f"explicit native solver library must not be a symlink: {lib_path}")
-    resolved = lib_path.resolve(strict=False)
-    if not resolved.exists():
-        raise ValueError(f"explicit native solver library does not exist: {resolved}")
-    if not resolved.is_file():
-        raise ValueError(f"explicit native solver library must be a regular file: {resolved}")
-    return resolved
+    """The validated, resolved path of an explicit library override (raises ``ValueError`` with the reference's texts)."""
+    return LibraryTrust(path).path
 
 
-def write_sha256_sidecar(path: Path) -> None:
-    path = Path(path)
-    path.with_suffix(path.suffix + ".sha256").write_text(f"{_sha256_file(path)}  {path.name}\n", encoding="utf-8")
+def verify_native_library_trust(path) -> str:
+    """SHA-256 of ``path`` after it matched its pinned digest (``ValueError`` otherwise)."""
+    return LibraryTrust(path).verify()
+
+
+def write_sha256_sidecar(path) -> None:
+    """Pin ``path`` with a ``sha256sum``-style sidecar next to it."""
+    t = LibraryTrust(path)
+    LibraryTrust.sidecar_path(Path(path)).write_text(f"{t.actual_digest()}  {Path(path).name}\n", encoding="utf-8")
 
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -103,8 +137,9 @@ class HPCBridge:
         explicit = lib_path or os.environ.get(_SOLVER_LIB_ENV)
         try:
             if explicit:
-                path = require_explicit_library_path(explicit)
-                verify_native_library_trust(path)
+                trust = LibraryTrust(explicit)
+                trust.verify()
+                path = trust.path
                 L = C.CDLL(str(path))
                 L.create_solver.restype = C.c_void_p
                 L.create_solver.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]

@@ -29,91 +29,111 @@ class BackendTier(IntEnum):
     NUMPY = 6
 
 
-_TIER_NAMES = {t: t.name.lower() for t in BackendTier}
-_registry: dict[str, list[tuple[BackendTier, Callable[..., Any]]]] = {}
-_class_registry: dict[str, list[tuple[BackendTier, Callable[[], type]]]] = {}
-_dispatch_cache: dict[str, tuple[BackendTier, Callable[..., Any]]] = {}
-_availability: dict[BackendTier, bool] = {}
-_lock = threading.RLock()
-_probed = False
+class _Seam:
+    """The registry behind the module-level functions.
+
+    Layout: one table per kind (``"fn"`` for kernels, ``"cls"`` for lazily loaded kernel classes) mapping a kernel name to a
+    ``{tier: implementation}`` dict -- a later registration of the same (name, tier) replaces the earlier one -- and a table
+    of tier probes (``{tier: () -> bool}``, only the GPU tier has one in this package) whose answers are memoised until
+    :meth:`forget`.  Selection is ``min()`` over the available tiers of a name (the enum value IS the preference)."""
+
+    def __init__(self, probes: dict[BackendTier, Callable[[], bool]]) -> None:
+        self._probes = dict(probes)
+        self._tables: dict[str, dict[str, dict[BackendTier, Any]]] = {"fn": {}, "cls": {}}
+        self._up: dict[BackendTier, bool] = {}      # memoised probe answers (and test overrides)
+        self._chosen: dict[str, Callable[..., Any]] = {}  # kernel name -> implementation picked by the last dispatch
+        self._guard = threading.RLock()
+
+    # ---- availability
+    def up(self, tier: BackendTier) -> bool:
+        with self._guard:
+            if tier not in self._up:
+                probe = self._probes.get(tier)
+                self._up[tier] = bool(probe()) if probe else False
+            return self._up[tier]
+
+    def force(self, tier: BackendTier, state: bool | None) -> None:
+        """Pin a tier's availability (``None``: back to its probe).  For tests and for ``SCPN_DISABLE_GPU``-style switches."""
+        with self._guard:
+            if state is None:
+                self._up.pop(tier, None)
+            else:
+                self._up[tier] = bool(state)
+            self._chosen.clear()
+
+    def forget(self) -> None:
+        with self._guard:
+            self._up.clear()
+            self._chosen.clear()
+
+    # ---- registration / selection
+    def add(self, kind: str, name: str, tier: BackendTier, impl: Any) -> None:
+        with self._guard:
+            self._tables[kind].setdefault(name, {})[BackendTier(tier)] = impl
+            self._chosen.pop(name, None)
+
+    def tiers(self, kind: str, name: str) -> list[BackendTier]:
+        return sorted(self._tables[kind].get(name, ()))
+
+    def pick(self, kind: str, name: str, missing: str, all_down: str) -> Any:
+        with self._guard:
+            offered = self._tables[kind].get(name)
+            if not offered:
+                raise KeyError(missing)
+            live = [t for t in offered if self.up(t)]
+            if not live:
+                raise RuntimeError(all_down)
+            return offered[min(live)]
 
 
-def _probe_gpu() -> bool:
-    """core/_multi_compat.py:101-120: honours SCPN_DISABLE_GPU, otherwise asks the native library."""
-    return _lib.gpu_available()
-
-
-def _ensure_probed() -> None:
-    global _probed
-    if _probed:
-        return
-    with _lock:
-        if _probed:
-            return
-        for t in BackendTier:
-            _availability[t] = False
-        _availability[BackendTier.GPU] = _probe_gpu()
-        _probed = True
+_seam = _Seam({BackendTier.GPU: _lib.gpu_available})  # core/_multi_compat.py:101-120: SCPN_DISABLE_GPU, then the native library
 
 
 def reset_probe_cache() -> None:
-    global _probed
-    with _lock:
-        _probed = False
-        _availability.clear()
-        _dispatch_cache.clear()
+    _seam.forget()
+
+
+def set_availability(tier: BackendTier, state: bool | None) -> None:
+    """Override (``True`` / ``False``) or restore (``None``) what :func:`is_available` reports for ``tier``."""
+    _seam.force(tier, state)
 
 
 def is_available(tier: BackendTier) -> bool:
-    _ensure_probed()
-    return bool(_availability.get(tier, False))
+    return _seam.up(BackendTier(tier))
 
 
 def available_backends() -> dict[str, bool]:
-    _ensure_probed()
-    return {_TIER_NAMES[t]: bool(_availability.get(t, False)) for t in BackendTier}
+    return {t.name.lower(): _seam.up(t) for t in BackendTier}
+
+
+def registered_tiers(name: str, *, kernel_class: bool = False) -> list[BackendTier]:
+    """Tiers that offer ``name`` (ascending = preference order), whether or not they are available here."""
+    return _seam.tiers("cls" if kernel_class else "fn", name)
 
 
 def register_kernel(name: str, tier: BackendTier, implementation: Callable[..., Any]) -> None:
-    with _lock:
-        _registry.setdefault(name, []).append((tier, implementation))
-        _registry[name].sort(key=lambda x: x[0])
-        _dispatch_cache.pop(name, None)
+    _seam.add("fn", name, tier, implementation)
 
 
 def dispatch(name: str) -> Callable[..., Any]:
     """Fastest available implementation; KeyError if nothing registered, RuntimeError if all unavailable."""
-    _ensure_probed()
-    cached = _dispatch_cache.get(name)
-    if cached is not None:
-        return cached[1]
-    with _lock:
-        entries = _registry.get(name)
-        if not entries:
-            raise KeyError(f"No implementations registered for kernel {name!r}")
-        for tier, impl in entries:
-            if _availability.get(tier, False):
-                _dispatch_cache[name] = (tier, impl)
-                return impl
-        raise RuntimeError(f"All registered backends for {name!r} are unavailable. "
-                           f"Registered tiers: {[_TIER_NAMES[t] for t, _ in entries]}")
+    hit = _seam._chosen.get(name)
+    if hit is None:
+        hit = _seam.pick("fn", name, f"No implementations registered for kernel {name!r}",
+                         f"All registered backends for {name!r} are unavailable. "
+                         f"Registered tiers: {[t.name.lower() for t in registered_tiers(name)]}")
+        _seam._chosen[name] = hit
+    return hit
 
 
 def register_kernel_class(name: str, tier: BackendTier, loader: Callable[[], type]) -> None:
-    with _lock:
-        _class_registry.setdefault(name, []).append((tier, loader))
-        _class_registry[name].sort(key=lambda x: x[0])
+    _seam.add("cls", name, tier, loader)
 
 
 def dispatch_kernel_class(name: str) -> type:
-    _ensure_probed()
-    entries = _class_registry.get(name)
-    if not entries:
-        raise KeyError(f"No kernel classes registered for {name!r}")
-    for tier, loader in entries:
-        if _availability.get(tier, False):
-            return loader()
-    raise RuntimeError(f"All registered backends for kernel class {name!r} are unavailable.")
+    loader = _seam.pick("cls", name, f"No kernel classes registered for {name!r}",
+                        f"All registered backends for kernel class {name!r} are unavailable.")
+    return loader()
 
 
 # ── GPU-tier providers (canonical signatures: core/_multi_compat_providers.py:322-344, 723-792) ───────────

@@ -10,36 +10,50 @@ from scpn_fusion_core_amd import multi_compat as multi
 from tests._problems import iter_like_cfg
 
 
-def test_backend_tier_order_and_registration(monkeypatch):
+def test_backend_tier_order_and_registration():
     assert [t.name for t in sorted(multi.BackendTier)] == ["RUST", "GPU", "MOJO", "JULIA", "GO", "JAX", "NUMPY"]
-    multi._ensure_probed()
-    calls = []
-    multi.register_kernel("unit_test_kernel", multi.BackendTier.NUMPY, lambda: calls.append("numpy") or "numpy")
-    multi.register_kernel("unit_test_kernel", multi.BackendTier.GPU, lambda: calls.append("gpu") or "gpu")
-    monkeypatch.setitem(multi._availability, multi.BackendTier.GPU, False)
-    monkeypatch.setitem(multi._availability, multi.BackendTier.NUMPY, True)
-    multi._dispatch_cache.pop("unit_test_kernel", None)
-    assert multi.dispatch("unit_test_kernel")() == "numpy"
-    monkeypatch.setitem(multi._availability, multi.BackendTier.GPU, True)
-    multi._dispatch_cache.pop("unit_test_kernel", None)
-    assert multi.dispatch("unit_test_kernel")() == "gpu"  # lower enum value preferred
-    with pytest.raises(KeyError):
-        multi.dispatch("no_such_kernel")
-    multi._dispatch_cache.pop("unit_test_kernel", None)
+    multi.register_kernel("unit_test_kernel", multi.BackendTier.NUMPY, lambda: "numpy")
+    multi.register_kernel("unit_test_kernel", multi.BackendTier.GPU, lambda: "gpu")
+    assert multi.registered_tiers("unit_test_kernel") == [multi.BackendTier.GPU, multi.BackendTier.NUMPY]
+    try:
+        multi.set_availability(multi.BackendTier.GPU, False)
+        multi.set_availability(multi.BackendTier.NUMPY, True)
+        assert multi.dispatch("unit_test_kernel")() == "numpy"
+        assert multi.available_backends()["numpy"] is True and multi.available_backends()["gpu"] is False
+        multi.set_availability(multi.BackendTier.GPU, True)
+        assert multi.dispatch("unit_test_kernel")() == "gpu"  # lower enum value preferred
+        multi.register_kernel("unit_test_kernel", multi.BackendTier.GPU, lambda: "gpu2")  # same (name, tier): replaced
+        assert multi.dispatch("unit_test_kernel")() == "gpu2"
+        multi.set_availability(multi.BackendTier.GPU, False)
+        multi.set_availability(multi.BackendTier.NUMPY, False)
+        with pytest.raises(RuntimeError, match="Registered tiers: \\['gpu', 'numpy'\\]"):
+            multi.dispatch("unit_test_kernel")
+        with pytest.raises(KeyError):
+            multi.dispatch("no_such_kernel")
+        with pytest.raises(KeyError):
+            multi.dispatch_kernel_class("no_such_class")
+    finally:
+        multi.set_availability(multi.BackendTier.GPU, None)
+        multi.set_availability(multi.BackendTier.NUMPY, None)
+    assert multi.is_available(multi.BackendTier.NUMPY) is False  # this package carries no CPU tier
+    assert multi.is_available(multi.BackendTier.GPU) == _lib.gpu_available()
 
 
 def test_gpu_tier_registered_for_the_three_seams(monkeypatch):
-    assert any(t == multi.BackendTier.GPU for t, _ in multi._registry["gs_rb_sor_smooth"])
-    assert any(t == multi.BackendTier.GPU for t, _ in multi._registry["multigrid_solve"])
-    assert any(t == multi.BackendTier.GPU for t, _ in multi._class_registry["equilibrium_kernel"])
+    assert multi.BackendTier.GPU in multi.registered_tiers("gs_rb_sor_smooth")
+    assert multi.BackendTier.GPU in multi.registered_tiers("multigrid_solve")
+    assert multi.BackendTier.GPU in multi.registered_tiers("equilibrium_kernel", kernel_class=True)
     monkeypatch.setenv("SCPN_DISABLE_GPU", "1")
     assert not _lib.gpu_available()  # core/_multi_compat.py:109-113
-    if _lib.device_count() == 0:
-        multi.reset_probe_cache()
+    multi.reset_probe_cache()
+    try:
         with pytest.raises(RuntimeError):
             multi.dispatch("multigrid_solve")
         with pytest.raises(RuntimeError):
             multi.dispatch_kernel_class("equilibrium_kernel")
+    finally:
+        monkeypatch.delenv("SCPN_DISABLE_GPU")
+        multi.reset_probe_cache()
 
 
 def test_gpu_tier_surface_without_device():
@@ -82,9 +96,21 @@ def test_trust_gate(tmp_path, monkeypatch):
     # manifest route
     (tmp_path / "libscpn_solver.so.sha256").unlink()
     man = tmp_path / "manifest.json"
-    man.write_text('{"libraries": {"libscpn_solver.so": "%s"}}' % hb._sha256_file(lib))
+    man.write_text('{"libraries": {"libscpn_solver.so": "%s"}}' % hb.LibraryTrust(lib).actual_digest())
     monkeypatch.setenv("SCPN_SOLVER_TRUST_MANIFEST", str(man))
     assert hb.HPCBridge(lib_path=str(lib)).loaded
+    man.write_text('{"%s": 5}' % lib)  # flat manifest keyed by path, with a digest of the wrong type
+    with pytest.raises(ValueError, match="must be a string"):
+        hb.HPCBridge(lib_path=str(lib))
+    man.write_text("[1, 2]")
+    with pytest.raises(ValueError, match="JSON object"):
+        hb.HPCBridge(lib_path=str(lib))
+    monkeypatch.delenv("SCPN_SOLVER_TRUST_MANIFEST")
+    with pytest.raises(ValueError, match="regular file"):
+        hb.HPCBridge(lib_path=str(tmp_path))
+    with pytest.raises(ValueError, match="64 hexadecimal"):
+        hb.LibraryTrust.parse_digest("abc")
+    assert hb.LibraryTrust.parse_digest("A" * 64 + "  libx.so\n") == "a" * 64
 
 
 def test_bridge_input_validation():
