@@ -152,23 +152,28 @@ SIGNATURES = {
 }
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile csrc/scpn_hip.hip for gfx950 into the in-tree libscpn_hip.so (hipcc cross-compiles without a GPU)."""
+def build(force: bool = False, verbose: bool = False, *, variant: str | None = None, defines: tuple[str, ...] = ()) -> Path:
+    """Compile csrc/scpn_hip.hip for gfx950 into the in-tree libscpn_hip.so (hipcc cross-compiles without a GPU).
+
+    ``variant`` / ``defines`` build an EXPERIMENT library ``libscpn_hip.<variant>.so`` with extra ``-D`` switches (another tile
+    geometry, in-kernel stamps ...) next to the shipped one; it is only ever loaded through ``SCPN_HIP_LIB`` by ``tools/`` and
+    by the bit-identity test of the switches.  The shipped library instantiates exactly what the default path launches."""
+    target = LIB_PATH if variant is None else LIB_PATH.with_name(f"libscpn_hip.{variant}.so")
     srcs = [CSRC / "scpn_hip.hip", *sorted(CSRC.glob("*.hip.h")), PKG_DIR.parent / "include" / "scpn_hip.h"]
-    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
-        return LIB_PATH
+    if not force and target.exists() and all(target.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+        return target
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     # build next to the target and rename: concurrent builders (one rank per GPU) never see a half-written library
-    tmp = LIB_PATH.with_name(f".{LIB_PATH.name}.{os.getpid()}.tmp")
-    cmd = [hipcc, *HIPCC_FLAGS, "-o", str(tmp), str(CSRC / "scpn_hip.hip")]
+    tmp = target.with_name(f".{target.name}.{os.getpid()}.tmp")
+    cmd = [hipcc, *HIPCC_FLAGS, *[f"-D{d}" for d in defines], "-o", str(tmp), str(CSRC / "scpn_hip.hip")]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode:
         print(" ".join(cmd), res.stdout, res.stderr, sep="\n")
     if res.returncode:
         tmp.unlink(missing_ok=True)
-        raise RuntimeError(f"hipcc failed building {LIB_PATH.name}:\n{res.stderr[-2000:]}")
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+        raise RuntimeError(f"hipcc failed building {target.name}:\n{res.stderr[-2000:]}")
+    os.replace(tmp, target)
+    return target
 
 
 _LIB = None

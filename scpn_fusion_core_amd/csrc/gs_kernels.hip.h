@@ -521,17 +521,11 @@ __device__ __forceinline__ double j_raw_at(double psi, double R, double inv_mu0R
     double j_f = inv_mu0R * ff;
     return 0.5 * j_p + 0.5 * j_f;
 }
-// Source generation fused into the pre-smoother (replaces k_jsum_final + k_source): every workgroup finishes the
-// J_raw reduction with the reduction tree of k_jsum_final, so all of them (and the unfused path) get the same scale.
-struct SrcGen {
-    const double* r_axis;
-    const double* inv_mu0R;
-    const double* neg_mu0R;
-    const double* part;  // J_raw partial sums [B][nblk] written by k_jsum
-    Member* st;
-    int nblk;
-    double dr, dz;
-    Prof pf;
+// lazy-source mode: the source field holds J_raw of k_jsum and Source = (-mu0 R) * (J_raw * scale) is formed on load with the
+// expression of k_source, so the separate source pass over the fine grid disappears (st == nullptr: the field is the source).
+struct LazySrc {
+    const Member* st = nullptr;
+    const double* neg_mu0R = nullptr;
 };
 #ifdef CV_STAMPS
 __device__ unsigned long long g_cv_stamps[64];
@@ -549,23 +543,23 @@ __device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (d
 #define CV_STAMP(i)
 #define TILE_STAMP(i)
 #endif
+// Tile geometry of the shipped library: 40 rows x 128 columns, 8 waves, register allocation capped so that three workgroups
+// share a CU (one loads while the others sweep).  A -D override builds another geometry for experiments (LZ % NW == 0).
+#ifndef TILE_LZ_N
+#define TILE_LZ_N 40
+#endif
 #ifndef TILE_NW
-#define TILE_NW 16  // waves per tile workgroup (16: ~75 VGPRs, leaves register headroom for the fused defect stage)
+#define TILE_NW 8
 #endif
 #ifndef TILE_WPE
-#define TILE_WPE 1
+#define TILE_WPE 6  // minimum waves per SIMD the register allocation must allow: <= 80 VGPRs
 #endif
-#ifndef TILE_WPE_P
-#define TILE_WPE_P (TILE_NW <= 8 ? 4 : 1)  // the prolongation variant needs the 128-VGPR cap only with 8-wave tiles
-#endif
-constexpr int TILE_LZ = 78;
+constexpr int TILE_LZ = TILE_LZ_N;
 // PROLONG: the tile is loaded as in + P(coarse) (bilinear prolongation of the coarse-grid correction,
 // multigrid_solve.py:329-330) -- the separate prolong-add pass over the fine grid disappears.
-// SRCGEN: the source is not loaded but evaluated from the incoming psi (update_plasma_source_nonlinear,
-// core/fusion_kernel.py:419-440 and newton_solver.py:513) and written out for the later consumers.
 // DEFECT: after the sweeps the tile also produces the coarse-grid right-hand side restrict_full_weight(-(L*psi - src))
 // (core/multigrid_solve.py:303-306) and zeroes the coarse correction: the halo grows by 2 (defect ring + restriction
-// stencil) and the separate defect/restrict pass over the fine grid disappears.  (coarseF = coarse rhs, coarse2F = coarse e.)
+// stencil) and the separate defect/restrict pass over the fine grid disappears.  (coarseF = coarse rhs, dd.e = coarse e.)
 struct TopoPart {
     double maxv;
     long maxi;
@@ -574,20 +568,6 @@ struct TopoPart {
     double minpsi;
     long pad;
 };
-// BLEND: the post-smoother of the Picard iteration also performs the tail of the iteration on its tile
-//   nxt = (1-alpha)*cur + alpha*psi_new (ring from bc), partial sum |psi_new-cur|, non-finite flag,
-//   partial max|r| / sum r^2 of r = L*nxt - src, topology partials of nxt for the next iteration
-// (the work of k_blend_fused) so psi_new never goes to HBM and cur / src are read once.
-struct BlendArgs {
-    Fld cur{nullptr, nullptr, 0, 0}, bc{nullptr, nullptr, 0, 0};
-    double alpha = 0, om_alpha = 0, dr = 1, dz = 1;
-    int n_mask_rows = 0, nblk = 0;
-    double* psum = nullptr;
-    int* pbad = nullptr;
-    double* rmax = nullptr;
-    double* rsum = nullptr;
-    TopoPart* topo = nullptr;
-};
 struct DefectDst {
     Fld e{nullptr, nullptr, 0, 0};
     double dr2 = 1, dz2 = 1, two_dr = 1, inv_dr2 = 1, inv_dz2 = 1, inv_two_dr = 1, lo_dr2 = 0, lo_dz2 = 0, lo_two_dr = 0;
@@ -595,14 +575,19 @@ struct DefectDst {
     const double* r_inv = nullptr;
     const double* r_inv_lo = nullptr;
 };
-// LZT rows x 128 columns per tile, NWT waves per workgroup, WPEU = minimum waves per SIMD the register allocation must allow
-// (78/16/1: one 16-wave workgroup per CU; 40/8/4: two 8-wave workgroups per CU, so one loads while the other computes)
-template <int S, bool PROLONG, bool SRCGEN, bool DEFECT, bool BLEND, int LZT = TILE_LZ, int NWT = TILE_NW,
-          int WPEU = (PROLONG ? TILE_WPE_P : TILE_WPE)>
+// Out-of-domain cells.  A tile that overhangs the grid stages CLAMPED copies of in-domain values in its out-of-domain LDS cells
+// (row index clamped on the scalar unit, the lane's column pair clamped once) and never masks them: a red-black update is only
+// performed at interior points (1 <= gz <= nz-2, 1 <= gc <= nr-2), whose four neighbours are all in the domain, the defect is
+// evaluated under the same condition (-0.0 elsewhere) and stores are confined to the in-domain part of the window -- so no
+// out-of-domain value ever reaches an output.  That is what keeps the load phase free of selects: per row two 16-B loads from
+// (scalar row pointer) + (per-lane byte offset), the lazy-source products and two LDS writes.
+template <int S, bool PROLONG, bool DEFECT, int LZT = TILE_LZ, int NWT = TILE_NW, int WPEU = TILE_WPE>
 __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
-                                                     const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, SrcGen sg,
-                                                     DefectDst dd, BlendArgs ba, int xcd_remap) {
-    constexpr int LZ = LZT, H = 2 * S + ((DEFECT || BLEND) ? 2 : 0), NW = NWT, NROWS = (LZ + NW - 1) / NW;
+                                                     const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, LazySrc lzs,
+                                                     DefectDst dd, int xcd_remap) {
+    constexpr int LZ = LZT, H = 2 * S + (DEFECT ? 2 : 0), NW = NWT, NROWS = LZ / NW;
+    static_assert(LZ % NW == 0 && (H % 2) == 0, "rows are dealt to waves evenly; the halo is even");
+    constexpr int RS = NW * 64;  // doubles between two rows of a wave inside a colour plane
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* A0 = lds;            // colour 0: (iz + ir) even
     double* A1 = lds + LZ * 64;  // colour 1
@@ -626,179 +611,131 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     const double* in = inF.at(b);
     double* out = outF.at(b);
     const int c0 = r0 + 2 * lane;  // global column of the lane's even element
-    const bool pass = active && !active[b];
-    if (pass) {
+    // the lane's pair is inside the window iff H/2 <= lane < 64 - H/2 (H even), and inside the grid iff c0 < nr; only the last
+    // pair of an odd-width grid is half inside (c0 == nr - 1)
+    const bool pair_own = lane >= H / 2 && lane < 64 - H / 2 && c0 < nr;
+    const bool pair_full = c0 + 1 < nr;
+    if (active && !active[b]) {  // frozen member: out = in on the window
 #pragma unroll
         for (int i = 0; i < NROWS; ++i) {
-            int lz = w + NW * i, gz = z0 + lz;
-            if (lz >= H && lz < LZ - H && gz < nz) {
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    int col = 2 * lane + p, gc = c0 + p;
-                    if (col >= H && col < 128 - H && gc < nr) out[(long)gz * ld + gc] = in[(long)gz * ld + gc];
-                }
+            const int lz = w + NW * i, gz = z0 + lz;
+            if (lz >= H && lz < LZ - H && gz < nz && pair_own) {
+                const long o = (long)gz * ld + c0;
+                if (pair_full) *reinterpret_cast<double2*>(out + o) = *reinterpret_cast<const double2*>(in + o);
+                else out[o] = in[o];
             }
         }
         return;
     }
     TILE_STAMP(0);
-#if defined(TILE_SKIP) && (TILE_SKIP & 16)
-    if (nz > 0) return;
-#endif
     const double* src = srcF.at(b);
-    // lazy-source mode (!SRCGEN && sg.st): srcF holds J_raw of k_jsum; Source = (-mu0 R) * (J_raw * scale) is formed on load
-    // with the expression of k_source, so the separate source pass over the fine grid disappears.  Otherwise scale = nm = 1.
+    const bool lazy = lzs.st != nullptr;  // uniform
     double lz_sc = 1.0, lz_n0 = 1.0, lz_n1 = 1.0;
-    if (!SRCGEN && sg.st) {
-        lz_sc = sg.st[b].jscale;
-        lz_n0 = (c0 >= 0 && c0 < nr) ? sg.neg_mu0R[c0] : 0.0;
-        lz_n1 = (c0 + 1 >= 0 && c0 + 1 < nr) ? sg.neg_mu0R[c0 + 1] : 0.0;
-    }
-    double g_pa = 0.0, g_den = 1.0, g_iden = 1.0, g_sc = 0.0;
-    if (SRCGEN) {
-        __shared__ double shj[4];
-        double sj = 0.0;
-        if (threadIdx.x < 256)
-            for (int i = threadIdx.x; i < sg.nblk; i += 256) sj += sg.part[(long)b * sg.nblk + i];
-        sj = wave_sum(sj);
-        if (lane == 0 && w < 4) shj[w] = sj;
-        __syncthreads();
-        double tot = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tot += shj[i];
-        const double ic = (tot * sg.dr) * sg.dz;  // core/fusion_kernel.py:436
-        const Member& m = sg.st[b];
-        g_pa = m.psi_axis; g_den = m.denom; g_iden = m.inv_denom;
-        g_sc = fabs(ic) > 1e-9 ? m.i_target / ic : 0.0;
-        if (bx_ == 0 && by_ == 0 && threadIdx.x == 0) { sg.st[b].i_current = ic; sg.st[b].jscale = g_sc; }
+    if (lazy) {
+        lz_sc = lzs.st[b].jscale;
+        lz_n0 = lzs.neg_mu0R[min(max(c0, 0), nr - 1)];
+        lz_n1 = lzs.neg_mu0R[min(max(c0 + 1, 0), nr - 1)];
     }
     double ae0 = 0.0, ae1 = 0.0, aw0 = 0.0, aw1 = 0.0;
     if (c0 >= 1 && c0 <= nr - 2) { ae0 = L.a_e[c0]; aw0 = L.a_w[c0]; }
     if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { ae1 = L.a_e[c0 + 1]; aw1 = L.a_w[c0 + 1]; }
     const double a_ns = L.a_ns, a_c = L.a_c, inv_a_c = L.inv_a_c, lo_a_c = L.lo_a_c;
-    // every row of this wave has the parity of w (lz = w + 8i), so the lane's element (0: even column, 1: odd
+    // every row of this wave has the parity of w (lz = w + NW*i, NW even), so the lane's element (0: even column, 1: odd
     // column) that carries colour c is e(c) = (c + w) & 1 for all rows: per-colour registers, no per-row selects
+    // (compiling the rest twice with e0 as a constant removes ~40 wave-uniform selects per wave but costs 15 VGPRs and puts the
+    //  kernel into scratch at the 80-register cap: measured by the compiler, not kept)
     const int e0 = w & 1;  // element index of colour 0
     const double aeC0 = e0 ? ae1 : ae0, awC0 = e0 ? aw1 : aw0, aeC1 = e0 ? ae0 : ae1, awC1 = e0 ? aw0 : aw1;
     double sC0[NROWS], sC1[NROWS];
-    // Load phase: every row's 16-B loads are issued unconditionally from CLAMPED addresses (row clamped into the domain,
-    // column pair clamped into the row pitch -- ld >= nr + 1 for odd nr, so the pair (nr-1, nr) reads pitch padding) and
-    // out-of-domain values are zeroed by selects afterwards.  Without the per-row bounds branches the compiler keeps all
-    // NROWS row loads in flight instead of draining vmcnt after each row.
-    const int cc = min(max(c0, 0), ld - 2);  // even, 16-B aligned
-    const bool okx = c0 >= 0 && c0 < nr, oky = c0 + 1 >= 0 && c0 + 1 < nr;
-    // PROLONG: the four coarse values around the lane's column pair are loaded the same way (clamped, unconditional);
-    // rows are processed in groups of LG so that psi + src + coarse loads of a group fit the register budget
+    const int rb = w * 64 + lane;           // slot of this lane in the wave's first row
+    double* const pe = (e0 ? A1 : A0) + rb;  // plane of the even column (colour (gz & 1) == e0 ? 1 : 0 since z0, c0 are even)
+    double* const po = (e0 ? A0 : A1) + rb;
+    // ---- load phase (see "Out-of-domain cells" above): all row loads of a group are issued before the first is consumed
+    const unsigned lane_off = (unsigned)min(max(c0, 0), ld - 2) * 8u;  // even column, 16-B aligned; ld >= nr + 1 for odd nr
+    const char* const in_b = reinterpret_cast<const char*>(in);
+    const char* const src_b = reinterpret_cast<const char*>(src);
+    // PROLONG: the four coarse values around the lane's column pair, loaded the same way; rows are processed in groups of LG so
+    // that psi + src + coarse loads of a group fit the register budget
     constexpr int LG = PROLONG ? (NROWS + 3) / 4 : NROWS;
-    const double* ccp = PROLONG ? coarseF.at(b) : nullptr;
+    const char* const cc_b = PROLONG ? reinterpret_cast<const char*>(coarseF.at(b)) : nullptr;
+    const unsigned ld8 = (unsigned)ld * 8u, ldc8 = (unsigned)ld_c * 8u;
     const int jc = max(c0, 0) >> 1;
-    const int jcc = PROLONG ? min(jc, nr_c - 1) : 0, jcc1 = PROLONG ? min(jc + 1, nr_c - 1) : 0;
+    const unsigned jc_off0 = PROLONG ? (unsigned)min(jc, nr_c - 1) * 8u : 0u, jc_off1 = PROLONG ? (unsigned)min(jc + 1, nr_c - 1) * 8u : 0u;
     const int h_end = PROLONG ? min(2 * (nr_c - 1), nr - 1) : 0, v_end = PROLONG ? min(2 * (nz_c - 1), nz - 1) : 0;
+    const bool odd_is_zero = c0 + 1 >= h_end;  // the odd column of the pair lies at / beyond the last coarse column: P = 0 there
 #pragma unroll
     for (int g0 = 0; g0 < NROWS; g0 += LG) {
         double2 pv[LG], sv2[LG];
         double ca0[LG], ca1[LG], cb0[LG], cb1[LG];
+        int gzs[LG];
 #pragma unroll
         for (int j = 0; j < LG; ++j) {
-            const int i = g0 + j, lz = w + NW * i;
-            const int gzc = min(max(z0 + min(lz, LZ - 1), 0), nz - 1);
-            const long o = (long)gzc * ld + cc;
-#if defined(TILE_SKIP) && (TILE_SKIP & 1)
-            pv[j] = double2{(double)(o & 1023), 1.0};
-            sv2[j] = double2{1.0, (double)(o & 255)};
-#else
-            pv[j] = *reinterpret_cast<const double2*>(in + o);
-            if (!SRCGEN) sv2[j] = *reinterpret_cast<const double2*>(src + o);
-            else sv2[j] = double2{0.0, 0.0};
-#endif
+            const int i = g0 + j;
+            if (i >= NROWS) continue;
+            const int gzc = min(max(z0 + w + NW * i, 0), nz - 1);  // scalar
+            gzs[j] = gzc;
+            // a member's field is < 4 GiB, so a load address is (scalar member base) + (32-bit byte offset): the row part of the
+            // offset is computed on the scalar unit, one vector add makes the lane's offset, psi and src share it
+            const unsigned vo = (unsigned)gzc * ld8 + lane_off;
+            pv[j] = *reinterpret_cast<const double2*>(in_b + vo);
+            sv2[j] = *reinterpret_cast<const double2*>(src_b + vo);
             if (PROLONG) {
                 const int ic = gzc >> 1, icc = min(ic, nz_c - 1), icc1 = (gzc & 1) ? min(ic + 1, nz_c - 1) : icc;
-                ca0[j] = ccp[(long)icc * ld_c + jcc];
-                ca1[j] = ccp[(long)icc * ld_c + jcc1];
-                cb0[j] = ccp[(long)icc1 * ld_c + jcc];
-                cb1[j] = ccp[(long)icc1 * ld_c + jcc1];
+                const unsigned ra = (unsigned)icc * ldc8, rbp = (unsigned)icc1 * ldc8;
+                ca0[j] = *reinterpret_cast<const double*>(cc_b + (ra + jc_off0));
+                ca1[j] = *reinterpret_cast<const double*>(cc_b + (ra + jc_off1));
+                cb0[j] = *reinterpret_cast<const double*>(cc_b + (rbp + jc_off0));
+                cb1[j] = *reinterpret_cast<const double*>(cc_b + (rbp + jc_off1));
             }
         }
 #pragma unroll
         for (int j = 0; j < LG; ++j) {
             const int i = g0 + j;
             if (i >= NROWS) continue;
-            const int lz = w + NW * i, gz = z0 + lz;
-            sC0[i] = 0.0;
-            sC1[i] = 0.0;
-            if (lz < LZ) {
-                const bool rowok = gz >= 0 && gz < nz;
-                double vx = (rowok && okx) ? pv[j].x : 0.0, vy = (rowok && oky) ? pv[j].y : 0.0;
-                double sx = (rowok && okx) ? sv2[j].x : 0.0, sy = (rowok && oky) ? sv2[j].y : 0.0;
-                if (!SRCGEN && sg.st) {  // wave-uniform
-                    const double tx_ = sx * lz_sc, ty_ = sy * lz_sc;
-                    sx = (rowok && okx) ? lz_n0 * (lz_sc != 0.0 ? tx_ : 0.0) : 0.0;
-                    sy = (rowok && oky) ? lz_n1 * (lz_sc != 0.0 ? ty_ : 0.0) : 0.0;
+            double vx = pv[j].x, vy = pv[j].y;
+            if (PROLONG) {
+                // bilinear prolongation, core/multigrid_solve.py:117-143 (same expressions as prolong_at); row tests are scalar
+                const int gzc = gzs[j];
+                double px, py;
+                if (!(gzc & 1)) {
+                    px = ca0[j];
+                    py = odd_is_zero ? 0.0 : 0.5 * (ca0[j] + ca1[j]);
+                } else if (gzc >= v_end) {
+                    px = 0.0;
+                    py = 0.0;
+                } else {
+                    px = 0.5 * (ca0[j] + cb0[j]);
+                    py = odd_is_zero ? 0.0 : 0.25 * (ca0[j] + cb0[j] + ca1[j] + cb1[j]);
                 }
-                if (PROLONG && rowok) {
-                    // bilinear prolongation, core/multigrid_solve.py:117-143 (same expressions as prolong_at)
-                    double px, py;
-                    if (!(gz & 1)) {
-                        px = ca0[j];
-                        py = (c0 + 1 >= h_end) ? 0.0 : 0.5 * (ca0[j] + ca1[j]);
-                    } else if (gz >= v_end) {
-                        px = 0.0;
-                        py = 0.0;
-                    } else {
-                        px = 0.5 * (ca0[j] + cb0[j]);
-                        py = (c0 + 1 >= h_end) ? 0.0 : 0.25 * (ca0[j] + cb0[j] + ca1[j] + cb1[j]);
-                    }
-                    if (okx) vx = vx + px;
-                    if (oky) vy = vy + py;
-                }
-                // even column has colour (gz & 1) == (lz & 1) == e0 ? 1 : 0 since z0, c0 are even
-                double* const pe = (e0 ? A1 : A0) + (w * 64 + lane);  // plane of the even column
-                double* const po = (e0 ? A0 : A1) + (w * 64 + lane);
-                pe[i * NW * 64] = vx;
-                po[i * NW * 64] = vy;
-                if (e0) { sC1[i] = sx; sC0[i] = sy; }
-                else { sC0[i] = sx; sC1[i] = sy; }
+                vx = vx + px;
+                vy = vy + py;
             }
+            pe[i * RS] = vx;
+            po[i * RS] = vy;
+            if (e0) { sC1[i] = sv2[j].x; sC0[i] = sv2[j].y; }
+            else { sC0[i] = sv2[j].x; sC1[i] = sv2[j].y; }
         }
         if (PROLONG) __builtin_amdgcn_sched_barrier(0);  // keep the next group's loads behind this group's LDS writes
     }
-    if (SRCGEN) {
-        // second pass over the wave's rows (psi read back from this lane's own LDS slots), one row at a time so the
-        // J_phi evaluation does not inflate the register footprint of the load phase
-        const bool ok0 = c0 >= 0 && c0 < nr, ok1 = c0 + 1 >= 0 && c0 + 1 < nr;
-        const double R0 = ok0 ? sg.r_axis[c0] : 1.0, R1 = ok1 ? sg.r_axis[c0 + 1] : 1.0;
-        const double im0 = ok0 ? sg.inv_mu0R[c0] : 0.0, im1 = ok1 ? sg.inv_mu0R[c0 + 1] : 0.0;
-        const double nm0 = ok0 ? sg.neg_mu0R[c0] : 0.0, nm1 = ok1 ? sg.neg_mu0R[c0 + 1] : 0.0;
+    if (lazy) {  // Source = (-mu0 R) * (scale != 0 ? J_raw * scale : 0), the expression of k_source; scale is per member (uniform)
+        const double nC0 = e0 ? lz_n1 : lz_n0, nC1 = e0 ? lz_n0 : lz_n1;  // (-mu0 R) of the column that carries colour 0 / 1
+        if (lz_sc != 0.0) {
 #pragma unroll
-        for (int i = 0; i < NROWS; ++i) {
-            const int lz = w + NW * i, gz = z0 + lz;
-            if (lz < LZ && gz >= 0 && gz < nz) {
-                const double vx = e0 ? A1[lz * 64 + lane] : A0[lz * 64 + lane];  // even column
-                const double vy = e0 ? A0[lz * 64 + lane] : A1[lz * 64 + lane];  // odd column
-                double sx = 0.0, sy = 0.0;
-                if (ok0) { const double jr = j_raw_at(vx, R0, im0, g_pa, g_den, g_iden, sg.pf); sx = nm0 * (g_sc != 0.0 ? jr * g_sc : 0.0); }
-                if (ok1) { const double jr = j_raw_at(vy, R1, im1, g_pa, g_den, g_iden, sg.pf); sy = nm1 * (g_sc != 0.0 ? jr * g_sc : 0.0); }
-                if (e0) { sC1[i] = sx; sC0[i] = sy; }
-                else { sC0[i] = sx; sC1[i] = sy; }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < NROWS; ++i) { sC0[i] = nC0 * (sC0[i] * lz_sc); sC1[i] = nC1 * (sC1[i] * lz_sc); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NROWS; ++i) { sC0[i] = nC0 * 0.0; sC1[i] = nC1 * 0.0; }
         }
     }
     __syncthreads();
     TILE_STAMP(1);
-#ifdef CV_STAMPS_DRAIN
-    __builtin_amdgcn_s_waitcnt(0);  // every counter to zero: is the long first pass a wait for loads still in flight?
-    __syncthreads();
-    TILE_STAMP(11);
-#endif
     // one half-sweep of colour c (compile-time, so the per-colour coefficients, source registers, column predicate and LDS
     // addresses are loop-invariant: the sweep loop is VALU-issue bound and every select / address add costs 4 cycles per row)
     // Every LDS address of the sweep is (one per-colour base pointer) + (compile-time row offset): the bases cost four
     // registers per colour and the row offsets become DS immediates.
-    const int rb = w * 64 + lane;  // slot of this lane in the wave's first row
     auto half_sweep = [&](auto colour, const int hs) {
         constexpr int c = decltype(colour)::value;
-        const int pr = (c + w) & 1;  // column parity of colour c in this wave's rows
+        const int pr = (c + e0) & 1;  // column parity of colour c in this wave's rows
         double* mine = (c ? A1 : A0) + rb;
         const double* oth = (c ? A0 : A1) + rb;
         const double* othWE = oth + (pr - 1);
@@ -809,7 +746,6 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
 #pragma unroll
         for (int i = 0; i < NROWS; ++i) {
             const int lz = w + NW * i, gz = z0 + lz;
-            constexpr int RS = NW * 64;  // doubles between two rows of a wave
             if (lz >= hs + 1 && lz <= LZ - 2 - hs && gz >= 1 && gz <= nz - 2) {  // wave-uniform
                 const double W = othWE[i * RS], E = othWE[i * RS + 1];
                 const double Sv = oth[i * RS - 64], N = oth[i * RS + 64];
@@ -821,9 +757,6 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             }
         }
     };
-#if defined(TILE_SKIP) && (TILE_SKIP & 2)
-    if (nz < 0)
-#endif
 #pragma unroll 1
     for (int sw = 0; sw < S; ++sw) {
         half_sweep(std::integral_constant<int, 0>{}, 2 * sw);
@@ -833,46 +766,26 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         __syncthreads();
         TILE_STAMP(3 + 2 * sw);
     }
-#if defined(TILE_SKIP) && (TILE_SKIP & 8)
-    if (nz < 0)
-#endif
-    if (!BLEND)
+    // ---- store the window
 #pragma unroll
     for (int i = 0; i < NROWS; ++i) {
         const int lz = w + NW * i, gz = z0 + lz;
-        if (lz >= H && lz < LZ - H && gz < nz) {
-            double vx, vy;
-            if (e0) { vx = (A1 + rb)[i * NW * 64]; vy = (A0 + rb)[i * NW * 64]; }
-            else { vx = (A0 + rb)[i * NW * 64]; vy = (A1 + rb)[i * NW * 64]; }
-            const int col = 2 * lane;
-            long o = (long)gz * ld + c0;
-            if (col >= H && col + 1 < 128 - H && c0 + 1 < nr) {
-                *reinterpret_cast<double2*>(out + o) = double2{vx, vy};
-            } else {
-                if (col >= H && col < 128 - H && c0 < nr) out[o] = vx;
-                if (col + 1 >= H && col + 1 < 128 - H && c0 + 1 < nr) out[o + 1] = vy;
-            }
-            if (SRCGEN) {  // publish the generated source of the window for defect / post-smooth / residual norms
-                double* so = srcF.at(b);
-                const double sx = e0 ? sC1[i] : sC0[i], sy = e0 ? sC0[i] : sC1[i];
-                if (col >= H && col < 128 - H && c0 < nr) so[o] = sx;
-                if (col + 1 >= H && col + 1 < 128 - H && c0 + 1 < nr) so[o + 1] = sy;
-            }
+        if (lz >= H && lz < LZ - H && gz < nz && pair_own) {  // (row test wave-uniform)
+            const double vx = pe[i * RS], vy = po[i * RS];
+            char* const o = reinterpret_cast<char*>(out) + ((unsigned)gz * ld8 + (unsigned)c0 * 8u);
+            if (pair_full) *reinterpret_cast<double2*>(o) = double2{vx, vy};
+            else *reinterpret_cast<double*>(o) = vx;
         }
     }
     TILE_STAMP(8);
-#if defined(TILE_SKIP) && (TILE_SKIP & 4)
-    if (DEFECT && nz < 0) {
-#else
     if (DEFECT) {
-#endif
         // (1) defect d = -(L*psi - src) of this wave's rows, both colours, into the source registers
         double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0;  // r_safe / its reciprocal (two words) of the lane's even / odd column
         if (c0 >= 1 && c0 <= nr - 2) { rs0 = dd.r_safe[c0]; ri0 = dd.r_inv[c0]; rl0 = dd.r_inv_lo[c0]; }
         if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { rs1 = dd.r_safe[c0 + 1]; ri1 = dd.r_inv[c0 + 1]; rl1 = dd.r_inv_lo[c0 + 1]; }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int pr = (c + w) & 1;
+            const int pr = (c + e0) & 1;
             const double* mine = (c ? A1 : A0) + rb;  // per-colour bases + compile-time row offsets, as in the sweeps
             const double* oth = (c ? A0 : A1) + rb;
             const double* othWE = oth + (pr - 1);
@@ -882,7 +795,6 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
 #pragma unroll
             for (int i = 0; i < NROWS; ++i) {
                 const int lz = w + NW * i, gz = z0 + lz;
-                constexpr int RS = NW * 64;
                 double d = -0.0;
                 if (lz >= H - 1 && lz <= LZ - H && gz >= 1 && gz <= nz - 2) {  // wave-uniform
                     const double W = othWE[i * RS], E = othWE[i * RS + 1];
@@ -901,180 +813,30 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         __syncthreads();  // every wave is done reading psi from the planes
         // (2) the planes now hold the defect
 #pragma unroll
-        for (int i = 0; i < NROWS; ++i) {
-            const int lz = w + NW * i;
-            if (lz < LZ) { (A0 + rb)[i * NW * 64] = sC0[i]; (A1 + rb)[i * NW * 64] = sC1[i]; }
-        }
+        for (int i = 0; i < NROWS; ++i) { (A0 + rb)[i * RS] = sC0[i]; (A1 + rb)[i * RS] = sC1[i]; }
         __syncthreads();
         TILE_STAMP(9);
-        // (3) full-weighting restriction of the window's even/even points; coarse ring = injected -0.0
+        // (3) full-weighting restriction of the window's even/even points; coarse ring = injected -0.0.  A coarse point sits at
+        // tile cell (lz, col) = (H + 2cz, H + 2cr), both even: the centre and the four diagonal neighbours are colour 0, the
+        // N/S/W/E neighbours colour 1, and with q = lz*64 + col/2 every address is q + constant.
         constexpr int CZ = (LZ - 2 * H) / 2, CR = (128 - 2 * H) / 2;
         double* rc = coarseF.at(b);
         double* ec = dd.e.at(b);
+        const int ic0 = (z0 + H) >> 1, jc0 = (r0 + H) >> 1;
         for (int t = threadIdx.x; t < CZ * CR; t += 64 * NW) {
             const int cz = t / CR, cr = t - cz * CR;
-            const int lz = H + 2 * cz, col = H + 2 * cr;
-            const int ic = (z0 + lz) >> 1, jc = (r0 + col) >> 1;
-            if (ic >= nz_c || jc >= nr_c) continue;
+            const int ic = ic0 + cz, jcn = jc0 + cr;
+            if (ic >= nz_c || jcn >= nr_c) continue;
             double v = -0.0;
-            if (ic >= 1 && ic <= nz_c - 2 && jc >= 1 && jc <= nr_c - 2) {
-                auto dget = [&](int z, int x) { return (((z + x) & 1) ? A1 : A0)[z * 64 + (x >> 1)]; };
-                v = fw9(dget(lz, col), dget(lz - 1, col), dget(lz + 1, col), dget(lz, col - 1), dget(lz, col + 1), dget(lz - 1, col - 1),
-                        dget(lz - 1, col + 1), dget(lz + 1, col - 1), dget(lz + 1, col + 1));
+            if (ic >= 1 && ic <= nz_c - 2 && jcn >= 1 && jcn <= nr_c - 2) {
+                const int q = (H + 2 * cz) * 64 + (H / 2 + cr);
+                v = fw9(A0[q], A1[q - 64], A1[q + 64], A1[q - 1], A1[q], A0[q - 65], A0[q - 64], A0[q + 63], A0[q + 64]);
             }
-            rc[(long)ic * ld_c + jc] = v;
-            ec[(long)ic * ld_c + jc] = 0.0;
+            rc[(long)ic * ld_c + jcn] = v;
+            ec[(long)ic * ld_c + jcn] = 0.0;
         }
     }
-    if (BLEND) {
-        double* red = lds + 2 * LZ * 64;  // reduction scratch behind the colour planes (part of the dynamic LDS)
-        const double* cur = ba.cur.at(b);
-        const double* bc = ba.bc.at(b);
-        double dsum = 0.0, minpsi = INFINITY, rmx = 0.0, rs2 = 0.0;
-        int bad = 0;
-        VI mx{0.0, -1}, mn{0.0, -1};
-        // (1) blend: cur rows loaded like the tile (clamped, all in flight); psi_new from this lane's plane slots
-        double2 cv[NROWS];
-#pragma unroll
-        for (int i = 0; i < NROWS; ++i) {
-            const int lz = w + NW * i;
-            const int gzc = min(max(z0 + min(lz, LZ - 1), 0), nz - 1);
-            cv[i] = *reinterpret_cast<const double2*>(cur + (long)gzc * ld + cc);
-        }
-#pragma unroll
-        for (int i = 0; i < NROWS; ++i) {
-            const int lz = w + NW * i, gz = z0 + lz;
-            if (lz >= H - 1 && lz <= LZ - H && gz >= 0 && gz < nz) {  // wave-uniform
-                double* px = (e0 ? A1 : A0) + lz * 64 + lane;  // even column
-                double* py = (e0 ? A0 : A1) + lz * 64 + lane;  // odd column
-                const bool rowring = gz == 0 || gz == nz - 1;
-                const bool rowown = lz >= H && lz < LZ - H;
-                double vx = 0.0, vy = 0.0;
-                const int col = 2 * lane;
-                if (okx) {
-                    const bool ring = rowring || c0 == 0 || c0 == nr - 1;
-                    const double pn = ring ? bc[(long)gz * ld + c0] : *px;
-                    const double pc = cv[i].x;
-                    vx = ba.om_alpha * pc + ba.alpha * pn;
-                    if (rowown && col >= H && col < 128 - H) {
-                        if (!finite_d(pn)) bad = 1;
-                        dsum += fabs(pn - pc);
-                        const long q = (long)gz * nr + c0;
-                        if (vx == vx) mx = vi_max(mx, VI{vx, q});
-                        if (finite_d(vx)) minpsi = fmin(minpsi, vx);
-                    }
-                }
-                if (oky) {
-                    const bool ring = rowring || c0 + 1 == 0 || c0 + 1 == nr - 1;
-                    const double pn = ring ? bc[(long)gz * ld + c0 + 1] : *py;
-                    const double pc = cv[i].y;
-                    vy = ba.om_alpha * pc + ba.alpha * pn;
-                    if (rowown && col + 1 >= H && col + 1 < 128 - H) {
-                        if (!finite_d(pn)) bad = 1;
-                        dsum += fabs(pn - pc);
-                        const long q = (long)gz * nr + c0 + 1;
-                        if (vy == vy) mx = vi_max(mx, VI{vy, q});
-                        if (finite_d(vy)) minpsi = fmin(minpsi, vy);
-                    }
-                }
-                *px = vx;
-                *py = vy;
-                if (rowown) {
-                    const long o = (long)gz * ld + c0;
-                    if (col >= H && col + 1 < 128 - H && c0 + 1 < nr) {
-                        *reinterpret_cast<double2*>(out + o) = double2{vx, vy};
-                    } else {
-                        if (col >= H && col < 128 - H && okx) out[o] = vx;
-                        if (col + 1 >= H && col + 1 < 128 - H && oky) out[o + 1] = vy;
-                    }
-                }
-            }
-        }
-        __syncthreads();  // the planes now hold nxt on [H-1, LZ-H] x all columns
-        // (2) residual norms and (divertor rows) |grad psi| of the owned points, one colour at a time
-        double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0;
-        if (c0 >= 1 && c0 <= nr - 2) { rs0 = dd.r_safe[c0]; ri0 = dd.r_inv[c0]; }
-        if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { rs1 = dd.r_safe[c0 + 1]; ri1 = dd.r_inv[c0 + 1]; }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const double* mine = c ? A1 : A0;
-            const double* oth = c ? A0 : A1;
-            const int pr = (c + w) & 1;
-            const int col = 2 * lane + pr, gc = r0 + col;
-            const bool colown = col >= H && col < 128 - H && gc >= 0 && gc < nr;
-            const bool colint = colown && gc >= 1 && gc <= nr - 2;
-            const double rs = pr ? rs1 : rs0, ri = pr ? ri1 : ri0;
-#pragma unroll
-            for (int i = 0; i < NROWS; ++i) {
-                const int lz = w + NW * i, gz = z0 + lz;
-                if (lz >= H && lz < LZ - H && gz >= 0 && gz < nz) {  // wave-uniform
-                    const double W = oth[lz * 64 + lane - 1 + pr], E = oth[lz * 64 + lane + pr];
-                    const double Sv = oth[(lz - 1) * 64 + lane], N = oth[(lz + 1) * 64 + lane];
-                    const double C = mine[lz * 64 + lane];
-                    if (colint && gz >= 1 && gz <= nz - 2) {
-                        const double sv = c ? sC1[i] : sC0[i];
-                        const double d2r = divc(E - 2.0 * C + W, dd.dr2, dd.inv_dr2);
-                        const double d1r = divc(E - W, dd.two_dr, dd.inv_two_dr);
-                        const double d2z = divc(N - 2.0 * C + Sv, dd.dz2, dd.inv_dz2);
-                        const double lpsi = d2r - divc(d1r, rs, ri) + d2z;
-                        const double r = sanitize1(lpsi - sv);
-                        rmx = fmax(rmx, fabs(r));
-                        rs2 += r * r;
-                    }
-                    if (colown && gz < ba.n_mask_rows) {  // np.gradient + hypot (fusion_kernel.py:276-288)
-                        const double ps = nan_to_num300(C);
-                        double gzv, grv;
-                        if (gz == 0) gzv = (nan_to_num300(N) - ps) / ba.dz;
-                        else if (gz == nz - 1) gzv = (ps - nan_to_num300(Sv)) / ba.dz;
-                        else gzv = (nan_to_num300(N) - nan_to_num300(Sv)) / (2.0 * ba.dz);
-                        if (gc == 0) grv = (nan_to_num300(E) - ps) / ba.dr;
-                        else if (gc == nr - 1) grv = (ps - nan_to_num300(W)) / ba.dr;
-                        else grv = (nan_to_num300(E) - nan_to_num300(W)) / (2.0 * ba.dr);
-                        const double bm = hypot(grv, gzv);
-                        if (finite_d(bm)) mn = vi_min(mn, VI{bm, (long)gz * nr + gc});
-                    }
-                }
-            }
-        }
-        // (3) workgroup reductions (fixed order: lanes by shuffle tree, then waves 0..NW-1) -> per-tile partials
-        dsum = wave_sum(dsum);
-        rs2 = wave_sum(rs2);
-        rmx = wave_max(rmx);
-        minpsi = -wave_max(-minpsi);
-        mx = wave_vi<true>(mx);
-        mn = wave_vi<false>(mn);
-        bad = __any(bad) ? 1 : 0;
-        double* r_dsum = red;
-        double* r_rs2 = red + NW;
-        double* r_rmx = red + 2 * NW;
-        double* r_minp = red + 3 * NW;
-        VI* r_mx = reinterpret_cast<VI*>(red + 4 * NW);
-        VI* r_mn = r_mx + NW;
-        int* r_bad = reinterpret_cast<int*>(r_mn + NW);
-        if (lane == 0) { r_dsum[w] = dsum; r_rs2[w] = rs2; r_rmx[w] = rmx; r_minp[w] = minpsi; r_mx[w] = mx; r_mn[w] = mn; r_bad[w] = bad; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double a = 0.0, c2 = 0.0, m1 = 0.0, mp = INFINITY;
-            VI vmx = r_mx[0], vmn = r_mn[0];
-            int bd = 0;
-            for (int i = 0; i < NW; ++i) {
-                a += r_dsum[i];
-                c2 += r_rs2[i];
-                m1 = fmax(m1, r_rmx[i]);
-                mp = fmin(mp, r_minp[i]);
-                bd |= r_bad[i];
-                if (i) { vmx = vi_max(vmx, r_mx[i]); vmn = vi_min(vmn, r_mn[i]); }
-            }
-            const long o = (long)b * ba.nblk + (long)by_ * gridDim.x + bx_;
-            ba.psum[o] = a;
-            ba.pbad[o] = bd;
-            ba.rmax[o] = m1;
-            ba.rsum[o] = m1 > 0.0 ? c2 / (m1 * m1) : 0.0;  // (max, sum (r/max)^2) convention of k_resid_norms
-            TopoPart tp;
-            tp.maxv = vmx.v; tp.maxi = vmx.i; tp.minb = vmn.v; tp.mini = vmn.i; tp.minpsi = mp; tp.pad = 0;
-            ba.topo[o] = tp;
-        }
-    }
+    static_assert(NW % 2 == 0, "row parity of a wave must be fixed");
     TILE_STAMP(10);
 }
 
@@ -1285,9 +1047,6 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
     if (active && !active[b]) return;
-#if defined(TILE_SKIP) && (TILE_SKIP & 128)
-    if (pre >= 0) return;
-#endif
     CV_STAMP(0);
     // stage the top-level rhs and the coefficient tables of every level.  The first five rhs values of a thread (all of a 65x65
     // level) are requested before the table loops run, so their round trip to memory overlaps the tables'
@@ -1736,9 +1495,6 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
     __shared__ double sh[4];
     int b = blockIdx.z;
     if (!st[b].active) return;
-#if defined(TILE_SKIP) && (TILE_SKIP & 64)
-    if (nz > 0) return;
-#endif
     const double* psi = psiF.at(b);
     double* raw = rawF.base ? rawF.at(b) : nullptr;  // lazy-source mode: J_raw is kept, consumers apply scale and -mu0 R
     const double pa = st[b].psi_axis, den = st[b].denom, iden = st[b].inv_denom;
@@ -1935,9 +1691,6 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
     __shared__ VI sh_mx[4], sh_mn[4];
     __shared__ double sh_dsum[4], sh_m[4], sh_minp[4], sh_s2[4];
     __shared__ int sh_bad[4];
-#if defined(TILE_SKIP) && (TILE_SKIP & 32)
-    if (nblk > 0) return;
-#endif
     // XCD-aware tile order (see k_smooth_tile): XCD k gets a contiguous run of tiles so halo rows are re-read from its own L2
     int bx_, by_, b;
     {
@@ -1965,29 +1718,6 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
     double dsum = 0.0, minpsi = INFINITY;
     int bad = 0;
     VI mx{0.0, -1}, mn{0.0, -1};
-#ifdef BLEND_SERIAL_LOADS
-    for (int i = tid; i < (BT_Z + 2) * (BT_R + 2); i += 256) {
-        const int lz = i / (BT_R + 2), lr = i - lz * (BT_R + 2);
-        const int gz = z0 + lz, gr = r0 + lr;
-        double v = 0.0;
-        if (gz >= 0 && gz < nz && gr >= 0 && gr < nr) {
-            const long c = (long)gz * ld + gr;
-            const bool ring = gz == 0 || gz == nz - 1 || gr == 0 || gr == nr - 1;
-            const double pn = ring ? bc[c] : nw[c];
-            const double pc = cur[c];
-            v = om_alpha * pc + alpha * pn;
-            if (lz >= lz_min && lz <= BT_Z && lr >= lr_min && lr <= BT_R) {  // owned point
-                if (!finite_d(pn)) bad = 1;
-                dsum += fabs(pn - pc);
-                nxt[c] = v;
-                const long q = (long)gz * nr + gr;
-                if (v == v) mx = vi_max(mx, VI{v, q});
-                if (finite_d(v)) minpsi = fmin(minpsi, v);
-            }
-        }
-        t[lz][lr] = v;
-    }
-#else
     // all loads of the thread's tile elements are issued before the first use (one memory round trip instead of one per element)
     constexpr int NEL = (BT_Z + 2) * (BT_R + 2), NLD = (NEL + 255) / 256;
     double pcv[NLD], pnv[NLD];
@@ -2026,7 +1756,6 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
         }
         t[lz][lr] = v;
     }
-#endif
     __syncthreads();
     double m = 0.0, rv[BT_Z / 4];
     const double lz_sc = lazy_nm ? st[b].jscale : 1.0;

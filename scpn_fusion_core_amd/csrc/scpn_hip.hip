@@ -346,103 +346,48 @@ struct DefectOut {  // coarse rhs / coarse correction produced by the fused defe
     Fld rhs{nullptr, nullptr, 0, 0}, e{nullptr, nullptr, 0, 0};
     int nz_c = 0, nr_c = 0, ld_c = 0;
 };
-// tile geometry variants: 0 = 78 rows / 16 waves (one workgroup per CU), 1 = 40 rows / 8 waves (two per CU), 2 = 46 rows / 16 waves
-struct TileGeo { int lz, nw; };
-#ifndef TILE_WPE_V1
-#define TILE_WPE_V1 6  // minimum waves per SIMD of the 40-row / 8-wave tile kernels: at most 80 VGPRs = three workgroups per CU
-                       // (tools/isa_regs.py on the hipcc -S output shows the allocation and any scratch the cap would force)
-#endif
-static int tile_variant_for(const Lvl& L) {
-    // SCPN_HIP_TILE="v0,v1,v2": variant for level 0, 1, 2+.  Default 1,1,1: measured on MI355X (513^2, 16 members per
-    // launch) the 40-row / 8-wave tile runs the fused pre-smoother in 49 us and the post-smoother in 40.5 us against
-    // 60 / 50 us for the 78-row / 16-wave tile, although its halo overhead is 21 % higher: with several workgroups per
-    // CU one loads its tile while another is in its LDS sweeps.
-    static const std::array<int, 3> cfg = [] {
-        std::array<int, 3> c{1, 1, 1};
-        if (const char* e = std::getenv("SCPN_HIP_TILE")) {
-            int a = 0, b = 0, d = 0;
-            int n = std::sscanf(e, "%d,%d,%d", &a, &b, &d);
-            if (n >= 1) c[0] = a;
-            if (n >= 2) c[1] = b;
-            if (n >= 3) c[2] = d;
-        }
-        return c;
-    }();
-    const int lvl = L.nz > 300 ? 0 : (L.nz > 150 ? 1 : 2);
-    return cfg[lvl];
-}
-template <int S, bool PROLONG, bool SRCGEN, bool DEFECT, bool BLEND, int LZT = TILE_LZ, int NWT = TILE_NW,
-          int WPEU = (PROLONG ? TILE_WPE_P : TILE_WPE)>
+template <int S, bool PROLONG, bool DEFECT>
 static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                        const SrcGen* sg, const DefectOut* dfo, const BlendArgs* bl = nullptr) {
+                        const DefectOut* dfo) {
     static std::once_flag attr_once;  // (two stream-group threads may reach a first launch at the same time)
-    const size_t lds = (size_t)LZT * 128 * sizeof(double) + (BLEND ? 2048 : 0);  // + reduction scratch of the blend stage
-    auto kern = &k_smooth_tile<S, PROLONG, SRCGEN, DEFECT, BLEND, LZT, NWT, WPEU>;
+    constexpr size_t lds = (size_t)TILE_LZ * 128 * sizeof(double);
+    auto kern = &k_smooth_tile<S, PROLONG, DEFECT>;
     std::call_once(attr_once, [&] {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
-    constexpr int H = 2 * S + ((DEFECT || BLEND) ? 2 : 0);
-    static_assert(LZT - 2 * H >= 2, "tile too short for its halo");
-    dim3 g(cdiv(L.nr, 128 - 2 * H), cdiv(L.nz, LZT - 2 * H), h->B);
+    constexpr int H = 2 * S + (DEFECT ? 2 : 0);
+    static_assert(TILE_LZ - 2 * H >= 2, "tile too short for its halo");
+    dim3 g(cdiv(L.nr, 128 - 2 * H), cdiv(L.nz, TILE_LZ - 2 * H), h->B);
     DefectDst dd;
     Fld cF = ps.c;
     int nz_c = ps.nz_c, nr_c = ps.nr_c, ld_c = ps.ld_c;
-    if (DEFECT || BLEND) {  // residual constants of this level
+    if (DEFECT) {  // residual constants of this level + where the coarse rhs / zeroed coarse correction go
         dd.dr2 = L.dr2; dd.dz2 = L.dz2; dd.two_dr = L.two_dr; dd.inv_dr2 = L.inv_dr2; dd.inv_dz2 = L.inv_dz2;
         dd.inv_two_dr = L.inv_two_dr; dd.r_safe = L.r_safe; dd.r_inv = L.r_inv;
         dd.lo_dr2 = L.lo_dr2; dd.lo_dz2 = L.lo_dz2; dd.lo_two_dr = L.lo_two_dr; dd.r_inv_lo = L.r_inv_lo;
-    }
-    if (DEFECT) {
         dd.e = dfo->e;
         cF = dfo->rhs; nz_c = dfo->nz_c; nr_c = dfo->nr_c; ld_c = dfo->ld_c;
     }
-    BlendArgs ba = bl ? *bl : BlendArgs{};
-    if (BLEND && (int)(g.x * g.y) != ba.nblk) throw std::runtime_error("blend partial layout mismatch");
     static const int xcd_env = [] { const char* e = std::getenv("SCPN_HIP_XCD"); return e ? std::atoi(e) : 1; }();
-    SrcGen sgv = sg ? *sg : SrcGen{};
-    if (!SRCGEN && h->lazy_src && src.base == h->lazy_src) { sgv.st = h->d_st.p; sgv.neg_mu0R = h->d_neg_mu0R.p; }
-    SCPN_LAUNCH(kern, g, dim3(64 * NWT), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c, ld_c,
-                       sgv, dd, ba, xcd_env);
+    LazySrc lzs;
+    if (h->lazy_src && src.base == h->lazy_src) { lzs.st = h->d_st.p; lzs.neg_mu0R = h->d_neg_mu0R.p; }
+    SCPN_LAUNCH(kern, g, dim3(64 * TILE_NW), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c, ld_c, lzs, dd,
+                xcd_env);
 }
-// the production roles (plain / +prolongation / +defect) and the blend-fused post-smoother exist in every geometry; source
-// generation only in the default one
-template <int S, bool PROLONG, bool DEFECT, bool BLEND = false>
-static void launch_tile_geo(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                            const DefectOut* dfo, const BlendArgs* bl = nullptr) {
-    switch (tile_variant_for(L)) {
-        case 1: launch_tile<S, PROLONG, false, DEFECT, BLEND, 40, 8, TILE_WPE_V1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
-        case 2: launch_tile<S, PROLONG, false, DEFECT, BLEND, 46, 16, 1>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
-        default: launch_tile<S, PROLONG, false, DEFECT, BLEND>(h, L, out, in, src, omega, active, ps, nullptr, dfo, bl); break;
-    }
-}
-static int tile_rows_for(const Lvl& L) {
-    const int v = tile_variant_for(L);
-    switch (v) { case 1: return 40; case 2: return 46; case 3: return 48; case 4: return 56; case 5: return 64; case 6: return 32;
-                 case 7: return 56; case 8: return 64; case 9: return 40; case 10: return 32; default: return TILE_LZ; }
-}
+// the three production roles of the tile kernel: plain, + prolongation on load, + defect / restriction on store
 template <int S>
 static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                          const SrcGen* sg, const DefectOut* dfo, const BlendArgs* bl) {
-    if (bl && ps.c.base) launch_tile_geo<S, true, false, true>(h, L, out, in, src, omega, active, ps, nullptr, bl);
-    else if (bl) launch_tile_geo<S, false, false, true>(h, L, out, in, src, omega, active, ps, nullptr, bl);
-    else if (dfo && sg) launch_tile<S, false, true, true, false>(h, L, out, in, src, omega, active, ps, sg, dfo);
-    else if (dfo) launch_tile_geo<S, false, true>(h, L, out, in, src, omega, active, ps, dfo);
-    else if (sg) launch_tile<S, false, true, false, false>(h, L, out, in, src, omega, active, ps, sg, nullptr);
-    else if (ps.c.base) launch_tile_geo<S, true, false>(h, L, out, in, src, omega, active, ps, nullptr);
-    else launch_tile_geo<S, false, false>(h, L, out, in, src, omega, active, ps, nullptr);
-}
-// tiles per member of the blend-fused post-smoother (its partial arrays are indexed by tile)
-static int blend_tiles(const Lvl& L, int post) {
-    const int S = ((post - 1) % 3) + 1, H = 2 * S + 2;
-    return cdiv(L.nr, 128 - 2 * H) * cdiv(L.nz, tile_rows_for(L) - 2 * H);
+                          const DefectOut* dfo) {
+    if (dfo) launch_tile<S, false, true>(h, L, out, in, src, omega, active, ps, dfo);
+    else if (ps.c.base) launch_tile<S, true, false>(h, L, out, in, src, omega, active, ps, nullptr);
+    else launch_tile<S, false, false>(h, L, out, in, src, omega, active, ps, nullptr);
 }
 
 // n_sweeps red-black SOR sweeps of (in, src).  Returns the field that holds the result: `in` itself for the
 // in-place kernels, or `in`/`alt` alternately for the out-of-place LDS-tiled kernel (`alt` must not alias `in`).
 static std::string lname(const char* kind, int lvl) { return std::string(kind) + "_L" + std::to_string(lvl); }
 static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omega, int n_sweeps, const int* active,
-                  bool clip = false, int lvl = 0, const ProlongSrc* prolong = nullptr, const SrcGen* srcgen = nullptr,
-                  const DefectOut* defect = nullptr, const BlendArgs* blend = nullptr, Fld blend_out = Fld{nullptr, nullptr, 0, 0}) {
+                  bool clip = false, int lvl = 0, const ProlongSrc* prolong = nullptr, const DefectOut* defect = nullptr) {
     if (n_sweeps <= 0 || L.nz < 3 || L.nr < 3) return in;
     const double om1 = 1.0 - omega;
     if (!clip && (long)L.nz * L.nr <= SMALL_MAX) {
@@ -457,20 +402,13 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
         Fld a = in, b = alt;
         int left = n_sweeps;
         ProlongSrc pso = prolong ? *prolong : ProlongSrc{};  // only the first launch adds the coarse correction
-        const SrcGen* sgo = srcgen;                          // ... and only the first launch generates the source
         while (left > 0) {
             const int S = std::min(3, left);
-            // the LAST launch of the sequence also produces the coarse rhs (it cannot be combined with source generation)
-            const DefectOut* dfo = (defect && left - S <= 0) ? defect : nullptr;
-            const bool last = left - S <= 0;
-            const BlendArgs* bl = (blend && last) ? blend : nullptr;  // the last launch writes the blended iterate
-            Fld dst = bl ? blend_out : b;
-            if (S == 3) launch_tile_p<3>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
-            else if (S == 2) launch_tile_p<2>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
-            else launch_tile_p<1>(h, L, dst, a, src, omega, active, pso, sgo, dfo, bl);
-            if (bl) return dst;
+            const DefectOut* dfo = (defect && left - S <= 0) ? defect : nullptr;  // the LAST launch also produces the coarse rhs
+            if (S == 3) launch_tile_p<3>(h, L, b, a, src, omega, active, pso, dfo);
+            else if (S == 2) launch_tile_p<2>(h, L, b, a, src, omega, active, pso, dfo);
+            else launch_tile_p<1>(h, L, b, a, src, omega, active, pso, dfo);
             pso = ProlongSrc{};
-            sgo = nullptr;
             std::swap(a, b);
             left -= S;
         }
@@ -489,16 +427,6 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
 
 // One V-cycle (core/multigrid_solve.py:252-335) of (in0, src0) on level 0.  in0 is left untouched; the improved
 // estimate is produced in bufA or bufB (returned).  `active` (may be null) freezes members.
-static bool vcycle_can_srcgen(Solver* h, int pre, int min_grid) {
-    Hier& H = get_hier(h, min_grid);
-    const Lvl& L0 = H.lv[0]->dev;
-    return h->use_fused && H.lv.size() > 1 && pre > 0 && (long)L0.nz * L0.nr > SMALL_MAX;
-}
-static bool vcycle_can_blend(Solver* h, int post, int min_grid) {
-    Hier& H = get_hier(h, min_grid);
-    const Lvl& L0 = H.lv[0]->dev;
-    return h->use_fused && H.lv.size() > 1 && post > 0 && (long)L0.nz * L0.nr > SMALL_MAX;
-}
 // every level-0 consumer of the source inside the V-cycle is a tile kernel (pre-smoother with fused defect, post-smoother)
 static bool vcycle_lazy_ok(Solver* h, int pre, int post, int min_grid) {
     Hier& H = get_hier(h, min_grid);
@@ -507,8 +435,7 @@ static bool vcycle_lazy_ok(Solver* h, int pre, int post, int min_grid) {
     return h->use_fused && H.lv.size() > 1 && pre > 0 && pre <= 3 && post > 0 && (long)L0.nz * L0.nr > SMALL_MAX && !(e && std::atoi(e) > 0);
 }
 static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega, int pre, int post, int min_grid,
-                  const int* active, const SrcGen* srcgen = nullptr, const BlendArgs* blend = nullptr,
-                  Fld blend_out = Fld{nullptr, nullptr, 0, 0}) {
+                  const int* active) {
     Hier& H = get_hier(h, min_grid);
     auto& lv = H.lv;
     const int k = (int)lv.size() - 1;
@@ -544,10 +471,10 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
             const bool df = k > 0 && defect_fusable(0);
             if (df) d0 = defect_out(0);
             if (n0 <= 3) {
-                cur[0] = smooth(h, L0, in0, bufA, src0, omega, n0, active, false, 0, nullptr, srcgen, df ? &d0 : nullptr);  // in0 -> bufA
+                cur[0] = smooth(h, L0, in0, bufA, src0, omega, n0, active, false, 0, nullptr, df ? &d0 : nullptr);  // in0 -> bufA
             } else {
-                Fld r = smooth(h, L0, in0, bufA, src0, omega, 3, active, false, 0, nullptr, srcgen);
-                cur[0] = smooth(h, L0, r, bufB, src0, omega, n0 - 3, active, false, 0, nullptr, nullptr, df ? &d0 : nullptr);
+                Fld r = smooth(h, L0, in0, bufA, src0, omega, 3, active, false, 0);
+                cur[0] = smooth(h, L0, r, bufB, src0, omega, n0 - 3, active, false, 0, nullptr, df ? &d0 : nullptr);
             }
             defect_done0 = df;
         } else {
@@ -564,7 +491,7 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
             const bool df = defect_fusable(l);
             DefectOut dl;
             if (df) dl = defect_out(l);
-            cur[l] = smooth(h, lv[l]->dev, cur[l], other_of(l, cur[l]), rhs_of(l), omega, pre, active, false, l, nullptr, nullptr,
+            cur[l] = smooth(h, lv[l]->dev, cur[l], other_of(l, cur[l]), rhs_of(l), omega, pre, active, false, l, nullptr,
                             df ? &dl : nullptr);
             done = df;
         }
@@ -595,8 +522,7 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
         if (tile_post) {  // prolongation fused into the post-smoother's tile load
             ProlongSrc pso;
             pso.c = cur[l + 1]; pso.nz_c = Lc.nz; pso.nr_c = Lc.nr; pso.ld_c = Lc.ld;
-            cur[l] = smooth(h, Lf, cur[l], other_of(l, cur[l]), rhs_of(l), omega, post, active, false, l, &pso, nullptr, nullptr,
-                            l == 0 ? blend : nullptr, blend_out);
+            cur[l] = smooth(h, Lf, cur[l], other_of(l, cur[l]), rhs_of(l), omega, post, active, false, l, &pso);
         } else {
             {
                 ProfScope ps(h, lname("prolong_add", l).c_str(), 1);
@@ -919,9 +845,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     // apply (-mu0 R) * (J_raw * scale) on load -- the k_source pass over the fine grid disappears (bit-identical; -1.1 % per
     // iteration on MI355X).  SCPN_HIP_LAZYSRC=0 restores the separate source pass
     static const bool lazy_env = [] { const char* e = std::getenv("SCPN_HIP_LAZYSRC"); return !(e && e[0] == '0'); }();
-    static const bool srcgen_env0 = [] { const char* e = std::getenv("SCPN_HIP_SRCGEN"); return e && e[0] == '1'; }();
-    static const bool blend_env0 = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1'; }();
-    const bool lazy = lazy_env && !srcgen_env0 && h->use_fused && p->method == 0 && !p->external_profile_mode &&
+    const bool lazy = lazy_env && h->use_fused && p->method == 0 && !p->external_profile_mode &&
                       vcycle_lazy_ok(h, 3, 3, 5);
     struct LazyGuard {
         Solver* h;
@@ -946,46 +870,22 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
                 SCPN_LAUNCH(k_xpoint_saddle, dim3(B), dim3(1024), 0, st, curF, h->d_st.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
                                    (const double*)h->d_r.p, (const double*)h->d_z.p);
         }
-        // source generation inside the pre-smoother is implemented and bit-exact, but its 160-VGPR footprint drops the
-        // tile kernel to one workgroup per CU and it measured slower (61.8 vs 48.9 us per launch): opt-in only
-        static const bool srcgen_env = [] { const char* e = std::getenv("SCPN_HIP_SRCGEN"); return e && e[0] == '1'; }();
-        const bool gen = srcgen_env && !p->external_profile_mode && p->method == 0 && vcycle_can_srcgen(h, 3, 5);
-        SrcGen sg{};
         if (!p->external_profile_mode) {
-            ProfScope ps(h, "source", gen ? 1 : (lazy ? 2 : 3));
+            ProfScope ps(h, "source", lazy ? 2 : 3);
             SCPN_LAUNCH(k_jsum, gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
                                (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, lazy ? srcF : Fld{nullptr, nullptr, 0, 0});
-            if (lazy) {  // the V-cycle's level-0 tiles and the fused tail form the source from J_raw on load
-                SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
-            } else if (gen) {  // scale + source are evaluated inside the pre-smoother's tile load
-                sg.r_axis = h->d_r.p; sg.inv_mu0R = h->d_inv_mu0R.p; sg.neg_mu0R = h->d_neg_mu0R.p; sg.part = h->d_jpart.p;
-                sg.st = h->d_st.p; sg.nblk = nblkj; sg.dr = h->dr; sg.dz = h->dz; sg.pf = pf;
-            } else {
-                SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
+            SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
+            if (!lazy)  // (lazy: the V-cycle's level-0 tiles and the fused tail form the source from J_raw on load)
                 SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, srcF, jF, 0, curF, (const Member*)h->d_st.p, nz, nr, ld,
                                    (const double*)h->d_r.p, (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
-            }
         }
         // _elliptic_solve (iterative_solver.py:361-380)
         Fld newF = WF;
-        // blend + norms + topology inside the post-smoother is implemented and bit-identical to k_blend_fused, but at one
-        // 16-wave workgroup per CU its extra compute is not hidden (160.8 vs 172.3 eq/s measured): opt-in (SCPN_HIP_BLENDFUSE=1).
-        // Round 2, 40-row tiles + lazy source: 344.5 vs 353-357 us per iteration (-2.7 %), but its residual sum squares r
-        // unscaled (overflow above |r| ~ 1e154, where k_blend_fused stays finite) and making it safe (power-of-two scaling by the
-        // previous residual) costs the gain back (347-350 vs 351-353): the kernel sits at its 80-VGPR cap with 36 B of scratch and
-        // every added live value shows.  Still opt-in.
-        static const bool blend_env = [] { const char* e = std::getenv("SCPN_HIP_BLENDFUSE"); return e && e[0] == '1'; }();
-        const bool blend_in_tile = blend_env && p->method == 0 && vcycle_can_blend(h, 3, 5);
+        // (source generation inside the pre-smoother and blend / norms / topology inside the post-smoother were implemented,
+        //  bit-exact and measured slower or unsafe in rounds 1-2: profiles/r02_negative/tile_kernel_r02_variants.hip.h.txt)
         int nb_d = nblk1, nb_r = nblk_r;
         if (p->method == 0) {
-            BlendArgs ba;
-            if (blend_in_tile) {  // the post-smoother's last launch blends, writes nxt and produces all partials
-                ba.cur = curF; ba.bc = bcF; ba.alpha = p->alpha; ba.om_alpha = om_alpha; ba.dr = h->dr; ba.dz = h->dz;
-                ba.n_mask_rows = n_mask_rows; ba.nblk = blend_tiles(L0, 3);
-                ba.psum = h->d_part1.p; ba.pbad = h->d_pbad.p; ba.rmax = h->d_part2.p; ba.rsum = h->d_part3.p; ba.topo = h->d_topo.p;
-                nb_d = nb_r = ba.nblk;
-            }
-            newF = vcycle(h, curF, WF, W2F, srcF, p->sor_omega, 3, 3, 5, act, gen ? &sg : nullptr, blend_in_tile ? &ba : nullptr, nxtF);
+            newF = vcycle(h, curF, WF, W2F, srcF, p->sor_omega, 3, 3, 5, act);
         } else if (p->method == 1 || p->method == 3 || p->method == 4) {  // "sor", "anderson" and any other method string (iterative_solver.py:376-378)
             SCPN_LAUNCH(k_sanitize, g2, BLK2D, 0, st, WF, curF, nz, nr, ld);
             SCPN_LAUNCH(k_sanitize, g2, BLK2D, 0, st, src2F, srcF, nz, nr, ld);
@@ -993,9 +893,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         } else {
             SCPN_LAUNCH(k_jacobi, g2, BLK2D, 0, st, WF, curF, srcF, L0, act);
         }
-        if (blend_in_tile) {
-            // nothing to do: blend, norms and next-iteration topology partials came out of the post-smoother
-        } else if (h->use_fused && p->method != 3) {
+        if (h->use_fused && p->method != 3) {
             ProfScope ps(h, "blend_fused", 1);
             nb_d = nb_r = nblk2;
             auto recip_lo = [](double d) { return std::fma(-d, 1.0 / d, 1.0) / d; };

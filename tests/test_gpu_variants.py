@@ -1,5 +1,5 @@
-"""Every tuning switch of the HIP path (tile geometry, XCD order, fusion variants, graph replay, lazy source) must give the
-same bits as the default: they only change where and when the reference's arithmetic is executed."""
+"""Every tuning switch of the HIP path (XCD order, fused / one-pass kernels, lazy source, group count, defect fusion level) and
+every experiment build (tile geometry, register cap) must give the same bits as the default: they only change where and when the reference's arithmetic is executed."""
 import json
 import os
 import subprocess
@@ -14,15 +14,15 @@ HERE = Path(__file__).resolve().parent
 SWITCHES = [
     {"SCPN_HIP_FUSED": "0"},
     {"SCPN_HIP_XCD": "0"},
-    {"SCPN_HIP_TILE": "0,0,0"},
-    {"SCPN_HIP_TILE": "2,2,2"},
     {"SCPN_HIP_LAZYSRC": "0"},
-    {"SCPN_HIP_SRCGEN": "1"},
-    {"SCPN_HIP_BLENDFUSE": "1"},
-
     {"SCPN_HIP_GROUPS": "2"},
     {"SCPN_HIP_DEFECT_MINLVL": "9"},
 ]
+# experiment builds (never shipped: `_lib.build(variant=...)` makes libscpn_hip.<variant>.so next to the product library)
+EXPERIMENT_BUILDS = {
+    "lz48": ("TILE_LZ_N=48",),            # another tile geometry: 48 rows x 128 columns, 6 rows per wave
+    "wpe8": ("TILE_WPE=8",),              # register allocation capped at 64: four tile workgroups per CU
+}
 
 
 def run(extra, n=257):
@@ -46,3 +46,14 @@ def test_switches_are_bit_identical():
         # fields bit-identical; the mean |dpsi| reduction groups its partial sums by tile, so it may differ in the last ulp
         assert (got["psi"], got["jphi"], got["iterations"]) == (base["psi"], base["jphi"], base["iterations"]), (sw, got, base)
         assert got["residual"] == pytest.approx(base["residual"], rel=1e-13), sw
+
+
+def test_experiment_builds_are_bit_identical():
+    from scpn_fusion_core_amd import _lib
+
+    _lib.require_gpu()
+    base = run({})
+    for name, defines in EXPERIMENT_BUILDS.items():
+        lib = _lib.build(variant=name, defines=defines)
+        got = run({"SCPN_HIP_LIB": str(lib)})
+        assert (got["psi"], got["jphi"], got["iterations"]) == (base["psi"], base["jphi"], base["iterations"]), (name, got, base)
