@@ -109,6 +109,32 @@ __device__ __forceinline__ double nan_to_num300(double x) {  // fusion_kernel.py
 }
 __device__ __forceinline__ bool finite_d(double x) { return fabs(x) <= 1.7976931348623157e308; }
 
+// ---------------------------------------------------------------- "last workgroup finishes" hand-off
+// A kernel whose workgroups each leave a few partials for a per-member final reduction can let the workgroup that ARRIVES LAST do
+// that reduction itself instead of ending and paying a dependent launch for it (k_jsum -> k_jsum_final, k_blend_fused ->
+// k_picard_final: two launches and two kernel boundaries off the ~11-launch chain of a Picard iteration).  Protocol
+// (MI355X_MICROARCH.md, "Valid forms", first row of the sc1 table, with the acquire kept):
+//   producer: thread 0 writes the workgroup's partials with agent-scope (sc1, write-through) stores, drains them
+//             (s_waitcnt vmcnt(0)) and takes a ticket with a relaxed agent-scope atomic add on the member's counter;
+//   consumer: the workgroup whose ticket is count-1 -- told through LDS + barrier to all its waves -- issues ONE agent-scope
+//             acquire (invalidates its L1) and reads every partial with agent-scope (sc1) loads.
+// No release fence anywhere: a buffer_wbl2 per workgroup writes back the whole XCD L2 each time and made this pattern 16x
+// slower in round 2.  The partials are combined in index order, so the result does not depend on which workgroup
+// came last.  The last workgroup resets the counter; the next launch sees that behind the kernel boundary.
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(long* p, long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool AGENT, typename T>
+__device__ __forceinline__ T ld_part(const T* p) {
+    if (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+// thread 0 of every arriving workgroup, after its partial stores: true for the last of `count` arrivals
+__device__ __forceinline__ bool take_ticket(unsigned* counter, unsigned count) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partials have left this CU before the ticket is taken
+    return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == count - 1u;
+}
+
 // ---------------------------------------------------------------- block reductions (256 thr)
 // Wave reductions on the DPP cross-lane network (row_shr within the 16-lane rows, then row_bcast:15 / row_bcast:31 across
 // rows; the total lands in lane 63 and is broadcast through an SGPR).  A __shfl_down butterfly costs two ds_bpermute
@@ -566,7 +592,7 @@ struct TopoPart {
     double minb;
     long mini;
     double minpsi;
-    long pad;
+    double psi_at_min;  // psi at `mini` (the X-point candidate): the final reduction needs no read of the field
 };
 struct DefectDst {
     Fld e{nullptr, nullptr, 0, 0};
@@ -1348,7 +1374,8 @@ __global__ void __launch_bounds__(256) k_topology(Fld psiF, const Member* st, in
     double rmp = -block_max<256>(-minpsi, shd);
     if (threadIdx.x == 0) {
         TopoPart t;
-        t.maxv = rmx.v; t.maxi = rmx.i; t.minb = rmn.v; t.mini = rmn.i; t.minpsi = rmp; t.pad = 0;
+        t.maxv = rmx.v; t.maxi = rmx.i; t.minb = rmn.v; t.mini = rmn.i; t.minpsi = rmp;
+        t.psi_at_min = rmn.i >= 0 ? psi[(rmn.i / nr) * (long)ld + (rmn.i % nr)] : 0.0;
         part[(long)b * nblk + blockIdx.x] = t;
     }
 }
@@ -1489,10 +1516,29 @@ __global__ void __launch_bounds__(1024) k_xpoint_saddle(Fld psiF, Member* st, in
 #define JS_ROWS_N 64
 #endif
 constexpr int JS_ROWS = JS_ROWS_N;  // rows per workgroup of the column-pair kernels (k_jsum, k_source)
+// finishes the J_raw sum of member b: I = (sum * dr) * dz, scale = I_target / I  (core/fusion_kernel.py:436-438); all 256 threads
+template <bool AGENT>
+__device__ __forceinline__ void jsum_final_body(int b, Member* st, const double* part, int nblk, double dr, double dz, double* sh) {
+    const double itg = st[b].i_target;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += ld_part<AGENT>(part + (long)b * nblk + i);
+    double tot = block_sum<256>(s, sh);
+    if (threadIdx.x == 0) {
+        double ic = (tot * dr) * dz;
+        st[b].i_current = ic;
+        st[b].jscale = fabs(ic) > 1e-9 ? itg / ic : 0.0;
+    }
+}
+struct JsumTail {  // counters != nullptr: the last workgroup of a member runs jsum_final_body (no k_jsum_final launch)
+    unsigned* counters = nullptr;
+    Member* st = nullptr;
+    double dr = 0, dz = 0;
+};
 __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz, int nr, int ld,
                                               const double* r_axis, const double* inv_mu0R, Prof pf,
-                                              double* part, int nblk, Fld rawF) {
+                                              double* part, int nblk, Fld rawF, JsumTail tail) {
     __shared__ double sh[4];
+    __shared__ int sh_last;
     int b = blockIdx.z;
     if (!st[b].active) return;
     const double* psi = psiF.at(b);
@@ -1533,24 +1579,27 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
         }
     }
     double bs = block_sum<256>(s, sh);
-    if (threadIdx.x == 0) part[(long)b * nblk + (long)blockIdx.y * gridDim.x + blockIdx.x] = bs;
+    double* mine = part + (long)b * nblk + (long)blockIdx.y * gridDim.x + blockIdx.x;
+    if (!tail.counters) {
+        if (threadIdx.x == 0) *mine = bs;
+        return;
+    }
+    if (threadIdx.x == 0) {
+        st_agent(mine, bs);
+        sh_last = take_ticket(tail.counters + b, (unsigned)nblk) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    jsum_final_body<true>(b, tail.st, part, nblk, tail.dr, tail.dz, sh);
+    if (threadIdx.x == 0) __hip_atomic_store(tail.counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ void __launch_bounds__(256) k_jsum_final(Member* st, const double* part, int nblk, double dr,
                                                     double dz) {
     __shared__ double sh[4];
     const int b = blockIdx.x;
-    const int act = st[b].active;           // requested together with the partials and the target current: one round trip
-    const double itg = st[b].i_target;
-    double s = 0.0;
-    if ((int)threadIdx.x < nblk) s += part[(long)b * nblk + threadIdx.x];
-    if (!act) return;
-    for (int i = threadIdx.x + 256; i < nblk; i += 256) s += part[(long)b * nblk + i];
-    double tot = block_sum<256>(s, sh);
-    if (threadIdx.x == 0) {
-        double ic = (tot * dr) * dz;  // core/fusion_kernel.py:436
-        st[b].i_current = ic;
-        st[b].jscale = fabs(ic) > 1e-9 ? itg / ic : 0.0;
-    }
+    if (!st[b].active) return;
+    jsum_final_body<false>(b, st, part, nblk, dr, dz, sh);
 }
 // Source = (-mu0*R) * (J_raw * scale)  (core/fusion_kernel.py:440, newton_solver.py:513); optionally stores J_phi.
 // Column pair per thread (16-B loads / stores); grid (ceil(nr/128), ceil(nz/16), B), 256 threads
@@ -1661,6 +1710,182 @@ __global__ void __launch_bounds__(256) k_blend(Fld nxtF, Fld curF, Fld newF, Fld
 // A 256-thread workgroup blends a (BT_Z+2) x (64+2) tile into LDS (1-cell halo recomputed from cur/new) and evaluates the
 // residual / np.gradient stencils from LDS.  grid (ceil(nr/64), ceil(nz/BT_Z), B).  All seven workgroup reductions share two
 // barriers: wave-level DPP reductions -> LDS -> barrier -> (block max, rescaled sum of squares) -> LDS -> barrier -> thread 0.
+struct PicardCtl {
+    double tol, gs_tol;
+    int require_gs, max_iter, iter, pad;
+    long n_total, n_interior;
+};
+// everything k_picard_final needs besides the member index (also handed to k_blend_fused, whose last workgroup per member runs it)
+struct PicardTail {
+    Member* st = nullptr;
+    const double* psum = nullptr;
+    const int* pbad = nullptr;
+    const double* rmax = nullptr;
+    const double* rsum = nullptr;
+    int nblk = 0, nblk_r = 0;
+    PicardCtl ctl{};
+    double* hist_diff = nullptr;
+    double* hist_gs = nullptr;
+    double* trace = nullptr;
+    int* n_active = nullptr;
+    int* f_cur = nullptr;
+    int* f_nxt = nullptr;
+    int* f_best = nullptr;
+    int* f_prev = nullptr;
+    int* f_active = nullptr;
+    const TopoPart* topo = nullptr;  // != nullptr: also finish the axis / X-point search of the NEXT iteration (k_topology_final's work)
+    int ntopo = 0;
+    int nr = 0;
+    const double* r_axis = nullptr;
+    const double* z_axis = nullptr;
+    unsigned* counters = nullptr;  // per-member arrival counters of the fused form (k_blend_fused)
+};
+// shared scratch of picard_final_body (declared by the calling kernel)
+struct PicardShared {
+    double sh[4], sh2[4], shd[4], shp[4];
+    int shbad[4];
+    VI shx[4], shn[4];
+};
+// One 256-thread workgroup finishes member b: diff / GS RMS, best / ping-pong slots, convergence
+// (core/fusion_kernel_newton_solver.py:518-571) and, with t.topo, the axis / X-point of the next iterate.  AGENT: the partials
+// were written by other workgroups of the SAME launch (agent-scope loads); the partial of index i is combined by thread i % 256
+// in ascending i, then lanes, then waves 0..3 -- independent of who runs it.
+template <bool AGENT>
+__device__ __forceinline__ void picard_final_body(const int b, const PicardTail& t, PicardShared& S) {
+    Member* st = t.st;
+    const int nblk = t.nblk, nblk_r = t.nblk_r, ntopo = t.ntopo;
+    const PicardCtl& ctl = t.ctl;
+    VI tmx{0.0, -1}, tmn{0.0, -1};
+    double tminpsi = INFINITY, tpsi = 0.0;  // tpsi: psi at this thread's arg-min candidate
+    const int m_it = st[b].iterations, m_cur = st[b].cur, m_nxt = st[b].nxt, m_best = st[b].best, m_prev = st[b].prev;
+    const double m_gs_best = st[b].gs_best, m_diff_best = st[b].diff_best;
+    double s = 0.0, rs = 0.0, rm = 0.0;
+    int bad = 0;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        s += ld_part<AGENT>(t.psum + (long)b * nblk + i);
+        bad |= ld_part<AGENT>(t.pbad + (long)b * nblk + i);
+    }
+    for (int i = threadIdx.x; i < nblk_r; i += 256) rm = fmax(rm, ld_part<AGENT>(t.rmax + (long)b * nblk_r + i));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wbad = __any(bad) ? 1 : 0;
+    if (lane == 0) S.shbad[w] = wbad;
+    const double rmx_all = block_max_all<256>(rm, S.sh);  // M = max_b m_b  (its barriers also publish shbad)
+    if (rmx_all > 0.0) {
+        for (int i = threadIdx.x; i < nblk_r; i += 256) {
+            const double f = ld_part<AGENT>(t.rmax + (long)b * nblk_r + i) / rmx_all;
+            rs += ld_part<AGENT>(t.rsum + (long)b * nblk_r + i) * (f * f);
+        }
+    }
+    if (t.topo) {
+        for (int i = threadIdx.x; i < ntopo; i += 256) {
+            const TopoPart* q = t.topo + (long)b * ntopo + i;
+            const VI cmx{ld_part<AGENT>(&q->maxv), ld_part<AGENT>(&q->maxi)}, cmn{ld_part<AGENT>(&q->minb), ld_part<AGENT>(&q->mini)};
+            const double cpsi = ld_part<AGENT>(&q->psi_at_min);
+            tmx = vi_max(tmx, cmx);
+            const VI nmn = vi_min(tmn, cmn);
+            if (nmn.i != tmn.i) tpsi = cpsi;
+            tmn = nmn;
+            tminpsi = fmin(tminpsi, ld_part<AGENT>(&q->minpsi));
+        }
+        const VI own = tmn;
+        tmx = wave_vi<true>(tmx);
+        tmn = wave_vi<false>(tmn);
+        tminpsi = wave_max(-tminpsi);
+        if (tmn.i >= 0 && own.i == tmn.i) S.shp[w] = tpsi;  // a grid index lives in exactly one partial: one lane per wave at most
+    }
+    // the sums (and the topology candidates) share one barrier (block_sum's combination order: wave totals added 0..3 by thread 0)
+    s = wave_sum(s);
+    rs = wave_sum(rs);
+    __syncthreads();  // (sh is still being read by block_max_all above)
+    if (lane == 0) { S.sh[w] = s; S.sh2[w] = rs; S.shx[w] = tmx; S.shn[w] = tmn; S.shd[w] = tminpsi; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double tot = 0.0, rtot = 0.0;
+    int anybad = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { tot += S.sh[i]; rtot += S.sh2[i]; anybad |= S.shbad[i]; }
+    const double rmx = rmx_all;
+    Member& m = st[b];
+    const int it = m_it;  // iteration index lives on the device: kernel arguments stay constant
+    m.iterations = it + 1;
+    if (anybad) {  // diverged: revert to best, stop (newton_solver.py:518-532); the Newton warm-up keeps Psi (:163-166)
+        int cur = m_cur, prev = m_prev;
+        if (!ctl.pad) {
+            prev = m_cur;
+            cur = m_best;
+            m.prev = prev;
+            m.cur = cur;
+        }
+        m.diverged = 1;
+        m.active = 0;
+        atomicSub(t.n_active, 1);
+        t.f_cur[b] = cur; t.f_nxt[b] = m_nxt; t.f_best[b] = m_best; t.f_prev[b] = prev; t.f_active[b] = 0;
+        return;
+    }
+    double diff = tot / (double)ctl.n_total;
+    // stable_rms (fusion_kernel_numerics.py:28-37): max * sqrt(mean((r/max)^2)), overflow-safe up to |r| = 1e250
+    double gs = rmx <= 0.0 ? 0.0 : rmx * sqrt(rtot / (double)ctl.n_interior);
+    m.diff = diff;
+    m.gs = gs;
+    if (gs < m_gs_best) m.gs_best = gs;
+    const int prev = m_cur, cur = m_nxt;
+    int best = m_best;
+    m.prev = prev;
+    m.cur = cur;
+    if (diff < m_diff_best) { m.diff_best = diff; best = cur; m.best = best; }
+    int nx = 0;
+    for (int k = 0; k < 3; ++k) if (k != cur && k != best) { nx = k; break; }
+    m.nxt = nx;
+    if (t.hist_diff) t.hist_diff[(long)b * ctl.max_iter + it] = diff;
+    if (t.hist_gs) t.hist_gs[(long)b * ctl.max_iter + it] = gs;
+    if (t.trace) {
+        double* tr = t.trace + ((long)b * ctl.max_iter + it) * 6;
+        tr[0] = m.psi_axis; tr[1] = m.psi_bnd; tr[2] = (double)m.x_idx; tr[3] = m.i_current; tr[4] = diff; tr[5] = gs;
+    }
+    bool upd = diff < ctl.tol;
+    bool gsc = (!ctl.require_gs) || (gs < ctl.gs_tol);
+    int active = 1;
+    if (upd && gsc) { m.converged = 1; active = 0; }
+    else if (it + 1 >= ctl.max_iter) active = 0;
+    if (!active) { m.active = 0; atomicSub(t.n_active, 1); }
+    // publish the slot indices / activity the field kernels index (was a separate k_publish_slots launch)
+    t.f_cur[b] = cur; t.f_nxt[b] = nx; t.f_best[b] = best; t.f_prev[b] = prev; t.f_active[b] = active;
+    if (t.topo && active) {  // k_topology_final for the next iteration, on the new current iterate
+        VI wmx = S.shx[0], wmn = S.shn[0];
+        double rmp = S.shd[0], pmin = S.shp[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+            wmx = vi_max(wmx, S.shx[i]);
+            const VI n2 = vi_min(wmn, S.shn[i]);
+            if (n2.i != wmn.i) pmin = S.shp[i];
+            wmn = n2;
+            rmp = fmax(rmp, S.shd[i]);
+        }
+        rmp = -rmp;
+        double pa = wmx.i >= 0 ? wmx.v : 0.0;
+        if (fabs(pa) < 1e-6) pa = 1e-6;
+        double pb, xr = 0.0, xz = 0.0;
+        if (wmn.i >= 0) {
+            int iz = (int)(wmn.i / t.nr), ir = (int)(wmn.i - (long)iz * t.nr);
+            pb = pmin;  // psi of the new iterate at the arg-min, carried with the partials
+            xr = t.r_axis[ir];
+            xz = t.z_axis[iz];
+            if (!finite_d(pb)) pb = nan_to_num300(pb);
+        } else {
+            pb = rmp;
+        }
+        if (fabs(pa - pb) < 0.1) pb = pa * 0.1;
+        double denom = pb - pa;  // core/fusion_kernel.py:415-417
+        if (fabs(denom) < 1e-9) denom = 1e-9;
+        m.psi_axis = pa; m.psi_bnd = pb; m.denom = denom; m.inv_denom = 1.0 / denom; m.x_idx = wmn.i; m.x_r = xr; m.x_z = xz;
+    }
+}
+__global__ void __launch_bounds__(256) k_picard_final(PicardTail t) {
+    __shared__ PicardShared S;
+    const int b = blockIdx.x;
+    if (!t.st[b].active) return;
+    picard_final_body<false>(b, t, S);
+}
 #ifndef BLEND_BT_Z
 #define BLEND_BT_Z 32
 #endif
@@ -1686,8 +1911,10 @@ struct GradRecip { double dz, inv_dz, lo_dz, two_dz, inv_two_dz, lo_two_dz, dr, 
         }
 __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
                                                      double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
-                                                     double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm, GradRecip gq) {
+                                                     double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm, GradRecip gq,
+                                                     PicardTail tail) {
     __shared__ double t[BT_Z + 2][BT_R + 2 + 1];
+    __shared__ int sh_last;
     __shared__ VI sh_mx[4], sh_mn[4];
     __shared__ double sh_dsum[4], sh_m[4], sh_minp[4], sh_s2[4];
     __shared__ int sh_bad[4];
@@ -1817,16 +2044,41 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
     VI rmx = sh_mx[0], rmn = sh_mn[0];
 #pragma unroll
     for (int i = 1; i < 4; ++i) { rmx = vi_max(rmx, sh_mx[i]); rmn = vi_min(rmn, sh_mn[i]); }
-    if (tid == 0) {
-        const long o = (long)b * nblk + (long)by_ * gridDim.x + bx_;
-        psum[o] = bsum;
-        pbad[o] = shbad;
-        rmax[o] = bmax;
-        rsum[o] = bs2;
-        TopoPart tp;
-        tp.maxv = rmx.v; tp.maxi = rmx.i; tp.minb = rmn.v; tp.mini = rmn.i; tp.minpsi = bminp; tp.pad = 0;
-        topo[o] = tp;
+    const long o = (long)b * nblk + (long)by_ * gridDim.x + bx_;
+    // psi of the blended iterate at this tile's arg-min candidate (still in the LDS tile): rides along with the partial
+    double pmin = 0.0;
+    if (tid == 0 && rmn.i >= 0) {
+        const int iz = (int)(rmn.i / nr), ir = (int)(rmn.i - (long)iz * nr);
+        pmin = t[iz - z0][ir - r0];
     }
+    if (!tail.counters) {
+        if (tid == 0) {
+            psum[o] = bsum;
+            pbad[o] = shbad;
+            rmax[o] = bmax;
+            rsum[o] = bs2;
+            TopoPart tp;
+            tp.maxv = rmx.v; tp.maxi = rmx.i; tp.minb = rmn.v; tp.mini = rmn.i; tp.minpsi = bminp; tp.psi_at_min = pmin;
+            topo[o] = tp;
+        }
+        return;
+    }
+    // fused tail: the last workgroup of this member to arrive runs k_picard_final's work (see "last workgroup finishes" above)
+    if (tid == 0) {
+        st_agent(psum + o, bsum);
+        st_agent(pbad + o, shbad);
+        st_agent(rmax + o, bmax);
+        st_agent(rsum + o, bs2);
+        st_agent(&topo[o].maxv, rmx.v); st_agent(&topo[o].maxi, rmx.i); st_agent(&topo[o].minb, rmn.v); st_agent(&topo[o].mini, rmn.i);
+        st_agent(&topo[o].minpsi, bminp); st_agent(&topo[o].psi_at_min, pmin);
+        sh_last = take_ticket(tail.counters + b, (unsigned)nblk) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    PicardShared& S = *reinterpret_cast<PicardShared*>(&t[0][0]);  // the tile is dead: every wave passed the barrier above
+    picard_final_body<true>(b, tail, S);
+    if (tid == 0) __hip_atomic_store(tail.counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 #undef SCPN_BLEND_GRAD
@@ -1951,168 +2203,6 @@ __global__ void k_and_mix(Fld nxtF, AndFields P, const double* alpha, const int*
     nxtF.at(b)[c] = v;
 }
 
-struct PicardCtl {
-    double tol, gs_tol;
-    int require_gs, max_iter, iter, pad;
-    long n_total, n_interior;
-};
-// one block per member: finish diff / GS RMS, update best / ping-pong slots, convergence
-// (core/fusion_kernel_newton_solver.py:518-571)
-__global__ void __launch_bounds__(256) k_picard_final(Member* st, const double* psum, const int* pbad,
-                                                      const double* rmax, const double* rsum, int nblk,
-                                                      int nblk_r, PicardCtl ctl, double* hist_diff,
-                                                      double* hist_gs, double* trace, int* n_active, int* f_cur, int* f_nxt,
-                                                      int* f_best, int* f_prev, int* f_active, const TopoPart* topo, int ntopo,
-                                                      Fld psiF, int nr, int ld, const double* r_axis, const double* z_axis) {
-    // topo != nullptr: the kernel also finishes the axis / X-point search of the NEXT iteration (the work of k_topology_final on
-    // the partials the fused tail just produced) for the members that stay active -- one launch less on the dependent chain
-    __shared__ double sh[4], sh2[4];
-    __shared__ int shbad[4];
-    __shared__ VI shx[4], shn[4];
-    __shared__ double shd[4];
-    const int b = blockIdx.x;
-    VI tmx{0.0, -1}, tmn{0.0, -1};
-    double tminpsi = INFINITY;
-    if (topo && (int)threadIdx.x < ntopo) {
-        const TopoPart t = topo[(long)b * ntopo + threadIdx.x];
-        tmx = VI{t.maxv, t.maxi};
-        tmn = VI{t.minb, t.mini};
-        tminpsi = t.minpsi;
-        if (tmx.i < 0) tmx = VI{0.0, -1};
-        if (tmn.i < 0) tmn = VI{0.0, -1};
-    }
-    // everything the block reads is requested before the first wait: activity, the member record (thread 0 updates it below)
-    // and the partials -- one round trip; the (max, sum) residual partials stay in registers for the rescaling pass
-    const int act = st[b].active;
-    const int m_it = st[b].iterations, m_cur = st[b].cur, m_nxt = st[b].nxt, m_best = st[b].best, m_prev = st[b].prev;
-    const double m_gs_best = st[b].gs_best, m_diff_best = st[b].diff_best;
-    double s = 0.0, rs = 0.0, rm = 0.0, rm0 = 0.0, rq0 = 0.0;
-    int bad = 0;
-    if ((int)threadIdx.x < nblk) {
-        s += psum[(long)b * nblk + threadIdx.x];
-        bad |= pbad[(long)b * nblk + threadIdx.x];
-    }
-    if ((int)threadIdx.x < nblk_r) {
-        rm0 = rmax[(long)b * nblk_r + threadIdx.x];
-        rq0 = rsum[(long)b * nblk_r + threadIdx.x];
-        rm = fmax(rm, rm0);
-    }
-    if (!act) return;
-    for (int i = threadIdx.x + 256; i < nblk; i += 256) {
-        s += psum[(long)b * nblk + i];
-        bad |= pbad[(long)b * nblk + i];
-    }
-    for (int i = threadIdx.x + 256; i < nblk_r; i += 256) rm = fmax(rm, rmax[(long)b * nblk_r + i]);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wbad = __any(bad) ? 1 : 0;
-    if (lane == 0) shbad[w] = wbad;
-    const double rmx_all = block_max_all<256>(rm, sh);  // M = max_b m_b  (its barriers also publish shbad)
-    if (rmx_all > 0.0) {
-        if ((int)threadIdx.x < nblk_r) {
-            const double f = rm0 / rmx_all;
-            rs += rq0 * (f * f);
-        }
-        for (int i = threadIdx.x + 256; i < nblk_r; i += 256) {
-            const double f = rmax[(long)b * nblk_r + i] / rmx_all;
-            rs += rsum[(long)b * nblk_r + i] * (f * f);
-        }
-    }
-    if (topo) {
-        for (int i = threadIdx.x + 256; i < ntopo; i += 256) {
-            const TopoPart t = topo[(long)b * ntopo + i];
-            tmx = vi_max(tmx, VI{t.maxv, t.maxi});
-            tmn = vi_min(tmn, VI{t.minb, t.mini});
-            tminpsi = fmin(tminpsi, t.minpsi);
-        }
-        tmx = wave_vi<true>(tmx);
-        tmn = wave_vi<false>(tmn);
-        tminpsi = wave_max(-tminpsi);
-    }
-    // the sums (and the topology candidates) share one barrier (block_sum's combination order: wave totals added 0..3 by thread 0)
-    s = wave_sum(s);
-    rs = wave_sum(rs);
-    __syncthreads();  // (sh is still being read by block_max_all above)
-    if (lane == 0) { sh[w] = s; sh2[w] = rs; shx[w] = tmx; shn[w] = tmn; shd[w] = tminpsi; }
-    __syncthreads();
-    double tot = 0.0, rtot = 0.0;
-    int anybad = 0;
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { tot += sh[i]; rtot += sh2[i]; anybad |= shbad[i]; }
-    }
-    double rmx = rmx_all;
-    if (threadIdx.x == 0) {
-        Member& m = st[b];
-        const int it = m_it;  // iteration index lives on the device: kernel arguments stay constant
-        m.iterations = it + 1;
-        if (anybad) {  // diverged: revert to best, stop (newton_solver.py:518-532); the Newton warm-up keeps Psi (:163-166)
-            int cur = m_cur, prev = m_prev;
-            if (!ctl.pad) {
-                prev = m_cur;
-                cur = m_best;
-                m.prev = prev;
-                m.cur = cur;
-            }
-            m.diverged = 1;
-            m.active = 0;
-            atomicSub(n_active, 1);
-            f_cur[b] = cur; f_nxt[b] = m_nxt; f_best[b] = m_best; f_prev[b] = prev; f_active[b] = 0;
-            return;
-        }
-        double diff = tot / (double)ctl.n_total;
-        // stable_rms (fusion_kernel_numerics.py:28-37): max * sqrt(mean((r/max)^2)), overflow-safe up to |r| = 1e250
-        double gs = rmx <= 0.0 ? 0.0 : rmx * sqrt(rtot / (double)ctl.n_interior);
-        m.diff = diff;
-        m.gs = gs;
-        if (gs < m_gs_best) m.gs_best = gs;
-        const int prev = m_cur, cur = m_nxt;
-        int best = m_best;
-        m.prev = prev;
-        m.cur = cur;
-        if (diff < m_diff_best) { m.diff_best = diff; best = cur; m.best = best; }
-        int nx = 0;
-        for (int k = 0; k < 3; ++k) if (k != cur && k != best) { nx = k; break; }
-        m.nxt = nx;
-        if (hist_diff) hist_diff[(long)b * ctl.max_iter + it] = diff;
-        if (hist_gs) hist_gs[(long)b * ctl.max_iter + it] = gs;
-        if (trace) {
-            double* t = trace + ((long)b * ctl.max_iter + it) * 6;
-            t[0] = m.psi_axis; t[1] = m.psi_bnd; t[2] = (double)m.x_idx; t[3] = m.i_current; t[4] = diff; t[5] = gs;
-        }
-        bool upd = diff < ctl.tol;
-        bool gsc = (!ctl.require_gs) || (gs < ctl.gs_tol);
-        int active = 1;
-        if (upd && gsc) { m.converged = 1; active = 0; }
-        else if (it + 1 >= ctl.max_iter) active = 0;
-        if (!active) { m.active = 0; atomicSub(n_active, 1); }
-        // publish the slot indices / activity the field kernels index (was a separate k_publish_slots launch)
-        f_cur[b] = cur; f_nxt[b] = nx; f_best[b] = best; f_prev[b] = prev; f_active[b] = active;
-        if (topo && active) {  // k_topology_final for the next iteration, on the new current iterate
-            VI rmx = shx[0], rmn = shn[0];
-            double rmp = shd[0];
-#pragma unroll
-            for (int i = 1; i < 4; ++i) { rmx = vi_max(rmx, shx[i]); rmn = vi_min(rmn, shn[i]); rmp = fmax(rmp, shd[i]); }
-            rmp = -rmp;
-            const double* psi = psiF.base + ((long)cur * psiF.nb + b) * psiF.stride;
-            double pa = rmx.i >= 0 ? rmx.v : 0.0;
-            if (fabs(pa) < 1e-6) pa = 1e-6;
-            double pb, xr = 0.0, xz = 0.0;
-            if (rmn.i >= 0) {
-                int iz = (int)(rmn.i / nr), ir = (int)(rmn.i - (long)iz * nr);
-                pb = psi[(long)iz * ld + ir];
-                xr = r_axis[ir];
-                xz = z_axis[iz];
-                if (!finite_d(pb)) pb = nan_to_num300(pb);
-            } else {
-                pb = rmp;
-            }
-            if (fabs(pa - pb) < 0.1) pb = pa * 0.1;
-            double denom = pb - pa;  // core/fusion_kernel.py:415-417
-            if (fabs(denom) < 1e-9) denom = 1e-9;
-            m.psi_axis = pa; m.psi_bnd = pb; m.denom = denom; m.inv_denom = 1.0 / denom; m.x_idx = rmn.i; m.x_r = xr; m.x_z = xz;
-        }
-    }
-}
 // copies the per-member slot indices into flat int arrays the kernels index (cur/nxt/best/prev/active)
 __global__ void k_publish_slots(const Member* st, int* cur, int* nxt, int* best, int* prev, int* active, int B) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;

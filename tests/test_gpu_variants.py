@@ -17,6 +17,7 @@ SWITCHES = [
     {"SCPN_HIP_LAZYSRC": "0"},
     {"SCPN_HIP_GROUPS": "2"},
     {"SCPN_HIP_DEFECT_MINLVL": "9"},
+    {"SCPN_HIP_TAILFUSE": "1"},
 ]
 # experiment builds (never shipped: `_lib.build(variant=...)` makes libscpn_hip.<variant>.so next to the product library)
 EXPERIMENT_BUILDS = {
