@@ -653,6 +653,15 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         }
         return;
     }
+#ifdef TILE_STAGGER
+    // experiment: the first three rounds of workgroups (dispatch order) start a third of a workgroup lifetime apart, so that the
+    // workgroups sharing a CU are not all loading / all sweeping at the same time
+    {
+        const unsigned lin0 = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lin0 < 768u)
+            for (unsigned k = 0; k < (lin0 >> 8) * TILE_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     TILE_STAMP(0);
     const double* src = srcF.at(b);
     const bool lazy = lzs.st != nullptr;  // uniform

@@ -1,7 +1,11 @@
+"""s_memrealtime stamps of eight sampled tile workgroups (load / six colour passes / store / defect / restriction).
+usage: [STAMPS_MODE=plain|defect] python tools/tile_stamps.py     (builds the -DCV_STAMPS experiment library on first use)"""
 import os, sys, ctypes as C
-os.environ["SCPN_HIP_LIB"] = os.path.abspath("build/libscpn_hip_stamps.so")
-os.environ["SCPN_HIP_GROUPS"] = "1"
 sys.path.insert(0, ".")
+from scpn_fusion_core_amd import _lib
+_mode = os.environ.get("STAMPS_MODE", "plain")
+os.environ["SCPN_HIP_LIB"] = str(_lib.build(variant="stamps_" + _mode, defines=("CV_STAMPS",) + (("STAMP_DEFECT=true",) if _mode == "defect" else ())))
+os.environ["SCPN_HIP_GROUPS"] = "1"
 import numpy as np
 from scpn_fusion_core_amd.ensemble import EnsembleSolver
 from scpn_fusion_core_amd.cases import iter_like_cfg, bench_problem
