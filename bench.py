@@ -42,6 +42,27 @@ FAMILY_BYTES = {"smooth_pre": (28.0, 106.0), "smooth_post": (26.0, 90.0), "smoot
                 "blend_fused": (32.0, 40.0), "source": (16.0, 24.0)}
 
 
+def counters_of(kernel_symbol: str) -> dict | None:
+    """SQ counter summary of the dominant kernel from the committed profile the traffic figures come from
+    (profiles/<tag>_sq_by_kernel.csv, tag recorded in profiles/pmc_traffic.json): never a hard-coded figure."""
+    import csv
+
+    try:
+        tag = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get("tag")
+        path = ROOT / "profiles" / f"{tag}_sq_by_kernel.csv"
+        want = {"smooth_pre": "k_smooth_tile<3, false, true", "smooth_post": "k_smooth_tile<3, true, false",
+                "smooth": "k_smooth_tile<3, false, false", "blend_fused": "k_blend_fused", "source": "k_jsum"}.get(kernel_symbol, kernel_symbol)
+        rows = [r for r in csv.DictReader(open(path)) if want in r["kernel"]]
+        if not rows:
+            return None
+        r = max(rows, key=lambda x: float(x["grid_size"]))  # the level-0 launch shape
+        pick = {k: float(r[k]) for k in ("valu_busy", "lds_busy", "waves_per_simd", "wait_frac", "stall_frac", "issue_frac", "clock_GHz") if r.get(k)}
+        pick.update({"source": f"profiles/{tag}_sq_by_kernel.csv", "kernel": r["kernel"], "grid_size": int(float(r["grid_size"]))})
+        return pick
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int) -> dict | None:
     """Roofline object of the dominant kernel.  `fam` = per-family HIP-event times ({name: {ms, launches}}); families of one
     role on different levels are ONE kernel symbol in a rocprofv3 trace (smooth_L{0,1,2}_pre = one template instance), and
@@ -87,7 +108,9 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
         per_level[name] = {"avg_launch_us": round(us, 2), "launches": v["launches"],
                            "achieved": round(fused_pt * pts * members_per_launch / (us * 1e-6) / 1e9, 1)}
     ach = bytes_fused / (tot_ms * 1e-3) / 1e9
-    return {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    ctr = counters_of(dom)
+    return {"kernel": dom, "bound": "hbm",  # the roofline `frac` is taken against (the contract's enum); what limits it: `limiter`
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": round(traffic / tot_launch) if traffic_ok else None,
             "alg_bytes_per_point": fused_pt, "alg_bytes_per_launch": round(bytes_fused / tot_launch),
@@ -95,11 +118,25 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
                                      "gbs_equivalent": round(bytes_survey / (tot_ms * 1e-3) / 1e9, 1)},
             "avg_launch_us": round(1e3 * tot_ms / tot_launch, 2), "launches": int(tot_launch),
             "groups": num_groups, "members_per_launch": int(members_per_launch), "isolated_kernel_timing": True,
-            "counters": "profiles/ (SQ / FETCH / WRITE passes of tools/collect_profiles.sh)",
-            "limiter": "not HBM: counter traffic equals the compulsory bytes; fp64 VALU 57 % busy, LDS 46 %, colour passes at the "
-                       "CU's LDS bandwidth, load / sweep / defect phases of the resident workgroups only partly overlapped "
-                       "(DESIGN.md section 6, profiles/r02d_sq_by_kernel.csv, profiles/r02c_phase_costs.md)",
+            "limiter": {"class": "on-chip issue / latency (fp64 VALU + LDS pipeline in lock step), not HBM: counter traffic equals the "
+                                 "compulsory bytes and the kernel keeps its speed when its working set sits in the Infinity Cache",
+                        "counters": ctr, "evidence": "profiles/r03_experiments.md, DESIGN.md section 6"},
             "per_level": per_level, "families_ms": fam}
+
+
+def iteration_roofline(ms_per_step: float, steps_iterations: int, members: int) -> dict | None:
+    """HBM bytes of ONE Picard iteration (PMC counters, every kernel of the iteration, per member) / the measured time of an
+    iteration of the whole ensemble: how much of the HBM peak the iteration as a whole uses."""
+    try:
+        pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        per_member = float(sum(pmc["hbm_bytes_per_member_launch"].values()))  # each family is launched once per iteration
+    except (OSError, ValueError, KeyError):
+        return None
+    us = 1e3 * ms_per_step / max(steps_iterations, 1)
+    gbs = per_member * members / (us * 1e-6) / 1e9
+    return {"hbm_bytes_per_member_iteration": round(per_member), "us_per_iteration": round(us, 2), "achieved": round(gbs, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "kernels_counted": sorted(pmc["hbm_bytes_per_member_launch"]), "source": pmc.get("source")}
 
 
 def make_cfg(n: int) -> dict:
@@ -119,6 +156,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-newton", action="store_true", help="skip the Newton-lane figure reported beside the metric")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config figures (BASELINE configs 2-4, smoother benchmark)")
     args = ap.parse_args()
 
     # ---- `python bench.py --gpus N` with nobody having started the ranks: this process becomes the launcher.  It has not
@@ -237,13 +275,17 @@ def main() -> int:
         es.profile(False)
         roofline = roofline_of(fam, args.grid, B / es.num_groups, es.num_groups) or {"error": "empty profile report"}
         try:
-            roofline["measured_copy_gbs"] = round(_lib.copy_bandwidth_probe(mode=0), 1)
-            roofline["measured_read_gbs"] = round(_lib.copy_bandwidth_probe(mode=1), 1)
+            probes = _lib.bandwidth_probes()
+            roofline["measured_bandwidth"] = {**probes, "bytes": 1 << 30,
+                                              "note": "copies count read + written bytes; 1 GiB per buffer (4x the Infinity Cache)"}
+            roofline["measured_copy_gbs"] = max(v for k, v in probes.items() if k != "read")
+            roofline["measured_read_gbs"] = probes["read"]
             if "achieved" in roofline:
                 roofline["frac_of_measured_copy"] = round(roofline["achieved"] / roofline["measured_copy_gbs"], 4)
         except Exception as exc:  # the probe needs 2 GiB of free HBM; report, do not fail the bench line
             roofline["measured_copy_gbs"] = None
             roofline["copy_probe_error"] = str(exc)
+        roofline["iteration"] = iteration_roofline(elapsed / args.steps * 1e3, max(picard_total), B)
         # the same kernels with the chip filled by ONE launch: all members of this GPU in one stream group (the production run
         # reaches this fill by overlapping its two groups).  HIP events again; the rocprofv3 durations of this configuration are
         # profiles/*_isolated_kernel_times.csv (tools/isolated_kernel_times.sh), ~6 us per launch shorter (event pair + dispatch)
@@ -367,20 +409,22 @@ def main() -> int:
             newton = {"error": str(exc)}
 
     # ---- strict-parity gate (outside the timed region): the HIP free-boundary solve of the DIII-D-like case at 129^2 against the
-    #      reference's own NumPy-lane flux map (fixture generated from the imported reference, tests/golden/freegs.npz), with the
+    #      reference's own NumPy-lane flux map (data file scpn_fusion_core_amd/data/d3d129_reference_lane.npz, made from the imported reference), with the
     #      metrics and thresholds of validation/benchmark_freegs_public_example_reconstruction.py:491-497
     parity = None
     if rank == 0:
         try:
             from scpn_fusion_core_amd.parity_gate import strict_parity_metrics
 
-            g = np.load(ROOT / "tests" / "golden" / "freegs.npz")
-            gcfg = json.loads(str(g["_configs"]))["d3d129"]
+            from scpn_fusion_core_amd.cases import diiid_like_cfg
+
+            g = np.load(ROOT / "scpn_fusion_core_amd" / "data" / "d3d129_reference_lane.npz")  # data only: the reference lane's flux map
+            gcfg = diiid_like_cfg(129)
             with EnsembleSolver(gcfg, batch=2, device=local_rank) as ges:
                 ges.solve_free_boundary(max_outer_iter=20, tol=1e-4)
                 gpsi = ges.get_psi(0)
-            gd, gax = gcfg["dimensions"], g["d3d129_axis_x"]
-            m = strict_parity_metrics(gpsi, g["d3d129_psi"], np.linspace(gd["R_min"], gd["R_max"], 129),
+            gd, gax = gcfg["dimensions"], g["axis_x"]
+            m = strict_parity_metrics(gpsi, g["psi"], np.linspace(gd["R_min"], gd["R_max"], 129),
                                       np.linspace(gd["Z_min"], gd["Z_max"], 129), x_points=[(gax[2], gax[3])])
             parity = {"case": "DIII-D-like free-boundary 129x129 (validation/diiid_config.json) vs the reference NumPy lane",
                       "psi_rmse_wb": m["psi_rmse"], "psi_n_rmse": m["psi_n_rmse"], "axis_error_m": m["axis_error_m"],
@@ -391,6 +435,16 @@ def main() -> int:
                                 "device Green's function to 2e-9 Wb (tests/test_gpu_freegs_gate.py)"}
         except Exception as exc:  # the gate must not cost the bench line
             parity = {"error": str(exc)}
+
+    # ---- one figure per BASELINE config (outside the timed region)
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        try:
+            from benchmarks.configs import measure_configs
+
+            configs = measure_configs(device=local_rank, members=B, check_every=args.check_every)
+        except Exception as exc:
+            configs = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         line = {
@@ -413,6 +467,8 @@ def main() -> int:
             line["parity"] = parity
         if newton is not None:
             line["newton_fd_mg"] = newton
+        if configs is not None:
+            line["configs"] = configs
         if world > 1 and comm is None:  # the N>1 metric includes the ensemble gather: without it the line is not a scaling point
             line["valid"] = False
             line["n_gpus_gathered"] = 0

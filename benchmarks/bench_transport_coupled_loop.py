@@ -24,12 +24,9 @@ from scpn_fusion_core_amd.ensemble import EnsembleSolver  # noqa: E402
 from scpn_fusion_core_amd.cases import iter_like_cfg  # noqa: E402
 
 
-def main():
-    from oracle import oracle as orc  # CPU baseline / checker only
-
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 513
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+def coupled_steps(n: int = 513, B: int = 32, steps: int = 4, device: int | None = None, verbose: bool = False) -> dict:
+    """`steps` coupled steps (after one warm-up step) of a B-member ensemble on the n x n ITER-like grid; returns the timing rows and
+    the mean seconds per coupled step.  Device work only (no oracle)."""
     cfg = iter_like_cfg(n, tol=1e-6, max_iter=400)
     rho = np.linspace(0, 1, 50)
     scale = 1.0 + 0.1 * np.linspace(-1, 1, B)[:, None]
@@ -37,7 +34,8 @@ def main():
     ne = 9.0 * (1 - 0.8 * rho**2)[None] * np.ones((B, 1))
     cd = tc.CurrentDiffusionSolver(rho, R0=6.2, a=2.0, B0=5.3, batch=B)
     rows = []
-    with EnsembleSolver(cfg, batch=B, current_targets=15.0 * scale[:, 0]) as es:
+    kw = {} if device is None else {"device": device}
+    with EnsembleSolver(cfg, batch=B, current_targets=15.0 * scale[:, 0], **kw) as es:
         es.solve_equilibrium()
         for k in range(steps + 1):
             t0 = time.perf_counter()
@@ -54,7 +52,20 @@ def main():
                 rows.append({"step": k, "profiles_host_s": t1 - t0, "map_and_resolve_s": t2 - t1, "current_diffusion_s": t3 - t2,
                              "picard_iterations": [min(r["iterations"] for r in res), max(r["iterations"] for r in res)],
                              "psi_residual_max": float(resid.max())})
-                print(rows[-1], flush=True)
+                if verbose:
+                    print(rows[-1], flush=True)
+    mean = float(np.mean([x["map_and_resolve_s"] + x["current_diffusion_s"] + x["profiles_host_s"] for x in rows]))
+    return {"cfg": cfg, "rho": rho, "te": te, "ne": ne, "rows": rows, "s_per_coupled_step_ensemble": mean, "member_steps_per_s": B / mean}
+
+
+def main():
+    from oracle import oracle as orc  # CPU baseline / checker only
+
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 513
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    run = coupled_steps(n, B, steps, verbose=True)
+    cfg, rho, te, ne, rows, mean = run["cfg"], run["rho"], run["te"], run["ne"], run["rows"], run["s_per_coupled_step_ensemble"]
     d = cfg["dimensions"]
     r, z = np.linspace(d["R_min"], d["R_max"], n), np.linspace(d["Z_min"], d["Z_max"], n)
     t = time.perf_counter()

@@ -1,0 +1,106 @@
+"""One figure per BASELINE config, measured on the device (called by bench.py outside its timed region).
+
+  config 2  ITER-like fixed-boundary 257x257 Picard + multigrid, tol 1e-8      -> converged solves/s of a resident ensemble
+  config 3  ONE DIII-D-like free-boundary equilibrium 513x513 (unbatched)       -> ms per solve (Picard lane, Newton lane)
+            + ONE member of the bench workload (ITER-like 513x513 free-boundary) -> ms per solve
+  config 4  transport + current-diffusion loop re-solving the equilibrium, 513^2 -> member-steps/s
+  smoother  benchmarks/bench_gpu_gs_solver.py's 200 red-black SOR sweeps, 513^2  -> ms, next to the reference's published numbers
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+# validation/reports/gpu_gs_solver_benchmark.json:35 (the reference's own published smoother benchmark, 513^2, 200 sweeps)
+PUBLISHED_SMOOTHER_513 = {"numpy_s": 18.85, "wgpu_f32_s": 0.66, "source": "validation/reports/gpu_gs_solver_benchmark.json:35"}
+
+
+def _best_of(fn, reps=3):
+    ts, out = [], None
+    for _ in range(reps):
+        t = time.perf_counter()
+        out = fn()
+        ts.append(time.perf_counter() - t)
+    return min(ts), out
+
+
+def measure_configs(device: int = 0, members: int = 32, check_every: int = 8) -> dict:
+    from scpn_fusion_core_amd.cases import bench_problem, diiid_like_cfg, iter_like_cfg
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    out: dict = {}
+    # ---- config 2
+    cfg2 = iter_like_cfg(257, tol=1e-8, max_iter=1000)
+    ip = cfg2["physics"]["plasma_current_target"]
+    rng = np.random.default_rng(2026)
+    with EnsembleSolver(cfg2, batch=members, current_targets=ip * (1.0 + 0.1 * (2.0 * rng.random(members) - 1.0)), device=device) as es:
+        def run2():
+            es.fill_psi(0.0)
+            r = es.solve_equilibrium(check_every=check_every)
+            es.sync()
+            return r
+        run2()
+        dt, res = _best_of(run2, 2)
+    out["config2_fixed_boundary_257"] = {
+        "value": round(members / dt, 2), "unit": "converged solves/s", "members": members, "ms_per_ensemble_solve": round(dt * 1e3, 2),
+        "converged_members": sum(int(r["converged"]) for r in res),
+        "picard_iterations": [min(r["iterations"] for r in res), max(r["iterations"] for r in res)],
+        "workload": "ITER-like fixed-boundary 257x257, Picard + V-cycle, tol 1e-8, plasma current +-10 % over the members"}
+
+    # ---- config 3: one equilibrium at a time
+    def single(cfg, newton=False):
+        c = cfg if not newton else {**cfg, "solver": {**cfg["solver"], "solver_method": "newton", "gmres_preconditioner": "multigrid",
+                                                       "newton_jacobian": "finite_difference", "newton_damping": 1.0,
+                                                       "max_iterations": 60, "newton_warmup_steps": 2}}
+        with EnsembleSolver(c, batch=1, device=device) as one:
+            def run():
+                one.fill_psi(0.0)
+                r = one.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=check_every)
+                one.sync()
+                return r
+            run()
+            t, r = _best_of(run, 3)
+        return {"ms_per_solve": round(t * 1e3, 2), "converged": bool(r[0]["converged"]), "outer_iterations": r[0]["outer_iterations"],
+                "inner_iterations": int(sum(r[0]["picard_iterations"]))}
+
+    d3d, it1 = diiid_like_cfg(513), iter_like_cfg(513, tol=1e-8, max_iter=1000)
+    out["config3_single_free_boundary_513"] = {
+        "unit": "ms per equilibrium (ONE member, unbatched)",
+        "diiid_like": {"picard": single(d3d), "newton_fd_mg": single(d3d, True)},
+        "iter_like_bench_member": {"picard": single(it1), "newton_fd_mg": single(it1, True)},
+        "workload": "solve_free_boundary(max_outer_iter=20, tol=1e-4, optimize_shape=False), 513x513, Picard tol 1e-8 "
+                    "(DIII-D-like: validation/diiid_config.json; the real shot g145419 is not in the reference checkout)"}
+
+    # ---- config 4
+    try:
+        from benchmarks.bench_transport_coupled_loop import coupled_steps
+
+        run = coupled_steps(513, members, 3, device=device)
+        out["config4_transport_coupled_loop_513"] = {
+            "value": round(run["member_steps_per_s"], 2), "unit": "member-steps/s", "members": members,
+            "s_per_coupled_step_ensemble": round(run["s_per_coupled_step_ensemble"], 4),
+            "picard_iterations_per_step": run["rows"][-1]["picard_iterations"],
+            "workload": "map_profiles_to_2d -> external-profile re-solve (tol 1e-6) -> flux change -> current-diffusion step, 513x513"}
+    except Exception as exc:  # an optional figure must not cost the bench line
+        out["config4_transport_coupled_loop_513"] = {"error": str(exc)}
+
+    # ---- smoother benchmark (resident fp64, 200 sweeps, omega 1.3)
+    n = 513
+    psi0, source, _rr, _r, _z = bench_problem(n, n)
+    cfgs = iter_like_cfg(n)
+    cfgs["dimensions"] = {"R_min": 4.0, "R_max": 8.0, "Z_min": -4.0, "Z_max": 4.0}
+    with EnsembleSolver(cfgs, batch=1, device=device) as es:
+        es.set_source(source, 0)
+
+        def sweeps():
+            es.set_psi(psi0, 0)
+            t = time.perf_counter()
+            es.rb_sor(1.3, 200)
+            return time.perf_counter() - t
+        sweeps()
+        ts = float(np.median([sweeps() for _ in range(3)]))
+    out["smoother_200_sweeps_513"] = {"value": round(ts * 1e3, 3), "unit": "ms", "published_reference": PUBLISHED_SMOOTHER_513,
+                                      "workload": "benchmarks/bench_gpu_gs_solver.py: 200 red-black SOR sweeps, omega 1.3, 513x513, fp64, "
+                                                  "fields resident (bit-exact vs the reference: tests/test_gpu_parity.py)"}
+    return out

@@ -231,11 +231,18 @@ def device_info() -> str | None:
 
 
 def copy_bandwidth_probe(nbytes: int = 1 << 30, reps: int = 10, mode: int = 0) -> float:
-    """GB/s of a 16-B/lane device copy (mode 0: read + written bytes) or read-only sum (mode 1) of ``nbytes`` (default 1 GiB:
-    four times the Infinity Cache), best of three grid sizes."""
+    """GB/s of a device copy (read + written bytes; mode 0 grid-stride, 2 contiguous chunks with 8 loads in flight, 3 the same
+    with non-temporal stores, 4 hipMemcpyDtoD) or of a read-only sum (mode 1) over ``nbytes`` (default 1 GiB: four times the
+    Infinity Cache), best of several grid sizes."""
     out = _d(0.0)
     check(require_gpu().scpn_bandwidth_probe(mode, nbytes, reps, C.byref(out)), "scpn_bandwidth_probe")
     return float(out.value)
+
+
+def bandwidth_probes(nbytes: int = 1 << 30, reps: int = 10) -> dict:
+    """All probe modes: ``{"copy_grid_stride", "read", "copy_chunked", "copy_chunked_nt", "memcpy_dtod"}`` in GB/s."""
+    names = ("copy_grid_stride", "read", "copy_chunked", "copy_chunked_nt", "memcpy_dtod")
+    return {n: round(copy_bandwidth_probe(nbytes, reps, m), 1) for m, n in enumerate(names)}
 
 
 def last_error() -> str:

@@ -47,6 +47,24 @@ def iter_like_cfg(n, method="multigrid", omega=1.0, tol=1e-8, max_iter=1000, alp
     }
 
 
+def diiid_like_cfg(n, tol=1e-8, max_iter=1000, alpha=0.12):
+    """DIII-D-like case of BASELINE config 3 (validation/diiid_config.json, values restated; solver block as the parity fixtures
+    use it: multigrid, sor_omega 1.0).  Coil positions are the reference's approximate ones (Luxon, Nucl. Fusion 42 (2002) 614)."""
+    coils = [("OH", 0.42, 0.0, -4.0), ("F1A", 0.86, 1.01, 2.0), ("F2A", 0.86, 0.60, 1.5), ("F3A", 0.86, 0.17, 0.8),
+             ("F4A", 0.86, -0.17, 0.8), ("F5A", 0.86, -0.60, 1.5), ("F6A", 0.86, -1.01, 2.0), ("F7A", 2.40, 1.10, -1.2),
+             ("F8A", 2.40, -1.10, -1.2), ("F9A", 2.00, 1.55, -0.5)]
+    return {
+        "reactor_name": "DIII-D (General Atomics)",
+        "grid_resolution": [n, n],
+        "dimensions": {"R_min": 0.8, "R_max": 2.6, "Z_min": -1.8, "Z_max": 1.8},
+        "physics": {"plasma_current_target": 1.6, "vacuum_permeability": 1.0},
+        "target": {"R_axis": 1.67, "Z_axis": 0.0},
+        "coils": [{"name": nm, "r": r, "z": z, "current": c} for nm, r, z, c in coils],
+        "solver": {"max_iterations": max_iter, "convergence_threshold": tol, "relaxation_factor": alpha,
+                   "solver_method": "multigrid", "sor_omega": 1.0},
+    }
+
+
 def scan_member_table(cfg: dict, total: int, seed: int = 2026) -> tuple[np.ndarray, np.ndarray]:
     """Coil/shape scan of BASELINE config 5: coil currents I_k*(1+0.1u) and plasma current Ip*(1+0.1u),
     u ~ U(-1, 1) from ``np.random.default_rng(seed)``; returns (currents [total, n_coils], I_p targets [total])."""

@@ -2663,24 +2663,32 @@ int scpn_verify_division(const double* x, const double* d, int n, double* q5, do
 // device bandwidth of this GPU, HIP events around `reps` launches on `bytes` of HBM: mode 0 = copy (read + written bytes per
 // second, best of three grid sizes), mode 1 = read-only sum
 int scpn_copy_bandwidth_probe(long bytes, int reps, double* gb_per_s) { return scpn_bandwidth_probe(0, bytes, reps, gb_per_s); }
+// mode 0: grid-stride copy (4 loads in flight); 1: read-only sum (8 in flight); 2: contiguous 32-KiB chunks per workgroup, 8 loads
+// in flight; 3: the same with non-temporal stores; 4: hipMemcpyDtoDAsync.  Copies count read + written bytes.  1 GiB per
+// buffer by default (4x the Infinity Cache); best over several grid sizes.
 int scpn_bandwidth_probe(int mode, long bytes, int reps, double* gb_per_s) {
-    if (!gb_per_s || bytes < (1L << 20) || reps < 1 || mode < 0 || mode > 1) return fail(SCPN_E_ARG, "scpn_bandwidth_probe: mode 0|1, bytes >= 1 MiB, reps >= 1");
+    if (!gb_per_s || bytes < (1L << 20) || reps < 1 || mode < 0 || mode > 4) return fail(SCPN_E_ARG, "scpn_bandwidth_probe: mode 0..4, bytes >= 1 MiB, reps >= 1");
     API_BEGIN
     HIP_TRY(hipSetDevice(g_device));
     const long n16 = bytes / 16;
     DBuf<double2> a, b;
     a.alloc((size_t)n16);
-    if (mode == 0) b.alloc((size_t)n16); else b.alloc(16);
+    if (mode != 1) b.alloc((size_t)n16); else b.alloc(16);
     HIP_TRY(hipMemset(a.p, 1, (size_t)n16 * 16));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     double best = 0.0;
-    for (int wg_per_cu : {8, 16, 32}) {
+    for (int wg_per_cu : {4, 8, 16, 32}) {
         const dim3 g(256 * wg_per_cu);
         auto launch = [&] {
-            if (mode == 0) SCPN_LAUNCH(k_copy_probe, g, dim3(256), 0, nullptr, b.p, (const double2*)a.p, n16);
-            else SCPN_LAUNCH(k_read_probe, g, dim3(256), 0, nullptr, reinterpret_cast<double*>(b.p), (const double2*)a.p, n16);
+            switch (mode) {
+                case 0: SCPN_LAUNCH(k_copy_probe, g, dim3(256), 0, nullptr, b.p, (const double2*)a.p, n16); break;
+                case 1: SCPN_LAUNCH(k_read_probe, g, dim3(256), 0, nullptr, reinterpret_cast<double*>(b.p), (const double2*)a.p, n16); break;
+                case 2: SCPN_LAUNCH(k_copy_probe_chunk<false>, g, dim3(256), 0, nullptr, b.p, (const double2*)a.p, n16); break;
+                case 3: SCPN_LAUNCH(k_copy_probe_chunk<true>, g, dim3(256), 0, nullptr, b.p, (const double2*)a.p, n16); break;
+                default: HIP_TRY(hipMemcpyDtoDAsync(b.p, a.p, (size_t)n16 * 16, nullptr)); break;
+            }
         };
         launch();  // warm-up
         HIP_TRY(hipEventRecord(e0, nullptr));
@@ -2689,7 +2697,8 @@ int scpn_bandwidth_probe(int mode, long bytes, int reps, double* gb_per_s) {
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        best = std::max(best, (mode == 0 ? 2.0 : 1.0) * (double)n16 * 16.0 * reps / ((double)ms * 1e-3) / 1e9);
+        best = std::max(best, (mode == 1 ? 1.0 : 2.0) * (double)n16 * 16.0 * reps / ((double)ms * 1e-3) / 1e9);
+        if (mode == 4) break;  // no grid to vary
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

@@ -349,6 +349,31 @@ def gen_free_boundary():
     save("free_boundary.npz", **out)
 
 
+# ── BASELINE config 3, second variant: solve_free_boundary(optimize_shape=True) with 8 isoflux control points on the DIII-D-like
+#    grid (validation/diiid_config.json; ellipse R0 1.67 m, a 0.6 m, kappa 1.8)  core/fusion_kernel_free_boundary.py:664-705 ─
+def gen_shape_d3d():
+    out = {}
+    cfg = d3d_cfg(129, tol=1e-6, max_iter=400)
+    cfg["physics"]["vacuum_permeability"] = 4e-7 * np.pi  # SI-consistent units, as in gen_shape
+    cfg["physics"]["plasma_current_target"] = 1.6e6
+    for c in cfg["coils"]:
+        c["current"] = c["current"] * 1.0e6
+    k = make_kernel(cfg)
+    th = np.linspace(0.0, 2.0 * np.pi, 8, endpoint=False)
+    pts = np.column_stack([1.67 + 0.6 * np.cos(th), 1.8 * 0.6 * np.sin(th)])
+    coils = CoilSet(positions=[(c["r"], c["z"]) for c in cfg["coils"]],
+                    currents=np.array([c["current"] for c in cfg["coils"]], dtype=float), turns=[1] * len(cfg["coils"]),
+                    current_limits=np.full(len(cfg["coils"]), 5.0e7), target_flux_points=pts)
+    r = k.solve_free_boundary(coils, max_outer_iter=4, tol=1e-6, optimize_shape=True)
+    out["psi"] = k.Psi
+    out["points"] = pts
+    out["currents"] = r["coil_currents"]
+    out["stats"] = np.array([r["outer_iterations"], r["final_diff"], r["shape_optimization"]["flux_rmse"]])
+    out["_configs"] = np.array(json.dumps({"shape_d3d129": cfg}))
+    print("shape d3d", r["outer_iterations"], r["final_diff"], r["coil_currents"], r["shape_optimization"])
+    save("shape_d3d.npz", **out)
+
+
 # ── shape optimisation  core/fusion_kernel_free_boundary.py:491-559,583-605,664-705 ─
 def gen_shape():
     out = {}
@@ -750,6 +775,6 @@ def gen_freegs():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["smooth", "operators", "mgsolve", "polyglot", "picard", "pieces", "green",
-                             "free_boundary", "fastsolver", "anderson", "shape", "eqdsk", "newton", "products", "transport", "saddle", "freegs"]
+                             "free_boundary", "fastsolver", "anderson", "shape", "shape_d3d", "eqdsk", "newton", "products", "transport", "saddle", "freegs"]
     for w in which:
         globals()[f"gen_{w}"]()
