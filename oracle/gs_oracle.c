@@ -1452,6 +1452,267 @@ int orc_newton_solve(const orc_picard_params *p, const orc_newton_opts *o, doubl
     return 0;
 }
 
+/* -------------------------------------------------------------------------------------
+ * Multigrid-preconditioned, finite-difference-Jacobian Newton lane (an extension of the HIP package, scpn_gs_newton_solve with
+ * gmres_preconditioner = "multigrid", newton_jacobian = "finite_difference"; precedent in the reference:
+ * core/jax_multigrid_precond.py:208-276).  CPU restatement of what the device lane computes, same arithmetic up to the order of the
+ * global reductions:
+ *   warm-up   : `warmup` Picard iterations of the reference's Newton dispatch (phase A above);
+ *   each step : axis / X-point / source at psi_k, r_k = L psi_k - S(psi_k), history + convergence test as orc_newton_solve;
+ *               solve J dx = -r_k by SciPy-style restarted GMRES (restart columns, maxiter cycles) LEFT-preconditioned by
+ *               z = M^-1 v = ONE V-cycle(3,3), omega 1, min_grid 5, of the GS* operator from a zero start with v as source;
+ *               J v = L v - (S(psi + eps v) - S(psi)) / eps with the FULL source map (axis, X-point, 0.1 heuristic, profile,
+ *               sum-J renormalisation) and eps = 1e-7 sqrt(n_interior) max(|psi_axis|, 1e-6) / ||v||_2 (||v|| := 1 for the unit
+ *               Krylov basis vectors, as the device does); x0 = 0; the LAST cycle of a capped solve exits on the Arnoldi
+ *               estimate (no true residual);
+ *               psi_interior += newton_alpha * dx, Dirichlet ring re-applied, NaN / Inf check.
+ * Vectors live on the full (nz, nr) grid with a zero ring.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const nctx *cx;
+    const double *psi, *source0; /* state of this Newton step */
+    double psi_axis;
+    double *psip, *jtmp, *srcp, *lv, *zero; /* scratch, full grids */
+} fdctx;
+
+static double grid_norm2(const double *a, long n) { return nrm2n(a, n); }
+
+/* out = J v on the interior (ring 0); unit: v is a unit-norm Krylov basis vector */
+static void fd_matvec(const fdctx *f, const double *v, int unit, double *out) {
+    const orc_picard_params *p = f->cx->p;
+    int nz = p->nz, nr = p->nr;
+    long n = (long)nz * nr, ni = (long)(nz - 2) * (nr - 2);
+    double nv2 = unit ? 1.0 : dotn(v, v, n);
+    double eps = nv2 > 0.0 ? 1e-7 * sqrt((double)ni) * fmax(fabs(f->psi_axis), 1e-6) / sqrt(nv2) : 0.0;
+    for (long i = 0; i < n; ++i) f->psip[i] = f->psi[i] + eps * v[i];
+    double pa, pb;
+    newton_topology_source(f->cx, f->psip, f->jtmp, &pa, &pb);
+    for (int iz = 0; iz < nz; ++iz)
+        for (int ir = 0; ir < nr; ++ir) f->srcp[IDX(iz, ir)] = ((-p->mu0) * f->cx->r_axis[ir]) * f->jtmp[IDX(iz, ir)];
+    orc_mg_residual(v, f->zero, f->cx->rr, nz, nr, f->cx->dr, f->cx->dz, f->lv); /* L v (zero source, zero ring) */
+    memset(out, 0, sizeof(double) * (size_t)n);
+    for (int iz = 1; iz < nz - 1; ++iz)
+        for (int ir = 1; ir < nr - 1; ++ir) {
+            double ds = eps != 0.0 ? (f->srcp[IDX(iz, ir)] - f->source0[IDX(iz, ir)]) / eps : 0.0;
+            out[IDX(iz, ir)] = f->lv[IDX(iz, ir)] - ds;
+        }
+}
+/* z = one V-cycle from zero with v as source; ring of z zeroed (Krylov-grid convention) */
+static void mg_precond(const nctx *cx, const double *v, double *z) {
+    const orc_picard_params *p = cx->p;
+    long n = (long)p->nz * p->nr;
+    memset(z, 0, sizeof(double) * (size_t)n);
+    orc_multigrid_vcycle(z, v, cx->rr, p->nz, p->nr, cx->dr, cx->dz, 1.0, 3, 3, 5);
+}
+
+static int gmres_mg_fd(const fdctx *f, const double *rhs, int restart, int maxiter, double atol_in, double rtol, double *x,
+                       long *inner_out) {
+    const orc_picard_params *p = f->cx->p;
+    const int nr = p->nr;
+    long n = (long)p->nz * p->nr;
+    double *r = dalloc(n), *w = dalloc(n), *av = dalloc(n), *v = dalloc((long)(restart + 1) * n);
+    double *h = dalloc((long)restart * (restart + 1)), *giv = dalloc(2L * restart), *S = dalloc(restart + 1), *y = dalloc(restart + 1);
+    memset(x, 0, sizeof(double) * (size_t)n);
+    long inner = 0;
+    int info = maxiter;
+    const double eps = 2.220446049250313e-16;
+    double bnrm2 = grid_norm2(rhs, n);
+    double atol = fmax(atol_in, rtol * bnrm2);
+    if (bnrm2 == 0.0 || bnrm2 < atol) { info = 0; goto done; } /* x = 0 is the answer */
+    {
+        mg_precond(f->cx, rhs, w);
+        double Mb = grid_norm2(w, n);
+        double ptol_max_factor = 1.0, ptol = Mb * fmin(1.0, atol / bnrm2), presid = 0.0, rnorm = bnrm2;
+        memcpy(r, rhs, sizeof(double) * (size_t)n);
+#define H(c, k) h[(long)(c) * (restart + 1) + (k)]
+        for (int it = 0; it < maxiter; ++it) {
+            if (it == 0) memcpy(v, w, sizeof(double) * (size_t)n); /* M^-1 b is the first (unscaled) Krylov vector */
+            else mg_precond(f->cx, r, v);
+            double tmp = grid_norm2(v, n), inv = 1.0 / tmp;
+            for (long i = 0; i < n; ++i) v[i] *= inv;
+            for (int i = 0; i <= restart; ++i) S[i] = 0.0;
+            S[0] = tmp;
+            int breakdown = 0, col = 0;
+            for (col = 0; col < restart; ++col) {
+                fd_matvec(f, v + (long)col * n, 1, av);
+                mg_precond(f->cx, av, w);
+                double h0 = grid_norm2(w, n);
+                for (int k = 0; k <= col; ++k) {
+                    const double *vk = v + (long)k * n;
+                    double t = dotn(vk, w, n);
+                    H(col, k) = t;
+                    for (long i = 0; i < n; ++i) w[i] -= t * vk[i];
+                }
+                double h1 = grid_norm2(w, n);
+                H(col, col + 1) = h1;
+                double *vn = v + (long)(col + 1) * n;
+                memcpy(vn, w, sizeof(double) * (size_t)n);
+                if (h1 <= eps * h0) { H(col, col + 1) = 0.0; breakdown = 1; }
+                else { double ih = 1.0 / h1; for (long i = 0; i < n; ++i) vn[i] *= ih; }
+                for (int k = 0; k < col; ++k) {
+                    double c = giv[2 * k], s_ = giv[2 * k + 1], n0 = H(col, k), n1 = H(col, k + 1);
+                    H(col, k) = c * n0 + s_ * n1;
+                    H(col, k + 1) = -s_ * n0 + c * n1;
+                }
+                double c, s_, mag;
+                orc_dlartg(H(col, col), H(col, col + 1), &c, &s_, &mag);
+                giv[2 * col] = c; giv[2 * col + 1] = s_;
+                H(col, col) = mag; H(col, col + 1) = 0.0;
+                double t2 = -s_ * S[col];
+                S[col] = c * S[col];
+                S[col + 1] = t2;
+                presid = fabs(t2);
+                inner += 1;
+                if (presid <= ptol || breakdown) break;
+            }
+            if (col == restart) col = restart - 1;
+            if (H(col, col) == 0.0) S[col] = 0.0;
+            for (int k = 0; k <= col; ++k) y[k] = S[k];
+            for (int k = col; k > 0; --k)
+                if (y[k] != 0.0) {
+                    y[k] /= H(k, k);
+                    double t = y[k];
+                    for (int j = 0; j < k; ++j) y[j] -= t * H(k, j);
+                }
+            if (y[0] != 0.0) y[0] /= H(0, 0);
+            for (long i = 0; i < n; ++i) {
+                double acc = 0.0;
+                for (int k = 0; k <= col; ++k) acc += y[k] * v[(long)k * n + i];
+                x[i] += acc;
+            }
+            if (it + 1 == maxiter) { /* capped inexact solve: judged on the Arnoldi estimate of the preconditioned residual */
+                info = (presid <= ptol || breakdown) ? 0 : maxiter;
+                break;
+            }
+            fd_matvec(f, x, 0, av);
+            for (long i = 0; i < n; ++i) r[i] = rhs[i] - av[i];
+            for (int ir = 0; ir < p->nr; ++ir) { r[IDX(0, ir)] = 0.0; r[IDX(p->nz - 1, ir)] = 0.0; }
+            for (int iz = 0; iz < p->nz; ++iz) { r[IDX(iz, 0)] = 0.0; r[IDX(iz, p->nr - 1)] = 0.0; }
+            rnorm = grid_norm2(r, n);
+            if (rnorm <= atol) { info = 0; break; }
+            else if (breakdown) { info = maxiter; break; }
+            else if (presid <= ptol) ptol_max_factor = fmax(eps, 0.25 * ptol_max_factor);
+            else ptol_max_factor = fmin(1.0, 1.5 * ptol_max_factor);
+            ptol = presid * fmin(ptol_max_factor, atol / rnorm);
+        }
+#undef H
+    }
+done:
+    if (inner_out) *inner_out = inner;
+    free(r); free(w); free(av); free(v); free(h); free(giv); free(S); free(y);
+    return info;
+}
+
+int orc_newton_mg_fd(const orc_picard_params *p, const orc_newton_mg_opts *o, double *psi, const double *boundary_flux,
+                     double *j_phi, orc_newton_result *res, double *hist, double *gs_hist) {
+    int nz = p->nz, nr = p->nr;
+    long n = (long)nz * nr;
+    memset(res, 0, sizeof(*res));
+    double *r_axis = dalloc(nr), *z_axis = dalloc(nz), *rr = dalloc(n);
+    orc_linspace(p->r_min, p->r_max, nr, r_axis);
+    orc_linspace(p->z_min, p->z_max, nz, z_axis);
+    double dr = r_axis[1] - r_axis[0], dz = z_axis[1] - z_axis[0];
+    meshgrid_r(r_axis, nz, nr, rr);
+    nctx cx = {p, r_axis, z_axis, rr, dr, dz};
+    double *bc = dalloc(n);
+    if (p->has_boundary_flux && boundary_flux) memcpy(bc, boundary_flux, sizeof(double) * (size_t)n);
+    else if (p->preserve_initial_state) memcpy(bc, psi, sizeof(double) * (size_t)n);
+    else orc_vacuum_field(r_axis, z_axis, nz, nr, p->n_coils, p->coil_r, p->coil_z, p->coil_i, p->mu0, bc);
+    if (p->preserve_initial_state) apply_bc(psi, bc, nz, nr);
+    else memcpy(psi, bc, sizeof(double) * (size_t)n);
+    double *source = dalloc(n), *psi_new = dalloc(n), *tmp = dalloc(n), *rk = dalloc(n), *rhs = dalloc(n), *dx = dalloc(n);
+    double *psip = dalloc(n), *jtmp = dalloc(n), *srcp = dalloc(n), *lv = dalloc(n), *zero = dalloc(n);
+    memset(zero, 0, sizeof(double) * (size_t)n);
+    int nh = 0, ngh = 0, converged = 0, final_iter = 0, have_source = 0;
+    double last_hist = INFINITY, gs_best = INFINITY, gs_last = INFINITY;
+    int max_iter = p->max_iter;
+    int warmup = o->warmup_steps >= 0 ? (o->warmup_steps < max_iter ? o->warmup_steps : max_iter) : (max_iter / 2 < 15 ? max_iter / 2 : 15);
+#define PUSH_H(v) do { last_hist = (v); if (hist) hist[nh] = (v); nh++; } while (0)
+#define PUSH_G(v) do { gs_last = (v); if (gs_hist) gs_hist[ngh] = (v); ngh++; if ((v) < gs_best) gs_best = (v); } while (0)
+#define MAKE_SOURCE(dst) do { for (int iz = 0; iz < nz; ++iz) for (int ir = 0; ir < nr; ++ir) \
+        (dst)[IDX(iz, ir)] = ((-p->mu0) * r_axis[ir]) * j_phi[IDX(iz, ir)]; } while (0)
+    /* _seed_plasma */
+    if (fabs(p->i_target) < 1e-12) {
+        memset(j_phi, 0, sizeof(double) * (size_t)n);
+    } else {
+        double r_center = (p->r_min + p->r_max) / 2.0;
+        for (int iz = 0; iz < nz; ++iz)
+            for (int ir = 0; ir < nr; ++ir) {
+                double a = r_axis[ir] - r_center;
+                j_phi[IDX(iz, ir)] = exp(-(a * a + z_axis[iz] * z_axis[iz]) / 2.0);
+            }
+        double i_seed = (orc_np_sum(j_phi, n) * dr) * dz;
+        if (i_seed > 0) { double s = p->i_target / i_seed; for (long i = 0; i < n; ++i) j_phi[i] *= s; }
+        MAKE_SOURCE(source);
+        for (int s = 0; s < 50; ++s) { orc_jacobi_step(psi, source, rr, nz, nr, dr, dz, tmp); memcpy(psi, tmp, sizeof(double) * (size_t)n); }
+    }
+    /* phase A: Picard warm-up, as orc_newton_solve */
+    for (int k = 0; k < warmup; ++k) {
+        final_iter = k;
+        double psi_axis, psi_bnd;
+        newton_topology_source(&cx, psi, j_phi, &psi_axis, &psi_bnd);
+        MAKE_SOURCE(source);
+        have_source = 1;
+        orc_sor_step(psi, source, rr, nz, nr, dr, dz, p->sor_omega, psi_new);
+        apply_bc(psi_new, bc, nz, nr);
+        int bad = 0;
+        for (long i = 0; i < n; ++i) if (!isfinite(psi_new[i])) { bad = 1; break; }
+        if (bad) { res->diverged = 1; break; }
+        for (long i = 0; i < n; ++i) tmp[i] = fabs(psi_new[i] - psi[i]);
+        double diff = orc_np_sum(tmp, n) / (double)n;
+        PUSH_H(diff);
+        for (long i = 0; i < n; ++i) psi[i] = (1.0 - p->alpha) * psi[i] + p->alpha * psi_new[i];
+        apply_bc(psi, bc, nz, nr);
+        double gs = orc_gs_residual_rms(psi, source, rr, nz, nr, dr, dz);
+        PUSH_G(gs);
+        if (diff < p->tol && ((!p->require_gs_residual) || gs < p->gs_tol)) { converged = 1; break; }
+    }
+    /* phase B */
+    if (!converged && !res->diverged) {
+        for (int k = warmup; k < max_iter; ++k) {
+            final_iter = k;
+            double psi_axis, psi_bnd;
+            newton_topology_source(&cx, psi, j_phi, &psi_axis, &psi_bnd);
+            MAKE_SOURCE(source);
+            have_source = 1;
+            orc_mg_residual(psi, source, rr, nz, nr, dr, dz, rk);
+            double res_norm, gs;
+            interior_norms(rk, nz, nr, &res_norm, &gs);
+            PUSH_H(res_norm);
+            PUSH_G(gs);
+            if (res_norm < p->tol && ((!p->require_gs_residual) || gs < p->gs_tol)) { converged = 1; break; }
+            memset(rhs, 0, sizeof(double) * (size_t)n);
+            for (int iz = 1; iz < nz - 1; ++iz)
+                for (int ir = 1; ir < nr - 1; ++ir) rhs[IDX(iz, ir)] = -rk[IDX(iz, ir)];
+            fdctx f = {&cx, psi, source, psi_axis, psip, jtmp, srcp, lv, zero};
+            long inner = 0;
+            int info = gmres_mg_fd(&f, rhs, o->gmres_restart, o->gmres_maxiter, o->gmres_atol, o->gmres_rtol, dx, &inner);
+            res->gmres_matvecs += inner;
+            res->gmres_last_info = info;
+            if (info > 0) res->gmres_nonconverged += 1;
+            for (int iz = 1; iz < nz - 1; ++iz)
+                for (int ir = 1; ir < nr - 1; ++ir) psi[IDX(iz, ir)] += o->newton_alpha * dx[IDX(iz, ir)];
+            apply_bc(psi, bc, nz, nr);
+            int bad = 0;
+            for (long i = 0; i < n; ++i) if (!isfinite(psi[i])) { bad = 1; break; }
+            if (bad) { res->diverged = 1; break; }
+        }
+    }
+#undef PUSH_H
+#undef PUSH_G
+#undef MAKE_SOURCE
+    res->converged = converged;
+    res->iterations = final_iter + 1;
+    res->residual = last_hist;
+    res->gs_residual = have_source ? gs_last : INFINITY;
+    res->gs_residual_best = have_source ? gs_best : INFINITY;
+    res->n_hist = nh;
+    res->n_gs_hist = ngh;
+    free(r_axis); free(z_axis); free(rr); free(bc); free(source); free(psi_new); free(tmp); free(rk); free(rhs); free(dx);
+    free(psip); free(jtmp); free(srcp); free(lv); free(zero);
+    return 0;
+}
+
 /* =====================================================================================
  * f3: field products  
  * ===================================================================================== */

@@ -225,6 +225,18 @@ int orc_newton_solve(const orc_picard_params *p, const orc_newton_opts *o, doubl
                      const double *boundary_flux, double *j_phi, orc_newton_result *res, double *hist,
                      double *gs_hist);
 
+/* Multigrid-preconditioned, finite-difference-Jacobian Newton lane of the HIP package (gmres_preconditioner = "multigrid",
+ * newton_jacobian = "finite_difference") restated on the CPU: the checker of that lane (tests/test_gpu_newton.py).
+ * warmup_steps < 0 -> the reference's rule min(15, max_iter / 2). */
+typedef struct orc_newton_mg_opts {
+    int warmup_steps;
+    double newton_alpha;      /* solver.newton_damping */
+    int gmres_restart, gmres_maxiter;
+    double gmres_atol, gmres_rtol;
+} orc_newton_mg_opts;
+int orc_newton_mg_fd(const orc_picard_params *p, const orc_newton_mg_opts *o, double *psi, const double *boundary_flux,
+                     double *j_phi, orc_newton_result *res, double *hist, double *gs_hist);
+
 /* ---- field products ----------------------------------------------------------
  * core/fusion_kernel_free_boundary.py:562-580 interp_psi (bilinear sample of psi) */
 double orc_interp_psi(const double *psi, const double *r_axis, const double *z_axis, int nz, int nr, double dr,

@@ -115,6 +115,9 @@ def lib() -> C.CDLL:
         L.orc_dlartg.argtypes = [_d, _d, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d)]
         L.orc_gmres_gs.argtypes = [_dp, _dp, _i, _i, _d, _d, _dp, C.c_void_p, _i, _i, _d, _d, _dp, C.POINTER(C.c_long)]
         L.orc_profile_jacobian.argtypes = [_dp, _dp, _dp, _i, _i, _d, _d, _d, _d, _d, _i, _dp]
+        L.orc_newton_mg_fd.restype = _i
+        L.orc_newton_mg_fd.argtypes = [C.POINTER(PicardParams), C.POINTER(NewtonMgOpts), _dp, C.c_void_p, _dp,
+                                       C.POINTER(NewtonResult), C.c_void_p, C.c_void_p]
         L.orc_newton_solve.argtypes = [C.POINTER(PicardParams), C.POINTER(NewtonOpts), _dp, C.c_void_p, _dp,
                                        C.POINTER(NewtonResult), C.c_void_p, C.c_void_p]
         _lib = L
@@ -347,6 +350,11 @@ class NewtonOpts(C.Structure):
     _fields_ = [("precond", _i), ("line_search", _i), ("line_search_c", _d), ("max_backtracks", _i)]
 
 
+class NewtonMgOpts(C.Structure):
+    _fields_ = [("warmup_steps", _i), ("newton_alpha", _d), ("gmres_restart", _i), ("gmres_maxiter", _i), ("gmres_atol", _d),
+                ("gmres_rtol", _d)]
+
+
 class NewtonResult(C.Structure):
     _fields_ = [
         ("converged", _i), ("iterations", _i), ("diverged", _i),
@@ -421,6 +429,29 @@ def newton_solve(cfg, psi0=None, boundary_flux=None, *, preserve=False, external
             "newton_line_search_rejects": res.ls_rejects, "gmres_nonconverged_count": res.gmres_nonconverged,
             "gmres_breakdown_count": res.gmres_breakdown, "gmres_last_info": res.gmres_last_info,
             "gmres_matvecs": res.gmres_matvecs, "solver_method": "newton"}
+
+
+def newton_mg_fd(cfg, psi0=None, boundary_flux=None, *, preserve=False):
+    """CPU restatement of the package's multigrid-preconditioned / finite-difference-Jacobian Newton lane (orc_newton_mg_fd):
+    the keys of ``cfg["solver"]`` that lane reads (newton_warmup_steps, newton_damping, gmres_restart / maxiter / rtol / atol),
+    with the package's defaults for that lane (GMRES(8) x 1, rtol 1e-3, atol 1e-8; damping as given, default 0.5)."""
+    sol = cfg["solver"]
+    p = make_params(cfg, preserve=preserve, has_bc=boundary_flux is not None)
+    o = NewtonMgOpts(int(sol.get("newton_warmup_steps", -1)), float(sol.get("newton_damping", 0.5)), int(sol.get("gmres_restart", 8)),
+                     int(sol.get("gmres_maxiter", 1)), float(sol.get("gmres_atol", 1e-8)), float(sol.get("gmres_rtol", 1e-3)))
+    nz, nr = p.nz, p.nr
+    psi = np.zeros((nz, nr)) if psi0 is None else _c(psi0).copy()
+    j = np.zeros((nz, nr))
+    res = NewtonResult()
+    hist = np.full(2 * p.max_iter + 2, np.nan)
+    gsh = np.full(2 * p.max_iter + 2, np.nan)
+    bf = None if boundary_flux is None else _c(boundary_flux)
+    lib().orc_newton_mg_fd(C.byref(p), C.byref(o), psi, None if bf is None else bf.ctypes.data, j, C.byref(res), hist.ctypes.data,
+                           gsh.ctypes.data)
+    return {"psi": psi, "converged": bool(res.converged), "iterations": res.iterations, "diverged": bool(res.diverged),
+            "residual": res.residual, "gs_residual": res.gs_residual, "residual_history": hist[: res.n_hist].copy(),
+            "gs_residual_history": gsh[: res.n_gs_hist].copy(), "gmres_nonconverged_count": res.gmres_nonconverged,
+            "gmres_last_info": res.gmres_last_info, "gmres_matvecs": res.gmres_matvecs}
 
 
 def interp_psi(psi, r_axis, z_axis, dr, dz, r_pt, z_pt):

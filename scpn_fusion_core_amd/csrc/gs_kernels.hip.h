@@ -269,6 +269,16 @@ __device__ __forceinline__ VI block_vi(VI x, VI* sh) {
     return r;
 }
 
+// ---------------------------------------------------------------- host-visible progress word
+// The host drivers poll a device counter every few iterations / Krylov columns.  A hipMemcpyAsync + stream synchronise costs
+// ~45 us of stream idle per poll (copy engine kernel, interrupt, relaunch latency: profiles/r03e_newton_timeline.txt); this
+// one-thread kernel instead posts {sequence number, value} as ONE aligned 8-byte store into host-mapped pinned memory, and the
+// host spins on that word (scpn_hip.hip: poll_word).
+__global__ void k_post_word(const int* value, unsigned long long* host_word, unsigned seq) {
+    const unsigned long long w = ((unsigned long long)seq << 32) | (unsigned long long)(unsigned)(*value);
+    __hip_atomic_store(host_word, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---------------------------------------------------------------- elementwise / copies
 // read-only bandwidth probe: grid-stride sum, 16 B per lane, eight independent loads in flight per lane
 __global__ void __launch_bounds__(256) k_read_probe(double* __restrict__ out, const double2* __restrict__ src, long n16) {

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -167,6 +168,9 @@ struct Solver {
     DBuf<TopoPart> d_topo;
     DBuf<double> d_scal;
     int* h_nactive = nullptr;  // pinned
+    unsigned long long* h_word = nullptr;  // pinned + mapped: {sequence, value} posted by k_post_word
+    unsigned long long* d_word = nullptr;  // device alias of h_word
+    unsigned word_seq = 0;
     std::vector<double> i_target;
     std::vector<double> vac_r, vac_z, vac_i;
     int n_vac = 0;
@@ -194,6 +198,7 @@ struct Solver {
             for (auto* l : kv.second.lv) delete l;
         for (auto& e : prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         if (h_nactive) (void)hipHostFree(h_nactive);
+        if (h_word) (void)hipHostFree(h_word);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -656,6 +661,9 @@ static Solver* create_impl(int nr, int nz, int batch, const double* r_axis, cons
         h->d_part2.alloc((size_t)batch * h->nblk());
         h->d_scal.alloc(8);
         HIP_TRY(hipHostMalloc((void**)&h->h_nactive, sizeof(int) * 4, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&h->h_word, 64, hipHostMallocMapped));
+        *h->h_word = 0ull;
+        HIP_TRY(hipHostGetDevicePointer((void**)&h->d_word, h->h_word, 0));
         h->i_target.assign(batch, 0.0);
         HIP_TRY(hipStreamSynchronize(h->stream));
     } catch (...) {
@@ -674,6 +682,35 @@ static Solver* create_impl(int nr, int nz, int batch, const double* r_axis, cons
     return SCPN_OK;
 
 static bool omega_ok(double w) { return std::isfinite(w) && w >= 1.0 && w < 2.0; }
+
+// Value of the device int at `dptr` once everything enqueued on the handle's stream so far has run (the stream is NOT
+// synchronised through the runtime: see k_post_word).  SCPN_HIP_POLL=memcpy restores hipMemcpyAsync + hipStreamSynchronize.
+static int poll_word(Solver* h, const int* dptr) {
+    static const bool use_memcpy = [] { const char* e = std::getenv("SCPN_HIP_POLL"); return e && std::string(e) == "memcpy"; }();
+    hipStream_t st = h->stream;
+    if (use_memcpy || !h->d_word) {
+        HIP_TRY(hipMemcpyAsync(h->h_nactive, dptr, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return h->h_nactive[0];
+    }
+    const unsigned seq = ++h->word_seq;
+    SCPN_LAUNCH(k_post_word, dim3(1), dim3(1), 0, st, dptr, h->d_word, seq);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned long long w = __atomic_load_n(h->h_word, __ATOMIC_ACQUIRE);
+        if ((unsigned)(w >> 32) == seq) return (int)(unsigned)(w & 0xffffffffull);
+        __builtin_ia32_pause();
+        if ((spins & 0xfffffu) == 0xfffffu) {  // (~every few ms: the runtime is not called while the word is on its way)
+            // a device fault would leave the word unposted for ever: fall back to the runtime, which reports the error
+            if (hipStreamQuery(st) == hipSuccess) {
+                const unsigned long long w2 = __atomic_load_n(h->h_word, __ATOMIC_ACQUIRE);
+                if ((unsigned)(w2 >> 32) == seq) return (int)(unsigned)(w2 & 0xffffffffull);
+                throw std::runtime_error("progress word was not posted although the stream is idle");
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) HIP_TRY(hipStreamSynchronize(st));
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------ Picard
 static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picard_result* results, double* hist_diff,
@@ -983,9 +1020,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         iteration(true);
         ++k;
         if (k % check_every == 0 || k >= max_iter) {
-            HIP_TRY(hipMemcpyAsync(h->h_nactive, h->d_nactive.p, sizeof(int), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            n_act = h->h_nactive[0];
+            n_act = poll_word(h, h->d_nactive.p);
         }
     }
     while (n_act > 0 && k < max_iter) {
@@ -993,9 +1028,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         iteration(false);
         ++k;
         if (k % check_every == 0 || k >= max_iter) {
-            HIP_TRY(hipMemcpyAsync(h->h_nactive, h->d_nactive.p, sizeof(int), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            n_act = h->h_nactive[0];
+            n_act = poll_word(h, h->d_nactive.p);
         }
     }
     HIP_TRY(hipStreamSynchronize(st));
@@ -1178,11 +1211,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         SCPN_LAUNCH(k_nt_resid_final, dim3(B), dim3(256), 0, st, h->d_st.p, h->nt_st.p, ctl, mode, o->line_search_c, d_hist.p, d_gs.p,
                            (const double*)P0, nb2, h->d_active.p, d_non);
     };
-    auto poll = [&](int* dptr) {
-        HIP_TRY(hipMemcpyAsync(h->h_nactive, dptr, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        return h->h_nactive[0];
-    };
+    auto poll = [&](int* dptr) { return poll_word(h, dptr); };
     // restarted GMRES on (L - diag) x = -r_k for the members that are `on` (scipy gmres, see newton_kernels.hip.h).
     // Preconditioner modes: 0 none, 1 diagonal (the reference's), 2 multigrid: z = M^-1 v is ONE V-cycle(3,3) of the GS* operator
     // from a zero start with v as right-hand side on the zero-ring Krylov grid -- M^-1 (L - D) = I - M^-1 D, the Jacobian's

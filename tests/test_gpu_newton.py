@@ -237,6 +237,31 @@ def test_newton_multigrid_fd_reaches_the_picard_solution(hip, n):
     assert hist[-1] < 1e-8 and hist[-1] < 1e-6 * hist[0]  # quadratic tail: six orders below the first Newton residual
 
 
+@pytest.mark.parametrize("n,warm", [(65, 15), (129, 15), (129, 2)])
+def test_newton_multigrid_fd_lane_matches_its_cpu_restatement(hip, n, warm):
+    """The lane against oracle/gs_oracle.c::orc_newton_mg_fd (same warm-up, same V-cycle preconditioner, same epsilon rule, same
+    SciPy-style GMRES bookkeeping, global reductions in a different order): identical Newton step count and GMRES column
+    count, the residual history step by step, and the flux map."""
+    from oracle import oracle as orc
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    c = iter_like_cfg(n, method="newton", tol=1e-8, max_iter=60)
+    c["solver"].update(gmres_preconditioner="multigrid", newton_jacobian="finite_difference", newton_damping=1.0, newton_warmup_steps=warm)
+    ref = orc.newton_mg_fd(c)
+    with EnsembleSolver(c, batch=2) as es:
+        rn = es.solve_equilibrium()
+        psi = es.get_psi()
+    assert ref["converged"] and rn[0]["converged"]
+    assert rn[0]["iterations"] == ref["iterations"] and rn[0]["gmres_inner_iterations"] == ref["gmres_matvecs"]
+    hist, want = np.array(rn[0]["residual_history"]), ref["residual_history"]
+    assert hist.shape == want.shape
+    big = want > 1e-6 * want[warm]  # entries above the noise floor of the finite-difference operator: digit-for-digit
+    np.testing.assert_allclose(hist[big], want[big], rtol=1e-5)
+    assert hist[-1] < c["solver"]["convergence_threshold"]
+    assert np.abs(psi[0] - ref["psi"]).max() <= 1e-9 * np.abs(ref["psi"]).max()
+    assert np.array_equal(psi[0], psi[1])
+
+
 def test_newton_multigrid_profile_jacobian_is_the_reference_iteration_with_exact_linear_solves(hip):
     """With the reference's profile Jacobian and its 0.5 damping, the V-cycle preconditioner only repairs the linear solves:
     the outer iteration then contracts by 1/2 per step (the signature of an accurate step taken half-way) and reaches the Picard

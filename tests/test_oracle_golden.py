@@ -459,3 +459,24 @@ def test_parity_gate_metrics_host_logic(golden):
     assert not bad["checks"]["axis_error_m"] and bad["axis_error_m"] == pytest.approx(3 * (r[1] - r[0]))
     with pytest.raises(ValueError):
         strict_parity_metrics(psi[:-1], psi, r, z)
+
+
+@pytest.mark.parametrize("n,warm", [(33, 15), (65, 15), (65, 2)])
+def test_newton_mg_fd_oracle_reaches_the_pinned_picard_fixed_point(n, warm):
+    """orc_newton_mg_fd (the CPU restatement of the package's multigrid-preconditioned / finite-difference-Jacobian Newton lane) is
+    anchored on the pinned part of the oracle: it must converge, with a superlinear tail, to the fixed point of orc_picard_solve
+    (which the reference fixtures pin) on the same config."""
+    from scpn_fusion_core_amd.cases import iter_like_cfg
+
+    cfg = iter_like_cfg(n, tol=1e-8, max_iter=600)
+    ref = orc.picard_solve(cfg)
+    c = iter_like_cfg(n, method="newton", tol=1e-8, max_iter=60)
+    c["solver"].update(newton_damping=1.0, newton_warmup_steps=warm)
+    r = orc.newton_mg_fd(c)
+    assert ref["converged"] and r["converged"] and not r["diverged"]
+    assert r["iterations"] - warm <= 9 and r["gmres_nonconverged_count"] <= 2
+    assert np.abs(r["psi"] - ref["psi"]).max() <= 2e-8 * np.abs(ref["psi"]).max()
+    h = r["residual_history"][warm:]
+    assert h[-1] < 1e-8 and h[-1] < 1e-6 * h[0]
+    fast = h[1:][h[:-1] < 1.0]  # once inside the basin: at least a decade per step down to the finite-difference noise floor (~1e-8)
+    assert np.all(fast[fast > 1e-7] < 0.1 * h[:-1][h[:-1] < 1.0][fast > 1e-7])
