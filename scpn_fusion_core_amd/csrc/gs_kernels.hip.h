@@ -725,7 +725,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     const char* const src_b = reinterpret_cast<const char*>(src);
     // PROLONG: the four coarse values around the lane's column pair, loaded the same way; rows are processed in groups of LG so
     // that psi + src + coarse loads of a group fit the register budget
-    constexpr int LG = PROLONG ? (NROWS + 3) / 4 : NROWS;
+    constexpr int LG = (PROLONG && NROWS > 3) ? (NROWS + 3) / 4 : NROWS;  // (three rows or fewer: everything in flight at once)
     const char* const cc_b = PROLONG ? reinterpret_cast<const char*>(coarseF.at(b)) : nullptr;
     const unsigned ld8 = (unsigned)ld * 8u, ldc8 = (unsigned)ld_c * 8u;
     const int jc = max(c0, 0) >> 1;

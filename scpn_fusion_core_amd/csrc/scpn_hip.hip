@@ -352,18 +352,18 @@ struct DefectOut {  // coarse rhs / coarse correction produced by the fused defe
     Fld rhs{nullptr, nullptr, 0, 0}, e{nullptr, nullptr, 0, 0};
     int nz_c = 0, nr_c = 0, ld_c = 0;
 };
-template <int S, bool PROLONG, bool DEFECT>
+template <int S, bool PROLONG, bool DEFECT, int LZT = TILE_LZ, int NWT = TILE_NW, int WPEU = TILE_WPE>
 static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
                         const DefectOut* dfo) {
     static std::once_flag attr_once;  // (two stream-group threads may reach a first launch at the same time)
-    constexpr size_t lds = (size_t)TILE_LZ * 128 * sizeof(double);
-    auto kern = &k_smooth_tile<S, PROLONG, DEFECT>;
+    constexpr size_t lds = (size_t)LZT * 128 * sizeof(double);
+    auto kern = &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, WPEU>;
     std::call_once(attr_once, [&] {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
     constexpr int H = 2 * S + (DEFECT ? 2 : 0);
-    static_assert(TILE_LZ - 2 * H >= 2, "tile too short for its halo");
-    dim3 g(cdiv(L.nr, 128 - 2 * H), cdiv(L.nz, TILE_LZ - 2 * H), h->B);
+    static_assert(LZT - 2 * H >= 2, "tile too short for its halo");
+    dim3 g(cdiv(L.nr, 128 - 2 * H), cdiv(L.nz, LZT - 2 * H), h->B);
     DefectDst dd;
     Fld cF = ps.c;
     int nz_c = ps.nz_c, nr_c = ps.nr_c, ld_c = ps.ld_c;
@@ -377,7 +377,7 @@ static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, doubl
     static const int xcd_env = [] { const char* e = std::getenv("SCPN_HIP_XCD"); return e ? std::atoi(e) : 1; }();
     LazySrc lzs;
     if (h->lazy_src && src.base == h->lazy_src) { lzs.st = h->d_st.p; lzs.neg_mu0R = h->d_neg_mu0R.p; }
-    SCPN_LAUNCH(kern, g, dim3(64 * TILE_NW), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c, ld_c, lzs, dd,
+    SCPN_LAUNCH(kern, g, dim3(64 * NWT), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c, ld_c, lzs, dd,
                 xcd_env);
 }
 // the three production roles of the tile kernel: plain, + prolongation on load, + defect / restriction on store
