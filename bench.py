@@ -278,7 +278,7 @@ def main() -> int:
             probes = _lib.bandwidth_probes()
             roofline["measured_bandwidth"] = {**probes, "bytes": 1 << 30,
                                               "note": "copies count read + written bytes; 1 GiB per buffer (4x the Infinity Cache)"}
-            roofline["measured_copy_gbs"] = max(v for k, v in probes.items() if k != "read")
+            roofline["measured_copy_gbs"] = max(v for k, v in probes.items() if k.startswith("copy") or k == "memcpy_dtod")
             roofline["measured_read_gbs"] = probes["read"]
             if "achieved" in roofline:
                 roofline["frac_of_measured_copy"] = round(roofline["achieved"] / roofline["measured_copy_gbs"], 4)

@@ -123,7 +123,7 @@ int scpn_verify_division(const double *x, const double *d, int n, double *q5, do
  * copy of `bytes` bytes, HIP-event timed over `reps` launches -- the measured HBM denominator printed next to the nominal one. */
 int scpn_copy_bandwidth_probe(long bytes, int reps, double *gb_per_s);
 /* the same with a mode: 0 = grid-stride copy, 1 = read-only sum, 2 = copy in contiguous 32-KiB chunks per workgroup with eight
- * 16-B loads in flight per lane, 3 = mode 2 with non-temporal stores, 4 = hipMemcpyDtoDAsync; copies count read + written bytes;
+ * 16-B loads in flight per lane, 3 = mode 2 with non-temporal stores, 4 = hipMemcpyDtoDAsync, 5 = three read streams + one write stream; all moved bytes count;
  * best over several grid sizes */
 int scpn_bandwidth_probe(int mode, long bytes, int reps, double *gb_per_s);
 /* polyglot lane diagnostics, core/jax_gs_solver.py:196-316: gs_delta_star_np (zero ring; out [nz][nr]) and

@@ -240,8 +240,8 @@ def copy_bandwidth_probe(nbytes: int = 1 << 30, reps: int = 10, mode: int = 0) -
 
 
 def bandwidth_probes(nbytes: int = 1 << 30, reps: int = 10) -> dict:
-    """All probe modes: ``{"copy_grid_stride", "read", "copy_chunked", "copy_chunked_nt", "memcpy_dtod"}`` in GB/s."""
-    names = ("copy_grid_stride", "read", "copy_chunked", "copy_chunked_nt", "memcpy_dtod")
+    """All probe modes: ``{"copy_grid_stride", "read", "copy_chunked", "copy_chunked_nt", "memcpy_dtod", "three_reads_one_write"}`` in GB/s."""
+    names = ("copy_grid_stride", "read", "copy_chunked", "copy_chunked_nt", "memcpy_dtod", "three_reads_one_write")
     return {n: round(copy_bandwidth_probe(nbytes, reps, m), 1) for m, n in enumerate(names)}
 
 

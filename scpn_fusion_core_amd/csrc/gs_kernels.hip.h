@@ -101,6 +101,11 @@ __device__ __forceinline__ double sanitize1(double x) {  // fusion_kernel_numeri
     if (x < -CAP) return -CAP;
     return x;
 }
+// the same as selects (no branches): for straight-line stencil code
+__device__ __forceinline__ double sanitize_sel(double x) {
+    const double c = fmin(fmax(x, -CAP), CAP);  // fmin / fmax return the non-NaN operand: a NaN input gives CAP here ...
+    return x != x ? 0.0 : c;                    // ... and is replaced by 0 as sanitize1 does
+}
 __device__ __forceinline__ double nan_to_num300(double x) {  // fusion_kernel.py:273
     if (x != x) return 0.0;
     if (x > 1.79e308) return 1e300;
@@ -111,7 +116,7 @@ __device__ __forceinline__ bool finite_d(double x) { return fabs(x) <= 1.7976931
 
 // ---------------------------------------------------------------- "last workgroup finishes" hand-off
 // A kernel whose workgroups each leave a few partials for a per-member final reduction can let the workgroup that ARRIVES LAST do
-// that reduction itself instead of ending and paying a dependent launch for it (k_jsum -> k_jsum_final, k_blend_fused ->
+// that reduction itself instead of ending and paying a dependent launch for it (k_jsum -> k_jsum_final, k_blend_tile ->
 // k_picard_final: two launches and two kernel boundaries off the ~11-launch chain of a Picard iteration).  Protocol
 // (MI355X_MICROARCH.md, "Valid forms", first row of the sc1 table, with the acquire kept):
 //   producer: thread 0 writes the workgroup's partials with agent-scope (sc1, write-through) stores, drains them
@@ -327,6 +332,20 @@ __global__ void __launch_bounds__(256) k_copy_probe_chunk(double2* __restrict__ 
         }
     }
     for (long i = nch * CH + (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+// three read streams + one write stream (the traffic mix of the fused Picard tail: cur, new, source in, next out), flat chunks
+__global__ void __launch_bounds__(256) k_mix31_probe(double2* __restrict__ dst, const double2* __restrict__ a, const double2* __restrict__ b,
+                                                     const double2* __restrict__ c, long n16) {
+    constexpr long CH = 256 * 4;
+    const long nch = n16 / CH;
+    for (long ch = blockIdx.x; ch < nch; ch += gridDim.x) {
+        const long o = ch * CH + threadIdx.x;
+        double2 va[4], vb[4], vc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { va[k] = a[o + 256 * k]; vb[k] = b[o + 256 * k]; vc[k] = c[o + 256 * k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[o + 256 * k] = double2{va[k].x + vb[k].x + vc[k].x, va[k].y + vb[k].y + vc[k].y};
+    }
 }
 
 // dst <- src over the logical (nz, nr) window; grid (ceil(nr/64), ceil(nz/4), B), block (64,4)
@@ -599,9 +618,12 @@ __device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (d
 #endif
 #define TILE_STAMP(i) do { if (DEFECT != STAMP_DEFECT || PROLONG != STAMP_PROLONG || L.nz < 300) break; const unsigned lin__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
         if (threadIdx.x == 0 && lin__ % 510 == 1 && lin__ / 510 < 8) g_tile_stamps[(lin__ / 510) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define BLEND_STAMP(i) do { const unsigned lin__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+        if (threadIdx.x == 0 && gridDim.y > 20 && lin__ % 577 == 1 && lin__ / 577 < 8) g_tile_stamps[(lin__ / 577) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CV_STAMP(i)
 #define TILE_STAMP(i)
+#define BLEND_STAMP(i)
 #endif
 // Tile geometry of the shipped library: 40 rows x 128 columns, 8 waves, register allocation capped so that three workgroups
 // share a CU (one loads while the others sweep).  A -D override builds another geometry for experiments (LZ % NW == 0).
@@ -1750,15 +1772,14 @@ __global__ void __launch_bounds__(256) k_blend(Fld nxtF, Fld curF, Fld newF, Fld
 //   partial sum |new-cur|, non-finite flag                             newton_solver.py:518,535
 //   partial max|r|, sum r^2 of r = L*nxt - src over the interior       fusion_kernel_solver_runtime.py:25-51
 //   topology partials of nxt for the NEXT iteration (argmax psi, masked argmin |grad psi|, min psi)
-// A 256-thread workgroup blends a (BT_Z+2) x (64+2) tile into LDS (1-cell halo recomputed from cur/new) and evaluates the
-// residual / np.gradient stencils from LDS.  grid (ceil(nr/64), ceil(nz/BT_Z), B).  All seven workgroup reductions share two
-// barriers: wave-level DPP reductions -> LDS -> barrier -> (block max, rescaled sum of squares) -> LDS -> barrier -> thread 0.
+// (kernel: k_blend_tile below.)  All seven workgroup reductions share two barriers: wave-level DPP reductions -> LDS -> barrier ->
+// (block max, rescaled sum of squares) -> LDS -> barrier -> thread 0.
 struct PicardCtl {
     double tol, gs_tol;
     int require_gs, max_iter, iter, pad;
     long n_total, n_interior;
 };
-// everything k_picard_final needs besides the member index (also handed to k_blend_fused, whose last workgroup per member runs it)
+// everything k_picard_final needs besides the member index (also handed to k_blend_tile, whose last workgroup per member can run it)
 struct PicardTail {
     Member* st = nullptr;
     const double* psum = nullptr;
@@ -1781,7 +1802,8 @@ struct PicardTail {
     int nr = 0;
     const double* r_axis = nullptr;
     const double* z_axis = nullptr;
-    unsigned* counters = nullptr;  // per-member arrival counters of the fused form (k_blend_fused)
+    unsigned* counters = nullptr;  // per-member arrival counters of the fused form (k_blend_tile)
+    int xcd_remap = 1;             // k_blend_tile: XCD-contiguous tile order (SCPN_HIP_XCD_BLEND=0: dispatch order)
 };
 // shared scratch of picard_final_body (declared by the calling kernel)
 struct PicardShared {
@@ -1929,156 +1951,188 @@ __global__ void __launch_bounds__(256) k_picard_final(PicardTail t) {
     if (!t.st[b].active) return;
     picard_final_body<false>(b, t, S);
 }
-#ifndef BLEND_BT_Z
-#define BLEND_BT_Z 32
-#endif
-#ifndef BLEND_WPE
-#define BLEND_WPE 1  // minimum waves per SIMD the register allocation of k_blend_fused must allow
-#endif
-constexpr int BT_Z = BLEND_BT_Z, BT_R = 64;
-// np.gradient + hypot inside the divertor rows (fusion_kernel.py:276-288) at tile point (LZ_, LR_) = grid point (GZ_, GR_)
-// (the divisions by dz, 2dz, dr, 2dr use divc4 with host reciprocals: bit-identical to IEEE division, 4 instructions instead of ~30)
+// reciprocals (two words) of dz, 2 dz, dr for the exact divisions of the divertor-row gradient (host IEEE division)
 struct GradRecip { double dz, inv_dz, lo_dz, two_dz, inv_two_dz, lo_two_dz, dr, inv_dr, lo_dr; };
-#define SCPN_BLEND_GRAD(LZ_, LR_, GZ_, GR_, P_)                                                                             \
-        if ((GZ_) < n_mask_rows) {                                                                                         \
-            double gzv, grv;                                                                                               \
-            const double ps = nan_to_num300(P_);                                                                           \
-            if ((GZ_) == 0) gzv = divc4(nan_to_num300(t[(LZ_) + 1][LR_]) - ps, gq.dz, gq.inv_dz, gq.lo_dz);                  \
-            else if ((GZ_) == nz - 1) gzv = divc4(ps - nan_to_num300(t[(LZ_) - 1][LR_]), gq.dz, gq.inv_dz, gq.lo_dz);        \
-            else gzv = divc4(nan_to_num300(t[(LZ_) + 1][LR_]) - nan_to_num300(t[(LZ_) - 1][LR_]), gq.two_dz, gq.inv_two_dz, gq.lo_two_dz); \
-            if ((GR_) == 0) grv = divc4(nan_to_num300(t[LZ_][(LR_) + 1]) - ps, gq.dr, gq.inv_dr, gq.lo_dr);                  \
-            else if ((GR_) == nr - 1) grv = divc4(ps - nan_to_num300(t[LZ_][(LR_) - 1]), gq.dr, gq.inv_dr, gq.lo_dr);        \
-            else grv = divc4(nan_to_num300(t[LZ_][(LR_) + 1]) - nan_to_num300(t[LZ_][(LR_) - 1]), L.two_dr, L.inv_two_dr, L.lo_two_dr); \
-            const double bm = hypot(grv, gzv);                                                                             \
-            if (finite_d(bm)) mn = vi_min(mn, VI{bm, (long)(GZ_) * nr + (GR_)});                                            \
-        }
-__global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
-                                                     double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
-                                                     double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm, GradRecip gq,
-                                                     PicardTail tail) {
-    __shared__ double t[BT_Z + 2][BT_R + 2 + 1];
+
+// ---------------------------------------------------------------- fused Picard tail, row-pair form (round 3)
+// One launch per Picard iteration: nxt = (1-alpha) cur + alpha new with the ring from bc, sum |new - cur|, non-finite flag,
+// (max, sum (r/max)^2) of r = L* nxt - Source, argmax / divertor-row argmin |grad| / min of nxt per tile.  Structured like the
+// tile smoother: a 256-thread workgroup owns an 18-row x 124-column window of a 20 x 128 tile; a lane owns the column pair
+// (2l, 2l+1) of its wave's five rows, so cur / new / source arrive as 16-B loads from (scalar row pointer) + (lane offset), the
+// blended pair stays in registers for its own stencil and only the N/S pairs and the two out-of-pair neighbours are read from
+// the LDS tile (five LDS reads per two points).  (Round 2's form -- one element per thread, 32 x 64 tiles, ~220 vector instructions per
+// grid point -- ran at the same speed: the kernel is bound by tiles in flight x tile lifetime, profiles/r03_experiments.md.)
+#ifndef BL_WZ_N
+#define BL_WZ_N 18
+#endif
+#ifndef BL_WPE
+#define BL_WPE 5  // minimum waves per SIMD the register allocation must allow (a workgroup puts one wave on each SIMD)
+#endif
+constexpr int BL_WZ = BL_WZ_N, BL_LB = BL_WZ + 2, BL_WR = 124, BL_NW = 4, BL_NROWS = BL_LB / BL_NW;
+static_assert(BL_LB % BL_NW == 0, "rows are dealt to the four waves evenly");
+__device__ __forceinline__ int blend_tiles_x(int nr) { return (nr + BL_WR - 1) / BL_WR; }
+__global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
+                                                             double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
+                                                             double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm,
+                                                             GradRecip gq, PicardTail tail) {
+    __shared__ __attribute__((aligned(16))) double t[BL_LB][128];
     __shared__ int sh_last;
-    __shared__ VI sh_mx[4], sh_mn[4];
-    __shared__ double sh_dsum[4], sh_m[4], sh_minp[4], sh_s2[4];
-    __shared__ int sh_bad[4];
-    // XCD-aware tile order (see k_smooth_tile): XCD k gets a contiguous run of tiles so halo rows are re-read from its own L2
+    __shared__ VI sh_mx[BL_NW], sh_mn[BL_NW];
+    __shared__ double sh_dsum[BL_NW], sh_m[BL_NW], sh_minp[BL_NW], sh_s2[BL_NW];
+    __shared__ int sh_bad[BL_NW];
     int bx_, by_, b;
     {
         const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
         unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        lin = xcd_contiguous(lin, total);
+        if (tail.xcd_remap) lin = xcd_contiguous(lin, total);
         bx_ = (int)(lin % gx);
         const unsigned t_ = lin / gx;
         by_ = (int)(t_ % gy);
         b = (int)(t_ / gy);
     }
     if (!st[b].active) return;
-    const int tid = threadIdx.x;
-    const int tx = tid & 63, ty = tid >> 6;
+    BLEND_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nz = L.nz, nr = L.nr, ld = L.ld;
-    // tile (by, bx) owns rows by*BT_Z + 1 .. by*BT_Z + BT_Z and the matching columns; the tiles of the first tile row / column
-    // also own grid row / column 0 (their halo row / column).  Grids of 2^k + 1 points are covered without sliver tiles.
-    const int z0 = by_ * BT_Z, r0 = bx_ * BT_R;
-    const int lz_min = by_ == 0 ? 0 : 1, lr_min = bx_ == 0 ? 0 : 1;
-    const double* cur = curF.at(b);
-    const double* nw = newF.at(b);
-    const double* bc = bcF.at(b);
-    const double* src = srcF.at(b);
-    double* nxt = nxtF.at(b);
+    // tile row lz <-> grid row z0 + lz, tile column lc <-> grid column r0 + lc; owned: lz in [1, BL_WZ], lc in [2, 125]
+    const int z0 = by_ * BL_WZ - 1, r0 = bx_ * BL_WR - 2;  // r0 even: the lane's pair is 16-B aligned
+    const int c0 = r0 + 2 * lane;
+    const bool pair_win = lane >= 1 && lane <= 62;
+    const bool own_x = pair_win && c0 < nr, own_y = pair_win && c0 + 1 < nr;  // (c0 >= 0 for window lanes)
+    const char* const cur_b = reinterpret_cast<const char*>(curF.at(b));
+    const char* const new_b = reinterpret_cast<const char*>(newF.at(b));
+    const char* const bc_b = reinterpret_cast<const char*>(bcF.at(b));
+    const char* const src_b = reinterpret_cast<const char*>(srcF.at(b));
+    char* const nxt_b = reinterpret_cast<char*>(nxtF.at(b));
+    const unsigned ld8 = (unsigned)ld * 8u;
+    const unsigned lane_off = (unsigned)min(max(c0, 0), ld - 2) * 8u;
+    // ring columns (grid column 0 / nr-1) take their value from bc; only tiles that touch them look (wave-uniform)
+    const bool edge_cols = r0 <= 0 || r0 + 127 >= nr - 1;
+    const bool cring_x = c0 == 0 || c0 == nr - 1, cring_y = c0 + 1 == nr - 1;
+    double2 pc[BL_NROWS], pn[BL_NROWS], sv[BL_NROWS];
+#pragma unroll
+    for (int i = 0; i < BL_NROWS; ++i) {
+        const int gzc = min(max(z0 + w + BL_NW * i, 0), nz - 1);  // scalar
+        const unsigned vo = (unsigned)gzc * ld8 + lane_off;
+        const bool rowring = gzc == 0 || gzc == nz - 1;
+        pc[i] = *reinterpret_cast<const double2*>(cur_b + vo);
+        pn[i] = *reinterpret_cast<const double2*>((rowring ? bc_b : new_b) + vo);
+        sv[i] = *reinterpret_cast<const double2*>(src_b + vo);
+    }
+    if (edge_cols) {
+#pragma unroll
+        for (int i = 0; i < BL_NROWS; ++i) {
+            const int gzc = min(max(z0 + w + BL_NW * i, 0), nz - 1);
+            const unsigned vo = (unsigned)gzc * ld8 + lane_off;
+            if (cring_x) pn[i].x = *reinterpret_cast<const double*>(bc_b + vo);
+            if (cring_y) pn[i].y = *reinterpret_cast<const double*>(bc_b + vo + 8u);
+        }
+    }
     double dsum = 0.0, minpsi = INFINITY;
     int bad = 0;
     VI mx{0.0, -1}, mn{0.0, -1};
-    // all loads of the thread's tile elements are issued before the first use (one memory round trip instead of one per element)
-    constexpr int NEL = (BT_Z + 2) * (BT_R + 2), NLD = (NEL + 255) / 256;
-    double pcv[NLD], pnv[NLD];
+    // (the blended pair is not kept in registers: the residual stage re-reads it from the tile -- 20 VGPRs less is one more
+    //  resident workgroup per SIMD, and this kernel lives on the number of tiles in flight: profiles/r03_experiments.md)
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int i = tid + 256 * k;
-        const int lz = i / (BT_R + 2), lr = i - lz * (BT_R + 2);
-        const int gz = z0 + lz, gr = r0 + lr;
-        pcv[k] = 0.0;
-        pnv[k] = 0.0;
-        if (i < NEL && gz >= 0 && gz < nz && gr >= 0 && gr < nr) {
-            const long c = (long)gz * ld + gr;
-            const bool ring = gz == 0 || gz == nz - 1 || gr == 0 || gr == nr - 1;
-            pnv[k] = ring ? bc[c] : nw[c];
-            pcv[k] = cur[c];
+    for (int i = 0; i < BL_NROWS; ++i) {
+        const int lz = w + BL_NW * i, gz = z0 + lz;
+        double2 vi;
+        vi.x = om_alpha * pc[i].x + alpha * pn[i].x;
+        vi.y = om_alpha * pc[i].y + alpha * pn[i].y;
+        if (lz >= 1 && lz <= BL_WZ && gz < nz) {  // owned row (wave-uniform)
+            const long q = (long)gz * nr + c0;
+            // straight-line: lanes that do not own a point contribute the neutral element (index -1 disables a candidate)
+            bad |= (own_x && !finite_d(pn[i].x)) || (own_y && !finite_d(pn[i].y)) ? 1 : 0;
+            dsum += own_x ? fabs(pn[i].x - pc[i].x) : 0.0;
+            dsum += own_y ? fabs(pn[i].y - pc[i].y) : 0.0;
+            mx = vi_max(mx, VI{vi.x, (own_x && vi.x == vi.x) ? q : -1L});
+            mx = vi_max(mx, VI{vi.y, (own_y && vi.y == vi.y) ? q + 1 : -1L});
+            minpsi = fmin(minpsi, (own_x && finite_d(vi.x)) ? vi.x : INFINITY);
+            minpsi = fmin(minpsi, (own_y && finite_d(vi.y)) ? vi.y : INFINITY);
+            char* const o = nxt_b + ((unsigned)gz * ld8 + (unsigned)c0 * 8u);
+            if (own_y) *reinterpret_cast<double2*>(o) = vi;
+            else if (own_x) *reinterpret_cast<double*>(o) = vi.x;
         }
+        *reinterpret_cast<double2*>(&t[lz][2 * lane]) = vi;
     }
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int i = tid + 256 * k;
-        if (i >= NEL) continue;
-        const int lz = i / (BT_R + 2), lr = i - lz * (BT_R + 2);
-        const int gz = z0 + lz, gr = r0 + lr;
-        double v = 0.0;
-        if (gz >= 0 && gz < nz && gr >= 0 && gr < nr) {
-            const double pn = pnv[k], pc = pcv[k];
-            v = om_alpha * pc + alpha * pn;
-            if (lz >= lz_min && lz <= BT_Z && lr >= lr_min && lr <= BT_R) {  // owned point
-                if (!finite_d(pn)) bad = 1;
-                dsum += fabs(pn - pc);
-                nxt[(long)gz * ld + gr] = v;
-                const long q = (long)gz * nr + gr;
-                if (v == v) mx = vi_max(mx, VI{v, q});
-                if (finite_d(v)) minpsi = fmin(minpsi, v);
-            }
-        }
-        t[lz][lr] = v;
-    }
+    BLEND_STAMP(1);
     __syncthreads();
-    double m = 0.0, rv[BT_Z / 4];
+    BLEND_STAMP(2);
+    // residual / gradient stage: own pair from registers, N / S pairs and the two out-of-pair neighbours from the tile
+    double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0, nm0 = 0.0, nm1 = 0.0;
+    const bool int_x = own_x && c0 >= 1 && c0 <= nr - 2, int_y = own_y && c0 + 1 <= nr - 2;  // (c0 + 1 >= 1 always)
+    if (int_x) { rs0 = L.r_safe[c0]; ri0 = L.r_inv[c0]; rl0 = L.r_inv_lo[c0]; if (lazy_nm) nm0 = lazy_nm[c0]; }
+    if (int_y) { rs1 = L.r_safe[c0 + 1]; ri1 = L.r_inv[c0 + 1]; rl1 = L.r_inv_lo[c0 + 1]; if (lazy_nm) nm1 = lazy_nm[c0 + 1]; }
     const double lz_sc = lazy_nm ? st[b].jscale : 1.0;
+    double m = 0.0;
+    double2 rv[BL_NROWS];
 #pragma unroll
-    for (int k = 0; k < BT_Z / 4; ++k) {
-        const int lz = 1 + ty + 4 * k, lr = 1 + tx;
-        const int gz = z0 + lz, gr = r0 + lr;
-        rv[k] = 0.0;
-        if (gz >= nz || gr >= nr) continue;
-        const double p = t[lz][lr];
-        if (gz >= 1 && gz <= nz - 2 && gr >= 1 && gr <= nr - 2) {
-            const double e = t[lz][lr + 1], w = t[lz][lr - 1], n = t[lz + 1][lr], so = t[lz - 1][lr];
-            const double d2r = divc4(e - 2.0 * p + w, L.dr2, L.inv_dr2, L.lo_dr2);
-            const double d1r = divc4(e - w, L.two_dr, L.inv_two_dr, L.lo_two_dr);
-            const double d2z = divc4(n - 2.0 * p + so, L.dz2, L.inv_dz2, L.lo_dz2);
-            const double lpsi = d2r - divc4(d1r, L.r_safe[gr], L.r_inv[gr], L.r_inv_lo[gr]) + d2z;
-            double sv = src[(long)gz * ld + gr];
-            if (lazy_nm) sv = lazy_nm[gr] * (lz_sc != 0.0 ? sv * lz_sc : 0.0);  // srcF holds J_raw (see k_smooth_tile)
-            const double r = sanitize1(lpsi - sv);
-            m = fmax(m, fabs(r));
-            rv[k] = r;
-        }
-        SCPN_BLEND_GRAD(lz, lr, gz, gr, p)
-    }
-    // grid row 0 / column 0 (ring points: no residual) of the first tile row / column: only the masked-gradient candidates
-    {
-        int elz = -1, elr = -1;
-        if (by_ == 0 && tid <= BT_R - lr_min) { elz = 0; elr = lr_min + tid; }                                   // row 0 (with the corner)
-        else if (bx_ == 0 && tid >= 128 && tid < 128 + BT_Z) { elz = 1 + (tid - 128); elr = 0; }                 // column 0 below the corner
-        if (elz >= 0) {
-            const int gz = z0 + elz, gr = r0 + elr;
-            if (gz < nz && gr < nr) {
-                const double p = t[elz][elr];
-                SCPN_BLEND_GRAD(elz, elr, gz, gr, p)
+    for (int i = 0; i < BL_NROWS; ++i) {
+        const int lz = w + BL_NW * i, gz = z0 + lz;
+        rv[i] = double2{0.0, 0.0};
+        if (!(lz >= 1 && lz <= BL_WZ && gz < nz)) continue;  // wave-uniform
+        const double2 N = *reinterpret_cast<const double2*>(&t[lz + 1][2 * lane]);
+        const double2 S = *reinterpret_cast<const double2*>(&t[lz - 1][2 * lane]);
+        const double Wn = (&t[lz][0])[2 * lane - 1], En = (&t[lz][0])[2 * lane + 2];
+        const double2 P = *reinterpret_cast<const double2*>(&t[lz][2 * lane]);
+        const double px = P.x, py = P.y;
+        if (gz >= 1 && gz <= nz - 2) {  // wave-uniform
+            double sx = sv[i].x, sy = sv[i].y;
+            if (lazy_nm) {  // the source field holds J_raw (see k_smooth_tile)
+                sx = nm0 * (lz_sc != 0.0 ? sx * lz_sc : 0.0);
+                sy = nm1 * (lz_sc != 0.0 ? sy * lz_sc : 0.0);
             }
+            // straight-line for both points of the pair (no per-lane branches: the two dependent chains interleave); lanes whose
+            // point is not an interior grid point compute on clamped copies and are deselected at the end
+            const double d2rx = divc4(py - 2.0 * px + Wn, L.dr2, L.inv_dr2, L.lo_dr2);
+            const double d2ry = divc4(En - 2.0 * py + px, L.dr2, L.inv_dr2, L.lo_dr2);
+            const double d1rx = divc4(py - Wn, L.two_dr, L.inv_two_dr, L.lo_two_dr);
+            const double d1ry = divc4(En - px, L.two_dr, L.inv_two_dr, L.lo_two_dr);
+            const double d2zx = divc4(N.x - 2.0 * px + S.x, L.dz2, L.inv_dz2, L.lo_dz2);
+            const double d2zy = divc4(N.y - 2.0 * py + S.y, L.dz2, L.inv_dz2, L.lo_dz2);
+            const double rx = sanitize_sel((d2rx - divc4(d1rx, rs0, ri0, rl0) + d2zx) - sx);
+            const double ry = sanitize_sel((d2ry - divc4(d1ry, rs1, ri1, rl1) + d2zy) - sy);
+            rv[i].x = int_x ? rx : 0.0;
+            rv[i].y = int_y ? ry : 0.0;
+            m = fmax(m, fmax(fabs(rv[i].x), fabs(rv[i].y)));
+        }
+        if (gz < n_mask_rows) {  // np.gradient + hypot inside the divertor rows (fusion_kernel.py:276-288); wave-uniform
+            auto grad = [&](bool on, double p, double n_, double s_, double e_, double w_, int gc) {
+                const double ps = nan_to_num300(p), nn = nan_to_num300(n_), ss = nan_to_num300(s_), ee = nan_to_num300(e_), ww = nan_to_num300(w_);
+                double gzv, grv;
+                if (gz == 0) gzv = divc4(nn - ps, gq.dz, gq.inv_dz, gq.lo_dz);  // (row tests are wave-uniform)
+                else if (gz == nz - 1) gzv = divc4(ps - ss, gq.dz, gq.inv_dz, gq.lo_dz);
+                else gzv = divc4(nn - ss, gq.two_dz, gq.inv_two_dz, gq.lo_two_dz);
+                grv = divc4(ee - ww, L.two_dr, L.inv_two_dr, L.lo_two_dr);
+                if (edge_cols) {  // wave-uniform: only tiles that touch grid column 0 / nr-1 evaluate the one-sided forms
+                    const double g0 = divc4(ee - ps, gq.dr, gq.inv_dr, gq.lo_dr), g1 = divc4(ps - ww, gq.dr, gq.inv_dr, gq.lo_dr);
+                    grv = gc == 0 ? g0 : (gc == nr - 1 ? g1 : grv);
+                }
+                const double bm = hypot(grv, gzv);
+                mn = vi_min(mn, VI{bm, (on && finite_d(bm)) ? (long)gz * nr + gc : -1L});
+            };
+            grad(own_x, px, N.x, S.x, py, Wn, c0);
+            grad(own_y, py, N.y, S.y, En, px, c0 + 1);
         }
     }
+    BLEND_STAMP(3);
     // wave-level reductions (results in every lane), one LDS hand-over per wave
     const double w_dsum = wave_sum(dsum), w_m = wave_max(m), w_minp = -wave_max(-minpsi);
     const VI w_mx = wave_vi<true>(mx), w_mn = wave_vi<false>(mn);
     const int w_bad = __any(bad) ? 1 : 0;
-    if (tx == 0) { sh_dsum[ty] = w_dsum; sh_m[ty] = w_m; sh_minp[ty] = w_minp; sh_mx[ty] = w_mx; sh_mn[ty] = w_mn; sh_bad[ty] = w_bad; }
+    if (lane == 0) { sh_dsum[w] = w_dsum; sh_m[w] = w_m; sh_minp[w] = w_minp; sh_mx[w] = w_mx; sh_mn[w] = w_mn; sh_bad[w] = w_bad; }
     __syncthreads();
+    BLEND_STAMP(4);
     // overflow-safe residual sum: (max, sum (r/max)^2) with the WORKGROUP max, see k_resid_norms
     const double bmax = fmax(fmax(sh_m[0], sh_m[1]), fmax(sh_m[2], sh_m[3]));
     double s2 = 0.0;
     if (bmax > 0.0) {
         const double ib = 1.0 / bmax;  // one IEEE division per thread instead of one per point (the rescaled sum is a norm estimate)
 #pragma unroll
-        for (int k = 0; k < BT_Z / 4; ++k) { const double q = rv[k] * ib; s2 += q * q; }
+        for (int i = 0; i < BL_NROWS; ++i) { const double qx = rv[i].x * ib, qy = rv[i].y * ib; s2 += qx * qx; s2 += qy * qy; }
     }
     const double w_s2 = wave_sum(s2);
-    if (tx == 0) sh_s2[ty] = w_s2;
+    if (lane == 0) sh_s2[w] = w_s2;
     __syncthreads();
     const double bsum = sh_dsum[0] + sh_dsum[1] + sh_dsum[2] + sh_dsum[3];
     const double bs2 = sh_s2[0] + sh_s2[1] + sh_s2[2] + sh_s2[3];
@@ -2086,10 +2140,10 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
     const int shbad = sh_bad[0] | sh_bad[1] | sh_bad[2] | sh_bad[3];
     VI rmx = sh_mx[0], rmn = sh_mn[0];
 #pragma unroll
-    for (int i = 1; i < 4; ++i) { rmx = vi_max(rmx, sh_mx[i]); rmn = vi_min(rmn, sh_mn[i]); }
+    for (int i = 1; i < BL_NW; ++i) { rmx = vi_max(rmx, sh_mx[i]); rmn = vi_min(rmn, sh_mn[i]); }
     const long o = (long)b * nblk + (long)by_ * gridDim.x + bx_;
-    // psi of the blended iterate at this tile's arg-min candidate (still in the LDS tile): rides along with the partial
-    double pmin = 0.0;
+    BLEND_STAMP(5);
+    double pmin = 0.0;  // psi of the blended iterate at this tile's arg-min candidate (still in the LDS tile)
     if (tid == 0 && rmn.i >= 0) {
         const int iz = (int)(rmn.i / nr), ir = (int)(rmn.i - (long)iz * nr);
         pmin = t[iz - z0][ir - r0];
@@ -2106,8 +2160,7 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
         }
         return;
     }
-    // fused tail: the last workgroup of this member to arrive runs k_picard_final's work (see "last workgroup finishes" above)
-    if (tid == 0) {
+    if (tid == 0) {  // fused tail: see "last workgroup finishes"
         st_agent(psum + o, bsum);
         st_agent(pbad + o, shbad);
         st_agent(rmax + o, bmax);
@@ -2123,8 +2176,6 @@ __global__ void __launch_bounds__(256, BLEND_WPE) k_blend_fused(Fld nxtF, Fld cu
     picard_final_body<true>(b, tail, S);
     if (tid == 0) __hip_atomic_store(tail.counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-#undef SCPN_BLEND_GRAD
 // ---------------------------------------------------------------- Anderson mixing (a10, method "anderson")
 // core/fusion_kernel_newton_solver.py:540-550 and core/fusion_kernel_iterative_solver.py:248-314
 constexpr int AND_MAX = 8;  // max mixing depth m

@@ -160,7 +160,7 @@ struct Solver {
     DBuf<Member> d_st;
     DBuf<MgMember> d_mg;
     DBuf<int> d_cur, d_nxt, d_best, d_prev, d_active, d_nactive, d_pbad;
-    DBuf<unsigned> d_tickets;  // [2][B] arrival counters of the "last workgroup finishes" kernels (k_jsum, k_blend_fused); zero between launches
+    DBuf<unsigned> d_tickets;  // [2][B] arrival counters of the "last workgroup finishes" kernels (k_jsum, k_blend_tile); zero between launches
     DBuf<int> d_scr_part, d_scr_zc, d_scr_sa, d_scr_mask;  // per-call masks of the Picard / free-boundary drivers
     DBuf<double> d_scr_diff;
     DBuf<Member> d_scr_st;
@@ -187,7 +187,7 @@ struct Solver {
 
     int nblk() const { return std::max(cdiv((long)nz * nr, 1024), nblk2()); }  // partial-array capacity
     int nblk1() const { return cdiv((long)nz * nr, 1024); }
-    int nblk2() const { return cdiv(nr - 1, BT_R) * cdiv(nz - 1, BT_Z); }  // tiles of k_blend_fused (first tile row / column also own row / column 0)
+    int nblk2() const { return cdiv(nr, BL_WR) * cdiv(nz, BL_WZ); }  // tiles per member of the fused Picard tail (k_blend_tile: 18 x 124 windows)
     int nblk_int() const { return cdiv((long)(nz - 2) * (nr - 2), 1024); }
 
     Fld slot_fld(const int* slot) { return Fld{psi_slots.p, slot, stride, B}; }
@@ -892,10 +892,10 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         ~LazyGuard() { h->lazy_src = nullptr; }
     } lazy_guard{h};
     if (lazy) h->lazy_src = srcF.base;
-    // the fused tail (k_blend_fused) leaves the topology partials of the next iterate, and k_picard_final finishes them for the
+    // the fused tail (k_blend_tile) leaves the topology partials of the next iterate, and k_picard_final finishes them for the
     // members that stay active: from the second iteration on there is no topology launch at all
     const bool topo_in_final = h->use_fused && p->method != 3 && !p->xpoint_saddle;
-    // "last workgroup finishes": k_jsum and k_blend_fused end with the per-member final reductions that used to be the launches
+    // "last workgroup finishes": k_jsum and k_blend_tile end with the per-member final reductions that used to be the launches
     // k_jsum_final and k_picard_final (two launches and two kernel boundaries off the dependent chain of an iteration).
     // Bit-identical, and MEASURED SLOWER on MI355X (32 x 513^2, fixed 200 iterations, same box: 345.4 / 346.6 us per iteration with
     // the separate launches, 349.7 / 350.8 fused -- profiles/r03_experiments.md): a dependent launch costs ~2 us, while the ticket
@@ -962,14 +962,17 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             gq.two_dz = 2.0 * L0.dz; gq.inv_two_dz = 1.0 / gq.two_dz; gq.lo_two_dz = recip_lo(gq.two_dz);
             gq.dr = L0.dr; gq.inv_dr = 1.0 / L0.dr; gq.lo_dr = recip_lo(L0.dr);
             PicardTail bt;  // counters == nullptr: the kernel only leaves its partials
+            static const int xcd_blend = [] { const char* e = std::getenv("SCPN_HIP_XCD_BLEND"); return e ? std::atoi(e) : 1; }();
+            bt.xcd_remap = xcd_blend;
             if (tail_fuse) {
                 bt = pt;
+                bt.xcd_remap = xcd_blend;
                 bt.nblk = bt.nblk_r = bt.ntopo = nblk2;
                 bt.topo = h->d_topo.p;
                 bt.counters = h->d_tickets.p + B;
                 final_done = true;
             }
-            SCPN_LAUNCH(k_blend_fused, dim3(cdiv(nr - 1, BT_R), cdiv(nz - 1, BT_Z), B), dim3(256), 0, st, nxtF, curF, newF, bcF, srcF,
+            SCPN_LAUNCH(k_blend_tile, dim3(cdiv(nr, BL_WR), cdiv(nz, BL_WZ), B), dim3(64 * BL_NW), 0, st, nxtF, curF, newF, bcF, srcF,
                                (const Member*)h->d_st.p, L0, p->alpha, om_alpha, n_mask_rows, h->d_part1.p, h->d_pbad.p, h->d_part2.p,
                                h->d_part3.p, h->d_topo.p, nblk2, lazy ? (const double*)h->d_neg_mu0R.p : (const double*)nullptr, gq, bt);
         } else {
@@ -2693,17 +2696,23 @@ int scpn_verify_division(const double* x, const double* d, int n, double* q5, do
 // second, best of three grid sizes), mode 1 = read-only sum
 int scpn_copy_bandwidth_probe(long bytes, int reps, double* gb_per_s) { return scpn_bandwidth_probe(0, bytes, reps, gb_per_s); }
 // mode 0: grid-stride copy (4 loads in flight); 1: read-only sum (8 in flight); 2: contiguous 32-KiB chunks per workgroup, 8 loads
-// in flight; 3: the same with non-temporal stores; 4: hipMemcpyDtoDAsync.  Copies count read + written bytes.  1 GiB per
+// in flight; 3: the same with non-temporal stores; 4: hipMemcpyDtoDAsync; 5: three read streams + one write stream (the mix of the
+// fused Picard tail).  Copies count read + written bytes.  1 GiB per
 // buffer by default (4x the Infinity Cache); best over several grid sizes.
 int scpn_bandwidth_probe(int mode, long bytes, int reps, double* gb_per_s) {
-    if (!gb_per_s || bytes < (1L << 20) || reps < 1 || mode < 0 || mode > 4) return fail(SCPN_E_ARG, "scpn_bandwidth_probe: mode 0..4, bytes >= 1 MiB, reps >= 1");
+    if (!gb_per_s || bytes < (1L << 20) || reps < 1 || mode < 0 || mode > 5) return fail(SCPN_E_ARG, "scpn_bandwidth_probe: mode 0..5, bytes >= 1 MiB, reps >= 1");
     API_BEGIN
     HIP_TRY(hipSetDevice(g_device));
     const long n16 = bytes / 16;
-    DBuf<double2> a, b;
+    DBuf<double2> a, b, c2, c3;
     a.alloc((size_t)n16);
     if (mode != 1) b.alloc((size_t)n16); else b.alloc(16);
     HIP_TRY(hipMemset(a.p, 1, (size_t)n16 * 16));
+    if (mode == 5) {  // three read streams + one write stream (four buffers of `bytes`)
+        c2.alloc((size_t)n16); c3.alloc((size_t)n16);
+        HIP_TRY(hipMemset(c2.p, 1, (size_t)n16 * 16));
+        HIP_TRY(hipMemset(c3.p, 1, (size_t)n16 * 16));
+    }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -2716,6 +2725,7 @@ int scpn_bandwidth_probe(int mode, long bytes, int reps, double* gb_per_s) {
                 case 1: SCPN_LAUNCH(k_read_probe, g, dim3(256), 0, nullptr, reinterpret_cast<double*>(b.p), (const double2*)a.p, n16); break;
                 case 2: SCPN_LAUNCH(k_copy_probe_chunk<false>, g, dim3(256), 0, nullptr, b.p, (const double2*)a.p, n16); break;
                 case 3: SCPN_LAUNCH(k_copy_probe_chunk<true>, g, dim3(256), 0, nullptr, b.p, (const double2*)a.p, n16); break;
+                case 5: SCPN_LAUNCH(k_mix31_probe, g, dim3(256), 0, nullptr, b.p, (const double2*)a.p, (const double2*)c2.p, (const double2*)c3.p, n16); break;
                 default: HIP_TRY(hipMemcpyDtoDAsync(b.p, a.p, (size_t)n16 * 16, nullptr)); break;
             }
         };
@@ -2726,7 +2736,7 @@ int scpn_bandwidth_probe(int mode, long bytes, int reps, double* gb_per_s) {
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        best = std::max(best, (mode == 1 ? 1.0 : 2.0) * (double)n16 * 16.0 * reps / ((double)ms * 1e-3) / 1e9);
+        best = std::max(best, (mode == 1 ? 1.0 : (mode == 5 ? 4.0 : 2.0)) * (double)n16 * 16.0 * reps / ((double)ms * 1e-3) / 1e9);
         if (mode == 4) break;  // no grid to vary
     }
     (void)hipEventDestroy(e0);

@@ -19,6 +19,7 @@ SWITCHES = [
     {"SCPN_HIP_DEFECT_MINLVL": "9"},
     {"SCPN_HIP_TAILFUSE": "1"},
     {"SCPN_HIP_POLL": "memcpy"},
+    {"SCPN_HIP_XCD_BLEND": "0"},
 ]
 # experiment builds (never shipped: `_lib.build(variant=...)` makes libscpn_hip.<variant>.so next to the product library)
 EXPERIMENT_BUILDS = {
