@@ -178,20 +178,32 @@ def spawn_ranks(argv: list[str], n: int, *, env=None, addr: str = "127.0.0.1", t
         while pending:
             for r in sorted(pending):
                 p = procs[r]
-                if r == 0 and p.poll() is None:
-                    try:  # keep rank 0's pipe drained while it runs
+                if r == 0:
+                    # rank 0's pipe is drained through communicate() ONLY (it keeps what earlier, timed-out calls already read;
+                    # a direct read of p.stdout afterwards would lose that part)
+                    try:
                         o, _ = p.communicate(timeout=0.2)
-                        out0 += o or ""
                     except subprocess.TimeoutExpired:
                         continue
-                code = p.poll()
-                if code is None:
-                    continue
-                if r == 0 and p.stdout is not None and not p.stdout.closed:
-                    out0 += p.stdout.read() or ""
+                    out0 = o or ""
+                    code = p.returncode
+                else:
+                    code = p.poll()
+                    if code is None:
+                        continue
                 pending.discard(r)
                 if code != 0 and rc == 0:
                     rc = code if code > 0 else 128 - code
+            if rc != 0 and 0 in pending:
+                # a rank failed while rank 0 is still running: give rank 0 a moment to print its line (the documented
+                # fall-back exits non-zero on every rank), then stop waiting
+                try:
+                    o, _ = procs[0].communicate(timeout=120.0)
+                    out0 = o or ""
+                    pending.discard(0)
+                except subprocess.TimeoutExpired:
+                    pass
+                break
             if rc != 0 or (deadline is not None and time.monotonic() > deadline):
                 if rc == 0:
                     rc = 124

@@ -41,9 +41,20 @@ def test_roofline_and_cpu_baseline_objects():
     assert full["members_per_launch"] == d["config"]["members_per_gpu"]
     for k in full["kernels"].values():
         assert 0.0 < k["frac"] <= 1.0 and abs(k["frac"] - k["achieved"] / r["peak"]) < 1e-3
-    assert isinstance(r["limiter"], str) and r["limiter"]
+    lim = r["limiter"]  # what limits the kernel, with the counters it is read from (never a hard-coded figure)
+    assert isinstance(lim, dict) and lim["class"] and "counters" in lim and lim["evidence"]
+    if lim["counters"] is not None:
+        assert lim["counters"]["source"].startswith("profiles/") and 0.0 < lim["counters"]["valu_busy"] <= 1.0
+    it = r["iteration"]  # HBM bytes of one Picard iteration (all its kernels, PMC) / iteration time
+    assert it is None or (0.0 < it["frac"] <= 1.0 and abs(it["frac"] - it["achieved"] / it["peak"]) < 1e-3 and it["kernels_counted"])
+    mb = r["measured_bandwidth"]
+    assert {"copy_chunked", "read", "memcpy_dtod"} <= set(mb) and r["measured_copy_gbs"] == max(v for k, v in mb.items() if k.startswith("copy") or k == "memcpy_dtod")
     n = d["newton_fd_mg"]  # the Newton lane beside the metric: same ensemble, same converged equilibria
     assert n["converged_members"] == d["config"]["members_per_gpu"] and n["psi_rel_linf_vs_picard"] < 1e-7 and n["value"] > d["value"]
+    cf = d["configs"]  # one figure per BASELINE config
+    assert cf["config2_fixed_boundary_257"]["converged_members"] == cf["config2_fixed_boundary_257"]["members"]
+    assert cf["config3_single_free_boundary_513"]["diiid_like"]["picard"]["converged"] and cf["config4_transport_coupled_loop_513"]["value"] > 0
+    assert cf["smoother_200_sweeps_513"]["value"] > 0 and cf["smoother_200_sweeps_513"]["published_reference"]["numpy_s"] == 18.85
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
 

@@ -124,11 +124,14 @@ print("chatter from rank", r)                            # non-JSON stdout of ra
 if r == {fail_rank}:
     sys.exit(7)
 if r == 0:
+    import time
+    time.sleep({rank0_delay})                            # rank 0 has more to do than its peers (result line, parity gate)
     print(json.dumps({{"n_gpus": w, "tmax": t, "argv": sys.argv[1:]}}))
+    sys.exit({rank0_rc})
 """
 
 
-def _run_stub(tmp_path, n, fail_rank=-1):
+def _run_stub(tmp_path, n, fail_rank=-1, rank0_delay=0.0, rank0_rc=0):
     import json
     import sys
 
@@ -136,7 +139,7 @@ def _run_stub(tmp_path, n, fail_rank=-1):
     from tests.conftest import ROOT
 
     stub = tmp_path / "stub_rank.py"
-    stub.write_text(_STUB.format(root=str(ROOT), fail_rank=fail_rank))
+    stub.write_text(_STUB.format(root=str(ROOT), fail_rank=fail_rank, rank0_delay=rank0_delay, rank0_rc=rank0_rc))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     rc, out = spawn_ranks([sys.executable, str(stub), "--gpus", str(n)], n, env=env, timeout=120)
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
@@ -152,6 +155,12 @@ def test_spawner_starts_one_rank_per_gpu_and_forwards_rank0(tmp_path):
 def test_spawner_reports_a_failed_rank(tmp_path):
     rc, _lines = _run_stub(tmp_path, 2, fail_rank=1)
     assert rc == 7
+
+
+def test_spawner_keeps_rank0_line_when_every_rank_exits_nonzero(tmp_path):
+    """The documented no-communicator fall-back: every rank exits 3, the peers before rank 0 has printed its (invalid-marked) line."""
+    rc, lines = _run_stub(tmp_path, 2, fail_rank=1, rank0_delay=1.0, rank0_rc=7)
+    assert rc == 7 and len(lines) == 1 and lines[0]["n_gpus"] == 2
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus(tmp_path):
