@@ -1960,8 +1960,8 @@ struct GradRecip { double dz, inv_dz, lo_dz, two_dz, inv_two_dz, lo_two_dz, dr, 
 // tile smoother: a 256-thread workgroup owns an 18-row x 124-column window of a 20 x 128 tile; a lane owns the column pair
 // (2l, 2l+1) of its wave's five rows, so cur / new / source arrive as 16-B loads from (scalar row pointer) + (lane offset), the
 // blended pair stays in registers for its own stencil and only the N/S pairs and the two out-of-pair neighbours are read from
-// the LDS tile (five LDS reads per two points).  (Round 2's form -- one element per thread, 32 x 64 tiles, ~220 vector instructions per
-// grid point -- ran at the same speed: the kernel is bound by tiles in flight x tile lifetime, profiles/r03_experiments.md.)
+// the LDS tile (five LDS reads per two points).  (Round 2's form -- one element per thread, 32 x 64 tiles -- ran at the same speed with
+// the same instruction count: the kernel is bound by tiles in flight x tile lifetime, profiles/r03_experiments.md.)
 #ifndef BL_WZ_N
 #define BL_WZ_N 18
 #endif

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/iso_trace
 rm -rf $out; mkdir -p $out
 export SCPN_HIP_GROUPS=${GROUPS_N:-1}
-rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-newton > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-newton --no-configs > $out/bench.log 2>&1
 f=$(find $out -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, re, statistics, sys

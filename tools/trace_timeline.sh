@@ -6,7 +6,7 @@ tag=${1:-tl}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/trace_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-newton > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out -o t -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-newton --no-configs > $out/bench.log 2>&1
 f=$(find $out -name "*kernel_trace.csv" | head -1)
 python3 tools/timeline_stats.py $f > $out/timeline.txt
 # keep only a compact binary of the trace (the csv is large)
