@@ -1,9 +1,9 @@
 import os, sys, ctypes as C
-os.environ["SCPN_HIP_LIB"] = os.path.abspath("build/libscpn_hip_stamps.so")
-os.environ["SCPN_HIP_GROUPS"] = "1"
 sys.path.insert(0, ".")
-import numpy as np
 from scpn_fusion_core_amd import _lib
+os.environ["SCPN_HIP_LIB"] = str(_lib.build(variant="stamps_plain", defines=("CV_STAMPS",)))  # experiment build, made on first use
+os.environ["SCPN_HIP_GROUPS"] = "1"
+import numpy as np
 from scpn_fusion_core_amd.ensemble import EnsembleSolver
 from scpn_fusion_core_amd.cases import iter_like_cfg, bench_problem
 n, B = 513, 16
