@@ -72,6 +72,41 @@ def measure_configs(device: int = 0, members: int = 32, check_every: int = 8) ->
         "workload": "solve_free_boundary(max_outer_iter=20, tol=1e-4, optimize_shape=False), 513x513, Picard tol 1e-8 "
                     "(DIII-D-like: validation/diiid_config.json; the real shot g145419 is not in the reference checkout)"}
 
+    # ---- config 3, second variant: the shape-optimisation outer loop (8 isoflux control points on the DIII-D-like grid, SI units as in
+    #      tests/golden/make_golden.py::gen_shape_d3d; device Picard + host bounded least squares per outer iteration, as the reference)
+    try:
+        import copy
+
+        from scpn_fusion_core_amd.free_boundary import CoilSet
+        from scpn_fusion_core_amd.fusion_kernel import FusionKernel
+
+        cs = copy.deepcopy(diiid_like_cfg(513, tol=1e-8, max_iter=1000))
+        cs["physics"]["vacuum_permeability"] = 4e-7 * np.pi
+        cs["physics"]["plasma_current_target"] = 1.6e6
+        for c in cs["coils"]:
+            c["current"] = c["current"] * 1.0e6
+        th = np.linspace(0.0, 2.0 * np.pi, 8, endpoint=False)
+        pts = np.column_stack([1.67 + 0.6 * np.cos(th), 1.8 * 0.6 * np.sin(th)])
+
+        def shape_run():
+            k = FusionKernel(copy.deepcopy(cs))
+            coils = CoilSet(positions=[(c["r"], c["z"]) for c in cs["coils"]], currents=np.array([c["current"] for c in cs["coils"]], dtype=float),
+                            turns=[1] * len(cs["coils"]), current_limits=np.full(len(cs["coils"]), 5.0e7), target_flux_points=pts)
+            t = time.perf_counter()
+            r = k.solve_free_boundary(coils, max_outer_iter=4, tol=1e-6, optimize_shape=True)
+            dt = time.perf_counter() - t
+            k.close()
+            return dt, r
+        shape_run()
+        dts, rs = zip(*(shape_run() for _ in range(2)))
+        out["config3_single_free_boundary_513"]["shape_optimisation"] = {
+            "ms_per_solve": round(min(dts) * 1e3, 2), "outer_iterations": int(rs[0]["outer_iterations"]),
+            "flux_rmse": float(rs[0]["shape_optimization"]["flux_rmse"]),
+            "workload": "solve_free_boundary(max_outer_iter=4, tol=1e-6, optimize_shape=True), 8 isoflux points (ellipse R0 1.67, a 0.6, kappa 1.8), "
+                        "DIII-D-like 513x513, one member; includes the host lsq_linear and the diagnostics of every outer iteration"}
+    except Exception as exc:
+        out["config3_single_free_boundary_513"]["shape_optimisation"] = {"error": str(exc)}
+
     # ---- config 4
     try:
         from benchmarks.bench_transport_coupled_loop import coupled_steps
