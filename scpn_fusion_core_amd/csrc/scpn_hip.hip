@@ -702,11 +702,13 @@ static int poll_word(Solver* h, const int* dptr) {
         __builtin_ia32_pause();
         if ((spins & 0xfffffu) == 0xfffffu) {  // (~every few ms: the runtime is not called while the word is on its way)
             // a device fault would leave the word unposted for ever: fall back to the runtime, which reports the error
-            if (hipStreamQuery(st) == hipSuccess) {
+            const hipError_t qs = hipStreamQuery(st);
+            if (qs == hipSuccess) {
                 const unsigned long long w2 = __atomic_load_n(h->h_word, __ATOMIC_ACQUIRE);
                 if ((unsigned)(w2 >> 32) == seq) return (int)(unsigned)(w2 & 0xffffffffull);
                 throw std::runtime_error("progress word was not posted although the stream is idle");
             }
+            if (qs != hipErrorNotReady) throw std::runtime_error(std::string("stream failed while polling: ") + hipGetErrorString(qs));
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) HIP_TRY(hipStreamSynchronize(st));
         }
     }
