@@ -2235,12 +2235,17 @@ __global__ void __launch_bounds__(256) k_and_gram(AndFields F, int nz, int nr, i
     }
 }
 // one thread per member: finish the sums, regularise, solve (LU, partial pivoting), mixing weights alpha[mk] (or fallback)
-__global__ void k_and_final(const double* part, int nblk, int mk, double* alpha_out, int* fallback, int B, const int* active) {
+__global__ void __launch_bounds__(64) k_and_final(const double* part, int nblk, int mk, double* alpha_out, int* fallback, int B, const int* active) {
+    // the member's 4x4 system lives in LDS: run-time indexed private arrays would go to scratch memory
+    __shared__ double sG[64][4][4], sv[64][4], sgamma[64][4], salpha[64][AND_MAX];
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     if (active && !active[b]) return;
     const int q = mk - 1;
-    double G[4][4], v[4], gamma[4], alpha[AND_MAX];
+    double (*G)[4] = sG[threadIdx.x];
+    double* v = sv[threadIdx.x];
+    double* gamma = sgamma[threadIdx.x];
+    double* alpha = salpha[threadIdx.x];
     for (int a = 0; a < 4; ++a) { v[a] = 0.0; gamma[a] = 0.0; for (int c = 0; c < 4; ++c) G[a][c] = 0.0; }
     for (int i = 0; i < nblk; ++i) {
         const double* p = part + ((long)b * nblk + i) * 20;
@@ -2875,7 +2880,7 @@ __global__ void k_gtsv(int batch, int n, double* dl, double* d, double* du, doub
 // CurrentDiffusionSolver.step (core/current_diffusion.py:277-353) for `batch` independent profiles: Sauter resistivity
 // (:175-207), Crank-Nicolson assembly, dgtsv.  one thread per member; scratch [batch][4n]
 struct CdConst { double r0, a, dt, z_eff, mu0_a2; };
-__global__ void k_current_diffusion(int batch, int n, const double* rho, double* psi, CdConst c, const double* te, const double* ne,
+__global__ void __launch_bounds__(64) k_current_diffusion(int batch, int n, const double* rho, double* psi, CdConst c, const double* te, const double* ne,
                                     const double* j_bs, const double* j_cd, const double* j_ext, double* scratch, int* info) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= batch) return;

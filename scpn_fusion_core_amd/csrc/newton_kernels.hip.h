@@ -702,7 +702,8 @@ __device__ __forceinline__ double block_sum_bcast(double v, double* sh) {  // su
     for (int i = 0; i < NT / 64; ++i) r += sh[i];
     return r;
 }
-constexpr int GM_SMALL_PTS = 5;  // register variant: up to 5 points per thread (65^2); larger small grids use k_gm_cycle_lds
+constexpr int GM_SMALL_PTS = 4;  // register variant: up to 4 points per thread (65^2 has 63^2 = 3969 interior points; 5 per thread spills at the
+                                 // 128-VGPR cap of a 1024-thread workgroup); larger small grids use k_gm_cycle_lds
 template <int MP>
 __global__ void __launch_bounds__(1024) k_gm_cycle_small(double* Vb, double* xb, double* rb, const double* rhsb, const double* dtermb,
                                                          const double* ivdb, long stride, int B, Lvl L, GmState* gm, NtMember* nt,
