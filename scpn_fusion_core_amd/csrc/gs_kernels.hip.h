@@ -931,6 +931,300 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     TILE_STAMP(10);
 }
 
+// ---------------------------------------------------------------- the same smoother with the tile in REGISTERS
+// Same tile, halo, window, arithmetic and results as k_smooth_tile; what differs is where the tile lives during the sweeps.
+// A wave owns NROWS CONSECUTIVE rows (NROWS even, so the parity of a row is a compile-time property of its index i), and a
+// lane the column pair (2l, 2l+1) of those rows: psi and source of the pair stay in registers from the global load to the
+// store.  Of the four neighbours of an update, one is the lane's other column, one belongs to the neighbouring LANE (a whole
+// 128-column row sits in one wave: a wave_shr / wave_shl DPP move, two per fp64 value) and two are the rows above / below,
+// which are registers too except for the first / last row of the wave.  LDS carries only those boundary rows between waves
+// (two 512-B writes and two reads per wave and colour pass instead of five reads and a write per ROW update), plus, for
+// DEFECT, the defect planes the restriction stencil is taken from.
+template <int CTRL>
+__device__ __forceinline__ double wave_shift(double x) {  // 0x138: wave_shr:1 = value of lane-1, 0x130: wave_shl:1 = value of lane+1
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT, int WPEU>
+__global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
+                                                    const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, LazySrc lzs,
+                                                    DefectDst dd, int xcd_remap) {
+    constexpr int LZ = LZT, H = 2 * S + (DEFECT ? 2 : 0), NW = NWT, NROWS = LZ / NW;
+    static_assert(LZ % NW == 0 && NROWS % 2 == 0 && NROWS >= 2, "a wave owns an even number of consecutive rows");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* A0 = lds;            // colour 0: (lz + column) even; cell (lz, col) at [lz * 64 + col / 2] as in k_smooth_tile
+    double* A1 = lds + LZ * 64;  // colour 1
+    int bx_, by_, b;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+        const unsigned total = gx * gy * gz;
+        unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        if (xcd_remap & 1) lin = xcd_contiguous(lin, total);
+        bx_ = (int)(lin % gx);
+        const unsigned t = lin / gx;
+        by_ = (int)(t % gy);
+        b = (int)(t / gy);
+    }
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lzb = w * NROWS;  // first tile row of this wave (even)
+    const int z0 = by_ * (LZ - 2 * H) - H, r0 = bx_ * (128 - 2 * H) - H;  // both even
+    const int nz = L.nz, nr = L.nr, ld = L.ld;
+    const double* in = inF.at(b);
+    double* out = outF.at(b);
+    const int c0 = r0 + 2 * lane;
+    const bool pair_own = lane >= H / 2 && lane < 64 - H / 2 && c0 < nr;
+    const bool pair_full = c0 + 1 < nr;
+    const unsigned ld8 = (unsigned)ld * 8u;
+    if (active && !active[b]) {  // frozen member: out = in on the window
+#pragma unroll
+        for (int i = 0; i < NROWS; ++i) {
+            const int lz = lzb + i, gz = z0 + lz;
+            if (lz >= H && lz < LZ - H && gz < nz && pair_own) {
+                const long o = (long)gz * ld + c0;
+                if (pair_full) *reinterpret_cast<double2*>(out + o) = *reinterpret_cast<const double2*>(in + o);
+                else out[o] = in[o];
+            }
+        }
+        return;
+    }
+    TILE_STAMP(0);
+    const double* src = srcF.at(b);
+    const bool lazy = lzs.st != nullptr;  // uniform
+    double lz_sc = 1.0, lz_n0 = 1.0, lz_n1 = 1.0;
+    if (lazy) {
+        lz_sc = lzs.st[b].jscale;
+        lz_n0 = lzs.neg_mu0R[min(max(c0, 0), nr - 1)];
+        lz_n1 = lzs.neg_mu0R[min(max(c0 + 1, 0), nr - 1)];
+    }
+    double ae0 = 0.0, ae1 = 0.0, aw0 = 0.0, aw1 = 0.0;  // even / odd column of the pair
+    if (c0 >= 1 && c0 <= nr - 2) { ae0 = L.a_e[c0]; aw0 = L.a_w[c0]; }
+    if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { ae1 = L.a_e[c0 + 1]; aw1 = L.a_w[c0 + 1]; }
+    const double a_ns = L.a_ns, a_c = L.a_c, inv_a_c = L.inv_a_c, lo_a_c = L.lo_a_c;
+    // column predicate of the even / odd column: inside the tile's updatable columns and the grid's interior
+    const bool colok0 = lane >= 1 && c0 >= 1 && c0 <= nr - 2;
+    const bool colok1 = lane <= 62 && c0 + 1 >= 1 && c0 + 1 <= nr - 2;
+    // v[c][i]: the colour-c element of row i of the pair, s[c][i] its source.  Row i (tile row lzb + i, parity i & 1) carries
+    // colour c in the column of parity (c + i) & 1.
+    double v0[NROWS], v1[NROWS], s0[NROWS], s1[NROWS];
+    // ---- load phase (out-of-domain cells hold clamped copies, see k_smooth_tile)
+    const unsigned lane_off = (unsigned)min(max(c0, 0), ld - 2) * 8u;
+    const char* const in_b = reinterpret_cast<const char*>(in);
+    const char* const src_b = reinterpret_cast<const char*>(src);
+#ifndef TILE_REG_LG
+#define TILE_REG_LG 2
+#endif
+    constexpr int LG = PROLONG ? TILE_REG_LG : NROWS;
+    const char* const cc_b = PROLONG ? reinterpret_cast<const char*>(coarseF.at(b)) : nullptr;
+    const unsigned ldc8 = (unsigned)ld_c * 8u;
+    const int jc = max(c0, 0) >> 1;
+    const unsigned jc_off0 = PROLONG ? (unsigned)min(jc, nr_c - 1) * 8u : 0u, jc_off1 = PROLONG ? (unsigned)min(jc + 1, nr_c - 1) * 8u : 0u;
+    const int h_end = PROLONG ? min(2 * (nr_c - 1), nr - 1) : 0, v_end = PROLONG ? min(2 * (nz_c - 1), nz - 1) : 0;
+    const bool odd_is_zero = c0 + 1 >= h_end;
+#pragma unroll
+    for (int g0 = 0; g0 < NROWS; g0 += LG) {
+        double2 pv[LG], sv2[LG];
+        double ca0[LG], ca1[LG], cb0[LG], cb1[LG];
+        int gzs[LG];
+#pragma unroll
+        for (int j = 0; j < LG; ++j) {
+            const int i = g0 + j;
+            const int gzc = min(max(z0 + lzb + i, 0), nz - 1);  // scalar
+            gzs[j] = gzc;
+            const unsigned vo = (unsigned)gzc * ld8 + lane_off;
+            pv[j] = *reinterpret_cast<const double2*>(in_b + vo);
+            sv2[j] = *reinterpret_cast<const double2*>(src_b + vo);
+            if (PROLONG) {
+                const int ic = gzc >> 1, icc = min(ic, nz_c - 1), icc1 = (gzc & 1) ? min(ic + 1, nz_c - 1) : icc;
+                const unsigned ra = (unsigned)icc * ldc8, rbp = (unsigned)icc1 * ldc8;
+                ca0[j] = *reinterpret_cast<const double*>(cc_b + (ra + jc_off0));
+                ca1[j] = *reinterpret_cast<const double*>(cc_b + (ra + jc_off1));
+                cb0[j] = *reinterpret_cast<const double*>(cc_b + (rbp + jc_off0));
+                cb1[j] = *reinterpret_cast<const double*>(cc_b + (rbp + jc_off1));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < LG; ++j) {
+            const int i = g0 + j;
+            double vx = pv[j].x, vy = pv[j].y;
+            if (PROLONG) {  // bilinear prolongation, core/multigrid_solve.py:117-143 (same expressions as prolong_at)
+                const int gzc = gzs[j];
+                double px, py;
+                if (!(gzc & 1)) {
+                    px = ca0[j];
+                    py = odd_is_zero ? 0.0 : 0.5 * (ca0[j] + ca1[j]);
+                } else if (gzc >= v_end) {
+                    px = 0.0;
+                    py = 0.0;
+                } else {
+                    px = 0.5 * (ca0[j] + cb0[j]);
+                    py = odd_is_zero ? 0.0 : 0.25 * (ca0[j] + cb0[j] + ca1[j] + cb1[j]);
+                }
+                vx = vx + px;
+                vy = vy + py;
+            }
+            if (i & 1) { v1[i] = vx; v0[i] = vy; s1[i] = sv2[j].x; s0[i] = sv2[j].y; }
+            else { v0[i] = vx; v1[i] = vy; s0[i] = sv2[j].x; s1[i] = sv2[j].y; }
+        }
+        if (PROLONG) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lazy) {  // Source = (-mu0 R) * (scale != 0 ? J_raw * scale : 0), the expression of k_source
+        if (lz_sc != 0.0) {
+#pragma unroll
+            for (int i = 0; i < NROWS; ++i) {
+                s0[i] = ((i & 1) ? lz_n1 : lz_n0) * (s0[i] * lz_sc);
+                s1[i] = ((i & 1) ? lz_n0 : lz_n1) * (s1[i] * lz_sc);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NROWS; ++i) {
+                s0[i] = ((i & 1) ? lz_n1 : lz_n0) * 0.0;
+                s1[i] = ((i & 1) ? lz_n0 : lz_n1) * 0.0;
+            }
+        }
+    }
+    // the wave's first and last row, both colours, for the waves above and below
+    double* const b0 = A0 + lzb * 64 + lane;
+    double* const b1 = A1 + lzb * 64 + lane;
+    b0[0] = v0[0];
+    b1[0] = v1[0];
+    b0[(NROWS - 1) * 64] = v0[NROWS - 1];
+    b1[(NROWS - 1) * 64] = v1[NROWS - 1];
+    // rows of the neighbouring waves (clamped at the tile's first / last row, which is never updated)
+    const int o_s = (w > 0 ? -64 : 0), o_n = (w < NW - 1 ? NROWS * 64 : (NROWS - 1) * 64);
+    __syncthreads();
+    TILE_STAMP(1);
+    // one update of row i, colour c (both compile-time): mine / oth are the register rows of colour c / 1 - c
+    auto update = [&](auto colour, auto row, const int hs, double (&mine)[NROWS], const double (&oth)[NROWS], const double Sb,
+                      const double Nb) {
+        constexpr int c = decltype(colour)::value, i = decltype(row)::value, p = (c + i) & 1;
+        const int lz = lzb + i, gz = z0 + lz;
+        if (lz >= hs + 1 && lz <= LZ - 2 - hs && gz >= 1 && gz <= nz - 2) {  // wave-uniform
+            const double O = oth[i];
+            const double W = p ? O : wave_shift<0x138>(O), E = p ? wave_shift<0x130>(O) : O;
+            const double Sv = i > 0 ? oth[i > 0 ? i - 1 : 0] : Sb, N = i < NROWS - 1 ? oth[i < NROWS - 1 ? i + 1 : 0] : Nb;
+            const double ae = p ? ae1 : ae0, aw = p ? aw1 : aw0;
+            const double sv = c ? s1[i] : s0[i];
+            const double gsv = divc4(ae * E + aw * W + a_ns * Sv + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
+            const double nw = om1 * mine[i] + omega * gsv;
+            if (p ? colok1 : colok0) mine[i] = nw;
+        }
+    };
+    auto half_sweep = [&](auto colour, const int hs) {
+        constexpr int c = decltype(colour)::value;
+        double(&mine)[NROWS] = c ? v1 : v0;
+        const double(&oth)[NROWS] = c ? v0 : v1;
+        const double* const ob = c ? b0 : b1;  // boundary rows of the other colour
+        const double Sb = ob[o_s], Nb = ob[o_n];
+        // rows that need no LDS value first
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (update(colour, std::integral_constant<int, I + 1>{}, hs, mine, oth, Sb, Nb), ...);
+        }(std::make_integer_sequence<int, NROWS - 2>{});
+        update(colour, std::integral_constant<int, 0>{}, hs, mine, oth, Sb, Nb);
+        update(colour, std::integral_constant<int, NROWS - 1>{}, hs, mine, oth, Sb, Nb);
+        double* const mb = c ? b1 : b0;
+        mb[0] = mine[0];
+        mb[(NROWS - 1) * 64] = mine[NROWS - 1];
+    };
+#pragma unroll 1
+    for (int sw = 0; sw < S; ++sw) {
+        half_sweep(std::integral_constant<int, 0>{}, 2 * sw);
+        __syncthreads();
+        TILE_STAMP(2 + 2 * sw);
+        half_sweep(std::integral_constant<int, 1>{}, 2 * sw + 1);
+        __syncthreads();
+        TILE_STAMP(3 + 2 * sw);
+    }
+    // ---- store the window
+#pragma unroll
+    for (int i = 0; i < NROWS; ++i) {
+        const int lz = lzb + i, gz = z0 + lz;
+        if (lz >= H && lz < LZ - H && gz < nz && pair_own) {  // (row test wave-uniform)
+            const double vx = (i & 1) ? v1[i] : v0[i], vy = (i & 1) ? v0[i] : v1[i];
+            char* const o = reinterpret_cast<char*>(out) + ((unsigned)gz * ld8 + (unsigned)c0 * 8u);
+            if (pair_full) *reinterpret_cast<double2*>(o) = double2{vx, vy};
+            else *reinterpret_cast<double*>(o) = vx;
+        }
+    }
+    TILE_STAMP(8);
+    if (DEFECT) {
+        // (1) defect d = -(L*psi - src) of this wave's rows, both colours, into the source registers
+        double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0;
+        if (c0 >= 1 && c0 <= nr - 2) { rs0 = dd.r_safe[c0]; ri0 = dd.r_inv[c0]; rl0 = dd.r_inv_lo[c0]; }
+        if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { rs1 = dd.r_safe[c0 + 1]; ri1 = dd.r_inv[c0 + 1]; rl1 = dd.r_inv_lo[c0 + 1]; }
+        const double Sb0 = b0[o_s], Nb0 = b0[o_n], Sb1 = b1[o_s], Nb1 = b1[o_n];
+        auto defect = [&](auto colour, auto row) {
+            constexpr int c = decltype(colour)::value, i = decltype(row)::value, p = (c + i) & 1;
+            const double(&mine)[NROWS] = c ? v1 : v0;
+            const double(&oth)[NROWS] = c ? v0 : v1;
+            const int lz = lzb + i, gz = z0 + lz;
+            double d = -0.0;
+            if (lz >= H - 1 && lz <= LZ - H && gz >= 1 && gz <= nz - 2) {  // wave-uniform
+                const double O = oth[i];
+                const double W = p ? O : wave_shift<0x138>(O), E = p ? wave_shift<0x130>(O) : O;
+                const double Sv = i > 0 ? oth[i > 0 ? i - 1 : 0] : (c ? Sb0 : Sb1);
+                const double N = i < NROWS - 1 ? oth[i < NROWS - 1 ? i + 1 : 0] : (c ? Nb0 : Nb1);
+                const double C = mine[i];
+                const double sv = c ? s1[i] : s0[i];
+                const double rs = p ? rs1 : rs0, ri = p ? ri1 : ri0, rl = p ? rl1 : rl0;
+                const double d2r = divc4(E - 2.0 * C + W, dd.dr2, dd.inv_dr2, dd.lo_dr2);
+                const double d1r = divc4(E - W, dd.two_dr, dd.inv_two_dr, dd.lo_two_dr);
+                const double d2z = divc4(N - 2.0 * C + Sv, dd.dz2, dd.inv_dz2, dd.lo_dz2);
+                const double lpsi = d2r - divc4(d1r, rs, ri, rl) + d2z;
+                if (p ? colok1 : colok0) d = -(lpsi - sv);
+            }
+            if (c) s1[i] = d; else s0[i] = d;
+        };
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ((defect(std::integral_constant<int, 0>{}, std::integral_constant<int, I>{}),
+              defect(std::integral_constant<int, 1>{}, std::integral_constant<int, I>{})), ...);
+        }(std::make_integer_sequence<int, NROWS>{});
+        __syncthreads();  // every wave has read its neighbours' boundary rows
+        // (2) the planes take the defect
+#pragma unroll
+        for (int i = 0; i < NROWS; ++i) { b0[i * 64] = s0[i]; b1[i * 64] = s1[i]; }
+        __syncthreads();
+        TILE_STAMP(9);
+        // (3) full-weighting restriction of the window's even/even points, as in k_smooth_tile
+        constexpr int CZ = (LZ - 2 * H) / 2, CR = (128 - 2 * H) / 2;
+        double* rc = coarseF.at(b);
+        double* ec = dd.e.at(b);
+        const int ic0 = (z0 + H) >> 1, jc0 = (r0 + H) >> 1;
+        for (int t = threadIdx.x; t < CZ * CR; t += 64 * NW) {
+            const int cz = t / CR, cr = t - cz * CR;
+            const int ic = ic0 + cz, jcn = jc0 + cr;
+            if (ic >= nz_c || jcn >= nr_c) continue;
+            double v = -0.0;
+            if (ic >= 1 && ic <= nz_c - 2 && jcn >= 1 && jcn <= nr_c - 2) {
+                const int q = (H + 2 * cz) * 64 + (H / 2 + cr);
+                v = fw9(A0[q], A1[q - 64], A1[q + 64], A1[q - 1], A1[q], A0[q - 65], A0[q - 64], A0[q + 63], A0[q + 64]);
+            }
+            rc[(long)ic * ld_c + jcn] = v;
+            ec[(long)ic * ld_c + jcn] = 0.0;
+        }
+    }
+    TILE_STAMP(10);
+}
+
+// geometry of the register-resident variant: REG_LZ rows dealt to REG_NW waves in blocks of REG_LZ / REG_NW (even) rows
+#ifndef TILE_REG_LZ
+#define TILE_REG_LZ 32
+#endif
+#ifndef TILE_REG_NW
+#define TILE_REG_NW 8
+#endif
+#ifndef TILE_REG_WPE
+#define TILE_REG_WPE 6
+#endif
+// ... and the geometry for one or two members (three-sweep launches only): 24 rows, two per wave
+#ifndef TILE_REG2_LZ
+#define TILE_REG2_LZ 24
+#endif
+#ifndef TILE_REG2_NW
+#define TILE_REG2_NW 12
+#endif
+
 // ---------------------------------------------------------------- whole coarse V-cycle in LDS
 // One 1024-thread workgroup per member runs the complete recursion from level `lc` down to the base
 // case and back (core/multigrid_solve.py:289-335) with every level resident in LDS: e_lc = Vcycle(0, rhs_lc).

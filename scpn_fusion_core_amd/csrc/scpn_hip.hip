@@ -352,12 +352,15 @@ struct DefectOut {  // coarse rhs / coarse correction produced by the fused defe
     Fld rhs{nullptr, nullptr, 0, 0}, e{nullptr, nullptr, 0, 0};
     int nz_c = 0, nr_c = 0, ld_c = 0;
 };
-template <int S, bool PROLONG, bool DEFECT, int LZT = TILE_LZ, int NWT = TILE_NW, int WPEU = TILE_WPE>
-static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                        const DefectOut* dfo) {
+template <int S, bool PROLONG, bool DEFECT, bool REG, int LZT, int NWT, int WPEU>
+static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
+                          const DefectOut* dfo) {
     static std::once_flag attr_once;  // (two stream-group threads may reach a first launch at the same time)
     constexpr size_t lds = (size_t)LZT * 128 * sizeof(double);
-    auto kern = &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, WPEU>;
+    auto kern = [] {
+        if constexpr (REG) return &k_smooth_reg<S, PROLONG, DEFECT, LZT, NWT, WPEU>;
+        else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, WPEU>;
+    }();
     std::call_once(attr_once, [&] {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
@@ -379,6 +382,26 @@ static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, doubl
     if (h->lazy_src && src.base == h->lazy_src) { lzs.st = h->d_st.p; lzs.neg_mu0R = h->d_neg_mu0R.p; }
     SCPN_LAUNCH(kern, g, dim3(64 * NWT), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c, ld_c, lzs, dd,
                 xcd_env);
+}
+template <int S, bool PROLONG, bool DEFECT>
+static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
+                        const DefectOut* dfo) {
+    // Small stream groups (a launch is a fraction of one round of workgroups, the iteration a chain of workgroup lifetimes) take the
+    // register-resident tile, one or two members its smallest geometry (two rows per wave: the shortest workgroup lifetime);
+    // SCPN_HIP_TILEREG=0 / 1 forces the LDS / the register kernel, SCPN_HIP_TILEREG_MAXB / _TINYB move the limits
+    static const int reg_env = [] { const char* e = std::getenv("SCPN_HIP_TILEREG"); return e ? std::atoi(e) : -1; }();
+    static const int reg_maxb = [] { const char* e = std::getenv("SCPN_HIP_TILEREG_MAXB"); return e ? std::atoi(e) : 12; }();
+    static const int reg_tinyb = [] { const char* e = std::getenv("SCPN_HIP_TILEREG_TINYB"); return e ? std::atoi(e) : 2; }();
+    if (reg_env == 1 || (reg_env < 0 && h->B <= reg_maxb)) {
+        if constexpr (S == 3) {
+            if (h->B <= reg_tinyb) {
+                launch_tile_g<S, PROLONG, DEFECT, true, TILE_REG2_LZ, TILE_REG2_NW, TILE_REG_WPE>(h, L, out, in, src, omega, active, ps, dfo);
+                return;
+            }
+        }
+        launch_tile_g<S, PROLONG, DEFECT, true, TILE_REG_LZ, TILE_REG_NW, TILE_REG_WPE>(h, L, out, in, src, omega, active, ps, dfo);
+    }
+    else launch_tile_g<S, PROLONG, DEFECT, false, TILE_LZ, TILE_NW, TILE_WPE>(h, L, out, in, src, omega, active, ps, dfo);
 }
 // the three production roles of the tile kernel: plain, + prolongation on load, + defect / restriction on store
 template <int S>

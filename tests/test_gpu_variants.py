@@ -20,6 +20,8 @@ SWITCHES = [
     {"SCPN_HIP_TAILFUSE": "1"},
     {"SCPN_HIP_POLL": "memcpy"},
     {"SCPN_HIP_XCD_BLEND": "0"},
+    {"SCPN_HIP_TILEREG": "0"},                                  # LDS colour-plane tile (what groups of more than 12 members run)
+    {"SCPN_HIP_TILEREG": "1", "SCPN_HIP_TILEREG_TINYB": "0"},   # register-resident tile, 32-row geometry (the default here is 24 rows)
 ]
 # experiment builds (never shipped: `_lib.build(variant=...)` makes libscpn_hip.<variant>.so next to the product library)
 EXPERIMENT_BUILDS = {
@@ -60,3 +62,19 @@ def test_experiment_builds_are_bit_identical():
         lib = _lib.build(variant=name, defines=defines)
         got = run({"SCPN_HIP_LIB": str(lib)})
         assert (got["psi"], got["jphi"], got["iterations"]) == (base["psi"], base["jphi"], base["iterations"]), (name, got, base)
+
+
+@pytest.mark.parametrize("env", [{"SCPN_HIP_TILEREG": "0"}, {"SCPN_HIP_TILEREG": "1", "SCPN_HIP_TILEREG_TINYB": "0"}],
+                         ids=["lds_tile", "register_tile_32_rows"])
+def test_operator_parity_suite_under_each_smoother_kernel(env):
+    """The smoother kernel is chosen by the size of a stream group (1-2 members: 24-row register tile, up to 12: 32-row register tile,
+    more: LDS tile), so the default run of tests/test_gpu_parity.py pins only the first against the reference fixtures and the oracle.
+    Run the same suite with each of the other two forced."""
+    from scpn_fusion_core_amd import _lib
+
+    _lib.require_gpu()
+    e = {k: v for k, v in os.environ.items() if not k.startswith("SCPN_HIP_") or k == "SCPN_HIP_LIB"}
+    e.update(env)
+    out = subprocess.run([sys.executable, "-m", "pytest", str(HERE / "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
+                         env=e, capture_output=True, text=True, timeout=900, cwd=str(HERE.parent))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]

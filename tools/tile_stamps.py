@@ -1,15 +1,18 @@
 """s_memrealtime stamps of eight sampled tile workgroups (load / six colour passes / store / defect / restriction).
-usage: [STAMPS_MODE=plain|defect] python tools/tile_stamps.py     (builds the -DCV_STAMPS experiment library on first use)"""
+usage: [STAMPS_MODE=plain|defect] [STAMPS_B=members] [STAMPS_DEFINES="A=1 B=2"] [SCPN_HIP_TILEREG=0|1] python tools/tile_stamps.py     (builds the -DCV_STAMPS experiment library on first use)"""
 import os, sys, ctypes as C
 sys.path.insert(0, ".")
 from scpn_fusion_core_amd import _lib
 _mode = os.environ.get("STAMPS_MODE", "plain")
-os.environ["SCPN_HIP_LIB"] = str(_lib.build(variant="stamps_" + _mode, defines=("CV_STAMPS",) + (("STAMP_DEFECT=true",) if _mode == "defect" else ())))
+_extra = tuple(x for x in os.environ.get("STAMPS_DEFINES", "").split() if x)  # e.g. "TILE_REG_LZ=24 TILE_REG_NW=12"
+_tag = "".join(c for c in "_".join(_extra) if c.isalnum() or c == "_")
+os.environ["SCPN_HIP_LIB"] = str(_lib.build(variant="stamps_" + _mode + ("_" + _tag if _tag else ""),
+                                            defines=("CV_STAMPS",) + (("STAMP_DEFECT=true",) if _mode == "defect" else ()) + _extra))
 os.environ["SCPN_HIP_GROUPS"] = "1"
 import numpy as np
 from scpn_fusion_core_amd.ensemble import EnsembleSolver
 from scpn_fusion_core_amd.cases import iter_like_cfg, bench_problem
-for n, B in ((513, 32),):
+for n, B in ((513, int(os.environ.get("STAMPS_B", "32"))),):
     es = EnsembleSolver(iter_like_cfg(n), batch=B)
     psi0, src, rr, r, z = bench_problem(n, n)
     es.set_psi(np.broadcast_to(psi0, (B, n, n)).copy()); es.set_source(np.broadcast_to(src, (B, n, n)).copy())
