@@ -71,6 +71,11 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned lin, unsigned total)
 }
 
 // A batched field whose member b may live in one of several ping-pong slots.
+// constants a branch-free load can point at when its real source is absent (see slot_ptr)
+// (never written; not declared const so that they live in the global address space like the pointers they stand in for -- a
+//  select between a global and a constant-address-space pointer would make the load a flat one)
+__device__ int g_const_i32[2] = {0, 1};
+__device__ double g_const_f64[2] = {0.0, 1.0};
 struct Fld {
     double* base;
     const int* slot;  // nullptr -> slot 0
@@ -80,6 +85,10 @@ struct Fld {
         int k = slot ? slot[b] : 0;
         return base + ((long)k * nb + b) * stride;
     }
+    // the two halves of at(): where the slot index of member b is read from (a constant 0 if the field has one slot), so that a
+    // kernel can put the slot words of all its fields in flight with ONE wait instead of a dependent load per field
+    __device__ __forceinline__ const int* slot_ptr(int b) const { return slot ? slot + b : &g_const_i32[0]; }
+    __device__ __forceinline__ double* at_slot(int b, int k) const { return base + ((long)k * nb + b) * stride; }
 };
 
 // per-member solver state kept on the device for the whole Picard solve
@@ -690,14 +699,27 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as a scalar: row arithmetic goes to the SALU
     const int z0 = by_ * (LZ - 2 * H) - H, r0 = bx_ * (128 - 2 * H) - H;  // both even
     const int nz = L.nz, nr = L.nr, ld = L.ld;
-    const double* in = inF.at(b);
-    double* out = outF.at(b);
     const int c0 = r0 + 2 * lane;  // global column of the lane's even element
+    // Everything that depends only on (member, column) is requested here, unconditionally and at once -- the member's activity
+    // word, the slot words of the three fields, the lazy-source scale, the column coefficients -- so that the row loads wait for
+    // ONE memory round trip, not for a chain of them (absent sources point at a constant).
+    const bool lazy = lzs.st != nullptr;  // uniform
+    const int act_w = *(active ? active + b : &g_const_i32[1]);
+    const int k_in = *inF.slot_ptr(b), k_out = *outF.slot_ptr(b), k_src = *srcF.slot_ptr(b);
+    const int k_cc = PROLONG ? *coarseF.slot_ptr(b) : 0;
+    const bool in0 = c0 >= 1 && c0 <= nr - 2, in1 = c0 + 1 >= 1 && c0 + 1 <= nr - 2;
+    double lz_sc = *(lazy ? &lzs.st[b].jscale : &g_const_f64[1]);
+    double lz_n0 = *(lazy ? lzs.neg_mu0R + min(max(c0, 0), nr - 1) : &g_const_f64[1]);
+    double lz_n1 = *(lazy ? lzs.neg_mu0R + min(max(c0 + 1, 0), nr - 1) : &g_const_f64[1]);
+    double ae0 = *(in0 ? L.a_e + c0 : &g_const_f64[0]), aw0 = *(in0 ? L.a_w + c0 : &g_const_f64[0]);
+    double ae1 = *(in1 ? L.a_e + c0 + 1 : &g_const_f64[0]), aw1 = *(in1 ? L.a_w + c0 + 1 : &g_const_f64[0]);
+    const double* in = inF.at_slot(b, k_in);
+    double* out = outF.at_slot(b, k_out);
     // the lane's pair is inside the window iff H/2 <= lane < 64 - H/2 (H even), and inside the grid iff c0 < nr; only the last
     // pair of an odd-width grid is half inside (c0 == nr - 1)
     const bool pair_own = lane >= H / 2 && lane < 64 - H / 2 && c0 < nr;
     const bool pair_full = c0 + 1 < nr;
-    if (active && !active[b]) {  // frozen member: out = in on the window
+    if (!act_w) {  // frozen member: out = in on the window
 #pragma unroll
         for (int i = 0; i < NROWS; ++i) {
             const int lz = w + NW * i, gz = z0 + lz;
@@ -719,17 +741,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     }
 #endif
     TILE_STAMP(0);
-    const double* src = srcF.at(b);
-    const bool lazy = lzs.st != nullptr;  // uniform
-    double lz_sc = 1.0, lz_n0 = 1.0, lz_n1 = 1.0;
-    if (lazy) {
-        lz_sc = lzs.st[b].jscale;
-        lz_n0 = lzs.neg_mu0R[min(max(c0, 0), nr - 1)];
-        lz_n1 = lzs.neg_mu0R[min(max(c0 + 1, 0), nr - 1)];
-    }
-    double ae0 = 0.0, ae1 = 0.0, aw0 = 0.0, aw1 = 0.0;
-    if (c0 >= 1 && c0 <= nr - 2) { ae0 = L.a_e[c0]; aw0 = L.a_w[c0]; }
-    if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { ae1 = L.a_e[c0 + 1]; aw1 = L.a_w[c0 + 1]; }
+    const double* src = srcF.at_slot(b, k_src);
     const double a_ns = L.a_ns, a_c = L.a_c, inv_a_c = L.inv_a_c, lo_a_c = L.lo_a_c;
     // every row of this wave has the parity of w (lz = w + NW*i, NW even), so the lane's element (0: even column, 1: odd
     // column) that carries colour c is e(c) = (c + w) & 1 for all rows: per-colour registers, no per-row selects
@@ -748,7 +760,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     // PROLONG: the four coarse values around the lane's column pair, loaded the same way; rows are processed in groups of LG so
     // that psi + src + coarse loads of a group fit the register budget
     constexpr int LG = (PROLONG && NROWS > 3) ? (NROWS + 3) / 4 : NROWS;  // (three rows or fewer: everything in flight at once)
-    const char* const cc_b = PROLONG ? reinterpret_cast<const char*>(coarseF.at(b)) : nullptr;
+    const char* const cc_b = PROLONG ? reinterpret_cast<const char*>(coarseF.at_slot(b, k_cc)) : nullptr;
     const unsigned ld8 = (unsigned)ld * 8u, ldc8 = (unsigned)ld_c * 8u;
     const int jc = max(c0, 0) >> 1;
     const unsigned jc_off0 = PROLONG ? (unsigned)min(jc, nr_c - 1) * 8u : 0u, jc_off1 = PROLONG ? (unsigned)min(jc + 1, nr_c - 1) * 8u : 0u;
@@ -943,8 +955,8 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
 template <int CTRL>
 __device__ __forceinline__ double wave_shift(double x) {  // 0x138: wave_shr:1 = value of lane-1, 0x130: wave_shl:1 = value of lane+1
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);  // (bound_ctrl: lane 0 / 63 receive 0, no prior value needed)
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT, int WPEU>
@@ -971,13 +983,24 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
     const int lzb = w * NROWS;  // first tile row of this wave (even)
     const int z0 = by_ * (LZ - 2 * H) - H, r0 = bx_ * (128 - 2 * H) - H;  // both even
     const int nz = L.nz, nr = L.nr, ld = L.ld;
-    const double* in = inF.at(b);
-    double* out = outF.at(b);
     const int c0 = r0 + 2 * lane;
+    // (member, column) words: all requested at once, one round trip in front of the row loads -- see k_smooth_tile
+    const bool lazy = lzs.st != nullptr;  // uniform
+    const int act_w = *(active ? active + b : &g_const_i32[1]);
+    const int k_in = *inF.slot_ptr(b), k_out = *outF.slot_ptr(b), k_src = *srcF.slot_ptr(b);
+    const int k_cc = PROLONG ? *coarseF.slot_ptr(b) : 0;
+    const bool in0 = c0 >= 1 && c0 <= nr - 2, in1 = c0 + 1 >= 1 && c0 + 1 <= nr - 2;
+    double lz_sc = *(lazy ? &lzs.st[b].jscale : &g_const_f64[1]);
+    double lz_n0 = *(lazy ? lzs.neg_mu0R + min(max(c0, 0), nr - 1) : &g_const_f64[1]);
+    double lz_n1 = *(lazy ? lzs.neg_mu0R + min(max(c0 + 1, 0), nr - 1) : &g_const_f64[1]);
+    double ae0 = *(in0 ? L.a_e + c0 : &g_const_f64[0]), aw0 = *(in0 ? L.a_w + c0 : &g_const_f64[0]);  // even / odd column of the pair
+    double ae1 = *(in1 ? L.a_e + c0 + 1 : &g_const_f64[0]), aw1 = *(in1 ? L.a_w + c0 + 1 : &g_const_f64[0]);
+    const double* in = inF.at_slot(b, k_in);
+    double* out = outF.at_slot(b, k_out);
     const bool pair_own = lane >= H / 2 && lane < 64 - H / 2 && c0 < nr;
     const bool pair_full = c0 + 1 < nr;
     const unsigned ld8 = (unsigned)ld * 8u;
-    if (active && !active[b]) {  // frozen member: out = in on the window
+    if (!act_w) {  // frozen member: out = in on the window
 #pragma unroll
         for (int i = 0; i < NROWS; ++i) {
             const int lz = lzb + i, gz = z0 + lz;
@@ -990,17 +1013,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
         return;
     }
     TILE_STAMP(0);
-    const double* src = srcF.at(b);
-    const bool lazy = lzs.st != nullptr;  // uniform
-    double lz_sc = 1.0, lz_n0 = 1.0, lz_n1 = 1.0;
-    if (lazy) {
-        lz_sc = lzs.st[b].jscale;
-        lz_n0 = lzs.neg_mu0R[min(max(c0, 0), nr - 1)];
-        lz_n1 = lzs.neg_mu0R[min(max(c0 + 1, 0), nr - 1)];
-    }
-    double ae0 = 0.0, ae1 = 0.0, aw0 = 0.0, aw1 = 0.0;  // even / odd column of the pair
-    if (c0 >= 1 && c0 <= nr - 2) { ae0 = L.a_e[c0]; aw0 = L.a_w[c0]; }
-    if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { ae1 = L.a_e[c0 + 1]; aw1 = L.a_w[c0 + 1]; }
+    const double* src = srcF.at_slot(b, k_src);
     const double a_ns = L.a_ns, a_c = L.a_c, inv_a_c = L.inv_a_c, lo_a_c = L.lo_a_c;
     // column predicate of the even / odd column: inside the tile's updatable columns and the grid's interior
     const bool colok0 = lane >= 1 && c0 >= 1 && c0 <= nr - 2;
@@ -1016,7 +1029,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
 #define TILE_REG_LG 2
 #endif
     constexpr int LG = PROLONG ? TILE_REG_LG : NROWS;
-    const char* const cc_b = PROLONG ? reinterpret_cast<const char*>(coarseF.at(b)) : nullptr;
+    const char* const cc_b = PROLONG ? reinterpret_cast<const char*>(coarseF.at_slot(b, k_cc)) : nullptr;
     const unsigned ldc8 = (unsigned)ld_c * 8u;
     const int jc = max(c0, 0) >> 1;
     const unsigned jc_off0 = PROLONG ? (unsigned)min(jc, nr_c - 1) * 8u : 0u, jc_off1 = PROLONG ? (unsigned)min(jc + 1, nr_c - 1) * 8u : 0u;
@@ -1095,21 +1108,31 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
     const int o_s = (w > 0 ? -64 : 0), o_n = (w < NW - 1 ? NROWS * 64 : (NROWS - 1) * 64);
     __syncthreads();
     TILE_STAMP(1);
+    // row i takes part in pass hs (hs = 0 .. 2S-1) iff it is an interior row of the grid and at least hs + 1 rows away from the
+    // tile's first / last row: hs <= hmax[i]
+    int hmax[NROWS];
+#pragma unroll
+    for (int i = 0; i < NROWS; ++i) {
+        const int lz = lzb + i, gz = z0 + lz;
+        hmax[i] = (gz >= 1 && gz <= nz - 2) ? min(lz - 1, LZ - 2 - lz) : -1;
+    }
     // one update of row i, colour c (both compile-time): mine / oth are the register rows of colour c / 1 - c
     auto update = [&](auto colour, auto row, const int hs, double (&mine)[NROWS], const double (&oth)[NROWS], const double Sb,
                       const double Nb) {
         constexpr int c = decltype(colour)::value, i = decltype(row)::value, p = (c + i) & 1;
-        const int lz = lzb + i, gz = z0 + lz;
-        if (lz >= hs + 1 && lz <= LZ - 2 - hs && gz >= 1 && gz <= nz - 2) {  // wave-uniform
-            const double O = oth[i];
-            const double W = p ? O : wave_shift<0x138>(O), E = p ? wave_shift<0x130>(O) : O;
-            const double Sv = i > 0 ? oth[i > 0 ? i - 1 : 0] : Sb, N = i < NROWS - 1 ? oth[i < NROWS - 1 ? i + 1 : 0] : Nb;
-            const double ae = p ? ae1 : ae0, aw = p ? aw1 : aw0;
-            const double sv = c ? s1[i] : s0[i];
-            const double gsv = divc4(ae * E + aw * W + a_ns * Sv + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
-            const double nw = om1 * mine[i] + omega * gsv;
-            if (p ? colok1 : colok0) mine[i] = nw;
-        }
+        // The row test (wave-uniform: hs <= hmax[i]) is NOT a branch: the update is evaluated for every row and kept under
+        // (row test & column predicate), so the dependent 11-instruction chains of the wave's rows are independent straight-line
+        // code the scheduler interleaves (a lone chain issues one fp64 instruction every ~13 cycles).  A row outside keeps its value.
+        const double O = oth[i];
+        const double W = p ? O : wave_shift<0x138>(O), E = p ? wave_shift<0x130>(O) : O;
+        const double Sv = i > 0 ? oth[i > 0 ? i - 1 : 0] : Sb, N = i < NROWS - 1 ? oth[i < NROWS - 1 ? i + 1 : 0] : Nb;
+        const double ae = p ? ae1 : ae0, aw = p ? aw1 : aw0;
+        const double sv = c ? s1[i] : s0[i];
+        const double gsv = divc4(ae * E + aw * W + a_ns * Sv + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
+        double nw = om1 * mine[i] + omega * gsv;
+        asm volatile("" : "+v"(nw));  // (an opaque use: keeps the compiler from sinking the chain into an exec-masked branch)
+        const bool keep = (hs <= hmax[i]) & (p ? colok1 : colok0);
+        mine[i] = keep ? nw : mine[i];
     };
     auto half_sweep = [&](auto colour, const int hs) {
         constexpr int c = decltype(colour)::value;
@@ -1158,22 +1181,23 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
             constexpr int c = decltype(colour)::value, i = decltype(row)::value, p = (c + i) & 1;
             const double(&mine)[NROWS] = c ? v1 : v0;
             const double(&oth)[NROWS] = c ? v0 : v1;
-            const int lz = lzb + i, gz = z0 + lz;
-            double d = -0.0;
-            if (lz >= H - 1 && lz <= LZ - H && gz >= 1 && gz <= nz - 2) {  // wave-uniform
-                const double O = oth[i];
-                const double W = p ? O : wave_shift<0x138>(O), E = p ? wave_shift<0x130>(O) : O;
-                const double Sv = i > 0 ? oth[i > 0 ? i - 1 : 0] : (c ? Sb0 : Sb1);
-                const double N = i < NROWS - 1 ? oth[i < NROWS - 1 ? i + 1 : 0] : (c ? Nb0 : Nb1);
-                const double C = mine[i];
-                const double sv = c ? s1[i] : s0[i];
-                const double rs = p ? rs1 : rs0, ri = p ? ri1 : ri0, rl = p ? rl1 : rl0;
-                const double d2r = divc4(E - 2.0 * C + W, dd.dr2, dd.inv_dr2, dd.lo_dr2);
-                const double d1r = divc4(E - W, dd.two_dr, dd.inv_two_dr, dd.lo_two_dr);
-                const double d2z = divc4(N - 2.0 * C + Sv, dd.dz2, dd.inv_dz2, dd.lo_dz2);
-                const double lpsi = d2r - divc4(d1r, rs, ri, rl) + d2z;
-                if (p ? colok1 : colok0) d = -(lpsi - sv);
-            }
+            // evaluated for every row (straight-line, as the sweeps) and kept where the row lies in the defect ring of the window
+            // (H - 1 <= lz <= LZ - H, an interior row of the grid: hmax[i] >= H - 2) and the column is updatable; -0.0 elsewhere
+            const double O = oth[i];
+            const double W = p ? O : wave_shift<0x138>(O), E = p ? wave_shift<0x130>(O) : O;
+            const double Sv = i > 0 ? oth[i > 0 ? i - 1 : 0] : (c ? Sb0 : Sb1);
+            const double N = i < NROWS - 1 ? oth[i < NROWS - 1 ? i + 1 : 0] : (c ? Nb0 : Nb1);
+            const double C = mine[i];
+            const double sv = c ? s1[i] : s0[i];
+            const double rs = p ? rs1 : rs0, ri = p ? ri1 : ri0, rl = p ? rl1 : rl0;
+            const double d2r = divc4(E - 2.0 * C + W, dd.dr2, dd.inv_dr2, dd.lo_dr2);
+            const double d1r = divc4(E - W, dd.two_dr, dd.inv_two_dr, dd.lo_two_dr);
+            const double d2z = divc4(N - 2.0 * C + Sv, dd.dz2, dd.inv_dz2, dd.lo_dz2);
+            const double lpsi = d2r - divc4(d1r, rs, ri, rl) + d2z;
+            double dv = -(lpsi - sv);
+            asm volatile("" : "+v"(dv));
+            const bool keep = (hmax[i] >= H - 2) & (p ? colok1 : colok0);
+            const double d = keep ? dv : -0.0;
             if (c) s1[i] = d; else s0[i] = d;
         };
         [&]<int... I>(std::integer_sequence<int, I...>) {
