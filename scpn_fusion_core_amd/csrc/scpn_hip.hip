@@ -386,15 +386,17 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
 template <int S, bool PROLONG, bool DEFECT>
 static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
                         const DefectOut* dfo) {
-    // Small stream groups (a launch is a fraction of one round of workgroups, the iteration a chain of workgroup lifetimes) take the
-    // register-resident tile, one or two members its smallest geometry (two rows per wave: the shortest workgroup lifetime);
-    // SCPN_HIP_TILEREG=0 / 1 forces the LDS / the register kernel, SCPN_HIP_TILEREG_MAXB / _TINYB move the limits
+    // Which smoother: by the members of this stream group.  Up to 14 (measured at 129^2 ... 1025^2: the launches of such a group
+    // are short chains of workgroup lifetimes whatever the grid) the register-resident tile -- in its smallest geometry (two rows
+    // per wave: the shortest lifetime) while a level-0 launch has at most REG_TINY tiles (two members at 513^2) --, beyond, the LDS
+    // tile.  SCPN_HIP_TILEREG=0 / 1 forces the LDS / the register kernel, SCPN_HIP_TILEREG_MAXB / _TINY move the limits.
     static const int reg_env = [] { const char* e = std::getenv("SCPN_HIP_TILEREG"); return e ? std::atoi(e) : -1; }();
-    static const int reg_maxb = [] { const char* e = std::getenv("SCPN_HIP_TILEREG_MAXB"); return e ? std::atoi(e) : 12; }();
-    static const int reg_tinyb = [] { const char* e = std::getenv("SCPN_HIP_TILEREG_TINYB"); return e ? std::atoi(e) : 2; }();
+    static const int reg_maxb = [] { const char* e = std::getenv("SCPN_HIP_TILEREG_MAXB"); return e ? std::atoi(e) : 14; }();
+    static const long reg_tiny = [] { const char* e = std::getenv("SCPN_HIP_TILEREG_TINY"); return e ? std::atol(e) : 220L; }();
+    const long tiles0 = (long)cdiv(h->nr, 128 - 16) * cdiv(h->nz, TILE_LZ - 16) * h->B;
     if (reg_env == 1 || (reg_env < 0 && h->B <= reg_maxb)) {
         if constexpr (S == 3) {
-            if (h->B <= reg_tinyb) {
+            if (tiles0 <= reg_tiny) {
                 launch_tile_g<S, PROLONG, DEFECT, true, TILE_REG2_LZ, TILE_REG2_NW, TILE_REG_WPE>(h, L, out, in, src, omega, active, ps, dfo);
                 return;
             }

@@ -21,7 +21,7 @@ SWITCHES = [
     {"SCPN_HIP_POLL": "memcpy"},
     {"SCPN_HIP_XCD_BLEND": "0"},
     {"SCPN_HIP_TILEREG": "0"},                                  # LDS colour-plane tile (what groups of more than 12 members run)
-    {"SCPN_HIP_TILEREG": "1", "SCPN_HIP_TILEREG_TINYB": "0"},   # register-resident tile, 32-row geometry (the default here is 24 rows)
+    {"SCPN_HIP_TILEREG": "1", "SCPN_HIP_TILEREG_TINY": "0"},   # register-resident tile, 32-row geometry (the default here is 24 rows)
 ]
 # experiment builds (never shipped: `_lib.build(variant=...)` makes libscpn_hip.<variant>.so next to the product library)
 EXPERIMENT_BUILDS = {
@@ -64,7 +64,7 @@ def test_experiment_builds_are_bit_identical():
         assert (got["psi"], got["jphi"], got["iterations"]) == (base["psi"], base["jphi"], base["iterations"]), (name, got, base)
 
 
-@pytest.mark.parametrize("env", [{"SCPN_HIP_TILEREG": "0"}, {"SCPN_HIP_TILEREG": "1", "SCPN_HIP_TILEREG_TINYB": "0"}],
+@pytest.mark.parametrize("env", [{"SCPN_HIP_TILEREG": "0"}, {"SCPN_HIP_TILEREG": "1", "SCPN_HIP_TILEREG_TINY": "0"}],
                          ids=["lds_tile", "register_tile_32_rows"])
 def test_operator_parity_suite_under_each_smoother_kernel(env):
     """The smoother kernel is chosen by the size of a stream group (1-2 members: 24-row register tile, up to 12: 32-row register tile,

@@ -1,5 +1,5 @@
 """Steady-state cost of one Picard iteration: 32 members, 513x513, exactly N iterations (tolerance far below reach), both
-stream groups.  usage: fixed_iters_bench.py [iters] [repeats]   (SCPN_HIP_LIB selects the library)"""
+stream groups.  usage: fixed_iters_bench.py [iters] [repeats] [n] [members]   (SCPN_HIP_LIB selects the library)"""
 import os
 import sys
 import time
@@ -13,7 +13,8 @@ from scpn_fusion_core_amd.ensemble import EnsembleSolver  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-B, n = 32, 513
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 513
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 32
 cfg = iter_like_cfg(n, tol=1e-300, max_iter=iters)
 ip = cfg["physics"]["plasma_current_target"]
 rng = np.random.default_rng(2026)
