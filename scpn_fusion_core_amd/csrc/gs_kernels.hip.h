@@ -755,8 +755,13 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     double* const po = (e0 ? A0 : A1) + rb;
     // ---- load phase (see "Out-of-domain cells" above): all row loads of a group are issued before the first is consumed
     const unsigned lane_off = (unsigned)min(max(c0, 0), ld - 2) * 8u;  // even column, 16-B aligned; ld >= nr + 1 for odd nr
+#ifdef TILE_FAKE_LOADS
+    const char* const in_b = reinterpret_cast<const char*>(inF.base);
+    const char* const src_b = reinterpret_cast<const char*>(srcF.base);
+#else
     const char* const in_b = reinterpret_cast<const char*>(in);
     const char* const src_b = reinterpret_cast<const char*>(src);
+#endif
     // PROLONG: the four coarse values around the lane's column pair, loaded the same way; rows are processed in groups of LG so
     // that psi + src + coarse loads of a group fit the register budget
     constexpr int LG = (PROLONG && NROWS > 3) ? (NROWS + 3) / 4 : NROWS;  // (three rows or fewer: everything in flight at once)
@@ -779,7 +784,11 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             gzs[j] = gzc;
             // a member's field is < 4 GiB, so a load address is (scalar member base) + (32-bit byte offset): the row part of the
             // offset is computed on the scalar unit, one vector add makes the lane's offset, psi and src share it
+#ifdef TILE_FAKE_LOADS  // experiment: every tile reads the same (cache-resident) block -- what is a tile's life without memory latency?
+            const unsigned vo = (unsigned)(w + NW * i) * ld8 + (unsigned)lane * 16u;
+#else
             const unsigned vo = (unsigned)gzc * ld8 + lane_off;
+#endif
             pv[j] = *reinterpret_cast<const double2*>(in_b + vo);
             sv2[j] = *reinterpret_cast<const double2*>(src_b + vo);
             if (PROLONG) {
@@ -1021,10 +1030,17 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
     // v[c][i]: the colour-c element of row i of the pair, s[c][i] its source.  Row i (tile row lzb + i, parity i & 1) carries
     // colour c in the column of parity (c + i) & 1.
     double v0[NROWS], v1[NROWS], s0[NROWS], s1[NROWS];
+    double* const b0 = A0 + lzb * 64 + lane;  // the lane's slot of the wave's first row in the colour-0 / colour-1 plane
+    double* const b1 = A1 + lzb * 64 + lane;
     // ---- load phase (out-of-domain cells hold clamped copies, see k_smooth_tile)
     const unsigned lane_off = (unsigned)min(max(c0, 0), ld - 2) * 8u;
+#ifdef TILE_FAKE_LOADS
+    const char* const in_b = reinterpret_cast<const char*>(inF.base);
+    const char* const src_b = reinterpret_cast<const char*>(srcF.base);
+#else
     const char* const in_b = reinterpret_cast<const char*>(in);
     const char* const src_b = reinterpret_cast<const char*>(src);
+#endif
 #ifndef TILE_REG_LG
 #define TILE_REG_LG 2
 #endif
@@ -1045,16 +1061,25 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
             const int i = g0 + j;
             const int gzc = min(max(z0 + lzb + i, 0), nz - 1);  // scalar
             gzs[j] = gzc;
+#ifdef TILE_FAKE_LOADS
+            const unsigned vo = (unsigned)(lzb + i) * ld8 + (unsigned)lane * 16u;
+#else
             const unsigned vo = (unsigned)gzc * ld8 + lane_off;
+#endif
             pv[j] = *reinterpret_cast<const double2*>(in_b + vo);
             sv2[j] = *reinterpret_cast<const double2*>(src_b + vo);
             if (PROLONG) {
-                const int ic = gzc >> 1, icc = min(ic, nz_c - 1), icc1 = (gzc & 1) ? min(ic + 1, nz_c - 1) : icc;
-                const unsigned ra = (unsigned)icc * ldc8, rbp = (unsigned)icc1 * ldc8;
+                // (the parity of an in-domain row is that of its index i: even rows need one coarse row, odd rows two; a clamped
+                //  out-of-domain row may take the other form -- its value is never used)
+                const int ic = gzc >> 1, icc = min(ic, nz_c - 1);
+                const unsigned ra = (unsigned)icc * ldc8;
                 ca0[j] = *reinterpret_cast<const double*>(cc_b + (ra + jc_off0));
                 ca1[j] = *reinterpret_cast<const double*>(cc_b + (ra + jc_off1));
-                cb0[j] = *reinterpret_cast<const double*>(cc_b + (rbp + jc_off0));
-                cb1[j] = *reinterpret_cast<const double*>(cc_b + (rbp + jc_off1));
+                if (i & 1) {
+                    const unsigned rbp = (unsigned)min(ic + 1, nz_c - 1) * ldc8;
+                    cb0[j] = *reinterpret_cast<const double*>(cc_b + (rbp + jc_off0));
+                    cb1[j] = *reinterpret_cast<const double*>(cc_b + (rbp + jc_off1));
+                }
             }
         }
 #pragma unroll
@@ -1064,7 +1089,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
             if (PROLONG) {  // bilinear prolongation, core/multigrid_solve.py:117-143 (same expressions as prolong_at)
                 const int gzc = gzs[j];
                 double px, py;
-                if (!(gzc & 1)) {
+                if (!(i & 1)) {
                     px = ca0[j];
                     py = odd_is_zero ? 0.0 : 0.5 * (ca0[j] + ca1[j]);
                 } else if (gzc >= v_end) {
@@ -1077,29 +1102,17 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
                 vx = vx + px;
                 vy = vy + py;
             }
-            if (i & 1) { v1[i] = vx; v0[i] = vy; s1[i] = sv2[j].x; s0[i] = sv2[j].y; }
-            else { v0[i] = vx; v1[i] = vy; s0[i] = sv2[j].x; s1[i] = sv2[j].y; }
+            double sx = sv2[j].x, sy = sv2[j].y;  // source of the even / odd column
+            if (lazy) {  // Source = (-mu0 R) * (scale != 0 ? J_raw * scale : 0), the expression of k_source (uniform branches)
+                if (lz_sc != 0.0) { sx = lz_n0 * (sx * lz_sc); sy = lz_n1 * (sy * lz_sc); }
+                else { sx = lz_n0 * 0.0; sy = lz_n1 * 0.0; }
+            }
+            if (i & 1) { v1[i] = vx; v0[i] = vy; } else { v0[i] = vx; v1[i] = vy; }
+            if (i & 1) { s1[i] = sx; s0[i] = sy; } else { s0[i] = sx; s1[i] = sy; }
         }
         if (PROLONG) __builtin_amdgcn_sched_barrier(0);
     }
-    if (lazy) {  // Source = (-mu0 R) * (scale != 0 ? J_raw * scale : 0), the expression of k_source
-        if (lz_sc != 0.0) {
-#pragma unroll
-            for (int i = 0; i < NROWS; ++i) {
-                s0[i] = ((i & 1) ? lz_n1 : lz_n0) * (s0[i] * lz_sc);
-                s1[i] = ((i & 1) ? lz_n0 : lz_n1) * (s1[i] * lz_sc);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NROWS; ++i) {
-                s0[i] = ((i & 1) ? lz_n1 : lz_n0) * 0.0;
-                s1[i] = ((i & 1) ? lz_n0 : lz_n1) * 0.0;
-            }
-        }
-    }
     // the wave's first and last row, both colours, for the waves above and below
-    double* const b0 = A0 + lzb * 64 + lane;
-    double* const b1 = A1 + lzb * 64 + lane;
     b0[0] = v0[0];
     b1[0] = v1[0];
     b0[(NROWS - 1) * 64] = v0[NROWS - 1];
