@@ -961,6 +961,27 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
 // which are registers too except for the first / last row of the wave.  LDS carries only those boundary rows between waves
 // (two 512-B writes and two reads per wave and colour pass instead of five reads and a write per ROW update), plus, for
 // DEFECT, the defect planes the restriction stencil is taken from.
+// geometry of the register-resident variant: REG_LZ rows dealt to REG_NW waves in blocks of REG_LZ / REG_NW (even) rows
+#ifndef TILE_REG_LZ
+#define TILE_REG_LZ 32
+#endif
+#ifndef TILE_REG_NW
+#define TILE_REG_NW 8
+#endif
+#ifndef TILE_REG_WPE
+#define TILE_REG_WPE 6
+#endif
+// ... and the geometry for one or two members (three-sweep launches only): 24 rows, two per wave
+#ifndef TILE_REG2_LZ
+#define TILE_REG2_LZ 24
+#endif
+#ifndef TILE_REG2_NW
+#define TILE_REG2_NW 12
+#endif
+// rows whose psi / source / coarse loads are in flight together in the PROLONG variant (register budget)
+#ifndef TILE_REG_LG
+#define TILE_REG_LG 2
+#endif
 template <int CTRL>
 __device__ __forceinline__ double wave_shift(double x) {  // 0x138: wave_shr:1 = value of lane-1, 0x130: wave_shl:1 = value of lane+1
     int lo = __double2loint(x), hi = __double2hiint(x);
@@ -1040,9 +1061,6 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
 #else
     const char* const in_b = reinterpret_cast<const char*>(in);
     const char* const src_b = reinterpret_cast<const char*>(src);
-#endif
-#ifndef TILE_REG_LG
-#define TILE_REG_LG 2
 #endif
     constexpr int LG = PROLONG ? TILE_REG_LG : NROWS;
     const char* const cc_b = PROLONG ? reinterpret_cast<const char*>(coarseF.at_slot(b, k_cc)) : nullptr;
@@ -1244,23 +1262,6 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
     TILE_STAMP(10);
 }
 
-// geometry of the register-resident variant: REG_LZ rows dealt to REG_NW waves in blocks of REG_LZ / REG_NW (even) rows
-#ifndef TILE_REG_LZ
-#define TILE_REG_LZ 32
-#endif
-#ifndef TILE_REG_NW
-#define TILE_REG_NW 8
-#endif
-#ifndef TILE_REG_WPE
-#define TILE_REG_WPE 6
-#endif
-// ... and the geometry for one or two members (three-sweep launches only): 24 rows, two per wave
-#ifndef TILE_REG2_LZ
-#define TILE_REG2_LZ 24
-#endif
-#ifndef TILE_REG2_NW
-#define TILE_REG2_NW 12
-#endif
 
 // ---------------------------------------------------------------- whole coarse V-cycle in LDS
 // One 1024-thread workgroup per member runs the complete recursion from level `lc` down to the base
