@@ -2312,6 +2312,7 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
     __shared__ VI sh_mx[BL_NW], sh_mn[BL_NW];
     __shared__ double sh_dsum[BL_NW], sh_m[BL_NW], sh_minp[BL_NW], sh_s2[BL_NW];
     __shared__ int sh_bad[BL_NW];
+    __shared__ double sh_coef[2 * BL_NW][64];  // r_safe, 1/r_safe (two words), -mu0 R of the lane's two columns: loaded by one wave each
     int bx_, by_, b;
     {
         const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
@@ -2322,7 +2323,11 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
         by_ = (int)(t_ % gy);
         b = (int)(t_ / gy);
     }
-    if (!st[b].active) return;
+    // the member's words -- activity, the slot of every field, the lazy-source scale -- in ONE round trip (see k_smooth_tile)
+    const int act_w = st[b].active;
+    const int k_cur = *curF.slot_ptr(b), k_new = *newF.slot_ptr(b), k_bc = *bcF.slot_ptr(b), k_src = *srcF.slot_ptr(b), k_nxt = *nxtF.slot_ptr(b);
+    const double lz_sc = *(lazy_nm ? &st[b].jscale : &g_const_f64[1]);
+    if (!act_w) return;
     BLEND_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nz = L.nz, nr = L.nr, ld = L.ld;
@@ -2331,11 +2336,11 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
     const int c0 = r0 + 2 * lane;
     const bool pair_win = lane >= 1 && lane <= 62;
     const bool own_x = pair_win && c0 < nr, own_y = pair_win && c0 + 1 < nr;  // (c0 >= 0 for window lanes)
-    const char* const cur_b = reinterpret_cast<const char*>(curF.at(b));
-    const char* const new_b = reinterpret_cast<const char*>(newF.at(b));
-    const char* const bc_b = reinterpret_cast<const char*>(bcF.at(b));
-    const char* const src_b = reinterpret_cast<const char*>(srcF.at(b));
-    char* const nxt_b = reinterpret_cast<char*>(nxtF.at(b));
+    const char* const cur_b = reinterpret_cast<const char*>(curF.at_slot(b, k_cur));
+    const char* const new_b = reinterpret_cast<const char*>(newF.at_slot(b, k_new));
+    const char* const bc_b = reinterpret_cast<const char*>(bcF.at_slot(b, k_bc));
+    const char* const src_b = reinterpret_cast<const char*>(srcF.at_slot(b, k_src));
+    char* const nxt_b = reinterpret_cast<char*>(nxtF.at_slot(b, k_nxt));
     const unsigned ld8 = (unsigned)ld * 8u;
     const unsigned lane_off = (unsigned)min(max(c0, 0), ld - 2) * 8u;
     // ring columns (grid column 0 / nr-1) take their value from bc; only tiles that touch them look (wave-uniform)
@@ -2359,6 +2364,17 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
             if (cring_x) pn[i].x = *reinterpret_cast<const double*>(bc_b + vo);
             if (cring_y) pn[i].y = *reinterpret_cast<const double*>(bc_b + vo + 8u);
         }
+    }
+    // column coefficients of the residual stage: wave k fetches the k-th of (r_safe, 1/r_safe, its low word, -mu0 R) for the lane's
+    // two columns now, behind the row loads, and hands them to the other waves through LDS at the barrier below -- the residual
+    // stage then starts without a memory round trip and no wave holds more than two of them through the blend
+    const bool int_x = own_x && c0 >= 1 && c0 <= nr - 2, int_y = own_y && c0 + 1 <= nr - 2;  // (c0 + 1 >= 1 always)
+    {
+        const double* const arr = w == 0 ? L.r_safe : (w == 1 ? L.r_inv : (w == 2 ? L.r_inv_lo : lazy_nm));
+        const double* const dflt = &g_const_f64[w <= 1 ? 1 : 0];  // r_safe, 1/r_safe: 1.0; low word, -mu0 R: 0.0
+        const bool have = arr != nullptr;
+        sh_coef[2 * w][lane] = *((have && int_x) ? arr + c0 : dflt);
+        sh_coef[2 * w + 1][lane] = *((have && int_y) ? arr + c0 + 1 : dflt);
     }
     double dsum = 0.0, minpsi = INFINITY;
     int bad = 0;
@@ -2391,11 +2407,8 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
     __syncthreads();
     BLEND_STAMP(2);
     // residual / gradient stage: own pair from registers, N / S pairs and the two out-of-pair neighbours from the tile
-    double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0, nm0 = 0.0, nm1 = 0.0;
-    const bool int_x = own_x && c0 >= 1 && c0 <= nr - 2, int_y = own_y && c0 + 1 <= nr - 2;  // (c0 + 1 >= 1 always)
-    if (int_x) { rs0 = L.r_safe[c0]; ri0 = L.r_inv[c0]; rl0 = L.r_inv_lo[c0]; if (lazy_nm) nm0 = lazy_nm[c0]; }
-    if (int_y) { rs1 = L.r_safe[c0 + 1]; ri1 = L.r_inv[c0 + 1]; rl1 = L.r_inv_lo[c0 + 1]; if (lazy_nm) nm1 = lazy_nm[c0 + 1]; }
-    const double lz_sc = lazy_nm ? st[b].jscale : 1.0;
+    const double rs0 = sh_coef[0][lane], rs1 = sh_coef[1][lane], ri0 = sh_coef[2][lane], ri1 = sh_coef[3][lane];
+    const double rl0 = sh_coef[4][lane], rl1 = sh_coef[5][lane], nm0 = sh_coef[6][lane], nm1 = sh_coef[7][lane];
     double m = 0.0;
     double2 rv[BL_NROWS];
 #pragma unroll

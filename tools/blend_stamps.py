@@ -14,7 +14,7 @@ import numpy as np  # noqa: E402
 from scpn_fusion_core_amd.cases import iter_like_cfg  # noqa: E402
 from scpn_fusion_core_amd.ensemble import EnsembleSolver  # noqa: E402
 
-B, n = 32, 513
+B, n = int(os.environ.get("STAMPS_B", "32")), 513
 cfg = iter_like_cfg(n, tol=1e-300, max_iter=40)
 with EnsembleSolver(cfg, batch=B) as es:
     es.solve_equilibrium(check_every=8)
