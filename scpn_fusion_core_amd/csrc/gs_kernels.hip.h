@@ -706,13 +706,21 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     const bool lazy = lzs.st != nullptr;  // uniform
     const int act_w = *(active ? active + b : &g_const_i32[1]);
     const int k_in = *inF.slot_ptr(b), k_out = *outF.slot_ptr(b), k_src = *srcF.slot_ptr(b);
-    const int k_cc = PROLONG ? *coarseF.slot_ptr(b) : 0;
+    const int k_cc = (PROLONG || DEFECT) ? *coarseF.slot_ptr(b) : 0;  // PROLONG: the coarse correction read; DEFECT: the coarse rhs written
+    const int k_ce = DEFECT ? *dd.e.slot_ptr(b) : 0;
     const bool in0 = c0 >= 1 && c0 <= nr - 2, in1 = c0 + 1 >= 1 && c0 + 1 <= nr - 2;
     double lz_sc = *(lazy ? &lzs.st[b].jscale : &g_const_f64[1]);
     double lz_n0 = *(lazy ? lzs.neg_mu0R + min(max(c0, 0), nr - 1) : &g_const_f64[1]);
     double lz_n1 = *(lazy ? lzs.neg_mu0R + min(max(c0 + 1, 0), nr - 1) : &g_const_f64[1]);
     double ae0 = *(in0 ? L.a_e + c0 : &g_const_f64[0]), aw0 = *(in0 ? L.a_w + c0 : &g_const_f64[0]);
     double ae1 = *(in1 ? L.a_e + c0 + 1 : &g_const_f64[0]), aw1 = *(in1 ? L.a_w + c0 + 1 : &g_const_f64[0]);
+    // DEFECT: r_safe / its reciprocal (two words) of the lane's even / odd column, requested with the rest (the defect stage
+    // then starts without a memory round trip)
+    double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0;
+    if (DEFECT) {
+        rs0 = *(in0 ? dd.r_safe + c0 : &g_const_f64[1]); ri0 = *(in0 ? dd.r_inv + c0 : &g_const_f64[1]); rl0 = *(in0 ? dd.r_inv_lo + c0 : &g_const_f64[0]);
+        rs1 = *(in1 ? dd.r_safe + c0 + 1 : &g_const_f64[1]); ri1 = *(in1 ? dd.r_inv + c0 + 1 : &g_const_f64[1]); rl1 = *(in1 ? dd.r_inv_lo + c0 + 1 : &g_const_f64[0]);
+    }
     const double* in = inF.at_slot(b, k_in);
     double* out = outF.at_slot(b, k_out);
     // the lane's pair is inside the window iff H/2 <= lane < 64 - H/2 (H even), and inside the grid iff c0 < nr; only the last
@@ -892,9 +900,6 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     TILE_STAMP(8);
     if (DEFECT) {
         // (1) defect d = -(L*psi - src) of this wave's rows, both colours, into the source registers
-        double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0;  // r_safe / its reciprocal (two words) of the lane's even / odd column
-        if (c0 >= 1 && c0 <= nr - 2) { rs0 = dd.r_safe[c0]; ri0 = dd.r_inv[c0]; rl0 = dd.r_inv_lo[c0]; }
-        if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { rs1 = dd.r_safe[c0 + 1]; ri1 = dd.r_inv[c0 + 1]; rl1 = dd.r_inv_lo[c0 + 1]; }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int pr = (c + e0) & 1;
@@ -932,8 +937,8 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         // tile cell (lz, col) = (H + 2cz, H + 2cr), both even: the centre and the four diagonal neighbours are colour 0, the
         // N/S/W/E neighbours colour 1, and with q = lz*64 + col/2 every address is q + constant.
         constexpr int CZ = (LZ - 2 * H) / 2, CR = (128 - 2 * H) / 2;
-        double* rc = coarseF.at(b);
-        double* ec = dd.e.at(b);
+        double* rc = coarseF.at_slot(b, k_cc);
+        double* ec = dd.e.at_slot(b, k_ce);
         const int ic0 = (z0 + H) >> 1, jc0 = (r0 + H) >> 1;
         for (int t = threadIdx.x; t < CZ * CR; t += 64 * NW) {
             const int cz = t / CR, cr = t - cz * CR;
@@ -1018,13 +1023,21 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
     const bool lazy = lzs.st != nullptr;  // uniform
     const int act_w = *(active ? active + b : &g_const_i32[1]);
     const int k_in = *inF.slot_ptr(b), k_out = *outF.slot_ptr(b), k_src = *srcF.slot_ptr(b);
-    const int k_cc = PROLONG ? *coarseF.slot_ptr(b) : 0;
+    const int k_cc = (PROLONG || DEFECT) ? *coarseF.slot_ptr(b) : 0;  // PROLONG: the coarse correction read; DEFECT: the coarse rhs written
+    const int k_ce = DEFECT ? *dd.e.slot_ptr(b) : 0;
     const bool in0 = c0 >= 1 && c0 <= nr - 2, in1 = c0 + 1 >= 1 && c0 + 1 <= nr - 2;
     double lz_sc = *(lazy ? &lzs.st[b].jscale : &g_const_f64[1]);
     double lz_n0 = *(lazy ? lzs.neg_mu0R + min(max(c0, 0), nr - 1) : &g_const_f64[1]);
     double lz_n1 = *(lazy ? lzs.neg_mu0R + min(max(c0 + 1, 0), nr - 1) : &g_const_f64[1]);
     double ae0 = *(in0 ? L.a_e + c0 : &g_const_f64[0]), aw0 = *(in0 ? L.a_w + c0 : &g_const_f64[0]);  // even / odd column of the pair
     double ae1 = *(in1 ? L.a_e + c0 + 1 : &g_const_f64[0]), aw1 = *(in1 ? L.a_w + c0 + 1 : &g_const_f64[0]);
+    // DEFECT: r_safe / its reciprocal (two words) of the lane's even / odd column, requested with the rest (the defect stage
+    // then starts without a memory round trip)
+    double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0;
+    if (DEFECT) {
+        rs0 = *(in0 ? dd.r_safe + c0 : &g_const_f64[1]); ri0 = *(in0 ? dd.r_inv + c0 : &g_const_f64[1]); rl0 = *(in0 ? dd.r_inv_lo + c0 : &g_const_f64[0]);
+        rs1 = *(in1 ? dd.r_safe + c0 + 1 : &g_const_f64[1]); ri1 = *(in1 ? dd.r_inv + c0 + 1 : &g_const_f64[1]); rl1 = *(in1 ? dd.r_inv_lo + c0 + 1 : &g_const_f64[0]);
+    }
     const double* in = inF.at_slot(b, k_in);
     double* out = outF.at_slot(b, k_out);
     const bool pair_own = lane >= H / 2 && lane < 64 - H / 2 && c0 < nr;
@@ -1204,9 +1217,6 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
     TILE_STAMP(8);
     if (DEFECT) {
         // (1) defect d = -(L*psi - src) of this wave's rows, both colours, into the source registers
-        double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0;
-        if (c0 >= 1 && c0 <= nr - 2) { rs0 = dd.r_safe[c0]; ri0 = dd.r_inv[c0]; rl0 = dd.r_inv_lo[c0]; }
-        if (c0 + 1 >= 1 && c0 + 1 <= nr - 2) { rs1 = dd.r_safe[c0 + 1]; ri1 = dd.r_inv[c0 + 1]; rl1 = dd.r_inv_lo[c0 + 1]; }
         const double Sb0 = b0[o_s], Nb0 = b0[o_n], Sb1 = b1[o_s], Nb1 = b1[o_n];
         auto defect = [&](auto colour, auto row) {
             constexpr int c = decltype(colour)::value, i = decltype(row)::value, p = (c + i) & 1;
@@ -1243,8 +1253,8 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
         TILE_STAMP(9);
         // (3) full-weighting restriction of the window's even/even points, as in k_smooth_tile
         constexpr int CZ = (LZ - 2 * H) / 2, CR = (128 - 2 * H) / 2;
-        double* rc = coarseF.at(b);
-        double* ec = dd.e.at(b);
+        double* rc = coarseF.at_slot(b, k_cc);
+        double* ec = dd.e.at_slot(b, k_ce);
         const int ic0 = (z0 + H) >> 1, jc0 = (r0 + H) >> 1;
         for (int t = threadIdx.x; t < CZ * CR; t += 64 * NW) {
             const int cz = t / CR, cr = t - cz * CR;
@@ -1469,12 +1479,14 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
                                                         int post, const int* active) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
-    if (active && !active[b]) return;
+    const int act_w = *(active ? active + b : &g_const_i32[1]);  // activity and the two slot words in one round trip
+    const int k_rhs = *rhsF.slot_ptr(b), k_e = *eF.slot_ptr(b);
+    if (!act_w) return;
     CV_STAMP(0);
     // stage the top-level rhs and the coefficient tables of every level.  The first five rhs values of a thread (all of a 65x65
     // level) are requested before the table loops run, so their round trip to memory overlaps the tables'
     {
-        const double* g = rhsF.at(b);
+        const double* g = rhsF.at_slot(b, k_rhs);
         double* rhs = lds + V.off_rhs[0];
         double* psi = lds + V.off_psi[0];
         const int nz = V.nz[0], nr = V.nr[0], n = nz * nr;
@@ -1582,7 +1594,7 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
         CV_STAMP(22 + 2 * l);
     }
     {
-        double* g = eF.at(b);
+        double* g = eF.at_slot(b, k_e);
         const double* psi = lds + V.off_psi[0];
         const int nz = V.nz[0], nr = V.nr[0], n = nz * nr;
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -1937,10 +1949,13 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
     __shared__ double sh[4];
     __shared__ int sh_last;
     int b = blockIdx.z;
-    if (!st[b].active) return;
-    const double* psi = psiF.at(b);
-    double* raw = rawF.base ? rawF.at(b) : nullptr;  // lazy-source mode: J_raw is kept, consumers apply scale and -mu0 R
+    // the member's words in one round trip (activity, slots, normalisation), as in the tile kernels
+    const int act_w = st[b].active;
+    const int k_psi = *psiF.slot_ptr(b), k_raw = *rawF.slot_ptr(b);
     const double pa = st[b].psi_axis, den = st[b].denom, iden = st[b].inv_denom;
+    if (!act_w) return;
+    const double* psi = psiF.at_slot(b, k_psi);
+    double* raw = rawF.base ? rawF.at_slot(b, k_raw) : nullptr;  // lazy-source mode: J_raw is kept, consumers apply scale and -mu0 R
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c0 = (blockIdx.x * 64 + tx) * 2;
     double s = 0.0;
