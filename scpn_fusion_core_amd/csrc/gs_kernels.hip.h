@@ -614,7 +614,29 @@ __device__ __forceinline__ double j_raw_at(double psi, double R, double inv_mu0R
 struct LazySrc {
     const Member* st = nullptr;
     const double* neg_mu0R = nullptr;
+    // part != nullptr: this launch is the FIRST consumer of J_raw after k_jsum and finishes the sum itself -- every wave adds the
+    // nblk (<= 256) per-workgroup partial sums of its member in the order of jsum_final_body and forms the scale, tile (0, 0) of
+    // the member also stores I and the scale for the later consumers: the k_jsum_final launch and its kernel boundary leave the
+    // dependent chain of an iteration
+    const double* part = nullptr;
+    int nblk = 0;
+    double dr = 0, dz = 0;
+    Member* st_rw = nullptr;
 };
+// the scale of member b from the partial sums (core/fusion_kernel.py:436-438, the arithmetic of jsum_final_body: wave totals of
+// 64-value chunks added in order to +0.0); x0 = this lane's value of the first chunk, already loaded
+__device__ __forceinline__ double lazy_scale_from_parts(const LazySrc& z, int b, int lane, double x0, double itg, bool store) {
+    double tot = 0.0;
+    tot += wave_sum(x0);
+    for (int k = 1; k * 64 < z.nblk; ++k) {  // (uniform; grids above ~1000^2 only)
+        const int i = k * 64 + lane;
+        tot += wave_sum(i < z.nblk ? z.part[(long)b * z.nblk + i] : 0.0);
+    }
+    const double ic = (tot * z.dr) * z.dz;
+    const double sc = fabs(ic) > 1e-9 ? itg / ic : 0.0;
+    if (store) { z.st_rw[b].i_current = ic; z.st_rw[b].jscale = sc; }
+    return sc;
+}
 #ifdef CV_STAMPS
 __device__ unsigned long long g_cv_stamps[64];
 __device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (dispatch-order ids 1, 511, 1021, ...) x 16 stamps
@@ -672,7 +694,7 @@ struct DefectDst {
 // evaluated under the same condition (-0.0 elsewhere) and stores are confined to the in-domain part of the window -- so no
 // out-of-domain value ever reaches an output.  That is what keeps the load phase free of selects: per row two 16-B loads from
 // (scalar row pointer) + (per-lane byte offset), the lazy-source products and two LDS writes.
-template <int S, bool PROLONG, bool DEFECT, int LZT = TILE_LZ, int NWT = TILE_NW, int WPEU = TILE_WPE>
+template <int S, bool PROLONG, bool DEFECT, int LZT = TILE_LZ, int NWT = TILE_NW, int WPEU = TILE_WPE, bool SUMF = false>
 __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
                                                      const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, LazySrc lzs,
                                                      DefectDst dd, int xcd_remap) {
@@ -709,7 +731,10 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     const int k_cc = (PROLONG || DEFECT) ? *coarseF.slot_ptr(b) : 0;  // PROLONG: the coarse correction read; DEFECT: the coarse rhs written
     const int k_ce = DEFECT ? *dd.e.slot_ptr(b) : 0;
     const bool in0 = c0 >= 1 && c0 <= nr - 2, in1 = c0 + 1 >= 1 && c0 + 1 <= nr - 2;
-    double lz_sc = *(lazy ? &lzs.st[b].jscale : &g_const_f64[1]);
+    constexpr bool lz_sum = SUMF;  // this instantiation finishes the J_raw sum (see LazySrc; lzs.part is set)
+    double lz_sc = *((lazy && !lz_sum) ? &lzs.st[b].jscale : &g_const_f64[1]);
+    const double lz_itg = *(lz_sum ? &lzs.st[b].i_target : &g_const_f64[1]);
+    const double lz_x0 = *((lz_sum && lane < lzs.nblk) ? lzs.part + ((long)b * lzs.nblk + lane) : &g_const_f64[0]);
     double lz_n0 = *(lazy ? lzs.neg_mu0R + min(max(c0, 0), nr - 1) : &g_const_f64[1]);
     double lz_n1 = *(lazy ? lzs.neg_mu0R + min(max(c0 + 1, 0), nr - 1) : &g_const_f64[1]);
     double ae0 = *(in0 ? L.a_e + c0 : &g_const_f64[0]), aw0 = *(in0 ? L.a_w + c0 : &g_const_f64[0]);
@@ -837,6 +862,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         }
         if (PROLONG) __builtin_amdgcn_sched_barrier(0);  // keep the next group's loads behind this group's LDS writes
     }
+    if constexpr (lz_sum) lz_sc = lazy_scale_from_parts(lzs, b, lane, lz_x0, lz_itg, bx_ == 0 && by_ == 0 && threadIdx.x == 0);
     if (lazy) {  // Source = (-mu0 R) * (scale != 0 ? J_raw * scale : 0), the expression of k_source; scale is per member (uniform)
         const double nC0 = e0 ? lz_n1 : lz_n0, nC1 = e0 ? lz_n0 : lz_n1;  // (-mu0 R) of the column that carries colour 0 / 1
         if (lz_sc != 0.0) {
@@ -994,7 +1020,7 @@ __device__ __forceinline__ double wave_shift(double x) {  // 0x138: wave_shr:1 =
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT, int WPEU>
+template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT, int WPEU, bool SUMF = false>
 __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
                                                     const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, LazySrc lzs,
                                                     DefectDst dd, int xcd_remap) {
@@ -1026,7 +1052,10 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
     const int k_cc = (PROLONG || DEFECT) ? *coarseF.slot_ptr(b) : 0;  // PROLONG: the coarse correction read; DEFECT: the coarse rhs written
     const int k_ce = DEFECT ? *dd.e.slot_ptr(b) : 0;
     const bool in0 = c0 >= 1 && c0 <= nr - 2, in1 = c0 + 1 >= 1 && c0 + 1 <= nr - 2;
-    double lz_sc = *(lazy ? &lzs.st[b].jscale : &g_const_f64[1]);
+    constexpr bool lz_sum = SUMF;  // this instantiation finishes the J_raw sum (see LazySrc; lzs.part is set)
+    double lz_sc = *((lazy && !lz_sum) ? &lzs.st[b].jscale : &g_const_f64[1]);
+    const double lz_itg = *(lz_sum ? &lzs.st[b].i_target : &g_const_f64[1]);
+    const double lz_x0 = *((lz_sum && lane < lzs.nblk) ? lzs.part + ((long)b * lzs.nblk + lane) : &g_const_f64[0]);
     double lz_n0 = *(lazy ? lzs.neg_mu0R + min(max(c0, 0), nr - 1) : &g_const_f64[1]);
     double lz_n1 = *(lazy ? lzs.neg_mu0R + min(max(c0 + 1, 0), nr - 1) : &g_const_f64[1]);
     double ae0 = *(in0 ? L.a_e + c0 : &g_const_f64[0]), aw0 = *(in0 ? L.a_w + c0 : &g_const_f64[0]);  // even / odd column of the pair
@@ -1113,6 +1142,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
                 }
             }
         }
+        if constexpr (lz_sum) if (g0 == 0) lz_sc = lazy_scale_from_parts(lzs, b, lane, lz_x0, lz_itg, bx_ == 0 && by_ == 0 && threadIdx.x == 0);
 #pragma unroll
         for (int j = 0; j < LG; ++j) {
             const int i = g0 + j;
@@ -1927,12 +1957,13 @@ __global__ void __launch_bounds__(1024) k_xpoint_saddle(Fld psiF, Member* st, in
 constexpr int JS_ROWS = JS_ROWS_N;  // rows per workgroup of the column-pair kernels (k_jsum, k_source)
 // finishes the J_raw sum of member b: I = (sum * dr) * dz, scale = I_target / I  (core/fusion_kernel.py:436-438); all 256 threads
 template <bool AGENT>
-__device__ __forceinline__ void jsum_final_body(int b, Member* st, const double* part, int nblk, double dr, double dz, double* sh) {
+__device__ __forceinline__ void jsum_final_body(int b, Member* st, const double* part, int nblk, double dr, double dz, double* sh,
+                                                bool commit = true) {
     const double itg = st[b].i_target;
     double s = 0.0;
     for (int i = threadIdx.x; i < nblk; i += 256) s += ld_part<AGENT>(part + (long)b * nblk + i);
     double tot = block_sum<256>(s, sh);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && commit) {
         double ic = (tot * dr) * dz;
         st[b].i_current = ic;
         st[b].jscale = fabs(ic) > 1e-9 ? itg / ic : 0.0;
@@ -2010,8 +2041,8 @@ __global__ void __launch_bounds__(256) k_jsum_final(Member* st, const double* pa
                                                     double dz) {
     __shared__ double sh[4];
     const int b = blockIdx.x;
-    if (!st[b].active) return;
-    jsum_final_body<false>(b, st, part, nblk, dr, dz, sh);
+    // (a frozen member's sum is formed and dropped: the activity word travels with the partial sums instead of in front of them)
+    jsum_final_body<false>(b, st, part, nblk, dr, dz, sh, st[b].active != 0);
 }
 // Source = (-mu0*R) * (J_raw * scale)  (core/fusion_kernel.py:440, newton_solver.py:513); optionally stores J_phi.
 // Column pair per thread (16-B loads / stores); grid (ceil(nr/128), ceil(nz/16), B), 256 threads

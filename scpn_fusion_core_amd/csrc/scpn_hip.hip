@@ -144,6 +144,8 @@ struct Solver {
     // multigrid hierarchies keyed by min_grid
     std::map<int, Hier> hier;
     const double* lazy_src = nullptr;  // base of the level-0 source field while it holds J_raw (lazy-source Picard iterations)
+    const double* jsum_part = nullptr;  // != nullptr: k_jsum's partial sums wait for the first lazy tile launch to finish them (LazySrc::part)
+    int jsum_nblk = 0;
     bool use_fused = true;  // SCPN_HIP_FUSED=0 selects the one-pass-per-launch kernels (A/B testing)
     // fields (B members each)
     DBuf<double> psi_slots;  // 3 ping-pong slots
@@ -361,8 +363,16 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
         if constexpr (REG) return &k_smooth_reg<S, PROLONG, DEFECT, LZT, NWT, WPEU>;
         else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, WPEU>;
     }();
+    // the instantiation that also finishes the J_raw sum (LazySrc::part) exists for the V-cycle's first level-0 launch only
+    constexpr bool HAS_SUMF = S == 3 && DEFECT && !PROLONG;
+    auto kern_sum = [] {
+        if constexpr (!HAS_SUMF) return (decltype(kern))nullptr;
+        else if constexpr (REG) return &k_smooth_reg<S, PROLONG, DEFECT, LZT, NWT, WPEU, true>;
+        else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, WPEU, true>;
+    }();
     std::call_once(attr_once, [&] {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (kern_sum) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
     constexpr int H = 2 * S + (DEFECT ? 2 : 0);
     static_assert(LZT - 2 * H >= 2, "tile too short for its halo");
@@ -379,9 +389,19 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
     }
     static const int xcd_env = [] { const char* e = std::getenv("SCPN_HIP_XCD"); return e ? std::atoi(e) : 1; }();
     LazySrc lzs;
-    if (h->lazy_src && src.base == h->lazy_src) { lzs.st = h->d_st.p; lzs.neg_mu0R = h->d_neg_mu0R.p; }
-    SCPN_LAUNCH(kern, g, dim3(64 * NWT), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c, ld_c, lzs, dd,
-                xcd_env);
+    if (h->lazy_src && src.base == h->lazy_src) {
+        lzs.st = h->d_st.p; lzs.neg_mu0R = h->d_neg_mu0R.p;
+        if (h->jsum_part) {  // the first consumer of J_raw after k_jsum finishes the sum
+            if (kern_sum) {
+                lzs.part = h->jsum_part; lzs.nblk = h->jsum_nblk; lzs.dr = h->dr; lzs.dz = h->dz; lzs.st_rw = h->d_st.p;
+            } else {  // (not the launch shape the fused sum is built for: finish it the ordinary way first)
+                SCPN_LAUNCH(k_jsum_final, dim3(h->B), dim3(256), 0, h->stream, h->d_st.p, (const double*)h->jsum_part, h->jsum_nblk, h->dr, h->dz);
+            }
+            h->jsum_part = nullptr;
+        }
+    }
+    SCPN_LAUNCH(lzs.part ? kern_sum : kern, g, dim3(64 * NWT), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c,
+                ld_c, lzs, dd, xcd_env);
 }
 template <int S, bool PROLONG, bool DEFECT>
 static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
@@ -916,7 +936,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
                       vcycle_lazy_ok(h, 3, 3, 5);
     struct LazyGuard {
         Solver* h;
-        ~LazyGuard() { h->lazy_src = nullptr; }
+        ~LazyGuard() { h->lazy_src = nullptr; h->jsum_part = nullptr; }
     } lazy_guard{h};
     if (lazy) h->lazy_src = srcF.base;
     // the fused tail (k_blend_tile) leaves the topology partials of the next iterate, and k_picard_final finishes them for the
@@ -930,6 +950,14 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     // kernel the next launch waits for.  Opt-in: SCPN_HIP_TAILFUSE=1.
     static const bool tailfuse_env = [] { const char* e = std::getenv("SCPN_HIP_TAILFUSE"); return e && e[0] == '1'; }();
     const bool tail_fuse = tailfuse_env && topo_in_final;
+    // The J_raw sum finished by its first consumer: in lazy-source mode the V-cycle's first level-0 tile launch adds the per-
+    // workgroup partial sums itself (every wave, redundantly: <= 256 values) and forms the scale, so k_jsum_final and its kernel
+    // boundary leave the chain -- no ticket, no atomics (contrast SCPN_HIP_TAILFUSE).  Measured (same box): ONE 513^2 equilibrium
+    // 122.7 -> 121.1 us per iteration, 2 x 16 members 347.6 -> 349.4: like every fused scalar tail before it, it pays only where
+    // the iteration is a chain of short launches -- default for stream groups of up to 14 members (the register-tile rule);
+    // SCPN_HIP_SUMFUSE=0 / 1 forces it off / on.
+    static const int sumfuse_env = [] { const char* e = std::getenv("SCPN_HIP_SUMFUSE"); return e ? std::atoi(e) : -1; }();
+    const bool sum_fuse = (sumfuse_env == 1 || (sumfuse_env < 0 && B <= 14)) && lazy && !tail_fuse && nblkj <= 256;
     auto iteration = [&](bool first) {
         if (first || !topo_in_final) {
             ProfScope ps(h, "topology", first || !h->use_fused || p->method == 3 || p->xpoint_saddle ? 2 : 1);
@@ -946,12 +974,13 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
                                    (const double*)h->d_r.p, (const double*)h->d_z.p);
         }
         if (!p->external_profile_mode) {
-            ProfScope ps(h, "source", (lazy ? 2 : 3) - (tail_fuse ? 1 : 0));
+            ProfScope ps(h, "source", (lazy ? 2 : 3) - ((tail_fuse || sum_fuse) ? 1 : 0));
             JsumTail jt;
             if (tail_fuse) { jt.counters = h->d_tickets.p; jt.st = h->d_st.p; jt.dr = h->dr; jt.dz = h->dz; }
             SCPN_LAUNCH(k_jsum, gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
                                (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, lazy ? srcF : Fld{nullptr, nullptr, 0, 0}, jt);
-            if (!tail_fuse)  // (fused: the last workgroup of each member finished the sum inside k_jsum)
+            if (sum_fuse) { h->jsum_part = h->d_jpart.p; h->jsum_nblk = nblkj; }  // (the V-cycle's first level-0 launch finishes the sum)
+            else if (!tail_fuse)  // (tail_fuse: the last workgroup of each member finished the sum inside k_jsum)
                 SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
             if (!lazy)  // (lazy: the V-cycle's level-0 tiles and the fused tail form the source from J_raw on load)
                 SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, srcF, jF, 0, curF, (const Member*)h->d_st.p, nz, nr, ld,

@@ -20,6 +20,8 @@ SWITCHES = [
     {"SCPN_HIP_TAILFUSE": "1"},
     {"SCPN_HIP_POLL": "memcpy"},
     {"SCPN_HIP_XCD_BLEND": "0"},
+    {"SCPN_HIP_SUMFUSE": "0"},                                  # separate k_jsum_final launch instead of the sum in its first consumer
+    {"SCPN_HIP_TILEREG": "0", "SCPN_HIP_SUMFUSE": "1"},          # (LDS tile as the finishing consumer)
     {"SCPN_HIP_TILEREG": "0"},                                  # LDS colour-plane tile (what groups of more than 12 members run)
     {"SCPN_HIP_TILEREG": "1", "SCPN_HIP_TILEREG_TINY": "0"},   # register-resident tile, 32-row geometry (the default here is 24 rows)
 ]
