@@ -118,8 +118,9 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
                                      "gbs_equivalent": round(bytes_survey / (tot_ms * 1e-3) / 1e9, 1)},
             "avg_launch_us": round(1e3 * tot_ms / tot_launch, 2), "launches": int(tot_launch),
             "groups": num_groups, "members_per_launch": int(members_per_launch), "isolated_kernel_timing": True,
-            "limiter": {"class": "on-chip issue / latency (fp64 VALU + LDS pipeline in lock step), not HBM: counter traffic equals the "
-                                 "compulsory bytes and the kernel keeps its speed when its working set sits in the Infinity Cache",
+            "limiter": {"class": "on-chip life of a tile (barrier-separated phases of dependent fp64 chains, three tiles per CU) x tiles per CU; "
+                                 "not HBM (counter traffic = compulsory bytes), not memory latency (every tile loading one cached block: V-cycle -6.5 %), "
+                                 "not the LDS pipeline (register tile: 73 % fewer LDS instructions, same time with the chip full)",
                         "counters": ctr, "evidence": "profiles/r03_experiments.md, DESIGN.md section 6"},
             "per_level": per_level, "families_ms": fam}
 
