@@ -1314,12 +1314,10 @@ struct CoarseV {
     int off_scr;           // scratch of nz[0]*nr[0] doubles: the defect field between its evaluation and its restriction
     double a_ns[CV_MAX], a_c[CV_MAX], dr2[CV_MAX], dz2[CV_MAX], two_dr[CV_MAX];
     double inv_a_c[CV_MAX], inv_dr2[CV_MAX], inv_dz2[CV_MAX], inv_two_dr[CV_MAX], lo_a_c[CV_MAX];
-    const double* r_inv[CV_MAX];
-    const double* a_e[CV_MAX];
-    const double* a_w[CV_MAX];
-    const double* r_safe[CV_MAX];
     int ld0;       // pitch of the global level-lc arrays
     long stride0;
+    const double* tabs;  // the tables of all levels packed as they lie in LDS from off_tab[0] on (tab_total doubles)
+    int tab_total;
 };
 // a double moved along its 16-lane DPP row (CTRL 0x101+n-1: row_shl:n = value of lane+n; 0x111+n-1: row_shr:n = value of lane-n;
 // lanes whose source is outside the row receive 0)
@@ -1528,15 +1526,7 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
             const int iz = i / nr, ir = i - iz * nr;
             tmp[k] = g[(long)iz * V.ld0 + ir];
         }
-        for (int l = 0; l < V.n; ++l) {
-            double* tab = lds + V.off_tab[l];
-            for (int i = threadIdx.x; i < V.nr[l]; i += blockDim.x) {
-                tab[i] = V.a_e[l][i];
-                tab[V.nr[l] + i] = V.a_w[l][i];
-                tab[2 * V.nr[l] + i] = V.r_safe[l][i];
-                tab[3 * V.nr[l] + i] = V.r_inv[l][i];
-            }
-        }
+        for (int i = threadIdx.x; i < V.tab_total; i += blockDim.x) lds[V.off_tab[0] + i] = V.tabs[i];  // (one round trip for all levels)
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
             const int i = threadIdx.x + k * (int)blockDim.x;

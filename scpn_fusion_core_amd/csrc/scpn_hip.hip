@@ -122,6 +122,7 @@ struct Hier {
     int lc = -1;          // first level handled by the in-LDS coarse V-cycle kernel (-1: none)
     CoarseV cv{};
     size_t cv_lds = 0;    // dynamic LDS bytes of k_vcycle_coarse
+    double* cv_tabs = nullptr;  // the coefficient tables of the levels it holds, packed in its LDS layout (one coalesced copy per launch)
 };
 
 static int pitch_of(int nr) { return ((nr + 7) / 8) * 8; }
@@ -196,8 +197,10 @@ struct Solver {
     Fld plain(double* p) { return Fld{p, nullptr, stride, B}; }
 
     ~Solver() {
-        for (auto& kv : hier)
+        for (auto& kv : hier) {
             for (auto* l : kv.second.lv) delete l;
+            if (kv.second.cv_tabs) (void)hipFree(kv.second.cv_tabs);
+        }
         for (auto& e : prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         if (h_nactive) (void)hipHostFree(h_nactive);
         if (h_word) (void)hipHostFree(h_word);
@@ -324,15 +327,25 @@ static Hier& get_hier(Solver* h, int min_grid) {
             V.n = k - lc + 1;
             int off = 0;
             auto al = [&](int nd) { int o = off; off += (nd + 1) & ~1; return o; };
+            // the tables of all levels first, contiguous: they are staged by one coalesced copy of a packed global image
+            for (int i = 0; i < V.n; ++i) V.off_tab[i] = al(4 * v[lc + i]->nr);
+            V.tab_total = off;
+            HIP_TRY(hipMalloc(&H.cv_tabs, sizeof(double) * (size_t)std::max(off, 1)));
+            HIP_TRY(hipMemset(H.cv_tabs, 0, sizeof(double) * (size_t)std::max(off, 1)));
+            for (int i = 0; i < V.n; ++i) {
+                LevelHost* L = v[lc + i];
+                const double* srcs[4] = {L->dev.a_e, L->dev.a_w, L->dev.r_safe, L->dev.r_inv};
+                for (int t = 0; t < 4; ++t)
+                    HIP_TRY(hipMemcpy(H.cv_tabs + V.off_tab[i] + (size_t)t * L->nr, srcs[t], sizeof(double) * L->nr, hipMemcpyDeviceToDevice));
+            }
+            V.tabs = H.cv_tabs;
             for (int i = 0; i < V.n; ++i) {
                 LevelHost* L = v[lc + i];
                 V.nz[i] = L->nz; V.nr[i] = L->nr;
                 V.off_psi[i] = al(L->nz * L->nr);
                 V.off_rhs[i] = al(L->nz * L->nr);
-                V.off_tab[i] = al(4 * L->nr);
                 V.a_ns[i] = L->dev.a_ns; V.a_c[i] = L->dev.a_c; V.dr2[i] = L->dev.dr2; V.dz2[i] = L->dev.dz2; V.two_dr[i] = L->dev.two_dr;
                 V.inv_a_c[i] = L->dev.inv_a_c; V.lo_a_c[i] = L->dev.lo_a_c; V.inv_dr2[i] = L->dev.inv_dr2; V.inv_dz2[i] = L->dev.inv_dz2; V.inv_two_dr[i] = L->dev.inv_two_dr;
-                V.a_e[i] = L->dev.a_e; V.a_w[i] = L->dev.a_w; V.r_safe[i] = L->dev.r_safe; V.r_inv[i] = L->dev.r_inv;
             }
             V.off_scr = al(v[lc]->nz * v[lc]->nr);
             V.ld0 = v[lc]->ld;
