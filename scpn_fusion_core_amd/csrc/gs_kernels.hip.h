@@ -571,16 +571,12 @@ __device__ __forceinline__ double prolong_at(const double* c, int ld_c, int nz_c
     return 0.25 * (c[(long)ic * ld_c + jc] + c[(long)(ic + 1) * ld_c + jc] + c[(long)ic * ld_c + jc + 1] +
                    c[(long)(ic + 1) * ld_c + jc + 1]);
 }
-// ---------------------------------------------------------------- LDS-tiled multi-sweep smoother
-// S full red-black sweeps per launch with temporal blocking.  A 512-thread workgroup stages a
-// TILE_LZ x 128 tile of psi (halo H = 2S) in LDS, de-interleaved into two colour planes so that every
-// wave access is 64 consecutive doubles (no stride-2 bank conflicts); lane l owns the column pair
-// (2l, 2l+1) of each of its rows, so source values and the a_e/a_w coefficients of the pair stay in
-// registers for all sweeps.  Each colour pass invalidates one more cell from every interior tile edge;
-// after 2S passes the centre (TILE_LZ-4S) x (128-4S) window is exact and is written to `out`
-// (out-of-place: neighbouring tiles read the halo from `in`).  Results are bit-identical to the
-// one-pass-per-launch kernel because a colour pass only reads the other colour.
-// Inactive members are passed through (out = in).  grid (tiles_r, tiles_z, B), dynamic LDS = TILE_LZ KiB.
+// ---------------------------------------------------------------- tile smoother: S sweeps per launch, the tile in registers
+// S full red-black sweeps per launch with temporal blocking.  A workgroup owns an LZ x 128 tile of psi (halo H = 2S, + 2 for
+// DEFECT); each colour pass invalidates one more cell from every interior tile edge; after 2S passes the centre
+// (LZ - 2H) x (128 - 2H) window is exact and is written to `out` (out-of-place: neighbouring tiles read the halo from `in`).
+// Results are bit-identical to the one-pass-per-launch kernel because a colour pass only reads the other colour.
+// Inactive members are passed through (out = in).  grid (tiles_r, tiles_z, B), dynamic LDS = LZ KiB.
 struct Prof {
     int hmode;
     double ped_p[4], ped_ff[4];
@@ -656,18 +652,35 @@ __device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (d
 #define TILE_STAMP(i)
 #define BLEND_STAMP(i)
 #endif
-// Tile geometry of the shipped library: 40 rows x 128 columns, 8 waves, register allocation capped so that three workgroups
-// share a CU (one loads while the others sweep).  A -D override builds another geometry for experiments (LZ % NW == 0).
-#ifndef TILE_LZ_N
-#define TILE_LZ_N 40
+// Tile geometries (rows x waves; rows / waves = an even number of consecutive rows per wave), chosen per launch by the size of
+// the stream group (scpn_hip.hip, launch_tile): BIG for groups that fill the chip (six rows per wave, the sources of a wave's
+// inner rows in LDS slots), MID for up to 14 members (four rows per wave), TINY while a level-0 launch has at most ~220 tiles
+// (two rows per wave: the shortest workgroup lifetime).  -D overrides build other geometries for experiments.
+#ifndef TILE_BIG_LZ
+#define TILE_BIG_LZ 48
 #endif
-#ifndef TILE_NW
-#define TILE_NW 8
+#ifndef TILE_BIG_NW
+#define TILE_BIG_NW 8
+#endif
+#ifndef TILE_MID_LZ
+#define TILE_MID_LZ 32
+#endif
+#ifndef TILE_MID_NW
+#define TILE_MID_NW 8
+#endif
+#ifndef TILE_TINY_LZ
+#define TILE_TINY_LZ 24
+#endif
+#ifndef TILE_TINY_NW
+#define TILE_TINY_NW 12
 #endif
 #ifndef TILE_WPE
-#define TILE_WPE 6  // minimum waves per SIMD the register allocation must allow: <= 80 VGPRs
+#define TILE_WPE 6  // minimum waves per SIMD the register allocation must allow: <= 80 VGPRs (three 8-wave workgroups per CU)
 #endif
-constexpr int TILE_LZ = TILE_LZ_N;
+// rows whose psi / source / coarse loads are in flight together in the PROLONG variant (register budget)
+#ifndef TILE_LG
+#define TILE_LG 1
+#endif
 // PROLONG: the tile is loaded as in + P(coarse) (bilinear prolongation of the coarse-grid correction,
 // multigrid_solve.py:329-330) -- the separate prolong-add pass over the fine grid disappears.
 // DEFECT: after the sweeps the tile also produces the coarse-grid right-hand side restrict_full_weight(-(L*psi - src))
@@ -688,331 +701,21 @@ struct DefectDst {
     const double* r_inv = nullptr;
     const double* r_inv_lo = nullptr;
 };
-// Out-of-domain cells.  A tile that overhangs the grid stages CLAMPED copies of in-domain values in its out-of-domain LDS cells
-// (row index clamped on the scalar unit, the lane's column pair clamped once) and never masks them: a red-black update is only
-// performed at interior points (1 <= gz <= nz-2, 1 <= gc <= nr-2), whose four neighbours are all in the domain, the defect is
-// evaluated under the same condition (-0.0 elsewhere) and stores are confined to the in-domain part of the window -- so no
-// out-of-domain value ever reaches an output.  That is what keeps the load phase free of selects: per row two 16-B loads from
-// (scalar row pointer) + (per-lane byte offset), the lazy-source products and two LDS writes.
-template <int S, bool PROLONG, bool DEFECT, int LZT = TILE_LZ, int NWT = TILE_NW, int WPEU = TILE_WPE, bool SUMF = false>
-__global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
-                                                     const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, LazySrc lzs,
-                                                     DefectDst dd, int xcd_remap) {
-    constexpr int LZ = LZT, H = 2 * S + (DEFECT ? 2 : 0), NW = NWT, NROWS = LZ / NW;
-    static_assert(LZ % NW == 0 && (H % 2) == 0, "rows are dealt to waves evenly; the halo is even");
-    constexpr int RS = NW * 64;  // doubles between two rows of a wave inside a colour plane
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* A0 = lds;            // colour 0: (iz + ir) even
-    double* A1 = lds + LZ * 64;  // colour 1
-    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs in linear-id order, so consecutive ids would put
-    // neighbouring tiles (which share halo rows / columns) on different L2s.  xcd_remap gives XCD k a contiguous run of
-    // tiles (whole members), so a tile's halo is usually still in that XCD's L2 from the neighbour that loaded it.
-    int bx_, by_, b;
-    {
-        const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
-        const unsigned total = gx * gy * gz;
-        unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        if (xcd_remap & 1) lin = xcd_contiguous(lin, total);
-        bx_ = (int)(lin % gx);
-        const unsigned t = lin / gx;
-        by_ = (int)(t % gy);
-        b = (int)(t / gy);
-    }
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index as a scalar: row arithmetic goes to the SALU
-    const int z0 = by_ * (LZ - 2 * H) - H, r0 = bx_ * (128 - 2 * H) - H;  // both even
-    const int nz = L.nz, nr = L.nr, ld = L.ld;
-    const int c0 = r0 + 2 * lane;  // global column of the lane's even element
-    // Everything that depends only on (member, column) is requested here, unconditionally and at once -- the member's activity
-    // word, the slot words of the three fields, the lazy-source scale, the column coefficients -- so that the row loads wait for
-    // ONE memory round trip, not for a chain of them (absent sources point at a constant).
-    const bool lazy = lzs.st != nullptr;  // uniform
-    const int act_w = *(active ? active + b : &g_const_i32[1]);
-    const int k_in = *inF.slot_ptr(b), k_out = *outF.slot_ptr(b), k_src = *srcF.slot_ptr(b);
-    const int k_cc = (PROLONG || DEFECT) ? *coarseF.slot_ptr(b) : 0;  // PROLONG: the coarse correction read; DEFECT: the coarse rhs written
-    const int k_ce = DEFECT ? *dd.e.slot_ptr(b) : 0;
-    const bool in0 = c0 >= 1 && c0 <= nr - 2, in1 = c0 + 1 >= 1 && c0 + 1 <= nr - 2;
-    constexpr bool lz_sum = SUMF;  // this instantiation finishes the J_raw sum (see LazySrc; lzs.part is set)
-    double lz_sc = *((lazy && !lz_sum) ? &lzs.st[b].jscale : &g_const_f64[1]);
-    const double lz_itg = *(lz_sum ? &lzs.st[b].i_target : &g_const_f64[1]);
-    const double lz_x0 = *((lz_sum && lane < lzs.nblk) ? lzs.part + ((long)b * lzs.nblk + lane) : &g_const_f64[0]);
-    double lz_n0 = *(lazy ? lzs.neg_mu0R + min(max(c0, 0), nr - 1) : &g_const_f64[1]);
-    double lz_n1 = *(lazy ? lzs.neg_mu0R + min(max(c0 + 1, 0), nr - 1) : &g_const_f64[1]);
-    double ae0 = *(in0 ? L.a_e + c0 : &g_const_f64[0]), aw0 = *(in0 ? L.a_w + c0 : &g_const_f64[0]);
-    double ae1 = *(in1 ? L.a_e + c0 + 1 : &g_const_f64[0]), aw1 = *(in1 ? L.a_w + c0 + 1 : &g_const_f64[0]);
-    // DEFECT: r_safe / its reciprocal (two words) of the lane's even / odd column, requested with the rest (the defect stage
-    // then starts without a memory round trip)
-    double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0;
-    if (DEFECT) {
-        rs0 = *(in0 ? dd.r_safe + c0 : &g_const_f64[1]); ri0 = *(in0 ? dd.r_inv + c0 : &g_const_f64[1]); rl0 = *(in0 ? dd.r_inv_lo + c0 : &g_const_f64[0]);
-        rs1 = *(in1 ? dd.r_safe + c0 + 1 : &g_const_f64[1]); ri1 = *(in1 ? dd.r_inv + c0 + 1 : &g_const_f64[1]); rl1 = *(in1 ? dd.r_inv_lo + c0 + 1 : &g_const_f64[0]);
-    }
-    const double* in = inF.at_slot(b, k_in);
-    double* out = outF.at_slot(b, k_out);
-    // the lane's pair is inside the window iff H/2 <= lane < 64 - H/2 (H even), and inside the grid iff c0 < nr; only the last
-    // pair of an odd-width grid is half inside (c0 == nr - 1)
-    const bool pair_own = lane >= H / 2 && lane < 64 - H / 2 && c0 < nr;
-    const bool pair_full = c0 + 1 < nr;
-    if (!act_w) {  // frozen member: out = in on the window
-#pragma unroll
-        for (int i = 0; i < NROWS; ++i) {
-            const int lz = w + NW * i, gz = z0 + lz;
-            if (lz >= H && lz < LZ - H && gz < nz && pair_own) {
-                const long o = (long)gz * ld + c0;
-                if (pair_full) *reinterpret_cast<double2*>(out + o) = *reinterpret_cast<const double2*>(in + o);
-                else out[o] = in[o];
-            }
-        }
-        return;
-    }
-#ifdef TILE_STAGGER
-    // experiment: the first three rounds of workgroups (dispatch order) start a third of a workgroup lifetime apart, so that the
-    // workgroups sharing a CU are not all loading / all sweeping at the same time
-    {
-        const unsigned lin0 = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (lin0 < 768u)
-            for (unsigned k = 0; k < (lin0 >> 8) * TILE_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-    TILE_STAMP(0);
-    const double* src = srcF.at_slot(b, k_src);
-    const double a_ns = L.a_ns, a_c = L.a_c, inv_a_c = L.inv_a_c, lo_a_c = L.lo_a_c;
-    // every row of this wave has the parity of w (lz = w + NW*i, NW even), so the lane's element (0: even column, 1: odd
-    // column) that carries colour c is e(c) = (c + w) & 1 for all rows: per-colour registers, no per-row selects
-    // (compiling the rest twice with e0 as a constant removes ~40 wave-uniform selects per wave but costs 15 VGPRs and puts the
-    //  kernel into scratch at the 80-register cap: measured by the compiler, not kept)
-    const int e0 = w & 1;  // element index of colour 0
-    const double aeC0 = e0 ? ae1 : ae0, awC0 = e0 ? aw1 : aw0, aeC1 = e0 ? ae0 : ae1, awC1 = e0 ? aw0 : aw1;
-    double sC0[NROWS], sC1[NROWS];
-    const int rb = w * 64 + lane;           // slot of this lane in the wave's first row
-    double* const pe = (e0 ? A1 : A0) + rb;  // plane of the even column (colour (gz & 1) == e0 ? 1 : 0 since z0, c0 are even)
-    double* const po = (e0 ? A0 : A1) + rb;
-    // ---- load phase (see "Out-of-domain cells" above): all row loads of a group are issued before the first is consumed
-    const unsigned lane_off = (unsigned)min(max(c0, 0), ld - 2) * 8u;  // even column, 16-B aligned; ld >= nr + 1 for odd nr
-#ifdef TILE_FAKE_LOADS
-    const char* const in_b = reinterpret_cast<const char*>(inF.base);
-    const char* const src_b = reinterpret_cast<const char*>(srcF.base);
-#else
-    const char* const in_b = reinterpret_cast<const char*>(in);
-    const char* const src_b = reinterpret_cast<const char*>(src);
-#endif
-    // PROLONG: the four coarse values around the lane's column pair, loaded the same way; rows are processed in groups of LG so
-    // that psi + src + coarse loads of a group fit the register budget
-    constexpr int LG = (PROLONG && NROWS > 3) ? (NROWS + 3) / 4 : NROWS;  // (three rows or fewer: everything in flight at once)
-    const char* const cc_b = PROLONG ? reinterpret_cast<const char*>(coarseF.at_slot(b, k_cc)) : nullptr;
-    const unsigned ld8 = (unsigned)ld * 8u, ldc8 = (unsigned)ld_c * 8u;
-    const int jc = max(c0, 0) >> 1;
-    const unsigned jc_off0 = PROLONG ? (unsigned)min(jc, nr_c - 1) * 8u : 0u, jc_off1 = PROLONG ? (unsigned)min(jc + 1, nr_c - 1) * 8u : 0u;
-    const int h_end = PROLONG ? min(2 * (nr_c - 1), nr - 1) : 0, v_end = PROLONG ? min(2 * (nz_c - 1), nz - 1) : 0;
-    const bool odd_is_zero = c0 + 1 >= h_end;  // the odd column of the pair lies at / beyond the last coarse column: P = 0 there
-#pragma unroll
-    for (int g0 = 0; g0 < NROWS; g0 += LG) {
-        double2 pv[LG], sv2[LG];
-        double ca0[LG], ca1[LG], cb0[LG], cb1[LG];
-        int gzs[LG];
-#pragma unroll
-        for (int j = 0; j < LG; ++j) {
-            const int i = g0 + j;
-            if (i >= NROWS) continue;
-            const int gzc = min(max(z0 + w + NW * i, 0), nz - 1);  // scalar
-            gzs[j] = gzc;
-            // a member's field is < 4 GiB, so a load address is (scalar member base) + (32-bit byte offset): the row part of the
-            // offset is computed on the scalar unit, one vector add makes the lane's offset, psi and src share it
-#ifdef TILE_FAKE_LOADS  // experiment: every tile reads the same (cache-resident) block -- what is a tile's life without memory latency?
-            const unsigned vo = (unsigned)(w + NW * i) * ld8 + (unsigned)lane * 16u;
-#else
-            const unsigned vo = (unsigned)gzc * ld8 + lane_off;
-#endif
-            pv[j] = *reinterpret_cast<const double2*>(in_b + vo);
-            sv2[j] = *reinterpret_cast<const double2*>(src_b + vo);
-            if (PROLONG) {
-                const int ic = gzc >> 1, icc = min(ic, nz_c - 1), icc1 = (gzc & 1) ? min(ic + 1, nz_c - 1) : icc;
-                const unsigned ra = (unsigned)icc * ldc8, rbp = (unsigned)icc1 * ldc8;
-                ca0[j] = *reinterpret_cast<const double*>(cc_b + (ra + jc_off0));
-                ca1[j] = *reinterpret_cast<const double*>(cc_b + (ra + jc_off1));
-                cb0[j] = *reinterpret_cast<const double*>(cc_b + (rbp + jc_off0));
-                cb1[j] = *reinterpret_cast<const double*>(cc_b + (rbp + jc_off1));
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < LG; ++j) {
-            const int i = g0 + j;
-            if (i >= NROWS) continue;
-            double vx = pv[j].x, vy = pv[j].y;
-            if (PROLONG) {
-                // bilinear prolongation, core/multigrid_solve.py:117-143 (same expressions as prolong_at); row tests are scalar
-                const int gzc = gzs[j];
-                double px, py;
-                if (!(gzc & 1)) {
-                    px = ca0[j];
-                    py = odd_is_zero ? 0.0 : 0.5 * (ca0[j] + ca1[j]);
-                } else if (gzc >= v_end) {
-                    px = 0.0;
-                    py = 0.0;
-                } else {
-                    px = 0.5 * (ca0[j] + cb0[j]);
-                    py = odd_is_zero ? 0.0 : 0.25 * (ca0[j] + cb0[j] + ca1[j] + cb1[j]);
-                }
-                vx = vx + px;
-                vy = vy + py;
-            }
-            pe[i * RS] = vx;
-            po[i * RS] = vy;
-            if (e0) { sC1[i] = sv2[j].x; sC0[i] = sv2[j].y; }
-            else { sC0[i] = sv2[j].x; sC1[i] = sv2[j].y; }
-        }
-        if (PROLONG) __builtin_amdgcn_sched_barrier(0);  // keep the next group's loads behind this group's LDS writes
-    }
-    if constexpr (lz_sum) lz_sc = lazy_scale_from_parts(lzs, b, lane, lz_x0, lz_itg, bx_ == 0 && by_ == 0 && threadIdx.x == 0);
-    if (lazy) {  // Source = (-mu0 R) * (scale != 0 ? J_raw * scale : 0), the expression of k_source; scale is per member (uniform)
-        const double nC0 = e0 ? lz_n1 : lz_n0, nC1 = e0 ? lz_n0 : lz_n1;  // (-mu0 R) of the column that carries colour 0 / 1
-        if (lz_sc != 0.0) {
-#pragma unroll
-            for (int i = 0; i < NROWS; ++i) { sC0[i] = nC0 * (sC0[i] * lz_sc); sC1[i] = nC1 * (sC1[i] * lz_sc); }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NROWS; ++i) { sC0[i] = nC0 * 0.0; sC1[i] = nC1 * 0.0; }
-        }
-    }
-    __syncthreads();
-    TILE_STAMP(1);
-    // one half-sweep of colour c (compile-time, so the per-colour coefficients, source registers, column predicate and LDS
-    // addresses are loop-invariant: the sweep loop is VALU-issue bound and every select / address add costs 4 cycles per row)
-    // Every LDS address of the sweep is (one per-colour base pointer) + (compile-time row offset): the bases cost four
-    // registers per colour and the row offsets become DS immediates.
-    auto half_sweep = [&](auto colour, const int hs) {
-        constexpr int c = decltype(colour)::value;
-        const int pr = (c + e0) & 1;  // column parity of colour c in this wave's rows
-        double* mine = (c ? A1 : A0) + rb;
-        const double* oth = (c ? A0 : A1) + rb;
-        const double* othWE = oth + (pr - 1);
-        const double ae = c ? aeC1 : aeC0, aw = c ? awC1 : awC0;
-        const int col = 2 * lane + pr, gc = r0 + col;
-        const bool colok = col >= 1 && col <= 126 && gc >= 1 && gc <= nr - 2;
-        // rows still needed for the final window shrink by one per pass: [hs+1, LZ-2-hs]
-#pragma unroll
-        for (int i = 0; i < NROWS; ++i) {
-            const int lz = w + NW * i, gz = z0 + lz;
-            if (lz >= hs + 1 && lz <= LZ - 2 - hs && gz >= 1 && gz <= nz - 2) {  // wave-uniform
-                const double W = othWE[i * RS], E = othWE[i * RS + 1];
-                const double Sv = oth[i * RS - 64], N = oth[i * RS + 64];
-                const double C = mine[i * RS];
-                const double sv = c ? sC1[i] : sC0[i];
-                const double gsv = divc4(ae * E + aw * W + a_ns * Sv + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
-                const double nw = om1 * C + omega * gsv;
-                if (colok) mine[i * RS] = nw;
-            }
-        }
-    };
-#pragma unroll 1
-    for (int sw = 0; sw < S; ++sw) {
-        half_sweep(std::integral_constant<int, 0>{}, 2 * sw);
-        __syncthreads();
-        TILE_STAMP(2 + 2 * sw);
-        half_sweep(std::integral_constant<int, 1>{}, 2 * sw + 1);
-        __syncthreads();
-        TILE_STAMP(3 + 2 * sw);
-    }
-    // ---- store the window
-#pragma unroll
-    for (int i = 0; i < NROWS; ++i) {
-        const int lz = w + NW * i, gz = z0 + lz;
-        if (lz >= H && lz < LZ - H && gz < nz && pair_own) {  // (row test wave-uniform)
-            const double vx = pe[i * RS], vy = po[i * RS];
-            char* const o = reinterpret_cast<char*>(out) + ((unsigned)gz * ld8 + (unsigned)c0 * 8u);
-            if (pair_full) *reinterpret_cast<double2*>(o) = double2{vx, vy};
-            else *reinterpret_cast<double*>(o) = vx;
-        }
-    }
-    TILE_STAMP(8);
-    if (DEFECT) {
-        // (1) defect d = -(L*psi - src) of this wave's rows, both colours, into the source registers
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int pr = (c + e0) & 1;
-            const double* mine = (c ? A1 : A0) + rb;  // per-colour bases + compile-time row offsets, as in the sweeps
-            const double* oth = (c ? A0 : A1) + rb;
-            const double* othWE = oth + (pr - 1);
-            const int col = 2 * lane + pr, gc = r0 + col;
-            const bool colok = col >= 1 && col <= 126 && gc >= 1 && gc <= nr - 2;
-            const double rs = pr ? rs1 : rs0, ri = pr ? ri1 : ri0, rl = pr ? rl1 : rl0;
-#pragma unroll
-            for (int i = 0; i < NROWS; ++i) {
-                const int lz = w + NW * i, gz = z0 + lz;
-                double d = -0.0;
-                if (lz >= H - 1 && lz <= LZ - H && gz >= 1 && gz <= nz - 2) {  // wave-uniform
-                    const double W = othWE[i * RS], E = othWE[i * RS + 1];
-                    const double Sv = oth[i * RS - 64], N = oth[i * RS + 64];
-                    const double C = mine[i * RS];
-                    const double sv = c ? sC1[i] : sC0[i];
-                    const double d2r = divc4(E - 2.0 * C + W, dd.dr2, dd.inv_dr2, dd.lo_dr2);
-                    const double d1r = divc4(E - W, dd.two_dr, dd.inv_two_dr, dd.lo_two_dr);
-                    const double d2z = divc4(N - 2.0 * C + Sv, dd.dz2, dd.inv_dz2, dd.lo_dz2);
-                    const double lpsi = d2r - divc4(d1r, rs, ri, rl) + d2z;
-                    if (colok) d = -(lpsi - sv);
-                }
-                if (c) sC1[i] = d; else sC0[i] = d;
-            }
-        }
-        __syncthreads();  // every wave is done reading psi from the planes
-        // (2) the planes now hold the defect
-#pragma unroll
-        for (int i = 0; i < NROWS; ++i) { (A0 + rb)[i * RS] = sC0[i]; (A1 + rb)[i * RS] = sC1[i]; }
-        __syncthreads();
-        TILE_STAMP(9);
-        // (3) full-weighting restriction of the window's even/even points; coarse ring = injected -0.0.  A coarse point sits at
-        // tile cell (lz, col) = (H + 2cz, H + 2cr), both even: the centre and the four diagonal neighbours are colour 0, the
-        // N/S/W/E neighbours colour 1, and with q = lz*64 + col/2 every address is q + constant.
-        constexpr int CZ = (LZ - 2 * H) / 2, CR = (128 - 2 * H) / 2;
-        double* rc = coarseF.at_slot(b, k_cc);
-        double* ec = dd.e.at_slot(b, k_ce);
-        const int ic0 = (z0 + H) >> 1, jc0 = (r0 + H) >> 1;
-        for (int t = threadIdx.x; t < CZ * CR; t += 64 * NW) {
-            const int cz = t / CR, cr = t - cz * CR;
-            const int ic = ic0 + cz, jcn = jc0 + cr;
-            if (ic >= nz_c || jcn >= nr_c) continue;
-            double v = -0.0;
-            if (ic >= 1 && ic <= nz_c - 2 && jcn >= 1 && jcn <= nr_c - 2) {
-                const int q = (H + 2 * cz) * 64 + (H / 2 + cr);
-                v = fw9(A0[q], A1[q - 64], A1[q + 64], A1[q - 1], A1[q], A0[q - 65], A0[q - 64], A0[q + 63], A0[q + 64]);
-            }
-            rc[(long)ic * ld_c + jcn] = v;
-            ec[(long)ic * ld_c + jcn] = 0.0;
-        }
-    }
-    static_assert(NW % 2 == 0, "row parity of a wave must be fixed");
-    TILE_STAMP(10);
-}
-
-// ---------------------------------------------------------------- the same smoother with the tile in REGISTERS
-// Same tile, halo, window, arithmetic and results as k_smooth_tile; what differs is where the tile lives during the sweeps.
-// A wave owns NROWS CONSECUTIVE rows (NROWS even, so the parity of a row is a compile-time property of its index i), and a
-// lane the column pair (2l, 2l+1) of those rows: psi and source of the pair stay in registers from the global load to the
-// store.  Of the four neighbours of an update, one is the lane's other column, one belongs to the neighbouring LANE (a whole
-// 128-column row sits in one wave: a wave_shr / wave_shl DPP move, two per fp64 value) and two are the rows above / below,
-// which are registers too except for the first / last row of the wave.  LDS carries only those boundary rows between waves
-// (two 512-B writes and two reads per wave and colour pass instead of five reads and a write per ROW update), plus, for
-// DEFECT, the defect planes the restriction stencil is taken from.
-// geometry of the register-resident variant: REG_LZ rows dealt to REG_NW waves in blocks of REG_LZ / REG_NW (even) rows
-#ifndef TILE_REG_LZ
-#define TILE_REG_LZ 32
-#endif
-#ifndef TILE_REG_NW
-#define TILE_REG_NW 8
-#endif
-#ifndef TILE_REG_WPE
-#define TILE_REG_WPE 6
-#endif
-// ... and the geometry for one or two members (three-sweep launches only): 24 rows, two per wave
-#ifndef TILE_REG2_LZ
-#define TILE_REG2_LZ 24
-#endif
-#ifndef TILE_REG2_NW
-#define TILE_REG2_NW 12
-#endif
-// rows whose psi / source / coarse loads are in flight together in the PROLONG variant (register budget)
-#ifndef TILE_REG_LG
-#define TILE_REG_LG 2
-#endif
+// Where the tile lives: a wave owns NROWS = LZ / NW CONSECUTIVE rows (NROWS even, so the parity of a row is a compile-time
+// property of its index i), and a lane the column pair (2l, 2l+1) of those rows: psi and source of the pair stay in registers
+// from the global load to the store.  Of the four neighbours of an update, one is the lane's other column, one belongs to the
+// neighbouring LANE (a whole 128-column row sits in one wave: a wave_shr / wave_shl DPP move, two per fp64 value) and two are
+// the rows above / below, which are registers too except for the first / last row of the wave.  LDS carries only those boundary
+// rows between waves (two 512-B writes and two reads per wave and colour pass), the inner-row sources of the six-row geometry
+// and, for DEFECT, the defect planes the restriction stencil is taken from.  (Rounds 1-3 kept the tile in two LDS colour planes,
+// five reads and a write per ROW update: profiles/r03_negative/lds_plane_tile_smoother.hip.h.txt, same bits, slower.)
+//
+// Out-of-domain cells.  A tile that overhangs the grid loads CLAMPED copies of in-domain values into its out-of-domain cells (row
+// index clamped on the scalar unit, the lane's column pair clamped once) and never masks them: a red-black update is only KEPT at
+// interior points (1 <= gz <= nz-2, 1 <= gc <= nr-2), whose four neighbours are all in the domain, the defect is kept under the
+// same condition (-0.0 elsewhere) and stores are confined to the in-domain part of the window -- so no out-of-domain value ever
+// reaches an output.  That keeps the load phase free of selects: per row two 16-B loads from (scalar member base) + (32-bit byte
+// offset: row part on the scalar unit, one vector add for the lane) and the lazy-source products.
 template <int CTRL>
 __device__ __forceinline__ double wave_shift(double x) {  // 0x138: wave_shr:1 = value of lane-1, 0x130: wave_shl:1 = value of lane+1
     int lo = __double2loint(x), hi = __double2hiint(x);
@@ -1021,13 +724,17 @@ __device__ __forceinline__ double wave_shift(double x) {  // 0x138: wave_shr:1 =
     return __hiloint2double(hi, lo);
 }
 template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT, int WPEU, bool SUMF = false>
-__global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
+__global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
                                                     const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, LazySrc lzs,
                                                     DefectDst dd, int xcd_remap) {
     constexpr int LZ = LZT, H = 2 * S + (DEFECT ? 2 : 0), NW = NWT, NROWS = LZ / NW;
     static_assert(LZ % NW == 0 && NROWS % 2 == 0 && NROWS >= 2, "a wave owns an even number of consecutive rows");
+    // With six or more rows per wave the sources of the wave's INNER rows (1 .. NROWS-2) live in the lane's own slots of the colour
+    // planes (written once, read back by the same lane: no conflict, no barrier) instead of in registers; the first / last row's
+    // slots carry psi to the neighbouring waves, so their sources stay in registers.
+    constexpr bool SRCL = NROWS >= 6;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* A0 = lds;            // colour 0: (lz + column) even; cell (lz, col) at [lz * 64 + col / 2] as in k_smooth_tile
+    double* A0 = lds;            // colour 0: (lz + column) even; cell (lz, col) at [lz * 64 + col / 2]
     double* A1 = lds + LZ * 64;  // colour 1
     int bx_, by_, b;
     {
@@ -1045,7 +752,9 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
     const int z0 = by_ * (LZ - 2 * H) - H, r0 = bx_ * (128 - 2 * H) - H;  // both even
     const int nz = L.nz, nr = L.nr, ld = L.ld;
     const int c0 = r0 + 2 * lane;
-    // (member, column) words: all requested at once, one round trip in front of the row loads -- see k_smooth_tile
+    // Everything that depends only on (member, column) is requested here, unconditionally and at once -- the member's activity
+    // word, the slot words of the fields, the lazy-source scale, the column coefficients -- so that the row loads wait for ONE
+    // memory round trip, not for a chain of them (absent sources point at a constant).
     const bool lazy = lzs.st != nullptr;  // uniform
     const int act_w = *(active ? active + b : &g_const_i32[1]);
     const int k_in = *inF.slot_ptr(b), k_out = *outF.slot_ptr(b), k_src = *srcF.slot_ptr(b);
@@ -1063,7 +772,8 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
     // DEFECT: r_safe / its reciprocal (two words) of the lane's even / odd column, requested with the rest (the defect stage
     // then starts without a memory round trip)
     double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0;
-    if (DEFECT) {
+    constexpr bool EARLY_D = DEFECT && NROWS < 6;  // (six rows per wave: no registers to spare through the sweeps, loaded at the defect stage)
+    if (EARLY_D) {
         rs0 = *(in0 ? dd.r_safe + c0 : &g_const_f64[1]); ri0 = *(in0 ? dd.r_inv + c0 : &g_const_f64[1]); rl0 = *(in0 ? dd.r_inv_lo + c0 : &g_const_f64[0]);
         rs1 = *(in1 ? dd.r_safe + c0 + 1 : &g_const_f64[1]); ri1 = *(in1 ? dd.r_inv + c0 + 1 : &g_const_f64[1]); rl1 = *(in1 ? dd.r_inv_lo + c0 + 1 : &g_const_f64[0]);
     }
@@ -1095,7 +805,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
     double v0[NROWS], v1[NROWS], s0[NROWS], s1[NROWS];
     double* const b0 = A0 + lzb * 64 + lane;  // the lane's slot of the wave's first row in the colour-0 / colour-1 plane
     double* const b1 = A1 + lzb * 64 + lane;
-    // ---- load phase (out-of-domain cells hold clamped copies, see k_smooth_tile)
+    // ---- load phase (out-of-domain cells hold clamped copies, see above)
     const unsigned lane_off = (unsigned)min(max(c0, 0), ld - 2) * 8u;
 #ifdef TILE_FAKE_LOADS
     const char* const in_b = reinterpret_cast<const char*>(inF.base);
@@ -1104,7 +814,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
     const char* const in_b = reinterpret_cast<const char*>(in);
     const char* const src_b = reinterpret_cast<const char*>(src);
 #endif
-    constexpr int LG = PROLONG ? TILE_REG_LG : NROWS;
+    constexpr int LG = PROLONG ? TILE_LG : NROWS;
     const char* const cc_b = PROLONG ? reinterpret_cast<const char*>(coarseF.at_slot(b, k_cc)) : nullptr;
     const unsigned ldc8 = (unsigned)ld_c * 8u;
     const int jc = max(c0, 0) >> 1;
@@ -1169,7 +879,11 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
                 else { sx = lz_n0 * 0.0; sy = lz_n1 * 0.0; }
             }
             if (i & 1) { v1[i] = vx; v0[i] = vy; } else { v0[i] = vx; v1[i] = vy; }
-            if (i & 1) { s1[i] = sx; s0[i] = sy; } else { s0[i] = sx; s1[i] = sy; }
+            if (SRCL && i > 0 && i < NROWS - 1) {
+                b0[i * 64] = (i & 1) ? sy : sx;
+                b1[i * 64] = (i & 1) ? sx : sy;
+            } else if (i & 1) { s1[i] = sx; s0[i] = sy; }
+            else { s0[i] = sx; s1[i] = sy; }
         }
         if (PROLONG) __builtin_amdgcn_sched_barrier(0);
     }
@@ -1201,7 +915,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
         const double W = p ? O : wave_shift<0x138>(O), E = p ? wave_shift<0x130>(O) : O;
         const double Sv = i > 0 ? oth[i > 0 ? i - 1 : 0] : Sb, N = i < NROWS - 1 ? oth[i < NROWS - 1 ? i + 1 : 0] : Nb;
         const double ae = p ? ae1 : ae0, aw = p ? aw1 : aw0;
-        const double sv = c ? s1[i] : s0[i];
+        const double sv = (SRCL && i > 0 && i < NROWS - 1) ? (c ? b1 : b0)[i * 64] : (c ? s1[i] : s0[i]);
         const double gsv = divc4(ae * E + aw * W + a_ns * Sv + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
         double nw = om1 * mine[i] + omega * gsv;
         asm volatile("" : "+v"(nw));  // (an opaque use: keeps the compiler from sinking the chain into an exec-masked branch)
@@ -1247,6 +961,10 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
     TILE_STAMP(8);
     if (DEFECT) {
         // (1) defect d = -(L*psi - src) of this wave's rows, both colours, into the source registers
+        if (!EARLY_D) {
+            rs0 = *(in0 ? dd.r_safe + c0 : &g_const_f64[1]); ri0 = *(in0 ? dd.r_inv + c0 : &g_const_f64[1]); rl0 = *(in0 ? dd.r_inv_lo + c0 : &g_const_f64[0]);
+            rs1 = *(in1 ? dd.r_safe + c0 + 1 : &g_const_f64[1]); ri1 = *(in1 ? dd.r_inv + c0 + 1 : &g_const_f64[1]); rl1 = *(in1 ? dd.r_inv_lo + c0 + 1 : &g_const_f64[0]);
+        }
         const double Sb0 = b0[o_s], Nb0 = b0[o_n], Sb1 = b1[o_s], Nb1 = b1[o_n];
         auto defect = [&](auto colour, auto row) {
             constexpr int c = decltype(colour)::value, i = decltype(row)::value, p = (c + i) & 1;
@@ -1259,7 +977,8 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
             const double Sv = i > 0 ? oth[i > 0 ? i - 1 : 0] : (c ? Sb0 : Sb1);
             const double N = i < NROWS - 1 ? oth[i < NROWS - 1 ? i + 1 : 0] : (c ? Nb0 : Nb1);
             const double C = mine[i];
-            const double sv = c ? s1[i] : s0[i];
+            constexpr bool inner = SRCL && i > 0 && i < NROWS - 1;
+            const double sv = inner ? (c ? b1 : b0)[i * 64] : (c ? s1[i] : s0[i]);
             const double rs = p ? rs1 : rs0, ri = p ? ri1 : ri0, rl = p ? rl1 : rl0;
             const double d2r = divc4(E - 2.0 * C + W, dd.dr2, dd.inv_dr2, dd.lo_dr2);
             const double d1r = divc4(E - W, dd.two_dr, dd.inv_two_dr, dd.lo_two_dr);
@@ -1269,7 +988,9 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
             asm volatile("" : "+v"(dv));
             const bool keep = (hmax[i] >= H - 2) & (p ? colok1 : colok0);
             const double d = keep ? dv : -0.0;
-            if (c) s1[i] = d; else s0[i] = d;
+            if (inner) (c ? b1 : b0)[i * 64] = d;  // (the slot its source came from: the planes become the defect planes)
+            else if (c) s1[i] = d;
+            else s0[i] = d;
         };
         [&]<int... I>(std::integer_sequence<int, I...>) {
             ((defect(std::integral_constant<int, 0>{}, std::integral_constant<int, I>{}),
@@ -1278,10 +999,13 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_reg(Fld outF, Fld inF
         __syncthreads();  // every wave has read its neighbours' boundary rows
         // (2) the planes take the defect
 #pragma unroll
-        for (int i = 0; i < NROWS; ++i) { b0[i * 64] = s0[i]; b1[i * 64] = s1[i]; }
+        for (int i = 0; i < NROWS; ++i)
+            if (!(SRCL && i > 0 && i < NROWS - 1)) { b0[i * 64] = s0[i]; b1[i * 64] = s1[i]; }
         __syncthreads();
         TILE_STAMP(9);
-        // (3) full-weighting restriction of the window's even/even points, as in k_smooth_tile
+        // (3) full-weighting restriction of the window's even/even points; coarse ring = injected -0.0.  A coarse point sits at
+        // tile cell (lz, col) = (H + 2cz, H + 2cr), both even: the centre and the four diagonal neighbours are colour 0, the
+        // N/S/W/E neighbours colour 1, and with q = lz*64 + col/2 every address is q + constant.
         constexpr int CZ = (LZ - 2 * H) / 2, CR = (128 - 2 * H) / 2;
         double* rc = coarseF.at_slot(b, k_cc);
         double* ec = dd.e.at_slot(b, k_ce);

@@ -367,21 +367,17 @@ struct DefectOut {  // coarse rhs / coarse correction produced by the fused defe
     Fld rhs{nullptr, nullptr, 0, 0}, e{nullptr, nullptr, 0, 0};
     int nz_c = 0, nr_c = 0, ld_c = 0;
 };
-template <int S, bool PROLONG, bool DEFECT, bool REG, int LZT, int NWT, int WPEU>
+template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT>
 static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
                           const DefectOut* dfo) {
     static std::once_flag attr_once;  // (two stream-group threads may reach a first launch at the same time)
     constexpr size_t lds = (size_t)LZT * 128 * sizeof(double);
-    auto kern = [] {
-        if constexpr (REG) return &k_smooth_reg<S, PROLONG, DEFECT, LZT, NWT, WPEU>;
-        else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, WPEU>;
-    }();
+    auto kern = &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE>;
     // the instantiation that also finishes the J_raw sum (LazySrc::part) exists for the V-cycle's first level-0 launch only
     constexpr bool HAS_SUMF = S == 3 && DEFECT && !PROLONG;
     auto kern_sum = [] {
         if constexpr (!HAS_SUMF) return (decltype(kern))nullptr;
-        else if constexpr (REG) return &k_smooth_reg<S, PROLONG, DEFECT, LZT, NWT, WPEU, true>;
-        else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, WPEU, true>;
+        else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE, true>;
     }();
     std::call_once(attr_once, [&] {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -419,24 +415,22 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
 template <int S, bool PROLONG, bool DEFECT>
 static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
                         const DefectOut* dfo) {
-    // Which smoother: by the members of this stream group.  Up to 14 (measured at 129^2 ... 1025^2: the launches of such a group
-    // are short chains of workgroup lifetimes whatever the grid) the register-resident tile -- in its smallest geometry (two rows
-    // per wave: the shortest lifetime) while a level-0 launch has at most REG_TINY tiles (two members at 513^2) --, beyond, the LDS
-    // tile.  SCPN_HIP_TILEREG=0 / 1 forces the LDS / the register kernel, SCPN_HIP_TILEREG_MAXB / _TINY move the limits.
-    static const int reg_env = [] { const char* e = std::getenv("SCPN_HIP_TILEREG"); return e ? std::atoi(e) : -1; }();
-    static const int reg_maxb = [] { const char* e = std::getenv("SCPN_HIP_TILEREG_MAXB"); return e ? std::atoi(e) : 14; }();
-    static const long reg_tiny = [] { const char* e = std::getenv("SCPN_HIP_TILEREG_TINY"); return e ? std::atol(e) : 220L; }();
-    const long tiles0 = (long)cdiv(h->nr, 128 - 16) * cdiv(h->nz, TILE_LZ - 16) * h->B;
-    if (reg_env == 1 || (reg_env < 0 && h->B <= reg_maxb)) {
-        if constexpr (S == 3) {
-            if (tiles0 <= reg_tiny) {
-                launch_tile_g<S, PROLONG, DEFECT, true, TILE_REG2_LZ, TILE_REG2_NW, TILE_REG_WPE>(h, L, out, in, src, omega, active, ps, dfo);
-                return;
-            }
-        }
-        launch_tile_g<S, PROLONG, DEFECT, true, TILE_REG_LZ, TILE_REG_NW, TILE_REG_WPE>(h, L, out, in, src, omega, active, ps, dfo);
+    // Which tile geometry: by the members of this stream group.  Up to 14 (measured at 129^2 ... 1025^2: the launches of such a
+    // group are short chains of workgroup lifetimes whatever the grid) 32 rows x 8 waves, and 24 rows x 12 waves (two rows per
+    // wave: the shortest lifetime) while a level-0 launch has at most TILE_TINY_MAX tiles (two members at 513^2); beyond, 48 rows x
+    // 8 waves (the least halo redundancy that fits three workgroups per CU).  One- and two-sweep launches (sweep counts that
+    // are not multiples of three) always take 32 x 8.  SCPN_HIP_TILEGEO=24 / 32 / 48 forces a geometry, SCPN_HIP_TILE_MAXB /
+    // SCPN_HIP_TILE_TINY move the limits.
+    static const int geo_env = [] { const char* e = std::getenv("SCPN_HIP_TILEGEO"); return e ? std::atoi(e) : 0; }();
+    static const int mid_maxb = [] { const char* e = std::getenv("SCPN_HIP_TILE_MAXB"); return e ? std::atoi(e) : 14; }();
+    static const long tiny_max = [] { const char* e = std::getenv("SCPN_HIP_TILE_TINY"); return e ? std::atol(e) : 220L; }();
+    if constexpr (S == 3) {
+        const long tiles0 = (long)cdiv(h->nr, 128 - 16) * cdiv(h->nz, 40 - 16) * h->B;  // (counted in 24-row windows of 112 columns)
+        const int geo = geo_env ? geo_env : (h->B > mid_maxb ? 48 : (tiles0 <= tiny_max ? 24 : 32));
+        if (geo == 48) return launch_tile_g<S, PROLONG, DEFECT, TILE_BIG_LZ, TILE_BIG_NW>(h, L, out, in, src, omega, active, ps, dfo);
+        if (geo == 24) return launch_tile_g<S, PROLONG, DEFECT, TILE_TINY_LZ, TILE_TINY_NW>(h, L, out, in, src, omega, active, ps, dfo);
     }
-    else launch_tile_g<S, PROLONG, DEFECT, false, TILE_LZ, TILE_NW, TILE_WPE>(h, L, out, in, src, omega, active, ps, dfo);
+    launch_tile_g<S, PROLONG, DEFECT, TILE_MID_LZ, TILE_MID_NW>(h, L, out, in, src, omega, active, ps, dfo);
 }
 // the three production roles of the tile kernel: plain, + prolongation on load, + defect / restriction on store
 template <int S>

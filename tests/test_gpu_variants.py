@@ -1,5 +1,5 @@
-"""Every tuning switch of the HIP path (XCD order, fused / one-pass kernels, lazy source, group count, defect fusion level) and
-every experiment build (tile geometry, register cap) must give the same bits as the default: they only change where and when the reference's arithmetic is executed."""
+"""Every tuning switch of the HIP path (XCD order, fused / one-pass kernels, lazy source, group count, defect fusion level, tile
+geometry) and every experiment build must give the same bits as the default: they only change where and when the reference's arithmetic is executed."""
 import json
 import os
 import subprocess
@@ -21,14 +21,14 @@ SWITCHES = [
     {"SCPN_HIP_POLL": "memcpy"},
     {"SCPN_HIP_XCD_BLEND": "0"},
     {"SCPN_HIP_SUMFUSE": "0"},                                  # separate k_jsum_final launch instead of the sum in its first consumer
-    {"SCPN_HIP_TILEREG": "0", "SCPN_HIP_SUMFUSE": "1"},          # (LDS tile as the finishing consumer)
-    {"SCPN_HIP_TILEREG": "0"},                                  # LDS colour-plane tile (what groups of more than 12 members run)
-    {"SCPN_HIP_TILEREG": "1", "SCPN_HIP_TILEREG_TINY": "0"},   # register-resident tile, 32-row geometry (the default here is 24 rows)
+    {"SCPN_HIP_TILEGEO": "32"},                                 # tile geometries: the default of this 2-member run is 24 rows x 12 waves
+    {"SCPN_HIP_TILEGEO": "48"},                                 # 48 rows x 8 waves (six rows per wave, inner sources in LDS slots): groups > 14 members
+    {"SCPN_HIP_TILEGEO": "48", "SCPN_HIP_SUMFUSE": "0"},
 ]
 # experiment builds (never shipped: `_lib.build(variant=...)` makes libscpn_hip.<variant>.so next to the product library)
 EXPERIMENT_BUILDS = {
-    "lz48": ("TILE_LZ_N=48",),            # another tile geometry: 48 rows x 128 columns, 6 rows per wave
-    "wpe8": ("TILE_WPE=8",),              # register allocation capped at 64: four tile workgroups per CU
+    "mid40": ("TILE_MID_LZ=40", "TILE_MID_NW=10"),   # another tile geometry: 40 rows x 10 waves (run with SCPN_HIP_TILEGEO=32: the MID slot)
+    "lg2": ("TILE_LG=2",),                           # two rows of the prolongation's coarse loads in flight together
 }
 
 
@@ -62,16 +62,15 @@ def test_experiment_builds_are_bit_identical():
     base = run({})
     for name, defines in EXPERIMENT_BUILDS.items():
         lib = _lib.build(variant=name, defines=defines)
-        got = run({"SCPN_HIP_LIB": str(lib)})
+        got = run({"SCPN_HIP_LIB": str(lib), "SCPN_HIP_TILEGEO": "32"})
         assert (got["psi"], got["jphi"], got["iterations"]) == (base["psi"], base["jphi"], base["iterations"]), (name, got, base)
 
 
-@pytest.mark.parametrize("env", [{"SCPN_HIP_TILEREG": "0"}, {"SCPN_HIP_TILEREG": "1", "SCPN_HIP_TILEREG_TINY": "0"}],
-                         ids=["lds_tile", "register_tile_32_rows"])
-def test_operator_parity_suite_under_each_smoother_kernel(env):
-    """The smoother kernel is chosen by the size of a stream group (1-2 members: 24-row register tile, up to 12: 32-row register tile,
-    more: LDS tile), so the default run of tests/test_gpu_parity.py pins only the first against the reference fixtures and the oracle.
-    Run the same suite with each of the other two forced."""
+@pytest.mark.parametrize("env", [{"SCPN_HIP_TILEGEO": "32"}, {"SCPN_HIP_TILEGEO": "48"}], ids=["tile_32_rows", "tile_48_rows"])
+def test_operator_parity_suite_under_each_tile_geometry(env):
+    """The tile geometry is chosen by the size of a stream group (a level-0 launch of at most ~220 tiles: 24 rows x 12 waves; up to
+    14 members: 32 x 8; more: 48 x 8), so the default run of tests/test_gpu_parity.py pins mostly the first against the reference
+    fixtures and the oracle.  Run the same suite with each of the other two forced."""
     from scpn_fusion_core_amd import _lib
 
     _lib.require_gpu()

@@ -56,7 +56,7 @@ with open(out / f"{tag}_pmc_fetch_write_by_kernel.csv", "w", newline="") as f:
             w.writerow([c, k, g, len(vals), round(statistics.median(vals), 1), round(max(vals), 1), round(sum(vals), 1)])
 
 
-def tile_grid(level: int, halo: int, lz: int = 40, nw: int = 8) -> int:
+def tile_grid(level: int, halo: int, lz: int = 48, nw: int = 8) -> int:  # (the geometry of groups of more than 14 members)
     n = (grid - 1) // 2**level + 1
     gx, gy = -(-n // (128 - 2 * halo)), -(-n // (lz - 2 * halo))
     return gx * gy * members * 64 * nw

@@ -1,10 +1,10 @@
 """s_memrealtime stamps of eight sampled tile workgroups (load / six colour passes / store / defect / restriction).
-usage: [STAMPS_MODE=plain|defect] [STAMPS_B=members] [STAMPS_DEFINES="A=1 B=2"] [SCPN_HIP_TILEREG=0|1] python tools/tile_stamps.py     (builds the -DCV_STAMPS experiment library on first use)"""
+usage: [STAMPS_MODE=plain|defect] [STAMPS_B=members] [STAMPS_DEFINES="A=1 B=2"] [SCPN_HIP_TILEGEO=24|32|48] python tools/tile_stamps.py     (builds the -DCV_STAMPS experiment library on first use)"""
 import os, sys, ctypes as C
 sys.path.insert(0, ".")
 from scpn_fusion_core_amd import _lib
 _mode = os.environ.get("STAMPS_MODE", "plain")
-_extra = tuple(x for x in os.environ.get("STAMPS_DEFINES", "").split() if x)  # e.g. "TILE_REG_LZ=24 TILE_REG_NW=12"
+_extra = tuple(x for x in os.environ.get("STAMPS_DEFINES", "").split() if x)  # e.g. "TILE_MID_LZ=40 TILE_MID_NW=10"
 _tag = "".join(c for c in "_".join(_extra) if c.isalnum() or c == "_")
 os.environ["SCPN_HIP_LIB"] = str(_lib.build(variant="stamps_" + _mode + ("_" + _tag if _tag else ""),
                                             defines=("CV_STAMPS",) + (("STAMP_DEFECT=true",) if _mode == "defect" else ()) + _extra))
