@@ -137,6 +137,7 @@ struct ProfEntry {
 
 struct Solver {
     int nr = 0, nz = 0, B = 0, ld = 0;
+    int ensemble_B = 0;  // members of the whole ensemble this stream group belongs to (0: it is the whole ensemble)
     long stride = 0;
     double dr = 0, dz = 0;
     std::vector<double> r_axis, z_axis;
@@ -415,18 +416,19 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
 template <int S, bool PROLONG, bool DEFECT>
 static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
                         const DefectOut* dfo) {
-    // Which tile geometry: by the members of this stream group.  Up to 14 (measured at 129^2 ... 1025^2: the launches of such a
-    // group are short chains of workgroup lifetimes whatever the grid) 32 rows x 8 waves, and 24 rows x 12 waves (two rows per
-    // wave: the shortest lifetime) while a level-0 launch has at most TILE_TINY_MAX tiles (two members at 513^2); beyond, 48 rows x
-    // 8 waves (the least halo redundancy that fits three workgroups per CU).  One- and two-sweep launches (sweep counts that
-    // are not multiples of three) always take 32 x 8.  SCPN_HIP_TILEGEO=24 / 32 / 48 forces a geometry, SCPN_HIP_TILE_MAXB /
-    // SCPN_HIP_TILE_TINY move the limits.
+    // Which tile geometry: by the members the chip works on at once (all stream groups of the ensemble).  More than 16: 48 rows x
+    // 8 waves (the least halo redundancy that fits three workgroups per CU); up to 16 (measured at 129^2 ... 1025^2: the launches
+    // are then short chains of workgroup lifetimes whatever the grid): 32 x 8, and 24 x 12 (two rows per wave: the shortest
+    // lifetime) while a level-0 launch has at most TILE_TINY tiles (two members at 513^2).  One- and two-sweep launches (sweep
+    // counts that are not multiples of three) always take 32 x 8.  SCPN_HIP_TILEGEO=24 / 32 / 48 forces a geometry,
+    // SCPN_HIP_TILE_MAXB / SCPN_HIP_TILE_TINY move the limits.
     static const int geo_env = [] { const char* e = std::getenv("SCPN_HIP_TILEGEO"); return e ? std::atoi(e) : 0; }();
-    static const int mid_maxb = [] { const char* e = std::getenv("SCPN_HIP_TILE_MAXB"); return e ? std::atoi(e) : 14; }();
+    static const int mid_maxb = [] { const char* e = std::getenv("SCPN_HIP_TILE_MAXB"); return e ? std::atoi(e) : 16; }();
     static const long tiny_max = [] { const char* e = std::getenv("SCPN_HIP_TILE_TINY"); return e ? std::atol(e) : 220L; }();
     if constexpr (S == 3) {
-        const long tiles0 = (long)cdiv(h->nr, 128 - 16) * cdiv(h->nz, 40 - 16) * h->B;  // (counted in 24-row windows of 112 columns)
-        const int geo = geo_env ? geo_env : (h->B > mid_maxb ? 48 : (tiles0 <= tiny_max ? 24 : 32));
+        const int members = h->ensemble_B > 0 ? h->ensemble_B : h->B;
+        const long tiles0 = (long)cdiv(h->nr, 128 - 16) * cdiv(h->nz, 40 - 16) * members;  // (counted in 24-row windows of 112 columns)
+        const int geo = geo_env ? geo_env : (members > mid_maxb ? 48 : (tiles0 <= tiny_max ? 24 : 32));
         if (geo == 48) return launch_tile_g<S, PROLONG, DEFECT, TILE_BIG_LZ, TILE_BIG_NW>(h, L, out, in, src, omega, active, ps, dfo);
         if (geo == 24) return launch_tile_g<S, PROLONG, DEFECT, TILE_TINY_LZ, TILE_TINY_NW>(h, L, out, in, src, omega, active, ps, dfo);
     }
@@ -2008,6 +2010,7 @@ int scpn_gs_create(scpn_gs** out, int nr, int nz, int batch, const double* r_axi
         Solver* k = nullptr;
         int rc = S_create(&k, nr, nz, cnt, r_axis, z_axis, dr, dz);
         if (rc) { delete g; return rc; }
+        k->ensemble_B = batch;
         g->kids.push_back(k);
         g->off.push_back(done);
         done += cnt;

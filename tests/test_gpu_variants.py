@@ -22,7 +22,7 @@ SWITCHES = [
     {"SCPN_HIP_XCD_BLEND": "0"},
     {"SCPN_HIP_SUMFUSE": "0"},                                  # separate k_jsum_final launch instead of the sum in its first consumer
     {"SCPN_HIP_TILEGEO": "32"},                                 # tile geometries: the default of this 2-member run is 24 rows x 12 waves
-    {"SCPN_HIP_TILEGEO": "48"},                                 # 48 rows x 8 waves (six rows per wave, inner sources in LDS slots): groups > 14 members
+    {"SCPN_HIP_TILEGEO": "48"},                                 # 48 rows x 8 waves (six rows per wave, inner sources in LDS slots): ensembles of more than 16 members
     {"SCPN_HIP_TILEGEO": "48", "SCPN_HIP_SUMFUSE": "0"},
 ]
 # experiment builds (never shipped: `_lib.build(variant=...)` makes libscpn_hip.<variant>.so next to the product library)
@@ -69,7 +69,7 @@ def test_experiment_builds_are_bit_identical():
 @pytest.mark.parametrize("env", [{"SCPN_HIP_TILEGEO": "32"}, {"SCPN_HIP_TILEGEO": "48"}], ids=["tile_32_rows", "tile_48_rows"])
 def test_operator_parity_suite_under_each_tile_geometry(env):
     """The tile geometry is chosen by the size of a stream group (a level-0 launch of at most ~220 tiles: 24 rows x 12 waves; up to
-    14 members: 32 x 8; more: 48 x 8), so the default run of tests/test_gpu_parity.py pins mostly the first against the reference
+    16 members: 32 x 8; more: 48 x 8), so the default run of tests/test_gpu_parity.py pins mostly the first against the reference
     fixtures and the oracle.  Run the same suite with each of the other two forced."""
     from scpn_fusion_core_amd import _lib
 
