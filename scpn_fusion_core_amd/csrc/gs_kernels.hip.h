@@ -677,6 +677,10 @@ __device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (d
 #ifndef TILE_WPE
 #define TILE_WPE 6  // minimum waves per SIMD the register allocation must allow: <= 80 VGPRs (three 8-wave workgroups per CU)
 #endif
+// rows per wave from which on a wave whose rows drop out of the passes skips them (see half_sweep)
+#ifndef TILE_SKIP_MIN_ROWS
+#define TILE_SKIP_MIN_ROWS 6
+#endif
 // rows whose psi / source / coarse loads are in flight together in the PROLONG variant (register budget)
 #ifndef TILE_LG
 #define TILE_LG 1
@@ -904,6 +908,9 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         const int lz = lzb + i, gz = z0 + lz;
         hmax[i] = (gz >= 1 && gz <= nz - 2) ? min(lz - 1, LZ - 2 - lz) : -1;
     }
+    int hmax_low = hmax[0];  // (wave-uniform: the first pass index at which some row of this wave is no longer updated, minus one)
+#pragma unroll
+    for (int i = 1; i < NROWS; ++i) hmax_low = min(hmax_low, hmax[i]);
     // one update of row i, colour c (both compile-time): mine / oth are the register rows of colour c / 1 - c
     auto update = [&](auto colour, auto row, const int hs, double (&mine)[NROWS], const double (&oth)[NROWS], const double Sb,
                       const double Nb) {
@@ -928,12 +935,21 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         const double(&oth)[NROWS] = c ? v0 : v1;
         const double* const ob = c ? b0 : b1;  // boundary rows of the other colour
         const double Sb = ob[o_s], Nb = ob[o_n];
-        // rows that need no LDS value first
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            (update(colour, std::integral_constant<int, I + 1>{}, hs, mine, oth, Sb, Nb), ...);
-        }(std::make_integer_sequence<int, NROWS - 2>{});
-        update(colour, std::integral_constant<int, 0>{}, hs, mine, oth, Sb, Nb);
-        update(colour, std::integral_constant<int, NROWS - 1>{}, hs, mine, oth, Sb, Nb);
+        if (NROWS >= TILE_SKIP_MIN_ROWS && hmax_low < 2 * S - 1) {
+            // a wave some of whose rows drop out before the last pass -- the tile's first / last wave (one row per pass, all of them
+            // by the last pass) and waves that overhang the grid: a row is SKIPPED under its wave-uniform test -- 15-20 % of a
+            // six-row tile's pass arithmetic; the rows left are short of the other waves' six interleaved chains anyway
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((hs <= hmax[I] ? update(colour, std::integral_constant<int, I>{}, hs, mine, oth, Sb, Nb) : (void)0), ...);
+            }(std::make_integer_sequence<int, NROWS>{});
+        } else {
+            // rows that need no LDS value first
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (update(colour, std::integral_constant<int, I + 1>{}, hs, mine, oth, Sb, Nb), ...);
+            }(std::make_integer_sequence<int, NROWS - 2>{});
+            update(colour, std::integral_constant<int, 0>{}, hs, mine, oth, Sb, Nb);
+            update(colour, std::integral_constant<int, NROWS - 1>{}, hs, mine, oth, Sb, Nb);
+        }
         double* const mb = c ? b1 : b0;
         mb[0] = mine[0];
         mb[(NROWS - 1) * 64] = mine[NROWS - 1];
@@ -992,10 +1008,21 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             else if (c) s1[i] = d;
             else s0[i] = d;
         };
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            ((defect(std::integral_constant<int, 0>{}, std::integral_constant<int, I>{}),
-              defect(std::integral_constant<int, 1>{}, std::integral_constant<int, I>{})), ...);
-        }(std::make_integer_sequence<int, NROWS>{});
+        int hmax_top = hmax[0];
+#pragma unroll
+        for (int i = 1; i < NROWS; ++i) hmax_top = max(hmax_top, hmax[i]);
+        if (hmax_top >= H - 2) {  // (wave-uniform: the tile's first / last wave may have no row in the defect ring at all)
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((defect(std::integral_constant<int, 0>{}, std::integral_constant<int, I>{}),
+                  defect(std::integral_constant<int, 1>{}, std::integral_constant<int, I>{})), ...);
+            }(std::make_integer_sequence<int, NROWS>{});
+        } else {
+#pragma unroll
+            for (int i = 0; i < NROWS; ++i) {
+                if (!(SRCL && i > 0 && i < NROWS - 1)) { s0[i] = -0.0; s1[i] = -0.0; }
+                else { b0[i * 64] = -0.0; b1[i * 64] = -0.0; }
+            }
+        }
         __syncthreads();  // every wave has read its neighbours' boundary rows
         // (2) the planes take the defect
 #pragma unroll
