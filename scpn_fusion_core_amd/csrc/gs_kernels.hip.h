@@ -679,7 +679,7 @@ __device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (d
 #endif
 // rows per wave from which on a wave whose rows drop out of the passes skips them (see half_sweep)
 #ifndef TILE_SKIP_MIN_ROWS
-#define TILE_SKIP_MIN_ROWS 6
+#define TILE_SKIP_MIN_ROWS 4
 #endif
 // rows whose psi / source / coarse loads are in flight together in the PROLONG variant (register budget)
 #ifndef TILE_LG
