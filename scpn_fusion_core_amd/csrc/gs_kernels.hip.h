@@ -592,13 +592,15 @@ __device__ __forceinline__ double mtanh1(double x, const double* p) {  // core/f
     }
     return pedestal + p[3] * core;
 }
+// HM: 1 / 0 = the profile mode as a compile-time constant (the L-mode form carries no pedestal code and half the registers), -1 = read pf.hmode
+template <int HM = -1>
 __device__ __forceinline__ double j_raw_at(double psi, double R, double inv_mu0R, double psi_axis,
                                            double denom, double inv_denom, const Prof& pf) {
     // core/fusion_kernel.py:419-434
     double pn = divc(psi - psi_axis, denom, inv_denom);
     double p = 0.0, ff = 0.0;
     if (pn >= 0.0 && pn < 1.0) {
-        if (pf.hmode) { p = mtanh1(pn, pf.ped_p); ff = mtanh1(pn, pf.ped_ff); }
+        if (HM < 0 ? pf.hmode != 0 : HM != 0) { p = mtanh1(pn, pf.ped_p); ff = mtanh1(pn, pf.ped_ff); }
         else { p = 1.0 - pn; ff = p; }
     }
     double j_p = R * p;
@@ -1715,6 +1717,7 @@ struct JsumTail {  // counters != nullptr: the last workgroup of a member runs j
     Member* st = nullptr;
     double dr = 0, dz = 0;
 };
+template <int HM>
 __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz, int nr, int ld,
                                               const double* r_axis, const double* inv_mu0R, Prof pf,
                                               double* part, int nblk, Fld rawF, JsumTail tail) {
@@ -1750,10 +1753,10 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
             for (int j = 0; j < JS_BATCH; ++j) {
                 const int iz = blockIdx.y * JS_ROWS + ty + 4 * (k0 + j);
                 if (k0 + j < JS_ROWS / 4 && iz < nz) {
-                    const double j0 = j_raw_at(v[j].x, R0, m0, pa, den, iden, pf);
+                    const double j0 = j_raw_at<HM>(v[j].x, R0, m0, pa, den, iden, pf);
                     s += j0;
                     double j1 = 0.0;
-                    if (two) { j1 = j_raw_at(v[j].y, R1, m1, pa, den, iden, pf); s += j1; }
+                    if (two) { j1 = j_raw_at<HM>(v[j].y, R1, m1, pa, den, iden, pf); s += j1; }
                     if (raw) {
                         if (two) *reinterpret_cast<double2*>(raw + (long)iz * ld + c0) = double2{j0, j1};
                         else raw[(long)iz * ld + c0] = j0;

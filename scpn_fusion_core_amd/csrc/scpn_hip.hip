@@ -986,7 +986,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             ProfScope ps(h, "source", (lazy ? 2 : 3) - ((tail_fuse || sum_fuse) ? 1 : 0));
             JsumTail jt;
             if (tail_fuse) { jt.counters = h->d_tickets.p; jt.st = h->d_st.p; jt.dr = h->dr; jt.dz = h->dz; }
-            SCPN_LAUNCH(k_jsum, gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
+            SCPN_LAUNCH((pf.hmode ? k_jsum<1> : k_jsum<0>), gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
                                (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, lazy ? srcF : Fld{nullptr, nullptr, 0, 0}, jt);
             if (sum_fuse) { h->jsum_part = h->d_jpart.p; h->jsum_nblk = nblkj; }  // (the V-cycle's first level-0 launch finishes the sum)
             else if (!tail_fuse)  // (tail_fuse: the last workgroup of each member finished the sum inside k_jsum)
@@ -1264,7 +1264,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         }
         if (!p->external_profile_mode) {
             ProfScope ps(h, "source", 3);
-            SCPN_LAUNCH(k_jsum, gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
+            SCPN_LAUNCH((pf.hmode ? k_jsum<1> : k_jsum<0>), gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
                                (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0}, JsumTail{});
             SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
             SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, dstSrc, jF, 1, curF, (const Member*)h->d_st.p, nz, nr, ld,
@@ -1324,7 +1324,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
                                h->d_topo.p, nblk1);
             SCPN_LAUNCH(k_topology_final, dim3(B), dim3(256), 0, st, pF, scr.p, (const TopoPart*)h->d_topo.p, nblk1, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_z.p);
-            SCPN_LAUNCH(k_jsum, gjs, dim3(256), 0, st, pF, (const Member*)scr.p, nz, nr, ld, (const double*)h->d_r.p,
+            SCPN_LAUNCH((pf.hmode ? k_jsum<1> : k_jsum<0>), gjs, dim3(256), 0, st, pF, (const Member*)scr.p, nz, nr, ld, (const double*)h->d_r.p,
                                (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0}, JsumTail{});
             SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, scr.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
             SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, src2F, jF, 0, pF, (const Member*)scr.p, nz, nr, ld, (const double*)h->d_r.p,
