@@ -51,7 +51,7 @@ def counters_of(kernel_symbol: str) -> dict | None:
         tag = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get("tag")
         path = ROOT / "profiles" / f"{tag}_sq_by_kernel.csv"
         want = {"smooth_pre": "k_smooth_tile<3, false, true", "smooth_post": "k_smooth_tile<3, true, false",
-                "smooth": "k_smooth_tile<3, false, false", "blend_fused": "k_blend_fused", "source": "k_jsum"}.get(kernel_symbol, kernel_symbol)
+                "smooth": "k_smooth_tile<3, false, false", "blend_fused": "k_blend_tile", "source": "k_jsum<"}.get(kernel_symbol, kernel_symbol)
         rows = [r for r in csv.DictReader(open(path)) if want in r["kernel"]]
         if not rows:
             return None

@@ -78,7 +78,7 @@ for lvl in (0, 1, 2):
     v = hbm_bytes("k_smooth_tile<3, true, false", tile_grid(lvl, 6))
     if v:
         traffic[f"smooth_tile_L{lvl}_post"] = round(v, 1)
-for fam, sub in (("blend_fused", "k_blend_tile"), ("vcycle_coarse", "k_vcycle_coarse"), ("jsum", "gs::k_jsum$"), ("picard_final", "k_picard_final"),
+for fam, sub in (("blend_fused", "k_blend_tile"), ("vcycle_coarse", "k_vcycle_coarse"), ("jsum", "gs::k_jsum<"), ("picard_final", "k_picard_final"),
                  ("jsum_final", "k_jsum_final")):
     v = hbm_bytes(sub, None)
     if v:
