@@ -2079,16 +2079,16 @@ struct GradRecip { double dz, inv_dz, lo_dz, two_dz, inv_two_dz, lo_two_dz, dr, 
 // ---------------------------------------------------------------- fused Picard tail, row-pair form (round 3)
 // One launch per Picard iteration: nxt = (1-alpha) cur + alpha new with the ring from bc, sum |new - cur|, non-finite flag,
 // (max, sum (r/max)^2) of r = L* nxt - Source, argmax / divertor-row argmin |grad| / min of nxt per tile.  Structured like the
-// tile smoother: a 256-thread workgroup owns an 18-row x 124-column window of a 20 x 128 tile; a lane owns the column pair
-// (2l, 2l+1) of its wave's five rows, so cur / new / source arrive as 16-B loads from (scalar row pointer) + (lane offset), the
+// tile smoother: a 256-thread workgroup owns a 14-row x 124-column window of a 16 x 128 tile; a lane owns the column pair
+// (2l, 2l+1) of its wave's four rows, so cur / new / source arrive as 16-B loads from (scalar row pointer) + (lane offset), the
 // blended pair stays in registers for its own stencil and only the N/S pairs and the two out-of-pair neighbours are read from
 // the LDS tile (five LDS reads per two points).  (Round 2's form -- one element per thread, 32 x 64 tiles -- ran at the same speed with
 // the same instruction count: the kernel is bound by tiles in flight x tile lifetime, profiles/r03_experiments.md.)
 #ifndef BL_WZ_N
-#define BL_WZ_N 18
+#define BL_WZ_N 14  // window rows (tile rows = + 2, a multiple of the four waves): 14 fits 80 VGPRs, 18 needs 81
 #endif
 #ifndef BL_WPE
-#define BL_WPE 5  // minimum waves per SIMD the register allocation must allow (a workgroup puts one wave on each SIMD)
+#define BL_WPE 6  // minimum waves per SIMD the register allocation must allow (a workgroup puts one wave on each SIMD): six workgroups per CU
 #endif
 constexpr int BL_WZ = BL_WZ_N, BL_LB = BL_WZ + 2, BL_WR = 124, BL_NW = 4, BL_NROWS = BL_LB / BL_NW;
 static_assert(BL_LB % BL_NW == 0, "rows are dealt to the four waves evenly");
@@ -2231,7 +2231,38 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
             rv[i].y = int_y ? ry : 0.0;
             m = fmax(m, fmax(fabs(rv[i].x), fabs(rv[i].y)));
         }
-        if (gz < n_mask_rows) {  // np.gradient + hypot inside the divertor rows (fusion_kernel.py:276-288); wave-uniform
+    }
+    BLEND_STAMP(3);
+    // wave-level reductions (results in every lane), one LDS hand-over per wave
+    const double w_dsum = wave_sum(dsum), w_m = wave_max(m), w_minp = -wave_max(-minpsi);
+    const VI w_mx = wave_vi<true>(mx);
+    const int w_bad = __any(bad) ? 1 : 0;
+    if (lane == 0) { sh_dsum[w] = w_dsum; sh_m[w] = w_m; sh_minp[w] = w_minp; sh_mx[w] = w_mx; sh_bad[w] = w_bad; }
+    __syncthreads();
+    BLEND_STAMP(4);
+    // overflow-safe residual sum: (max, sum (r/max)^2) with the WORKGROUP max, see k_resid_norms
+    const double bmax = fmax(fmax(sh_m[0], sh_m[1]), fmax(sh_m[2], sh_m[3]));
+    double s2 = 0.0;
+    if (bmax > 0.0) {
+        const double ib = 1.0 / bmax;  // one IEEE division per thread instead of one per point (the rescaled sum is a norm estimate)
+#pragma unroll
+        for (int i = 0; i < BL_NROWS; ++i) { const double qx = rv[i].x * ib, qy = rv[i].y * ib; s2 += qx * qx; s2 += qy * qy; }
+    }
+    const double w_s2 = wave_sum(s2);
+    // Divertor rows (a quarter of the tiles): np.gradient + hypot + masked arg-min (fusion_kernel.py:276-288).  Done HERE, after the
+    // residuals have been consumed, and from the LDS tile: the stage then needs none of the registers the residual stage holds,
+    // the kernel fits 80 VGPRs and every tile -- also the three quarters without divertor rows -- gets a sixth resident workgroup per CU.
+    VI w_mn{0.0, -1};
+    if (z0 + 1 < n_mask_rows) {  // (uniform: the tile owns at least one masked row)
+#pragma unroll
+        for (int i = 0; i < BL_NROWS; ++i) {
+            const int lz = w + BL_NW * i, gz = z0 + lz;
+            if (!(lz >= 1 && lz <= BL_WZ && gz < nz) || gz >= n_mask_rows) continue;  // wave-uniform
+            const double2 N = *reinterpret_cast<const double2*>(&t[lz + 1][2 * lane]);
+            const double2 S = *reinterpret_cast<const double2*>(&t[lz - 1][2 * lane]);
+            const double Wn = (&t[lz][0])[2 * lane - 1], En = (&t[lz][0])[2 * lane + 2];
+            const double2 P = *reinterpret_cast<const double2*>(&t[lz][2 * lane]);
+            const double px = P.x, py = P.y;
             auto grad = [&](bool on, double p, double n_, double s_, double e_, double w_, int gc) {
                 const double ps = nan_to_num300(p), nn = nan_to_num300(n_), ss = nan_to_num300(s_), ee = nan_to_num300(e_), ww = nan_to_num300(w_);
                 double gzv, grv;
@@ -2249,25 +2280,9 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
             grad(own_x, px, N.x, S.x, py, Wn, c0);
             grad(own_y, py, N.y, S.y, En, px, c0 + 1);
         }
+        w_mn = wave_vi<false>(mn);
     }
-    BLEND_STAMP(3);
-    // wave-level reductions (results in every lane), one LDS hand-over per wave
-    const double w_dsum = wave_sum(dsum), w_m = wave_max(m), w_minp = -wave_max(-minpsi);
-    const VI w_mx = wave_vi<true>(mx), w_mn = wave_vi<false>(mn);
-    const int w_bad = __any(bad) ? 1 : 0;
-    if (lane == 0) { sh_dsum[w] = w_dsum; sh_m[w] = w_m; sh_minp[w] = w_minp; sh_mx[w] = w_mx; sh_mn[w] = w_mn; sh_bad[w] = w_bad; }
-    __syncthreads();
-    BLEND_STAMP(4);
-    // overflow-safe residual sum: (max, sum (r/max)^2) with the WORKGROUP max, see k_resid_norms
-    const double bmax = fmax(fmax(sh_m[0], sh_m[1]), fmax(sh_m[2], sh_m[3]));
-    double s2 = 0.0;
-    if (bmax > 0.0) {
-        const double ib = 1.0 / bmax;  // one IEEE division per thread instead of one per point (the rescaled sum is a norm estimate)
-#pragma unroll
-        for (int i = 0; i < BL_NROWS; ++i) { const double qx = rv[i].x * ib, qy = rv[i].y * ib; s2 += qx * qx; s2 += qy * qy; }
-    }
-    const double w_s2 = wave_sum(s2);
-    if (lane == 0) sh_s2[w] = w_s2;
+    if (lane == 0) { sh_s2[w] = w_s2; sh_mn[w] = w_mn; }
     __syncthreads();
     const double bsum = sh_dsum[0] + sh_dsum[1] + sh_dsum[2] + sh_dsum[3];
     const double bs2 = sh_s2[0] + sh_s2[1] + sh_s2[2] + sh_s2[3];
