@@ -328,12 +328,17 @@ int scpn_gs_num_groups(scpn_gs *h);
  * ---------------------------------------------------------------------------------------- */
 #define SCPN_COMM_ID_BYTES 128
 int scpn_comm_unique_id(char *id128);
-int scpn_comm_init(int rank, int world, const char *id128, int device); /* selects `device` for this process */
+/* the LOCAL part of scpn_comm_init -- librccl loaded, `device` visible and selected, NCCL 2.x ABI -- without entering a
+ * collective: the host exchanges the ranks' results of this step and calls scpn_comm_init only if every rank passed, so a
+ * rank that fails here cannot leave its peers blocked inside ncclCommInitRank */
+int scpn_comm_prepare(int device, int *rccl_version);
+int scpn_comm_init(int rank, int world, const char *id128, int device); /* selects `device` for this process; collective */
 int scpn_comm_info(int *rank, int *world, int *rccl_version);           /* as RCCL sees them */
 /* pack + ncclAllGather of psi: every rank sends a block of `per_rank_members` members (>= its own batch; the rank that owns the
  * short last block of an uneven ensemble is padded with zeros, so all ranks issue the same count), recv_device =
  * [world][per_rank_members][nz][nr] doubles on this GPU; asynchronous on the communicator's stream, ordered behind the solver
- * streams by events (overlaps the next solve) -- scpn_comm_wait() before the buffer is read or the next gather is issued */
+ * streams by events (overlaps the next solve) -- scpn_comm_wait() before the buffer is read.  The send block is the
+ * communicator's own buffer (not the staging buffer of scpn_gs_pack_psi_device); a second gather waits for the first */
 int scpn_comm_allgather_psi(scpn_gs *h, int per_rank_members, void *recv_device);
 int scpn_comm_wait(void);
 int scpn_comm_allreduce_max(double *value); /* in place, blocking: the max-over-ranks of a timing and the barrier */

@@ -140,6 +140,7 @@ SIGNATURES = {
     "scpn_gs_num_groups": (_i, [_vp]),
     # ensemble gather over RCCL
     "scpn_comm_unique_id": (_i, [C.c_char_p]),
+    "scpn_comm_prepare": (_i, [_i, C.POINTER(_i)]),
     "scpn_comm_init": (_i, [_i, _i, C.c_char_p, _i]),
     "scpn_comm_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "scpn_comm_allgather_psi": (_i, [_vp, _i, _vp]),

@@ -47,6 +47,8 @@ struct State {
     hipStream_t stream = nullptr;
     int rank = -1, world = 0, device = 0;
     double* d_scalar = nullptr;  // one device double for the scalar all-reduce / barrier
+    double* send = nullptr;      // the all-gather's send block (grown only while the communicator's stream is idle)
+    size_t send_cap = 0;         // ... in doubles
     std::vector<hipEvent_t> ready;  // one per solver group: "this group's psi is packed" (the gather waits on them, not the host)
 };
 inline State& state() {

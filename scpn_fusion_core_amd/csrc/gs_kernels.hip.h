@@ -687,6 +687,17 @@ __device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (d
 #ifndef TILE_LG
 #define TILE_LG 1
 #endif
+// PROLONG: distinct coarse rows fetched once in front of the row loads (1) or per fine row (0); rows in flight together in the wide form
+// DEFECT, six rows per wave: residual coefficients shared through LDS (1) or loaded by every wave at the defect stage (0)
+#ifndef TILE_SHARE_D
+#define TILE_SHARE_D 1
+#endif
+#ifndef TILE_PWIDE
+#define TILE_PWIDE 1
+#endif
+#ifndef TILE_LG_WIDE
+#define TILE_LG_WIDE 2
+#endif
 // PROLONG: the tile is loaded as in + P(coarse) (bilinear prolongation of the coarse-grid correction,
 // multigrid_solve.py:329-330) -- the separate prolong-add pass over the fine grid disappears.
 // DEFECT: after the sweeps the tile also produces the coarse-grid right-hand side restrict_full_weight(-(L*psi - src))
@@ -773,12 +784,30 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     const double lz_x0 = *((lz_sum && lane < lzs.nblk) ? lzs.part + ((long)b * lzs.nblk + lane) : &g_const_f64[0]);
     double lz_n0 = *(lazy ? lzs.neg_mu0R + min(max(c0, 0), nr - 1) : &g_const_f64[1]);
     double lz_n1 = *(lazy ? lzs.neg_mu0R + min(max(c0 + 1, 0), nr - 1) : &g_const_f64[1]);
-    double ae0 = *(in0 ? L.a_e + c0 : &g_const_f64[0]), aw0 = *(in0 ? L.a_w + c0 : &g_const_f64[0]);  // even / odd column of the pair
-    double ae1 = *(in1 ? L.a_e + c0 + 1 : &g_const_f64[0]), aw1 = *(in1 ? L.a_w + c0 + 1 : &g_const_f64[0]);
+    // (PROLONG, wide load: the stencil coefficients are first used by the sweeps -- they are requested behind the LAST group of row
+    //  loads, so that they hold no registers while the earlier groups are in flight)
+    constexpr bool COEF_LATE = PROLONG && (TILE_PWIDE != 0);
+    const double* const pe0 = in0 ? L.a_e + c0 : &g_const_f64[0];
+    const double* const pw0 = in0 ? L.a_w + c0 : &g_const_f64[0];
+    const double* const pe1 = in1 ? L.a_e + c0 + 1 : &g_const_f64[0];
+    const double* const pw1 = in1 ? L.a_w + c0 + 1 : &g_const_f64[0];
+    double ae0 = 0.0, aw0 = 0.0, ae1 = 0.0, aw1 = 0.0;  // even / odd column of the pair
+    if (!COEF_LATE) { ae0 = *pe0; aw0 = *pw0; ae1 = *pe1; aw1 = *pw1; }
     // DEFECT: r_safe / its reciprocal (two words) of the lane's even / odd column, requested with the rest (the defect stage
     // then starts without a memory round trip)
     double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0;
-    constexpr bool EARLY_D = DEFECT && NROWS < 6;  // (six rows per wave: no registers to spare through the sweeps, loaded at the defect stage)
+    constexpr bool EARLY_D = DEFECT && NROWS < 6;  // (six rows per wave: no registers to spare through the sweeps)
+    // Six rows per wave: the six values are the same for all waves of the tile (same columns), so wave k requests the k-th of them
+    // here -- one double in flight per lane -- parks it in LDS behind the tile's planes, and the defect stage reads all six from
+    // there (an LDS access instead of a memory round trip in the middle of the tile's life).
+    constexpr bool SHARE_D = DEFECT && !EARLY_D && NW >= 6 && (TILE_SHARE_D != 0);
+    double* const CO = lds + LZ * 128;  // [6][64] doubles (allocated by the launcher for SHARE_D instantiations)
+    double co_x = 0.0;
+    if (SHARE_D) {
+        const double* const arr = (w % 3) == 0 ? dd.r_safe : ((w % 3) == 1 ? dd.r_inv : dd.r_inv_lo);  // (w < 6 used; scalar selects)
+        const bool odd = w >= 3, okc = odd ? in1 : in0;
+        co_x = *((okc && w < 6) ? arr + c0 + (odd ? 1 : 0) : &g_const_f64[(w % 3) == 2 ? 0 : 1]);
+    }
     if (EARLY_D) {
         rs0 = *(in0 ? dd.r_safe + c0 : &g_const_f64[1]); ri0 = *(in0 ? dd.r_inv + c0 : &g_const_f64[1]); rl0 = *(in0 ? dd.r_inv_lo + c0 : &g_const_f64[0]);
         rs1 = *(in1 ? dd.r_safe + c0 + 1 : &g_const_f64[1]); ri1 = *(in1 ? dd.r_inv + c0 + 1 : &g_const_f64[1]); rl1 = *(in1 ? dd.r_inv_lo + c0 + 1 : &g_const_f64[0]);
@@ -820,18 +849,39 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     const char* const in_b = reinterpret_cast<const char*>(in);
     const char* const src_b = reinterpret_cast<const char*>(src);
 #endif
-    constexpr int LG = PROLONG ? TILE_LG : NROWS;
+    // PROLONG: the NROWS consecutive rows of a wave (first row even) need only NROWS / 2 + 1 DISTINCT coarse rows -- fine rows
+    // 2k and 2k + 1 both start from coarse row k, odd rows add coarse row k + 1 -- so the coarse correction is fetched once per
+    // distinct row (two 8-B loads: columns jc, jc + 1) IN FRONT of the row loads instead of two / four loads per fine row inside a
+    // row-at-a-time loop: 8 instead of 18 coarse loads per lane at six rows per wave, and the tile's load phase is one memory
+    // round trip instead of a chain of NROWS / TILE_LG of them (TILE_PWIDE=0 restores the per-row form).
+    constexpr bool PWIDE = PROLONG && (TILE_PWIDE != 0);
+    constexpr int LG = PROLONG ? (PWIDE ? (TILE_LG_WIDE < NROWS ? TILE_LG_WIDE : NROWS) : TILE_LG) : NROWS;
     const char* const cc_b = PROLONG ? reinterpret_cast<const char*>(coarseF.at_slot(b, k_cc)) : nullptr;
     const unsigned ldc8 = (unsigned)ld_c * 8u;
     const int jc = max(c0, 0) >> 1;
     const unsigned jc_off0 = PROLONG ? (unsigned)min(jc, nr_c - 1) * 8u : 0u, jc_off1 = PROLONG ? (unsigned)min(jc + 1, nr_c - 1) * 8u : 0u;
     const int h_end = PROLONG ? min(2 * (nr_c - 1), nr - 1) : 0, v_end = PROLONG ? min(2 * (nz_c - 1), nz - 1) : 0;
     const bool odd_is_zero = c0 + 1 >= h_end;
+    constexpr int NCR = PWIDE ? NROWS / 2 + 1 : 1;
+    double cr0[NCR], cr1[NCR];  // distinct coarse rows cbase .. cbase + NROWS/2 at columns jc / jc + 1 (clamped into the coarse grid)
+    const int cbase = (z0 + lzb) >> 1;  // (z0 + lzb is even; negative above the grid: clamped, those rows are never used)
 #pragma unroll
     for (int g0 = 0; g0 < NROWS; g0 += LG) {
         double2 pv[LG], sv2[LG];
         double ca0[LG], ca1[LG], cb0[LG], cb1[LG];
         int gzs[LG];
+        if (PWIDE) {
+            // the coarse rows this group of fine rows needs and no earlier group has fetched: rows g0 .. g0 + LG - 1 read coarse
+            // rows g0 >> 1 .. (g0 + LG) >> 1 (requested together with the group's row loads: one round trip per group)
+#pragma unroll
+            for (int k = 0; k < NCR; ++k) {
+                if (k >= (g0 == 0 ? 0 : (g0 >> 1) + 1) && k <= ((g0 + LG) >> 1)) {
+                    const unsigned ra = (unsigned)min(max(cbase + k, 0), nz_c - 1) * ldc8;
+                    cr0[k] = *reinterpret_cast<const double*>(cc_b + (ra + jc_off0));
+                    cr1[k] = *reinterpret_cast<const double*>(cc_b + (ra + jc_off1));
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < LG; ++j) {
             const int i = g0 + j;
@@ -844,7 +894,13 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
 #endif
             pv[j] = *reinterpret_cast<const double2*>(in_b + vo);
             sv2[j] = *reinterpret_cast<const double2*>(src_b + vo);
-            if (PROLONG) {
+            if (PWIDE) {
+                // (an in-domain row z0 + lzb + i >= 0 has coarse row (z0 + lzb + i) >> 1 = cbase + (i >> 1); rows clamped into the
+                //  domain take some other in-domain coarse value -- never used)
+                ca0[j] = cr0[i >> 1];
+                ca1[j] = cr1[i >> 1];
+                if (i & 1) { cb0[j] = cr0[(i >> 1) + (PWIDE ? 1 : 0)]; cb1[j] = cr1[(i >> 1) + (PWIDE ? 1 : 0)]; }
+            } else if (PROLONG) {
                 // (the parity of an in-domain row is that of its index i: even rows need one coarse row, odd rows two; a clamped
                 //  out-of-domain row may take the other form -- its value is never used)
                 const int ic = gzc >> 1, icc = min(ic, nz_c - 1);
@@ -858,6 +914,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
                 }
             }
         }
+        if (COEF_LATE && g0 + LG >= NROWS) { ae0 = *pe0; aw0 = *pw0; ae1 = *pe1; aw1 = *pw1; }
         if constexpr (lz_sum) if (g0 == 0) lz_sc = lazy_scale_from_parts(lzs, b, lane, lz_x0, lz_itg, bx_ == 0 && by_ == 0 && threadIdx.x == 0);
 #pragma unroll
         for (int j = 0; j < LG; ++j) {
@@ -893,6 +950,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         }
         if (PROLONG) __builtin_amdgcn_sched_barrier(0);
     }
+    if (SHARE_D) { if (w < 6) CO[w * 64 + lane] = co_x; }
     // the wave's first and last row, both colours, for the waves above and below
     b0[0] = v0[0];
     b1[0] = v1[0];
@@ -979,7 +1037,9 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     TILE_STAMP(8);
     if (DEFECT) {
         // (1) defect d = -(L*psi - src) of this wave's rows, both colours, into the source registers
-        if (!EARLY_D) {
+        if (SHARE_D) {
+            rs0 = CO[lane]; ri0 = CO[64 + lane]; rl0 = CO[128 + lane]; rs1 = CO[192 + lane]; ri1 = CO[256 + lane]; rl1 = CO[320 + lane];
+        } else if (!EARLY_D) {
             rs0 = *(in0 ? dd.r_safe + c0 : &g_const_f64[1]); ri0 = *(in0 ? dd.r_inv + c0 : &g_const_f64[1]); rl0 = *(in0 ? dd.r_inv_lo + c0 : &g_const_f64[0]);
             rs1 = *(in1 ? dd.r_safe + c0 + 1 : &g_const_f64[1]); ri1 = *(in1 ? dd.r_inv + c0 + 1 : &g_const_f64[1]); rl1 = *(in1 ? dd.r_inv_lo + c0 + 1 : &g_const_f64[0]);
         }

@@ -372,7 +372,9 @@ template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT>
 static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
                           const DefectOut* dfo) {
     static std::once_flag attr_once;  // (two stream-group threads may reach a first launch at the same time)
-    constexpr size_t lds = (size_t)LZT * 128 * sizeof(double);
+    // (+ 3 KiB behind the planes: the residual coefficients the waves of a six-row DEFECT tile share, see SHARE_D in the kernel)
+    constexpr bool share_d = DEFECT && LZT / NWT >= 6 && NWT >= 6 && (TILE_SHARE_D != 0);
+    constexpr size_t lds = (size_t)LZT * 128 * sizeof(double) + (share_d ? 6 * 64 * sizeof(double) : 0);
     auto kern = &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE>;
     // the instantiation that also finishes the J_raw sum (LazySrc::part) exists for the V-cycle's first level-0 launch only
     constexpr bool HAS_SUMF = S == 3 && DEFECT && !PROLONG;
@@ -2180,19 +2182,35 @@ int scpn_comm_unique_id(char* id128) {
     std::memcpy(id128, &id, sizeof(id));
     API_END
 }
+// Everything scpn_comm_init does BEFORE its collective call -- librccl loaded and complete, this rank's device selectable, NCCL 2.x
+// ABI -- without entering the collective: the host exchanges the ranks' verdicts on this step first, so that a rank that cannot
+// even get this far never leaves its peers blocked inside ncclCommInitRank (scpn_fusion_core_amd/distributed.py).
+static void comm_preflight(comm::State& c, int device, int* version) {
+    if (const char* miss = comm::load(c.api)) throw std::runtime_error(miss);
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev)
+        throw std::runtime_error("device " + std::to_string(device) + " is not visible to this rank (" + std::to_string(n_dev) + " device(s))");
+    HIP_TRY(hipSetDevice(device));
+    g_device = device;
+    int ver = 0;
+    RCCL_TRY(c.api.GetVersion(&ver));
+    if (ver < 20000) throw std::runtime_error("librccl reports version " + std::to_string(ver) + ": the NCCL 2.x ABI is required");
+    if (version) *version = ver;
+}
+int scpn_comm_prepare(int device, int* rccl_version) {
+    API_BEGIN
+    comm_preflight(comm::state(), device, rccl_version);
+    API_END
+}
 int scpn_comm_init(int rank, int world, const char* id128, int device) {
     if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(SCPN_E_ARG, "scpn_comm_init: need 0 <= rank < world and an id");
     API_BEGIN
     comm::State& c = comm::state();
     if (c.comm) throw std::runtime_error("scpn_comm_init: communicator already initialised");
-    if (const char* miss = comm::load(c.api)) throw std::runtime_error(miss);
-    HIP_TRY(hipSetDevice(device));
-    g_device = device;
+    comm_preflight(c, device, nullptr);
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
-    int ver = 0;
-    RCCL_TRY(c.api.GetVersion(&ver));
-    if (ver < 20000) throw std::runtime_error("librccl reports version " + std::to_string(ver) + ": the NCCL 2.x ABI is required");
     RCCL_TRY(c.api.CommInitRank(&c.comm, world, id, rank));
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void**)&c.d_scalar, 2 * sizeof(double)));
@@ -2216,7 +2234,10 @@ int scpn_comm_info(int* rank, int* world, int* rccl_version) {
 // `per` (>= this handle's batch) is the block size EVERY rank sends: a rank that owns fewer members (the short last block of an
 // uneven ensemble) pads with zeros, so the collective counts agree on all ranks and recv_device holds `world` whole blocks.
 // The pack copies run on the solver groups' streams and the collective on the communicator's own stream, ordered behind them by
-// events; nothing here waits on the host, so the gather overlaps the next solve (scpn_comm_wait).
+// events; the only host wait is the read-back of the members' slot indices on each group's stream (S_pack_psi_into), so the
+// gather itself overlaps the next solve (scpn_comm_wait).  The send block is the communicator's OWN buffer: it is only ever
+// grown after the communicator's stream has drained, and nothing else (scpn_gs_pack_psi_device stages in the handle's buffer)
+// writes to it, so a pack or a larger gather issued while a collective is in flight cannot touch what that collective reads.
 int scpn_comm_allgather_psi(scpn_gs* g, int per, void* recv_device) {
     if (!g || !recv_device) return fail(SCPN_E_ARG, "scpn_comm_allgather_psi: null handle / buffer");
     if (per < g->B) return fail(SCPN_E_ARG, "scpn_comm_allgather_psi: the common block is smaller than this rank's batch");
@@ -2224,19 +2245,26 @@ int scpn_comm_allgather_psi(scpn_gs* g, int per, void* recv_device) {
     comm::State& c = comm::state();
     if (!c.comm) throw std::runtime_error("communicator not initialised");
     const size_t n = (size_t)g->nz * g->nr;
-    g->dense.alloc((size_t)per * n);
+    // the previous gather still reads the send block: it has to finish before the block is refilled (or re-allocated)
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    if (c.send_cap < (size_t)per * n) {
+        if (c.send) { HIP_TRY(hipFree(c.send)); c.send = nullptr; c.send_cap = 0; }
+        HIP_TRY(hipSetDevice(c.device));
+        HIP_TRY(hipMalloc((void**)&c.send, sizeof(double) * (size_t)per * n));
+        c.send_cap = (size_t)per * n;
+    }
     while (c.ready.size() < g->kids.size()) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c.ready.push_back(e);
     }
-    if (per > g->B) HIP_TRY(hipMemsetAsync(g->dense.p + (size_t)g->B * n, 0, sizeof(double) * (per - g->B) * n, c.stream));
+    if (per > g->B) HIP_TRY(hipMemsetAsync(c.send + (size_t)g->B * n, 0, sizeof(double) * (per - g->B) * n, c.stream));
     for (size_t gi = 0; gi < g->kids.size(); ++gi) {
-        if (int rc = S_pack_psi_into(g->kids[gi], g->dense.p + (size_t)g->off[gi] * n, false)) return rc;
+        if (int rc = S_pack_psi_into(g->kids[gi], c.send + (size_t)g->off[gi] * n, false)) return rc;
         HIP_TRY(hipEventRecord(c.ready[gi], g->kids[gi]->stream));
         HIP_TRY(hipStreamWaitEvent(c.stream, c.ready[gi], 0));
     }
-    RCCL_TRY(c.api.AllGather(g->dense.p, recv_device, (size_t)per * n, ncclDouble, c.comm, c.stream));
+    RCCL_TRY(c.api.AllGather(c.send, recv_device, (size_t)per * n, ncclDouble, c.comm, c.stream));
     API_END
 }
 int scpn_comm_wait(void) {
@@ -2263,6 +2291,7 @@ int scpn_comm_finalize(void) {
     if (c.stream) { (void)hipStreamSynchronize(c.stream); }
     if (c.comm) { (void)c.api.CommDestroy(c.comm); c.comm = nullptr; }
     if (c.d_scalar) { (void)hipFree(c.d_scalar); c.d_scalar = nullptr; }
+    if (c.send) { (void)hipFree(c.send); c.send = nullptr; c.send_cap = 0; }
     for (hipEvent_t e : c.ready) (void)hipEventDestroy(e);
     c.ready.clear();
     if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }

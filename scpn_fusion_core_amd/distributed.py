@@ -256,6 +256,25 @@ class HostSync:
         self.allreduce_max(0.0)
 
 
+def negotiate_communicator(rank: int, world: int, *, preflight, init, finalize, addr: str, port: int) -> None:
+    """Bring the communicator up in two steps with one verdict after each, so that no rank is ever alone inside a collective.
+
+    ``preflight()`` is the LOCAL part (library loaded, this rank's device selectable, ABI version) and ``init()`` the collective
+    part (``ncclCommInitRank``); both return ``b""`` or an error text.  The pre-flight verdicts are exchanged first: a rank that
+    fails there (no librccl, ``LOCAL_RANK`` beyond the visible devices, wrong ABI) makes EVERY rank raise :class:`CommUnavailable`
+    before anybody calls ``init`` -- its peers would otherwise sit inside ``ncclCommInitRank`` waiting for a rank that never
+    comes, and the failed rank at a rendezvous nobody serves.  The verdicts of ``init`` are exchanged the same way; a rank whose
+    own ``init`` succeeded tears its communicator down (``finalize``) when a peer's did not."""
+    common_verdict(rank, world, preflight(), addr=addr, port=port)
+    err = init()
+    try:
+        common_verdict(rank, world, err, addr=addr, port=port)
+    except CommUnavailable:
+        if not err:
+            finalize()
+        raise
+
+
 # ------------------------------------------------------------------------------------------------- RCCL communicator
 class EnsembleComm:
     """The RCCL communicator of one rank (``scpn_comm_*``).  Create with :meth:`from_env` BEFORE the first device call of the
@@ -280,28 +299,32 @@ class EnsembleComm:
         got = exchange(rank, world, payload, addr=addr, port=port)[0]
         if len(got) != ID_BYTES:
             raise ConnectionError("no RCCL unique id from rank 0: " + (got[4:].decode(errors="replace") if got[:4] == b"ERR " else "malformed"))
-        # RCCL prints a version banner on the C stdout of rank 0 while it initialises; callers of this module own stdout (bench.py
-        # prints exactly one JSON line there), so fd 1 points at stderr for the duration of the call and C stdio is flushed
-        # before it is restored
-        sys.stdout.flush()
-        saved = os.dup(1)
-        try:
-            os.dup2(2, 1)
-            rc = L.scpn_comm_init(rank, world, got, device)
+
+        def text(rc: int, what: str) -> bytes:
+            return b"" if rc == _lib.SCPN_OK else (_lib.last_error() or f"{what} failed").encode()[:300]
+
+        def preflight() -> bytes:
+            return text(L.scpn_comm_prepare(device, None), "scpn_comm_prepare")
+
+        def init() -> bytes:
+            # RCCL prints a version banner on the C stdout of rank 0 while it initialises; callers of this module own stdout
+            # (bench.py prints exactly one JSON line there), so fd 1 points at stderr for the duration of the call and C stdio is
+            # flushed before it is restored
+            sys.stdout.flush()
+            saved = os.dup(1)
             try:
-                C.CDLL(None).fflush(None)
-            except Exception:
-                pass
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
-        err = b"" if rc == _lib.SCPN_OK else (_lib.last_error() or "scpn_comm_init failed").encode()[:300]
-        try:
-            common_verdict(rank, world, err, addr=addr, port=port)
-        except CommUnavailable:
-            if rc == _lib.SCPN_OK:
-                L.scpn_comm_finalize()
-            raise
+                os.dup2(2, 1)
+                rc = L.scpn_comm_init(rank, world, got, device)
+                try:
+                    C.CDLL(None).fflush(None)
+                except Exception:
+                    pass
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+            return text(rc, "scpn_comm_init")
+
+        negotiate_communicator(rank, world, preflight=preflight, init=init, finalize=L.scpn_comm_finalize, addr=addr, port=port)
         self._recv = None
         self._recv_bytes = 0
         self._per_checked: set[int] = set()

@@ -33,7 +33,8 @@ class _Seam:
     """The registry behind the module-level functions.
 
     Layout: one table per kind (``"fn"`` for kernels, ``"cls"`` for lazily loaded kernel classes) mapping a kernel name to a
-    ``{tier: implementation}`` dict -- a later registration of the same (name, tier) replaces the earlier one -- and a table
+    ``{tier: implementation}`` dict -- the FIRST registration of a (name, tier) pair stays, as in the reference, whose registry
+    appends and stable-sorts by tier (core/_multi_compat.py:240-262) -- and a table
     of tier probes (``{tier: () -> bool}``, only the GPU tier has one in this package) whose answers are memoised until
     :meth:`forget`.  Selection is ``min()`` over the available tiers of a name (the enum value IS the preference)."""
 
@@ -69,8 +70,17 @@ class _Seam:
     # ---- registration / selection
     def add(self, kind: str, name: str, tier: BackendTier, impl: Any) -> None:
         with self._guard:
-            self._tables[kind].setdefault(name, {})[BackendTier(tier)] = impl
-            self._chosen.pop(name, None)
+            self._tables[kind].setdefault(name, {}).setdefault(BackendTier(tier), impl)
+            if kind == "fn":  # (kernel classes are not memoised: a class registration leaves the kernels' choices alone)
+                self._chosen.pop(name, None)
+
+    def chosen(self, name: str, missing: str, all_down: str) -> Callable[..., Any]:
+        """The memoised pick of kernel ``name`` (read and written under the registry lock)."""
+        with self._guard:
+            hit = self._chosen.get(name)
+            if hit is None:
+                hit = self._chosen[name] = self.pick("fn", name, missing, all_down)
+            return hit
 
     def tiers(self, kind: str, name: str) -> list[BackendTier]:
         return sorted(self._tables[kind].get(name, ()))
@@ -117,13 +127,9 @@ def register_kernel(name: str, tier: BackendTier, implementation: Callable[..., 
 
 def dispatch(name: str) -> Callable[..., Any]:
     """Fastest available implementation; KeyError if nothing registered, RuntimeError if all unavailable."""
-    hit = _seam._chosen.get(name)
-    if hit is None:
-        hit = _seam.pick("fn", name, f"No implementations registered for kernel {name!r}",
-                         f"All registered backends for {name!r} are unavailable. "
-                         f"Registered tiers: {[t.name.lower() for t in registered_tiers(name)]}")
-        _seam._chosen[name] = hit
-    return hit
+    return _seam.chosen(name, f"No implementations registered for kernel {name!r}",
+                        f"All registered backends for {name!r} are unavailable. "
+                        f"Registered tiers: {[t.name.lower() for t in registered_tiers(name)]}")
 
 
 def register_kernel_class(name: str, tier: BackendTier, loader: Callable[[], type]) -> None:

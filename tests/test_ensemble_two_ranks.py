@@ -101,6 +101,61 @@ def test_two_rank_sharded_ensemble_matches_serial(tmp_path):
         assert "rank 1: ncclCommInitRank" in str(got["raised"])
 
 
+def _preflight_worker(rank, world, port, out_dir, fail_rank):
+    """A rank whose LOCAL pre-flight fails (no such device, no librccl) must take every rank out BEFORE the collective init."""
+    import time
+
+    from scpn_fusion_core_amd.distributed import CommUnavailable, negotiate_communicator
+
+    calls = []
+
+    def preflight():
+        calls.append("preflight")
+        return b"device 1 is not visible to this rank (1 device(s))" if rank == fail_rank else b""
+
+    def init():  # stands for ncclCommInitRank: a collective that never returns when a peer is missing
+        calls.append("init")
+        if fail_rank >= 0:
+            time.sleep(600)
+        return b""
+
+    t0 = time.monotonic()
+    raised = ""
+    try:
+        negotiate_communicator(rank, world, preflight=preflight, init=init, finalize=lambda: calls.append("finalize"), addr="127.0.0.1",
+                               port=port)
+    except CommUnavailable as exc:
+        raised = str(exc)
+    np.savez(os.path.join(out_dir, f"pre{rank}.npz"), raised=np.array(raised), calls=np.array(",".join(calls)), dt=time.monotonic() - t0)
+
+
+def _run_preflight(tmp_path, fail_rank):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_preflight_worker, args=(r, 2, port, str(tmp_path), fail_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return [np.load(tmp_path / f"pre{r}.npz") for r in range(2)]
+
+
+def test_a_rank_failing_before_the_collective_takes_every_rank_out(tmp_path):
+    for got in _run_preflight(tmp_path, fail_rank=1):
+        assert "rank 1: device 1 is not visible" in str(got["raised"])
+        assert str(got["calls"]) == "preflight"  # nobody entered the collective, nothing to tear down
+        assert float(got["dt"]) < 30.0
+
+
+def test_two_step_negotiation_passes_when_every_rank_is_ok(tmp_path):
+    for got in _run_preflight(tmp_path, fail_rank=-1):
+        assert str(got["raised"]) == "" and str(got["calls"]) == "preflight,init"
+
+
 def test_gather_rows_rejects_wrong_block_size():
     import pytest
 

@@ -22,8 +22,12 @@ def test_backend_tier_order_and_registration():
         assert multi.available_backends()["numpy"] is True and multi.available_backends()["gpu"] is False
         multi.set_availability(multi.BackendTier.GPU, True)
         assert multi.dispatch("unit_test_kernel")() == "gpu"  # lower enum value preferred
-        multi.register_kernel("unit_test_kernel", multi.BackendTier.GPU, lambda: "gpu2")  # same (name, tier): replaced
-        assert multi.dispatch("unit_test_kernel")() == "gpu2"
+        # same (name, tier) again: the FIRST registration stays (the reference appends and stable-sorts, core/_multi_compat.py:256-260)
+        multi.register_kernel("unit_test_kernel", multi.BackendTier.GPU, lambda: "gpu2")
+        assert multi.dispatch("unit_test_kernel")() == "gpu"
+        # registering a kernel CLASS of the same name leaves the kernel's memoised choice alone
+        multi.register_kernel_class("unit_test_kernel", multi.BackendTier.GPU, lambda: dict)
+        assert multi.dispatch("unit_test_kernel")() == "gpu" and multi.dispatch_kernel_class("unit_test_kernel") is dict
         multi.set_availability(multi.BackendTier.GPU, False)
         multi.set_availability(multi.BackendTier.NUMPY, False)
         with pytest.raises(RuntimeError, match="Registered tiers: \\['gpu', 'numpy'\\]"):
