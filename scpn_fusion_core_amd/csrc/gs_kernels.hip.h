@@ -695,6 +695,10 @@ __device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (d
 #ifndef TILE_PWIDE
 #define TILE_PWIDE 1
 #endif
+// PROLONG, six rows per wave: inner-row sources by LDS-DMA into the lane's slots (1) or through registers (0)
+#ifndef TILE_GLDS
+#define TILE_GLDS 1
+#endif
 #ifndef TILE_LG_WIDE
 #define TILE_LG_WIDE 2
 #endif
@@ -855,7 +859,16 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     // row-at-a-time loop: 8 instead of 18 coarse loads per lane at six rows per wave, and the tile's load phase is one memory
     // round trip instead of a chain of NROWS / TILE_LG of them (TILE_PWIDE=0 restores the per-row form).
     constexpr bool PWIDE = PROLONG && (TILE_PWIDE != 0);
-    constexpr int LG = PROLONG ? (PWIDE ? (TILE_LG_WIDE < NROWS ? TILE_LG_WIDE : NROWS) : TILE_LG) : NROWS;
+    // PROLONG with six or more rows per wave: the sources of the wave's INNER rows never need registers -- they go straight to
+    // the lane's LDS slots by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per row, lane-linear: the slot layout of
+    // these rows is the lane's (even column, odd column) PAIR here, two rows per KiB-pair of the wave's own inner plane rows), and
+    // with them out of the register budget ALL rows of the wave are in flight at once: one memory round trip per tile.
+    // The lazy-source factors are applied in place once the data has landed (the issuing wave's own vmcnt orders its reads).
+    constexpr bool GLDS = PWIDE && SRCL && (TILE_GLDS != 0);
+    constexpr int LG = PROLONG ? (GLDS ? NROWS : (PWIDE ? (TILE_LG_WIDE < NROWS ? TILE_LG_WIDE : NROWS) : TILE_LG)) : NROWS;
+    constexpr int GHALF = (NROWS - 2) / 2 > 0 ? (NROWS - 2) / 2 : 1;  // inner rows per plane chunk (GLDS)
+    // wave-uniform base (doubles) of the pair row of inner row i: rows 1 .. GHALF in the wave's inner rows of plane 0, the rest in plane 1
+    auto pair_base = [&](int i) { return (i - 1 < GHALF ? A0 : A1) + (lzb + 1) * 64 + ((i - 1) % GHALF) * 128; };
     const char* const cc_b = PROLONG ? reinterpret_cast<const char*>(coarseF.at_slot(b, k_cc)) : nullptr;
     const unsigned ldc8 = (unsigned)ld_c * 8u;
     const int jc = max(c0, 0) >> 1;
@@ -893,7 +906,11 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             const unsigned vo = (unsigned)gzc * ld8 + lane_off;
 #endif
             pv[j] = *reinterpret_cast<const double2*>(in_b + vo);
-            sv2[j] = *reinterpret_cast<const double2*>(src_b + vo);
+            if (GLDS && i > 0 && i < NROWS - 1)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_b + vo),
+                                                 (__attribute__((address_space(3))) void*)pair_base(i), 16, 0, 0);
+            else
+                sv2[j] = *reinterpret_cast<const double2*>(src_b + vo);
             if (PWIDE) {
                 // (an in-domain row z0 + lzb + i >= 0 has coarse row (z0 + lzb + i) >> 1 = cbase + (i >> 1); rows clamped into the
                 //  domain take some other in-domain coarse value -- never used)
@@ -936,13 +953,19 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
                 vx = vx + px;
                 vy = vy + py;
             }
-            double sx = sv2[j].x, sy = sv2[j].y;  // source of the even / odd column
+            if (i & 1) { v1[i] = vx; v0[i] = vy; } else { v0[i] = vx; v1[i] = vy; }
+            constexpr bool dma_row_possible = GLDS;
+            const bool dma_row = dma_row_possible && i > 0 && i < NROWS - 1;
+            double2* const pr = dma_row ? reinterpret_cast<double2*>(pair_base(i)) + lane : nullptr;
+            if (dma_row) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's DMA has landed; everything else is needed by now anyway)
+            double sx = dma_row ? pr->x : sv2[j].x, sy = dma_row ? pr->y : sv2[j].y;  // source of the even / odd column
             if (lazy) {  // Source = (-mu0 R) * (scale != 0 ? J_raw * scale : 0), the expression of k_source (uniform branches)
                 if (lz_sc != 0.0) { sx = lz_n0 * (sx * lz_sc); sy = lz_n1 * (sy * lz_sc); }
                 else { sx = lz_n0 * 0.0; sy = lz_n1 * 0.0; }
             }
-            if (i & 1) { v1[i] = vx; v0[i] = vy; } else { v0[i] = vx; v1[i] = vy; }
-            if (SRCL && i > 0 && i < NROWS - 1) {
+            if (dma_row) {
+                if (lazy) *pr = double2{sx, sy};  // (in place; a plain right-hand side is already what the sweeps read)
+            } else if (SRCL && i > 0 && i < NROWS - 1) {
                 b0[i * 64] = (i & 1) ? sy : sx;
                 b1[i * 64] = (i & 1) ? sx : sy;
             } else if (i & 1) { s1[i] = sx; s0[i] = sy; }
@@ -982,7 +1005,8 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         const double W = p ? O : wave_shift<0x138>(O), E = p ? wave_shift<0x130>(O) : O;
         const double Sv = i > 0 ? oth[i > 0 ? i - 1 : 0] : Sb, N = i < NROWS - 1 ? oth[i < NROWS - 1 ? i + 1 : 0] : Nb;
         const double ae = p ? ae1 : ae0, aw = p ? aw1 : aw0;
-        const double sv = (SRCL && i > 0 && i < NROWS - 1) ? (c ? b1 : b0)[i * 64] : (c ? s1[i] : s0[i]);
+        const double sv = (GLDS && i > 0 && i < NROWS - 1) ? pair_base(i)[2 * lane + p]
+                          : ((SRCL && i > 0 && i < NROWS - 1) ? (c ? b1 : b0)[i * 64] : (c ? s1[i] : s0[i]));
         const double gsv = divc4(ae * E + aw * W + a_ns * Sv + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
         double nw = om1 * mine[i] + omega * gsv;
         asm volatile("" : "+v"(nw));  // (an opaque use: keeps the compiler from sinking the chain into an exec-masked branch)
@@ -2008,31 +2032,51 @@ __device__ __forceinline__ void picard_final_body(const int b, const PicardTail&
     const double m_gs_best = st[b].gs_best, m_diff_best = st[b].diff_best;
     double s = 0.0, rs = 0.0, rm = 0.0;
     int bad = 0;
-    for (int i = threadIdx.x; i < nblk; i += 256) {
+    // Every partial this thread combines FIRST (index threadIdx.x of each array: all there is up to 256 tiles per member) is
+    // requested here, before anything is computed -- one memory round trip for the kernel instead of one per reduction stage
+    // (sum / flags, maximum, rescaled squares behind the maximum's barrier, topology candidates).  Absent entries read a constant.
+    const int i0 = threadIdx.x;
+    const bool in_d = i0 < nblk, in_r = i0 < nblk_r, in_t = t.topo != nullptr && i0 < ntopo;
+    const double f_ps = ld_part<AGENT>(in_d ? t.psum + (long)b * nblk + i0 : &g_const_f64[0]);
+    const int f_pb = ld_part<AGENT>(in_d ? t.pbad + (long)b * nblk + i0 : &g_const_i32[0]);
+    const double f_rm = ld_part<AGENT>(in_r ? t.rmax + (long)b * nblk_r + i0 : &g_const_f64[0]);
+    const double f_rs = ld_part<AGENT>(in_r ? t.rsum + (long)b * nblk_r + i0 : &g_const_f64[0]);
+    const TopoPart* const q0 = in_t ? t.topo + (long)b * ntopo + i0 : nullptr;
+    const double f_maxv = in_t ? ld_part<AGENT>(&q0->maxv) : 0.0, f_minb = in_t ? ld_part<AGENT>(&q0->minb) : 0.0;
+    const long f_maxi = in_t ? ld_part<AGENT>(&q0->maxi) : -1L, f_mini = in_t ? ld_part<AGENT>(&q0->mini) : -1L;
+    const double f_minpsi = in_t ? ld_part<AGENT>(&q0->minpsi) : INFINITY, f_pam = in_t ? ld_part<AGENT>(&q0->psi_at_min) : 0.0;
+    s += f_ps;
+    bad |= f_pb;
+    for (int i = threadIdx.x + 256; i < nblk; i += 256) {
         s += ld_part<AGENT>(t.psum + (long)b * nblk + i);
         bad |= ld_part<AGENT>(t.pbad + (long)b * nblk + i);
     }
-    for (int i = threadIdx.x; i < nblk_r; i += 256) rm = fmax(rm, ld_part<AGENT>(t.rmax + (long)b * nblk_r + i));
+    rm = fmax(rm, f_rm);
+    for (int i = threadIdx.x + 256; i < nblk_r; i += 256) rm = fmax(rm, ld_part<AGENT>(t.rmax + (long)b * nblk_r + i));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wbad = __any(bad) ? 1 : 0;
     if (lane == 0) S.shbad[w] = wbad;
     const double rmx_all = block_max_all<256>(rm, S.sh);  // M = max_b m_b  (its barriers also publish shbad)
     if (rmx_all > 0.0) {
-        for (int i = threadIdx.x; i < nblk_r; i += 256) {
+        { const double f = f_rm / rmx_all; rs += f_rs * (f * f); }
+        for (int i = threadIdx.x + 256; i < nblk_r; i += 256) {
             const double f = ld_part<AGENT>(t.rmax + (long)b * nblk_r + i) / rmx_all;
             rs += ld_part<AGENT>(t.rsum + (long)b * nblk_r + i) * (f * f);
         }
     }
     if (t.topo) {
-        for (int i = threadIdx.x; i < ntopo; i += 256) {
-            const TopoPart* q = t.topo + (long)b * ntopo + i;
-            const VI cmx{ld_part<AGENT>(&q->maxv), ld_part<AGENT>(&q->maxi)}, cmn{ld_part<AGENT>(&q->minb), ld_part<AGENT>(&q->mini)};
-            const double cpsi = ld_part<AGENT>(&q->psi_at_min);
+        auto take = [&](const VI cmx, const VI cmn, const double cpsi, const double cminpsi) {
             tmx = vi_max(tmx, cmx);
             const VI nmn = vi_min(tmn, cmn);
             if (nmn.i != tmn.i) tpsi = cpsi;
             tmn = nmn;
-            tminpsi = fmin(tminpsi, ld_part<AGENT>(&q->minpsi));
+            tminpsi = fmin(tminpsi, cminpsi);
+        };
+        if (in_t) take(VI{f_maxv, f_maxi}, VI{f_minb, f_mini}, f_pam, f_minpsi);
+        for (int i = threadIdx.x + 256; i < ntopo; i += 256) {
+            const TopoPart* q = t.topo + (long)b * ntopo + i;
+            take(VI{ld_part<AGENT>(&q->maxv), ld_part<AGENT>(&q->maxi)}, VI{ld_part<AGENT>(&q->minb), ld_part<AGENT>(&q->mini)},
+                 ld_part<AGENT>(&q->psi_at_min), ld_part<AGENT>(&q->minpsi));
         }
         const VI own = tmn;
         tmx = wave_vi<true>(tmx);
@@ -2153,6 +2197,7 @@ struct GradRecip { double dz, inv_dz, lo_dz, two_dz, inv_two_dz, lo_two_dz, dr, 
 constexpr int BL_WZ = BL_WZ_N, BL_LB = BL_WZ + 2, BL_WR = 124, BL_NW = 4, BL_NROWS = BL_LB / BL_NW;
 static_assert(BL_LB % BL_NW == 0, "rows are dealt to the four waves evenly");
 __device__ __forceinline__ int blend_tiles_x(int nr) { return (nr + BL_WR - 1) / BL_WR; }
+#ifdef BLEND_R03
 __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
                                                              double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
                                                              double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm,
@@ -2386,6 +2431,291 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
     picard_final_body<true>(b, tail, S);
     if (tid == 0) __hip_atomic_store(tail.counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+#else
+// Round 4: the same kernel with the per-point bookkeeping taken out of the point loop.  What a LANE accumulates is kept per COLUMN
+// of its pair (sum |new - cur|, min, running max + the row it came from, max |r|), so the lane's column predicates (window lane,
+// inside the grid, interior column) are applied ONCE per lane after the rows instead of as selects per point; the non-finite
+// check of the elliptic solve's output is read off the partial sum of |new - cur| (a non-finite `new` makes its owner's sum
+// non-finite: `cur` is an accepted iterate); the arg-max candidate travels as (value, row tag) and becomes a grid index once per
+// lane; the (value, index) wave reductions are a value reduction plus a 32-bit index reduction among the lanes that hold the
+// extreme value; the residual is sanitised on a cold path (a wave that sees |r| > CAP or a NaN -- never in a healthy run) and its
+// sum of squares is scaled by a power of two taken from the WAVE's own largest |r| (exact scaling, no division, no workgroup
+// barrier between the maximum and the squares).  Outputs are those of round 3's kernel (profiles/r04_negative/) to rounding:
+// rmax is the power of two the tile's sum is relative to.
+__device__ __forceinline__ double pow2_floor_or_zero(double m) {  // 2^floor(log2 m) for finite m > 0 (subnormals: 2^-1022), 0 for m == 0
+    const unsigned long b = (unsigned long)__double_as_longlong(m);
+    const unsigned long ex = (b >> 52) & 0x7ffUL;
+    return m > 0.0 ? __longlong_as_double((long long)((ex ? ex : 1UL) << 52)) : 0.0;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {  // result in every lane
+#define SCPN_U32_STEP(CTRL, RM) v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, RM, 0xf, false));
+    SCPN_U32_STEP(0x111, 0xf) SCPN_U32_STEP(0x112, 0xf) SCPN_U32_STEP(0x114, 0xf) SCPN_U32_STEP(0x118, 0xf) SCPN_U32_STEP(0x142, 0xa) SCPN_U32_STEP(0x143, 0xc)
+#undef SCPN_U32_STEP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
+                                                             double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
+                                                             double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm,
+                                                             GradRecip gq, PicardTail tail) {
+    __shared__ __attribute__((aligned(16))) double t[BL_LB][128];
+    __shared__ int sh_last;
+    __shared__ VI sh_mx[BL_NW], sh_mn[BL_NW];
+    __shared__ double sh_dsum[BL_NW], sh_p2[BL_NW], sh_minp[BL_NW], sh_s2[BL_NW];
+    __shared__ double sh_coef[2 * BL_NW][64];  // r_safe, 1/r_safe (two words), -mu0 R of the lane's two columns: loaded by one wave each
+    int bx_, by_, b;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+        unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        if (tail.xcd_remap) lin = xcd_contiguous(lin, total);
+        bx_ = (int)(lin % gx);
+        const unsigned t_ = lin / gx;
+        by_ = (int)(t_ % gy);
+        b = (int)(t_ / gy);
+    }
+    // the member's words -- activity, the slot of every field, the lazy-source scale -- in ONE round trip (see k_smooth_tile)
+    const int act_w = st[b].active;
+    const int k_cur = *curF.slot_ptr(b), k_new = *newF.slot_ptr(b), k_bc = *bcF.slot_ptr(b), k_src = *srcF.slot_ptr(b), k_nxt = *nxtF.slot_ptr(b);
+    const double lz_sc = *(lazy_nm ? &st[b].jscale : &g_const_f64[1]);
+    if (!act_w) return;
+    BLEND_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nz = L.nz, nr = L.nr, ld = L.ld;
+    // tile row lz <-> grid row z0 + lz, tile column lc <-> grid column r0 + lc; owned: lz in [1, BL_WZ], lc in [2, 125]
+    const int z0 = by_ * BL_WZ - 1, r0 = bx_ * BL_WR - 2;  // r0 even: the lane's pair is 16-B aligned
+    const int c0 = r0 + 2 * lane;
+    const bool pair_win = lane >= 1 && lane <= 62;
+    const bool own_x = pair_win && c0 < nr, own_y = pair_win && c0 + 1 < nr;  // (c0 >= 0 for window lanes)
+    const char* const cur_b = reinterpret_cast<const char*>(curF.at_slot(b, k_cur));
+    const char* const new_b = reinterpret_cast<const char*>(newF.at_slot(b, k_new));
+    const char* const bc_b = reinterpret_cast<const char*>(bcF.at_slot(b, k_bc));
+    const char* const src_b = reinterpret_cast<const char*>(srcF.at_slot(b, k_src));
+    char* const nxt_b = reinterpret_cast<char*>(nxtF.at_slot(b, k_nxt));
+    const unsigned ld8 = (unsigned)ld * 8u;
+    const unsigned lane_off = (unsigned)min(max(c0, 0), ld - 2) * 8u;
+    // ring columns (grid column 0 / nr-1) take their value from bc; only tiles that touch them look (wave-uniform)
+    const bool edge_cols = r0 <= 0 || r0 + 127 >= nr - 1;
+    const bool cring_x = c0 == 0 || c0 == nr - 1, cring_y = c0 + 1 == nr - 1;
+    double2 pc[BL_NROWS], pn[BL_NROWS], sv[BL_NROWS];
+#pragma unroll
+    for (int i = 0; i < BL_NROWS; ++i) {
+        const int gzc = min(max(z0 + w + BL_NW * i, 0), nz - 1);  // scalar
+        const unsigned vo = (unsigned)gzc * ld8 + lane_off;
+        const bool rowring = gzc == 0 || gzc == nz - 1;
+        pc[i] = *reinterpret_cast<const double2*>(cur_b + vo);
+        pn[i] = *reinterpret_cast<const double2*>((rowring ? bc_b : new_b) + vo);
+        sv[i] = *reinterpret_cast<const double2*>(src_b + vo);
+    }
+    if (edge_cols) {
+#pragma unroll
+        for (int i = 0; i < BL_NROWS; ++i) {
+            const int gzc = min(max(z0 + w + BL_NW * i, 0), nz - 1);
+            const unsigned vo = (unsigned)gzc * ld8 + lane_off;
+            if (cring_x) pn[i].x = *reinterpret_cast<const double*>(bc_b + vo);
+            if (cring_y) pn[i].y = *reinterpret_cast<const double*>(bc_b + vo + 8u);
+        }
+    }
+    // column coefficients of the residual stage: wave k fetches the k-th of (r_safe, 1/r_safe, its low word, -mu0 R) for the lane's
+    // two columns now, behind the row loads, and hands them to the other waves through LDS at the barrier below
+    const bool int_x = own_x && c0 >= 1 && c0 <= nr - 2, int_y = own_y && c0 + 1 <= nr - 2;  // (c0 + 1 >= 1 always)
+    {
+        const double* const arr = w == 0 ? L.r_safe : (w == 1 ? L.r_inv : (w == 2 ? L.r_inv_lo : lazy_nm));
+        // r_safe, 1/r_safe: 1.0; low word: 0.0; -mu0 R: 0.0 outside the interior, 1.0 when the source field already holds the source
+        const double* const dflt = &g_const_f64[(w <= 1 || (w == 3 && !lazy_nm)) ? 1 : 0];
+        const bool have = arr != nullptr;
+        sh_coef[2 * w][lane] = *((have && int_x) ? arr + c0 : dflt);
+        sh_coef[2 * w + 1][lane] = *((have && int_y) ? arr + c0 + 1 : dflt);
+    }
+    // ---- stage 1: blend, store, stage the tile; per-COLUMN accumulators, no per-point predicates (rows: wave-uniform tests)
+    double dsx = 0.0, dsy = 0.0, mnx = INFINITY, mny = INFINITY, bvx = -INFINITY, bvy = -INFINITY;
+    int btx = -1, bty = -1;  // row slot i of the running maximum (ascending i = ascending grid row: `>` keeps the first occurrence)
+#pragma unroll
+    for (int i = 0; i < BL_NROWS; ++i) {
+        const int lz = w + BL_NW * i, gz = z0 + lz;
+        double2 vi;
+        vi.x = om_alpha * pc[i].x + alpha * pn[i].x;
+        vi.y = om_alpha * pc[i].y + alpha * pn[i].y;
+        if (lz >= 1 && lz <= BL_WZ && gz < nz) {  // owned row (wave-uniform)
+            dsx += fabs(pn[i].x - pc[i].x);
+            dsy += fabs(pn[i].y - pc[i].y);
+            mnx = fmin(mnx, vi.x);
+            mny = fmin(mny, vi.y);
+            const bool gx = vi.x > bvx, gy = vi.y > bvy;  // (a NaN never wins)
+            bvx = gx ? vi.x : bvx; btx = gx ? i : btx;
+            bvy = gy ? vi.y : bvy; bty = gy ? i : bty;
+            char* const o = nxt_b + ((unsigned)gz * ld8 + (unsigned)c0 * 8u);
+            if (own_y) *reinterpret_cast<double2*>(o) = vi;
+            else if (own_x) *reinterpret_cast<double*>(o) = vi.x;
+        }
+        *reinterpret_cast<double2*>(&t[lz][2 * lane]) = vi;
+    }
+    BLEND_STAMP(1);
+    __syncthreads();
+    BLEND_STAMP(2);
+    // ---- stage 2: residual r = L* nxt - Source of the owned interior rows: own pair, N / S pairs and the two out-of-pair neighbours
+    // from the tile; lanes whose column is not an interior grid column compute on clamped copies and are dropped after the rows
+    const double rs0 = sh_coef[0][lane], rs1 = sh_coef[1][lane], ri0 = sh_coef[2][lane], ri1 = sh_coef[3][lane];
+    const double rl0 = sh_coef[4][lane], rl1 = sh_coef[5][lane], nm0 = sh_coef[6][lane], nm1 = sh_coef[7][lane];
+    double2 rv[BL_NROWS];
+#pragma unroll
+    for (int i = 0; i < BL_NROWS; ++i) {
+        const int lz = w + BL_NW * i, gz = z0 + lz;
+        rv[i] = double2{0.0, 0.0};
+        if (!(lz >= 1 && lz <= BL_WZ && gz >= 1 && gz <= nz - 2)) continue;  // wave-uniform
+        const double2 N = *reinterpret_cast<const double2*>(&t[lz + 1][2 * lane]);
+        const double2 S = *reinterpret_cast<const double2*>(&t[lz - 1][2 * lane]);
+        const double Wn = (&t[lz][0])[2 * lane - 1], En = (&t[lz][0])[2 * lane + 2];
+        const double2 P = *reinterpret_cast<const double2*>(&t[lz][2 * lane]);
+        const double px = P.x, py = P.y;
+        // Source = (-mu0 R) * (J_raw * scale) when the source field holds J_raw (lazy source, see k_smooth_tile); otherwise the
+        // factors are 1.0 (exact identity).  Branch- and select-free: for scale == 0 the product is +-0 where k_source writes
+        // (-mu0 R) * 0.0 -- the same |r| (only the sign of a zero source can differ, for finite J_raw).
+        const double sx = nm0 * (sv[i].x * lz_sc), sy = nm1 * (sv[i].y * lz_sc);
+        const double d2rx = divc4(py - 2.0 * px + Wn, L.dr2, L.inv_dr2, L.lo_dr2);
+        const double d2ry = divc4(En - 2.0 * py + px, L.dr2, L.inv_dr2, L.lo_dr2);
+        const double d1rx = divc4(py - Wn, L.two_dr, L.inv_two_dr, L.lo_two_dr);
+        const double d1ry = divc4(En - px, L.two_dr, L.inv_two_dr, L.lo_two_dr);
+        const double d2zx = divc4(N.x - 2.0 * px + S.x, L.dz2, L.inv_dz2, L.lo_dz2);
+        const double d2zy = divc4(N.y - 2.0 * py + S.y, L.dz2, L.inv_dz2, L.lo_dz2);
+        rv[i].x = (d2rx - divc4(d1rx, rs0, ri0, rl0) + d2zx) - sx;
+        rv[i].y = (d2ry - divc4(d1ry, rs1, ri1, rl1) + d2zy) - sy;
+    }
+    // largest |r| of the lane's interior columns; a NaN is invisible to fmax and shows up in the squares below
+    auto col_max = [&](bool on_x, bool on_y) {
+        double ax = 0.0, ay = 0.0;
+#pragma unroll
+        for (int i = 0; i < BL_NROWS; ++i) { ax = fmax(ax, fabs(rv[i].x)); ay = fmax(ay, fabs(rv[i].y)); }
+        return fmax(on_x ? ax : 0.0, on_y ? ay : 0.0);
+    };
+    double w_m = wave_max(col_max(int_x, int_y));
+    double p2 = pow2_floor_or_zero(w_m);  // (wave-uniform) the power of two the wave's squares are relative to
+    auto sum_sq = [&](double inv_p2) {
+        double qx = 0.0, qy = 0.0;
+#pragma unroll
+        for (int i = 0; i < BL_NROWS; ++i) {
+            const double ux = rv[i].x * inv_p2, uy = rv[i].y * inv_p2;  // exact (power of two), |u| < 2
+            qx += ux * ux;
+            qy += uy * uy;
+        }
+        return (int_x ? qx : 0.0) + (int_y ? qy : 0.0);
+    };
+    double s2 = p2 > 0.0 ? sum_sq(1.0 / p2) : 0.0;  // (1 / 2^k is exact; the branch is wave-uniform)
+    if (__any(!(w_m <= CAP) || s2 != s2)) {
+        // cold path: sanitise as the reference does (fusion_kernel_numerics.py:19-25: NaN -> 0, clip to +-CAP) and redo the norms
+#pragma unroll
+        for (int i = 0; i < BL_NROWS; ++i) { rv[i].x = sanitize_sel(rv[i].x); rv[i].y = sanitize_sel(rv[i].y); }
+        w_m = wave_max(col_max(int_x, int_y));
+        p2 = pow2_floor_or_zero(w_m);
+        s2 = p2 > 0.0 ? sum_sq(1.0 / p2) : 0.0;
+    }
+    BLEND_STAMP(3);
+    // ---- wave-level reductions (results in every lane), one LDS hand-over per wave
+    const double w_dsum = wave_sum((own_x ? dsx : 0.0) + (own_y ? dsy : 0.0));
+    const double w_minp = -wave_max(-fmin(own_x ? mnx : INFINITY, own_y ? mny : INFINITY));
+    const double w_s2 = wave_sum(s2);
+    // arg-max candidate of the wave: the largest value, then the smallest flattened index among the lanes that hold it
+    // (local index = tile row * 128 + tile column: ascending in the grid index within a tile)
+    const bool hx = own_x && btx >= 0, hy = own_y && bty >= 0;
+    const bool y_wins = hy && (!hx || bvy > bvx || (bvy == bvx && bty < btx));  // (same row: x comes first)
+    const double lv = y_wins ? bvy : (hx ? bvx : -INFINITY);
+    const unsigned lloc = (hx || hy) ? (unsigned)((w + BL_NW * (y_wins ? bty : btx)) * 128 + 2 * lane + (y_wins ? 1 : 0)) : 0xffffffffu;
+    const double w_bv = wave_max(lv);
+    const unsigned w_loc = wave_min_u32((lv == w_bv) ? lloc : 0xffffffffu);
+    VI w_mx{0.0, -1};
+    if (w_loc != 0xffffffffu) { w_mx.v = w_bv; w_mx.i = (long)(z0 + (int)(w_loc >> 7)) * nr + (r0 + (int)(w_loc & 127u)); }
+    // Divertor rows (a quarter of the tiles): np.gradient + hypot + masked arg-min (fusion_kernel.py:276-288), from the LDS tile
+    VI w_mn{0.0, -1};
+    if (z0 + 1 < n_mask_rows) {  // (uniform: the tile owns at least one masked row)
+        double gvx = INFINITY, gvy = INFINITY;
+        int gtx = -1, gty = -1;
+#pragma unroll
+        for (int i = 0; i < BL_NROWS; ++i) {
+            const int lz = w + BL_NW * i, gz = z0 + lz;
+            if (!(lz >= 1 && lz <= BL_WZ && gz < nz) || gz >= n_mask_rows) continue;  // wave-uniform
+            const double2 N = *reinterpret_cast<const double2*>(&t[lz + 1][2 * lane]);
+            const double2 S = *reinterpret_cast<const double2*>(&t[lz - 1][2 * lane]);
+            const double Wn = (&t[lz][0])[2 * lane - 1], En = (&t[lz][0])[2 * lane + 2];
+            const double2 P = *reinterpret_cast<const double2*>(&t[lz][2 * lane]);
+            const double px = P.x, py = P.y;
+            auto grad = [&](double p, double n_, double s_, double e_, double w_, int gc) {
+                const double ps = nan_to_num300(p), nn = nan_to_num300(n_), ss = nan_to_num300(s_), ee = nan_to_num300(e_), ww = nan_to_num300(w_);
+                double gzv, grv;
+                if (gz == 0) gzv = divc4(nn - ps, gq.dz, gq.inv_dz, gq.lo_dz);  // (row tests are wave-uniform)
+                else if (gz == nz - 1) gzv = divc4(ps - ss, gq.dz, gq.inv_dz, gq.lo_dz);
+                else gzv = divc4(nn - ss, gq.two_dz, gq.inv_two_dz, gq.lo_two_dz);
+                grv = divc4(ee - ww, L.two_dr, L.inv_two_dr, L.lo_two_dr);
+                if (edge_cols) {  // wave-uniform: only tiles that touch grid column 0 / nr-1 evaluate the one-sided forms
+                    const double g0 = divc4(ee - ps, gq.dr, gq.inv_dr, gq.lo_dr), g1 = divc4(ps - ww, gq.dr, gq.inv_dr, gq.lo_dr);
+                    grv = gc == 0 ? g0 : (gc == nr - 1 ? g1 : grv);
+                }
+                return hypot(grv, gzv);
+            };
+            const double bmx = grad(px, N.x, S.x, py, Wn, c0), bmy = grad(py, N.y, S.y, En, px, c0 + 1);
+            const bool lx = bmx < gvx, ly = bmy < gvy;  // (a NaN / an overflowed hypot never wins: +inf < +inf is false)
+            gvx = lx ? bmx : gvx; gtx = lx ? i : gtx;
+            gvy = ly ? bmy : gvy; gty = ly ? i : gty;
+        }
+        const bool kx = own_x && gtx >= 0 && finite_d(gvx), ky = own_y && gty >= 0 && finite_d(gvy);
+        const bool yw = ky && (!kx || gvy < gvx || (gvy == gvx && gty < gtx));
+        const double gl = yw ? gvy : (kx ? gvx : INFINITY);
+        const unsigned gloc = (kx || ky) ? (unsigned)((w + BL_NW * (yw ? gty : gtx)) * 128 + 2 * lane + (yw ? 1 : 0)) : 0xffffffffu;
+        const double w_gv = -wave_max(-gl);
+        const unsigned w_gl = wave_min_u32((gl == w_gv) ? gloc : 0xffffffffu);
+        if (w_gl != 0xffffffffu) { w_mn.v = w_gv; w_mn.i = (long)(z0 + (int)(w_gl >> 7)) * nr + (r0 + (int)(w_gl & 127u)); }
+    }
+    if (lane == 0) { sh_dsum[w] = w_dsum; sh_p2[w] = p2; sh_s2[w] = w_s2; sh_minp[w] = w_minp; sh_mx[w] = w_mx; sh_mn[w] = w_mn; }
+    __syncthreads();
+    BLEND_STAMP(4);
+    const long o = (long)b * nblk + (long)by_ * gridDim.x + bx_;
+    double bsum = 0.0, bs2 = 0.0, bp2 = 0.0, bminp = INFINITY, pmin = 0.0;
+    VI rmx{0.0, -1}, rmn{0.0, -1};
+    if (tid == 0) {
+        bsum = sh_dsum[0] + sh_dsum[1] + sh_dsum[2] + sh_dsum[3];
+        bp2 = fmax(fmax(sh_p2[0], sh_p2[1]), fmax(sh_p2[2], sh_p2[3]));
+        if (bp2 > 0.0) {
+            const double ip = 1.0 / bp2;  // exact
+#pragma unroll
+            for (int i = 0; i < BL_NW; ++i) { const double f = sh_p2[i] * ip; bs2 += sh_s2[i] * (f * f); }  // exact rescaling
+        }
+        bminp = fmin(fmin(sh_minp[0], sh_minp[1]), fmin(sh_minp[2], sh_minp[3]));
+        rmx = sh_mx[0]; rmn = sh_mn[0];
+#pragma unroll
+        for (int i = 1; i < BL_NW; ++i) { rmx = vi_max(rmx, sh_mx[i]); rmn = vi_min(rmn, sh_mn[i]); }
+        // psi of the blended iterate at this tile's arg-min candidate (still in the LDS tile)
+        if (rmn.i >= 0) {
+            const int iz = (int)(rmn.i / nr), ir = (int)(rmn.i - (long)iz * nr);
+            pmin = t[iz - z0][ir - r0];
+        }
+    }
+    BLEND_STAMP(5);
+    if (!tail.counters) {
+        if (tid == 0) {
+            psum[o] = bsum;
+            pbad[o] = finite_d(bsum) ? 0 : 1;  // (a non-finite psi_new somewhere in the tile: see the header)
+            rmax[o] = bp2;
+            rsum[o] = bs2;
+            TopoPart tp;
+            tp.maxv = rmx.v; tp.maxi = rmx.i; tp.minb = rmn.v; tp.mini = rmn.i; tp.minpsi = bminp; tp.psi_at_min = pmin;
+            topo[o] = tp;
+        }
+        return;
+    }
+    if (tid == 0) {  // fused tail: see "last workgroup finishes"
+        st_agent(psum + o, bsum);
+        st_agent(pbad + o, finite_d(bsum) ? 0 : 1);
+        st_agent(rmax + o, bp2);
+        st_agent(rsum + o, bs2);
+        st_agent(&topo[o].maxv, rmx.v); st_agent(&topo[o].maxi, rmx.i); st_agent(&topo[o].minb, rmn.v); st_agent(&topo[o].mini, rmn.i);
+        st_agent(&topo[o].minpsi, bminp); st_agent(&topo[o].psi_at_min, pmin);
+        sh_last = take_ticket(tail.counters + b, (unsigned)nblk) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    PicardShared& S = *reinterpret_cast<PicardShared*>(&t[0][0]);  // the tile is dead: every wave passed the barrier above
+    picard_final_body<true>(b, tail, S);
+    if (tid == 0) __hip_atomic_store(tail.counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
 // ---------------------------------------------------------------- Anderson mixing (a10, method "anderson")
 // core/fusion_kernel_newton_solver.py:540-550 and core/fusion_kernel_iterative_solver.py:248-314
 constexpr int AND_MAX = 8;  // max mixing depth m

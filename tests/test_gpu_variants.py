@@ -26,9 +26,14 @@ SWITCHES = [
     {"SCPN_HIP_TILEGEO": "48", "SCPN_HIP_SUMFUSE": "0"},
 ]
 # experiment builds (never shipped: `_lib.build(variant=...)` makes libscpn_hip.<variant>.so next to the product library)
+# name -> (defines, tile geometry the run forces)
 EXPERIMENT_BUILDS = {
-    "mid40": ("TILE_MID_LZ=40", "TILE_MID_NW=10"),   # another tile geometry: 40 rows x 10 waves (run with SCPN_HIP_TILEGEO=32: the MID slot)
-    "lg2": ("TILE_LG=2",),                           # two rows of the prolongation's coarse loads in flight together
+    "mid40": (("TILE_MID_LZ=40", "TILE_MID_NW=10"), "32"),  # another tile geometry: 40 rows x 10 waves (the MID slot)
+    "pw0": (("TILE_PWIDE=0",), "48"),                # prolongation: coarse loads per fine row, one row at a time (rounds 1-3)
+    "pw0lg2": (("TILE_PWIDE=0", "TILE_LG=2"), "48"), # ... two rows in flight
+    "glds0": (("TILE_GLDS=0",), "48"),               # six-row post-smoother: inner-row sources through registers instead of LDS-DMA
+    "shd0": (("TILE_SHARE_D=0",), "48"),             # six-row pre-smoother: residual coefficients loaded by every wave at the defect stage
+    "bl3": (("BLEND_R03",), "48"),                   # round 3's Picard tail (fields identical; its norms differ in the last bits)
 }
 
 
@@ -60,9 +65,9 @@ def test_experiment_builds_are_bit_identical():
 
     _lib.require_gpu()
     base = run({})
-    for name, defines in EXPERIMENT_BUILDS.items():
+    for name, (defines, geo) in EXPERIMENT_BUILDS.items():
         lib = _lib.build(variant=name, defines=defines)
-        got = run({"SCPN_HIP_LIB": str(lib), "SCPN_HIP_TILEGEO": "32"})
+        got = run({"SCPN_HIP_LIB": str(lib), "SCPN_HIP_TILEGEO": geo})
         assert (got["psi"], got["jphi"], got["iterations"]) == (base["psi"], base["jphi"], base["iterations"]), (name, got, base)
 
 
