@@ -189,9 +189,12 @@ struct Solver {
     std::vector<ProfEntry> prof;
     std::vector<std::string> prof_names;
 
-    int nblk() const { return std::max(cdiv((long)nz * nr, 1024), nblk2()); }  // partial-array capacity
+    // partial-array capacity: whatever tiling a reduction kernel uses (1024-point blocks, the Picard tail's windows, the column-pair
+    // kernels' row bands -- all three move with -D experiment builds), its per-member partial count fits
+    int nblk() const { return std::max({(int)cdiv((long)nz * nr, 1024), nblk2(), nblkj()}); }
+    int nblkj() const { return (int)(cdiv(nr, 128) * cdiv(nz, JS_ROWS)); }  // workgroups per member of k_jsum / k_source
     int nblk1() const { return cdiv((long)nz * nr, 1024); }
-    int nblk2() const { return cdiv(nr, BL_WR) * cdiv(nz, BL_WZ); }  // tiles per member of the fused Picard tail (k_blend_tile: 18 x 124 windows)
+    int nblk2() const { return cdiv(nr, BL_WR) * cdiv(nz, BL_WZ); }  // tiles per member of the fused Picard tail (k_blend_tile: BL_WZ x BL_WR windows)
     int nblk_int() const { return cdiv((long)(nz - 2) * (nr - 2), 1024); }
 
     Fld slot_fld(const int* slot) { return Fld{psi_slots.p, slot, stride, B}; }
@@ -741,6 +744,15 @@ static bool omega_ok(double w) { return std::isfinite(w) && w >= 1.0 && w < 2.0;
 
 // Value of the device int at `dptr` once everything enqueued on the handle's stream so far has run (the stream is NOT
 // synchronised through the runtime: see k_post_word).  SCPN_HIP_POLL=memcpy restores hipMemcpyAsync + hipStreamSynchronize.
+static inline void cpu_relax() {  // a spin-wait hint where the host ISA has one
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
 static int poll_word(Solver* h, const int* dptr) {
     static const bool use_memcpy = [] { const char* e = std::getenv("SCPN_HIP_POLL"); return e && std::string(e) == "memcpy"; }();
     hipStream_t st = h->stream;
@@ -751,22 +763,30 @@ static int poll_word(Solver* h, const int* dptr) {
     }
     const unsigned seq = ++h->word_seq;
     SCPN_LAUNCH(k_post_word, dim3(1), dim3(1), 0, st, dptr, h->d_word, seq);
-    const auto t0 = std::chrono::steady_clock::now();
+    // Spin on the host-mapped word: tight for the first ~50 us (the usual wait is a few kernel times), then yielding the core
+    // between looks (two stream-group threads per rank and eight ranks per node must not pin sixteen cores for a long wait); the
+    // runtime is asked every ~2 ms of WALL time whether the stream has failed -- a device fault would otherwise leave the word
+    // unposted for ever.
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    auto next_query = t0 + std::chrono::milliseconds(2);
     for (unsigned spins = 0;; ++spins) {
         const unsigned long long w = __atomic_load_n(h->h_word, __ATOMIC_ACQUIRE);
         if ((unsigned)(w >> 32) == seq) return (int)(unsigned)(w & 0xffffffffull);
-        __builtin_ia32_pause();
-        if ((spins & 0xfffffu) == 0xfffffu) {  // (~every few ms: the runtime is not called while the word is on its way)
-            // a device fault would leave the word unposted for ever: fall back to the runtime, which reports the error
-            const hipError_t qs = hipStreamQuery(st);
-            if (qs == hipSuccess) {
-                const unsigned long long w2 = __atomic_load_n(h->h_word, __ATOMIC_ACQUIRE);
-                if ((unsigned)(w2 >> 32) == seq) return (int)(unsigned)(w2 & 0xffffffffull);
-                throw std::runtime_error("progress word was not posted although the stream is idle");
-            }
-            if (qs != hipErrorNotReady) throw std::runtime_error(std::string("stream failed while polling: ") + hipGetErrorString(qs));
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) HIP_TRY(hipStreamSynchronize(st));
+        cpu_relax();
+        if ((spins & 0xffu) != 0xffu) continue;
+        const auto now = clk::now();
+        if (now - t0 > std::chrono::microseconds(50)) std::this_thread::yield();
+        if (now < next_query) continue;
+        next_query = now + std::chrono::milliseconds(2);
+        const hipError_t qs = hipStreamQuery(st);
+        if (qs == hipSuccess) {
+            const unsigned long long w2 = __atomic_load_n(h->h_word, __ATOMIC_ACQUIRE);
+            if ((unsigned)(w2 >> 32) == seq) return (int)(unsigned)(w2 & 0xffffffffull);
+            throw std::runtime_error("progress word was not posted although the stream is idle");
         }
+        if (qs != hipErrorNotReady) throw std::runtime_error(std::string("stream failed while polling: ") + hipGetErrorString(qs));
+        if (now - t0 > std::chrono::seconds(120)) HIP_TRY(hipStreamSynchronize(st));
     }
 }
 

@@ -219,3 +219,33 @@ def test_shard_ranges():
     assert cover == list(range(7))
     with pytest.raises(ValueError):
         shard_range(4, 4, 4)
+
+
+def test_second_handle_without_hardware_queues_warns_once(monkeypatch):
+    """Stream groups beyond HIP's default of four hardware queues share queues and serialise: the package says so once
+    (the library itself never touches the environment)."""
+    import warnings
+
+    from scpn_fusion_core_amd import ensemble
+
+    monkeypatch.setattr(ensemble, "_live_streams", 0)
+    monkeypatch.setattr(ensemble, "_warned_queues", False)
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        ensemble._note_live_handle(+1, 2)      # one handle, two groups: fits
+        assert not seen
+        ensemble._note_live_handle(+1, 2)      # a second handle alive: four streams + the null stream
+        assert len(seen) == 1 and "GPU_MAX_HW_QUEUES" in str(seen[0].message)
+        ensemble._note_live_handle(+1, 2)      # said once
+        assert len(seen) == 1
+    ensemble._note_live_handle(-1, 2)
+    assert ensemble._live_streams == 4
+    monkeypatch.setattr(ensemble, "_warned_queues", False)
+    monkeypatch.setattr(ensemble, "_live_streams", 0)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        for _ in range(4):
+            ensemble._note_live_handle(+1, 2)
+        assert not seen
