@@ -645,8 +645,17 @@ __device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (d
 #ifndef STAMP_PROLONG
 #define STAMP_PROLONG false
 #endif
-#define TILE_STAMP(i) do { if (DEFECT != STAMP_DEFECT || PROLONG != STAMP_PROLONG || L.nz < 300) break; const unsigned lin__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
-        if (threadIdx.x == 0 && lin__ % 510 == 1 && lin__ / 510 < 8) g_tile_stamps[(lin__ / 510) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifndef STAMP_NZ_MIN
+#define STAMP_NZ_MIN 300  // which level is stamped: rows of the level in [STAMP_NZ_MIN, STAMP_NZ_MAX]
+#endif
+#ifndef STAMP_NZ_MAX
+#define STAMP_NZ_MAX 100000
+#endif
+#ifndef STAMP_STRIDE
+#define STAMP_STRIDE 510  // every STAMP_STRIDE-th workgroup (dispatch order) is sampled, eight in all
+#endif
+#define TILE_STAMP(i) do { if (DEFECT != STAMP_DEFECT || PROLONG != STAMP_PROLONG || L.nz < STAMP_NZ_MIN || L.nz > STAMP_NZ_MAX) break; const unsigned lin__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+        if (threadIdx.x == 0 && lin__ % STAMP_STRIDE == 1 && lin__ / STAMP_STRIDE < 8) g_tile_stamps[(lin__ / STAMP_STRIDE) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define BLEND_STAMP(i) do { const unsigned lin__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
         if (threadIdx.x == 0 && gridDim.y > 20 && lin__ % 577 == 1 && lin__ / 577 < 8) g_tile_stamps[(lin__ / 577) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
