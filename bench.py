@@ -118,10 +118,12 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
                                      "gbs_equivalent": round(bytes_survey / (tot_ms * 1e-3) / 1e9, 1)},
             "avg_launch_us": round(1e3 * tot_ms / tot_launch, 2), "launches": int(tot_launch),
             "groups": num_groups, "members_per_launch": int(members_per_launch), "isolated_kernel_timing": True,
-            "limiter": {"class": "on-chip life of a tile (barrier-separated phases of dependent fp64 chains, three tiles per CU) x tiles per CU; "
-                                 "not HBM (counter traffic = compulsory bytes), not memory latency (every tile loading one cached block: V-cycle -6.5 %), "
-                                 "not the LDS pipeline (register tile: 73 % fewer LDS instructions, same time with the chip full)",
-                        "counters": ctr, "evidence": "profiles/r03_experiments.md, DESIGN.md section 6"},
+            "limiter": {"class": "tiles in flight x tile lifetime on a chip where neither VALU (see counters) nor HBM (counter traffic = compulsory bytes) is "
+                                 "saturated; what shortens a tile's life is memory round trips in its load phase (post-smoother six -> one by LDS-DMA: -5 % per "
+                                 "iteration) and vector work outside the stencil (Picard tail -31 % VALU: -2 %); bytes alone do not (a tail with 25 % less traffic and "
+                                 "8 % more arithmetic is slower), larger tiles pack worse than the arithmetic they save, and the launch chain below level 0 is not "
+                                 "what the two-group iteration waits for (129^2 launches removed + their work added to the coarse kernel: unchanged)",
+                        "counters": ctr, "evidence": "profiles/r04_experiments.md, profiles/r03_experiments.md, DESIGN.md section 6"},
             "per_level": per_level, "families_ms": fam}
 
 

@@ -2206,242 +2206,7 @@ struct GradRecip { double dz, inv_dz, lo_dz, two_dz, inv_two_dz, lo_two_dz, dr, 
 constexpr int BL_WZ = BL_WZ_N, BL_LB = BL_WZ + 2, BL_WR = 124, BL_NW = 4, BL_NROWS = BL_LB / BL_NW;
 static_assert(BL_LB % BL_NW == 0, "rows are dealt to the four waves evenly");
 __device__ __forceinline__ int blend_tiles_x(int nr) { return (nr + BL_WR - 1) / BL_WR; }
-#ifdef BLEND_R03
-__global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
-                                                             double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
-                                                             double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm,
-                                                             GradRecip gq, PicardTail tail) {
-    __shared__ __attribute__((aligned(16))) double t[BL_LB][128];
-    __shared__ int sh_last;
-    __shared__ VI sh_mx[BL_NW], sh_mn[BL_NW];
-    __shared__ double sh_dsum[BL_NW], sh_m[BL_NW], sh_minp[BL_NW], sh_s2[BL_NW];
-    __shared__ int sh_bad[BL_NW];
-    __shared__ double sh_coef[2 * BL_NW][64];  // r_safe, 1/r_safe (two words), -mu0 R of the lane's two columns: loaded by one wave each
-    int bx_, by_, b;
-    {
-        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
-        unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        if (tail.xcd_remap) lin = xcd_contiguous(lin, total);
-        bx_ = (int)(lin % gx);
-        const unsigned t_ = lin / gx;
-        by_ = (int)(t_ % gy);
-        b = (int)(t_ / gy);
-    }
-    // the member's words -- activity, the slot of every field, the lazy-source scale -- in ONE round trip (see k_smooth_tile)
-    const int act_w = st[b].active;
-    const int k_cur = *curF.slot_ptr(b), k_new = *newF.slot_ptr(b), k_bc = *bcF.slot_ptr(b), k_src = *srcF.slot_ptr(b), k_nxt = *nxtF.slot_ptr(b);
-    const double lz_sc = *(lazy_nm ? &st[b].jscale : &g_const_f64[1]);
-    if (!act_w) return;
-    BLEND_STAMP(0);
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nz = L.nz, nr = L.nr, ld = L.ld;
-    // tile row lz <-> grid row z0 + lz, tile column lc <-> grid column r0 + lc; owned: lz in [1, BL_WZ], lc in [2, 125]
-    const int z0 = by_ * BL_WZ - 1, r0 = bx_ * BL_WR - 2;  // r0 even: the lane's pair is 16-B aligned
-    const int c0 = r0 + 2 * lane;
-    const bool pair_win = lane >= 1 && lane <= 62;
-    const bool own_x = pair_win && c0 < nr, own_y = pair_win && c0 + 1 < nr;  // (c0 >= 0 for window lanes)
-    const char* const cur_b = reinterpret_cast<const char*>(curF.at_slot(b, k_cur));
-    const char* const new_b = reinterpret_cast<const char*>(newF.at_slot(b, k_new));
-    const char* const bc_b = reinterpret_cast<const char*>(bcF.at_slot(b, k_bc));
-    const char* const src_b = reinterpret_cast<const char*>(srcF.at_slot(b, k_src));
-    char* const nxt_b = reinterpret_cast<char*>(nxtF.at_slot(b, k_nxt));
-    const unsigned ld8 = (unsigned)ld * 8u;
-    const unsigned lane_off = (unsigned)min(max(c0, 0), ld - 2) * 8u;
-    // ring columns (grid column 0 / nr-1) take their value from bc; only tiles that touch them look (wave-uniform)
-    const bool edge_cols = r0 <= 0 || r0 + 127 >= nr - 1;
-    const bool cring_x = c0 == 0 || c0 == nr - 1, cring_y = c0 + 1 == nr - 1;
-    double2 pc[BL_NROWS], pn[BL_NROWS], sv[BL_NROWS];
-#pragma unroll
-    for (int i = 0; i < BL_NROWS; ++i) {
-        const int gzc = min(max(z0 + w + BL_NW * i, 0), nz - 1);  // scalar
-        const unsigned vo = (unsigned)gzc * ld8 + lane_off;
-        const bool rowring = gzc == 0 || gzc == nz - 1;
-        pc[i] = *reinterpret_cast<const double2*>(cur_b + vo);
-        pn[i] = *reinterpret_cast<const double2*>((rowring ? bc_b : new_b) + vo);
-        sv[i] = *reinterpret_cast<const double2*>(src_b + vo);
-    }
-    if (edge_cols) {
-#pragma unroll
-        for (int i = 0; i < BL_NROWS; ++i) {
-            const int gzc = min(max(z0 + w + BL_NW * i, 0), nz - 1);
-            const unsigned vo = (unsigned)gzc * ld8 + lane_off;
-            if (cring_x) pn[i].x = *reinterpret_cast<const double*>(bc_b + vo);
-            if (cring_y) pn[i].y = *reinterpret_cast<const double*>(bc_b + vo + 8u);
-        }
-    }
-    // column coefficients of the residual stage: wave k fetches the k-th of (r_safe, 1/r_safe, its low word, -mu0 R) for the lane's
-    // two columns now, behind the row loads, and hands them to the other waves through LDS at the barrier below -- the residual
-    // stage then starts without a memory round trip and no wave holds more than two of them through the blend
-    const bool int_x = own_x && c0 >= 1 && c0 <= nr - 2, int_y = own_y && c0 + 1 <= nr - 2;  // (c0 + 1 >= 1 always)
-    {
-        const double* const arr = w == 0 ? L.r_safe : (w == 1 ? L.r_inv : (w == 2 ? L.r_inv_lo : lazy_nm));
-        const double* const dflt = &g_const_f64[w <= 1 ? 1 : 0];  // r_safe, 1/r_safe: 1.0; low word, -mu0 R: 0.0
-        const bool have = arr != nullptr;
-        sh_coef[2 * w][lane] = *((have && int_x) ? arr + c0 : dflt);
-        sh_coef[2 * w + 1][lane] = *((have && int_y) ? arr + c0 + 1 : dflt);
-    }
-    double dsum = 0.0, minpsi = INFINITY;
-    int bad = 0;
-    VI mx{0.0, -1}, mn{0.0, -1};
-    // (the blended pair is not kept in registers: the residual stage re-reads it from the tile -- 20 VGPRs less is one more
-    //  resident workgroup per SIMD, and this kernel lives on the number of tiles in flight: profiles/r03_experiments.md)
-#pragma unroll
-    for (int i = 0; i < BL_NROWS; ++i) {
-        const int lz = w + BL_NW * i, gz = z0 + lz;
-        double2 vi;
-        vi.x = om_alpha * pc[i].x + alpha * pn[i].x;
-        vi.y = om_alpha * pc[i].y + alpha * pn[i].y;
-        if (lz >= 1 && lz <= BL_WZ && gz < nz) {  // owned row (wave-uniform)
-            const long q = (long)gz * nr + c0;
-            // straight-line: lanes that do not own a point contribute the neutral element (index -1 disables a candidate)
-            bad |= (own_x && !finite_d(pn[i].x)) || (own_y && !finite_d(pn[i].y)) ? 1 : 0;
-            dsum += own_x ? fabs(pn[i].x - pc[i].x) : 0.0;
-            dsum += own_y ? fabs(pn[i].y - pc[i].y) : 0.0;
-            mx = vi_max(mx, VI{vi.x, (own_x && vi.x == vi.x) ? q : -1L});
-            mx = vi_max(mx, VI{vi.y, (own_y && vi.y == vi.y) ? q + 1 : -1L});
-            minpsi = fmin(minpsi, (own_x && finite_d(vi.x)) ? vi.x : INFINITY);
-            minpsi = fmin(minpsi, (own_y && finite_d(vi.y)) ? vi.y : INFINITY);
-            char* const o = nxt_b + ((unsigned)gz * ld8 + (unsigned)c0 * 8u);
-            if (own_y) *reinterpret_cast<double2*>(o) = vi;
-            else if (own_x) *reinterpret_cast<double*>(o) = vi.x;
-        }
-        *reinterpret_cast<double2*>(&t[lz][2 * lane]) = vi;
-    }
-    BLEND_STAMP(1);
-    __syncthreads();
-    BLEND_STAMP(2);
-    // residual / gradient stage: own pair from registers, N / S pairs and the two out-of-pair neighbours from the tile
-    const double rs0 = sh_coef[0][lane], rs1 = sh_coef[1][lane], ri0 = sh_coef[2][lane], ri1 = sh_coef[3][lane];
-    const double rl0 = sh_coef[4][lane], rl1 = sh_coef[5][lane], nm0 = sh_coef[6][lane], nm1 = sh_coef[7][lane];
-    double m = 0.0;
-    double2 rv[BL_NROWS];
-#pragma unroll
-    for (int i = 0; i < BL_NROWS; ++i) {
-        const int lz = w + BL_NW * i, gz = z0 + lz;
-        rv[i] = double2{0.0, 0.0};
-        if (!(lz >= 1 && lz <= BL_WZ && gz < nz)) continue;  // wave-uniform
-        const double2 N = *reinterpret_cast<const double2*>(&t[lz + 1][2 * lane]);
-        const double2 S = *reinterpret_cast<const double2*>(&t[lz - 1][2 * lane]);
-        const double Wn = (&t[lz][0])[2 * lane - 1], En = (&t[lz][0])[2 * lane + 2];
-        const double2 P = *reinterpret_cast<const double2*>(&t[lz][2 * lane]);
-        const double px = P.x, py = P.y;
-        if (gz >= 1 && gz <= nz - 2) {  // wave-uniform
-            double sx = sv[i].x, sy = sv[i].y;
-            if (lazy_nm) {  // the source field holds J_raw (see k_smooth_tile)
-                sx = nm0 * (lz_sc != 0.0 ? sx * lz_sc : 0.0);
-                sy = nm1 * (lz_sc != 0.0 ? sy * lz_sc : 0.0);
-            }
-            // straight-line for both points of the pair (no per-lane branches: the two dependent chains interleave); lanes whose
-            // point is not an interior grid point compute on clamped copies and are deselected at the end
-            const double d2rx = divc4(py - 2.0 * px + Wn, L.dr2, L.inv_dr2, L.lo_dr2);
-            const double d2ry = divc4(En - 2.0 * py + px, L.dr2, L.inv_dr2, L.lo_dr2);
-            const double d1rx = divc4(py - Wn, L.two_dr, L.inv_two_dr, L.lo_two_dr);
-            const double d1ry = divc4(En - px, L.two_dr, L.inv_two_dr, L.lo_two_dr);
-            const double d2zx = divc4(N.x - 2.0 * px + S.x, L.dz2, L.inv_dz2, L.lo_dz2);
-            const double d2zy = divc4(N.y - 2.0 * py + S.y, L.dz2, L.inv_dz2, L.lo_dz2);
-            const double rx = sanitize_sel((d2rx - divc4(d1rx, rs0, ri0, rl0) + d2zx) - sx);
-            const double ry = sanitize_sel((d2ry - divc4(d1ry, rs1, ri1, rl1) + d2zy) - sy);
-            rv[i].x = int_x ? rx : 0.0;
-            rv[i].y = int_y ? ry : 0.0;
-            m = fmax(m, fmax(fabs(rv[i].x), fabs(rv[i].y)));
-        }
-    }
-    BLEND_STAMP(3);
-    // wave-level reductions (results in every lane), one LDS hand-over per wave
-    const double w_dsum = wave_sum(dsum), w_m = wave_max(m), w_minp = -wave_max(-minpsi);
-    const VI w_mx = wave_vi<true>(mx);
-    const int w_bad = __any(bad) ? 1 : 0;
-    if (lane == 0) { sh_dsum[w] = w_dsum; sh_m[w] = w_m; sh_minp[w] = w_minp; sh_mx[w] = w_mx; sh_bad[w] = w_bad; }
-    __syncthreads();
-    BLEND_STAMP(4);
-    // overflow-safe residual sum: (max, sum (r/max)^2) with the WORKGROUP max, see k_resid_norms
-    const double bmax = fmax(fmax(sh_m[0], sh_m[1]), fmax(sh_m[2], sh_m[3]));
-    double s2 = 0.0;
-    if (bmax > 0.0) {
-        const double ib = 1.0 / bmax;  // one IEEE division per thread instead of one per point (the rescaled sum is a norm estimate)
-#pragma unroll
-        for (int i = 0; i < BL_NROWS; ++i) { const double qx = rv[i].x * ib, qy = rv[i].y * ib; s2 += qx * qx; s2 += qy * qy; }
-    }
-    const double w_s2 = wave_sum(s2);
-    // Divertor rows (a quarter of the tiles): np.gradient + hypot + masked arg-min (fusion_kernel.py:276-288).  Done HERE, after the
-    // residuals have been consumed, and from the LDS tile: the stage then needs none of the registers the residual stage holds,
-    // the kernel fits 80 VGPRs and every tile -- also the three quarters without divertor rows -- gets a sixth resident workgroup per CU.
-    VI w_mn{0.0, -1};
-    if (z0 + 1 < n_mask_rows) {  // (uniform: the tile owns at least one masked row)
-#pragma unroll
-        for (int i = 0; i < BL_NROWS; ++i) {
-            const int lz = w + BL_NW * i, gz = z0 + lz;
-            if (!(lz >= 1 && lz <= BL_WZ && gz < nz) || gz >= n_mask_rows) continue;  // wave-uniform
-            const double2 N = *reinterpret_cast<const double2*>(&t[lz + 1][2 * lane]);
-            const double2 S = *reinterpret_cast<const double2*>(&t[lz - 1][2 * lane]);
-            const double Wn = (&t[lz][0])[2 * lane - 1], En = (&t[lz][0])[2 * lane + 2];
-            const double2 P = *reinterpret_cast<const double2*>(&t[lz][2 * lane]);
-            const double px = P.x, py = P.y;
-            auto grad = [&](bool on, double p, double n_, double s_, double e_, double w_, int gc) {
-                const double ps = nan_to_num300(p), nn = nan_to_num300(n_), ss = nan_to_num300(s_), ee = nan_to_num300(e_), ww = nan_to_num300(w_);
-                double gzv, grv;
-                if (gz == 0) gzv = divc4(nn - ps, gq.dz, gq.inv_dz, gq.lo_dz);  // (row tests are wave-uniform)
-                else if (gz == nz - 1) gzv = divc4(ps - ss, gq.dz, gq.inv_dz, gq.lo_dz);
-                else gzv = divc4(nn - ss, gq.two_dz, gq.inv_two_dz, gq.lo_two_dz);
-                grv = divc4(ee - ww, L.two_dr, L.inv_two_dr, L.lo_two_dr);
-                if (edge_cols) {  // wave-uniform: only tiles that touch grid column 0 / nr-1 evaluate the one-sided forms
-                    const double g0 = divc4(ee - ps, gq.dr, gq.inv_dr, gq.lo_dr), g1 = divc4(ps - ww, gq.dr, gq.inv_dr, gq.lo_dr);
-                    grv = gc == 0 ? g0 : (gc == nr - 1 ? g1 : grv);
-                }
-                const double bm = hypot(grv, gzv);
-                mn = vi_min(mn, VI{bm, (on && finite_d(bm)) ? (long)gz * nr + gc : -1L});
-            };
-            grad(own_x, px, N.x, S.x, py, Wn, c0);
-            grad(own_y, py, N.y, S.y, En, px, c0 + 1);
-        }
-        w_mn = wave_vi<false>(mn);
-    }
-    if (lane == 0) { sh_s2[w] = w_s2; sh_mn[w] = w_mn; }
-    __syncthreads();
-    const double bsum = sh_dsum[0] + sh_dsum[1] + sh_dsum[2] + sh_dsum[3];
-    const double bs2 = sh_s2[0] + sh_s2[1] + sh_s2[2] + sh_s2[3];
-    const double bminp = fmin(fmin(sh_minp[0], sh_minp[1]), fmin(sh_minp[2], sh_minp[3]));
-    const int shbad = sh_bad[0] | sh_bad[1] | sh_bad[2] | sh_bad[3];
-    VI rmx = sh_mx[0], rmn = sh_mn[0];
-#pragma unroll
-    for (int i = 1; i < BL_NW; ++i) { rmx = vi_max(rmx, sh_mx[i]); rmn = vi_min(rmn, sh_mn[i]); }
-    const long o = (long)b * nblk + (long)by_ * gridDim.x + bx_;
-    BLEND_STAMP(5);
-    double pmin = 0.0;  // psi of the blended iterate at this tile's arg-min candidate (still in the LDS tile)
-    if (tid == 0 && rmn.i >= 0) {
-        const int iz = (int)(rmn.i / nr), ir = (int)(rmn.i - (long)iz * nr);
-        pmin = t[iz - z0][ir - r0];
-    }
-    if (!tail.counters) {
-        if (tid == 0) {
-            psum[o] = bsum;
-            pbad[o] = shbad;
-            rmax[o] = bmax;
-            rsum[o] = bs2;
-            TopoPart tp;
-            tp.maxv = rmx.v; tp.maxi = rmx.i; tp.minb = rmn.v; tp.mini = rmn.i; tp.minpsi = bminp; tp.psi_at_min = pmin;
-            topo[o] = tp;
-        }
-        return;
-    }
-    if (tid == 0) {  // fused tail: see "last workgroup finishes"
-        st_agent(psum + o, bsum);
-        st_agent(pbad + o, shbad);
-        st_agent(rmax + o, bmax);
-        st_agent(rsum + o, bs2);
-        st_agent(&topo[o].maxv, rmx.v); st_agent(&topo[o].maxi, rmx.i); st_agent(&topo[o].minb, rmn.v); st_agent(&topo[o].mini, rmn.i);
-        st_agent(&topo[o].minpsi, bminp); st_agent(&topo[o].psi_at_min, pmin);
-        sh_last = take_ticket(tail.counters + b, (unsigned)nblk) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!sh_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    PicardShared& S = *reinterpret_cast<PicardShared*>(&t[0][0]);  // the tile is dead: every wave passed the barrier above
-    picard_final_body<true>(b, tail, S);
-    if (tid == 0) __hip_atomic_store(tail.counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-#else
-// Round 4: the same kernel with the per-point bookkeeping taken out of the point loop.  What a LANE accumulates is kept per COLUMN
+// Round 4: the per-point bookkeeping taken out of the point loop (round 3's form: profiles/r04_negative/blend_tile_round3.hip.h.txt).  What a LANE accumulates is kept per COLUMN
 // of its pair (sum |new - cur|, min, running max + the row it came from, max |r|), so the lane's column predicates (window lane,
 // inside the grid, interior column) are applied ONCE per lane after the rows instead of as selects per point; the non-finite
 // check of the elliptic solve's output is read off the partial sum of |new - cur| (a non-finite `new` makes its owner's sum
@@ -2449,7 +2214,7 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
 // lane; the (value, index) wave reductions are a value reduction plus a 32-bit index reduction among the lanes that hold the
 // extreme value; the residual is sanitised on a cold path (a wave that sees |r| > CAP or a NaN -- never in a healthy run) and its
 // sum of squares is scaled by a power of two taken from the WAVE's own largest |r| (exact scaling, no division, no workgroup
-// barrier between the maximum and the squares).  Outputs are those of round 3's kernel (profiles/r04_negative/) to rounding:
+// barrier between the maximum and the squares).  Outputs are those of round 3's kernel to rounding:
 // rmax is the power of two the tile's sum is relative to.
 __device__ __forceinline__ double pow2_floor_or_zero(double m) {  // 2^floor(log2 m) for finite m > 0 (subnormals: 2^-1022), 0 for m == 0
     const unsigned long b = (unsigned long)__double_as_longlong(m);
@@ -2724,7 +2489,6 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
     picard_final_body<true>(b, tail, S);
     if (tid == 0) __hip_atomic_store(tail.counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-#endif
 // ---------------------------------------------------------------- Anderson mixing (a10, method "anderson")
 // core/fusion_kernel_newton_solver.py:540-550 and core/fusion_kernel_iterative_solver.py:248-314
 constexpr int AND_MAX = 8;  // max mixing depth m

@@ -33,7 +33,6 @@ EXPERIMENT_BUILDS = {
     "pw0lg2": (("TILE_PWIDE=0", "TILE_LG=2"), "48"), # ... two rows in flight
     "glds0": (("TILE_GLDS=0",), "48"),               # six-row post-smoother: inner-row sources through registers instead of LDS-DMA
     "shd0": (("TILE_SHARE_D=0",), "48"),             # six-row pre-smoother: residual coefficients loaded by every wave at the defect stage
-    "bl3": (("BLEND_R03",), "48"),                   # round 3's Picard tail (fields identical; its norms differ in the last bits)
 }
 
 
