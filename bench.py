@@ -210,6 +210,19 @@ def main() -> int:
     from scpn_fusion_core_amd.cases import member_cfg, scan_member_table
     from scpn_fusion_core_amd.ensemble import EnsembleSolver
 
+    if comm is None and world > 1:
+        # No communicator.  The documented fall-back (every rank solves its shard, the line is marked invalid) needs every rank to
+        # HAVE a device: the ranks say so to each other before anybody starts, and a job in which one rank has none ends at once
+        # on every rank instead of leaving the others at a barrier the missing rank never reaches.
+        from scpn_fusion_core_amd.distributed import exchange, rendezvous_port
+
+        mine = b"" if _lib.device_count() > local_rank else f"device {local_rank} is not visible ({_lib.device_count()} device(s))".encode()
+        seen = exchange(rank, world, mine, addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), port=rendezvous_port())
+        missing = [f"rank {r}: {v.decode()}" for r, v in enumerate(seen) if v]
+        if missing:
+            if rank == 0:
+                print(f"bench.py: no communicator ({comm_error}) and not every rank has a GPU -- {'; '.join(missing)}", file=sys.stderr)
+            return 3
     _lib.require_gpu()
     cfg = make_cfg(args.grid)
     B = args.batch

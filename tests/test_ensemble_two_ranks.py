@@ -227,3 +227,24 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus(tmp_path):
     env = {**os.environ, "WORLD_SIZE": "1", "RANK": "0"}
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_ends_at_once_when_a_rank_has_no_gpu_and_no_communicator():
+    """No GPU here: both ranks fail the communicator's pre-flight, tell each other that they have no device either, and the job ends
+    with the documented exit code 3 within seconds -- not at a barrier the missing rank never reaches."""
+    import subprocess
+    import sys
+    import time
+
+    from tests.conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["SCPN_DISABLE_GPU_TEST_MARK"] = "1"
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--no-roofline", "--no-newton", "--no-configs"], env=env, capture_output=True, text=True, timeout=170)
+    if "not every rank has a GPU" not in r.stderr:  # (a GPU box: the rehearsal there is tools' business, not this CPU test's)
+        import pytest
+
+        pytest.skip("GPUs are visible to this process")
+    assert r.returncode == 3 and not r.stdout.strip() and time.monotonic() - t0 < 60.0
