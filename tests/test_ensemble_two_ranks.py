@@ -239,7 +239,6 @@ def test_bench_ends_at_once_when_a_rank_has_no_gpu_and_no_communicator():
     from tests.conftest import ROOT
 
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
-    env["SCPN_DISABLE_GPU_TEST_MARK"] = "1"
     t0 = time.monotonic()
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
                         "--no-roofline", "--no-newton", "--no-configs"], env=env, capture_output=True, text=True, timeout=170)

@@ -573,3 +573,45 @@ def test_config5_scan_256_members_on_one_gpu(hip, orc):
                                       max_outer=20, tol=1e-4)
         assert res[m]["outer_iterations"] == ref["outer_iterations"] and res[m]["picard_iterations"] == ref["picard_iterations"], m
         assert np.abs(psi - ref["psi"]).max() <= 1e-10 * np.abs(ref["psi"]).max(), m
+
+
+def test_picard_on_a_tall_grid_with_more_than_256_tail_tiles_per_member(hip, orc):
+    """250 x 1900 (nr x nz): 3 x 136 = 408 tiles of the fused Picard tail per member, so every per-member final reduction
+    (k_picard_final, k_jsum_final) walks its partials in more than one chunk of 256; non-square, not of the 2^k + 1 family."""
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    cfg = iter_like_cfg(65, tol=1e-12, max_iter=7)
+    cfg["grid_resolution"] = [250, 1900]
+    ref = orc.picard_solve(cfg, trace=True)
+    with EnsembleSolver(cfg, batch=2) as es:
+        res = es.solve_equilibrium(history=True, trace=True, check_every=3)
+        psi = es.get_psi()
+    assert res[0]["iterations"] == ref["iterations"] == 7
+    assert np.abs(psi[0] - ref["psi"]).max() <= 1e-11 * np.abs(ref["psi"]).max()
+    assert np.array_equal(psi[0], psi[1])
+    tr = np.asarray(res[0]["trace"])
+    assert np.array_equal(tr[:, 2], ref["trace"][:, 2])  # the X-point index of every iteration
+    np.testing.assert_allclose(tr[:, :2], ref["trace"][:, :2], rtol=1e-11)  # psi_axis, psi_boundary
+    np.testing.assert_allclose(tr[:, 4:], ref["trace"][:, 4:], rtol=1e-9)   # mean |dpsi|, GS residual RMS
+    assert res[0]["gs_residual"] == pytest.approx(ref["gs_residual"], rel=1e-9)
+
+
+def test_picard_tail_cold_path_sanitises_an_overflowing_residual(hip, orc):
+    """A start whose GS residual exceeds the sanitising cap (1e250) in part of the grid: the fused tail takes its cold path (NaN -> 0,
+    clip, power-of-two rescaling of the squares) in the waves that see it and reports the reference's stable RMS."""
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    cfg = iter_like_cfg(65, tol=1e-12, max_iter=3)
+    cfg["solver"]["relaxation_factor"] = 0.01  # the blended iterate stays the rough start: |L* psi| ~ 1e254 in the patch
+    nz = nr = 65
+    psi0 = np.zeros((nz, nr))
+    zz, rr = np.indices((nz, nr))
+    psi0[8:30, 8:40] = np.where((zz[8:30, 8:40] + rr[8:30, 8:40]) % 2 == 0, 1e251, -1e251)
+    ref = orc.picard_solve(cfg, psi0=psi0, preserve=True, trace=True)
+    with EnsembleSolver(cfg, batch=1) as es:
+        es.set_psi(psi0[None])
+        res = es.solve_equilibrium(preserve_initial_state=True, history=True, trace=True)[0]
+    assert res["iterations"] == ref["iterations"]
+    got, want = np.asarray(res["trace"])[:, 5], ref["trace"][:, 5]
+    assert np.all(np.isfinite(got)) and 1e249 < want.max() <= 1e250  # residuals beyond the cap were clipped, the squares did not overflow
+    np.testing.assert_allclose(got, want, rtol=1e-9)
