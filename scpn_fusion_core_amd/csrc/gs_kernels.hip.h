@@ -1504,16 +1504,21 @@ __global__ void k_jacobi(Fld outF, Fld psiF, Fld srcF, Lvl L, const int* active)
     }
     outF.at(b)[c] = v;
 }
-// S Jacobi steps per launch (temporal blocking of the 50-step seed relaxation, core/fusion_kernel_iterative_solver.py:408-410):
-// a (JT_Z+2S) x (JT_R+2S) tile of psi and src is staged in LDS, every step updates the whole tile out of place (the stale rim
-// moves inward one cell per step and never reaches the JT_Z x JT_R core), the Dirichlet ring keeps its (sanitised) value.
-// Same arithmetic as k_jacobi (x / a_c through divc: bit-identical for finite x).  grid (ceil(nr/JT_R), ceil(nz/JT_Z), B)
-constexpr int JT_Z = 32, JT_R = 64;
+// S Jacobi steps per launch (temporal blocking of the 50-step seed relaxation, core/fusion_kernel_iterative_solver.py:408-410) in
+// the register-tile form of k_smooth_tile (round 4; the LDS-tile form of rounds 1-3: profiles/r04_negative/): a 48 x 128 tile, eight waves,
+// a wave owns six consecutive rows and a lane the column pair (2l, 2l+1) of those rows -- psi, source and the column coefficients
+// stay in VGPRs from the load to the store.  A step updates every cell from the OLD values of its four neighbours: E / W of the
+// pair's outer sides by wave_shl / wave_shr DPP moves, N / S from the registers of the neighbouring rows (a two-row rolling copy
+// of the old values while the rows are overwritten in place), the wave's first / last row from the neighbouring waves through
+// LDS (double-buffered by step parity: ONE barrier per step).  Halo 6 (even: pairs stay aligned) >= S, window 36 x 116.
+// Out-of-domain cells hold clamped copies that no kept update or store reads, as in the smoother.  Same arithmetic as k_jacobi
+// (sanitised inputs, x / a_c through divc4, clip), bit-identical for finite x.
 template <int S>
-__global__ void __launch_bounds__(256) k_jacobi_tile(Fld outF, Fld psiF, Fld srcF, Lvl L, const int* active) {
-    constexpr int WZ = JT_Z + 2 * S, WR = JT_R + 2 * S, LDW = WR + 1, NPT = (WZ * WR + 255) / 256;
-    __shared__ double bufA[WZ * LDW], bufB[WZ * LDW];
-    int bx_, by_, b;  // XCD-contiguous tile order (halo cells come from the XCD's own L2)
+__global__ void __launch_bounds__(512, 6) k_jacobi_reg(Fld outF, Fld psiF, Fld srcF, Lvl L, const int* active) {
+    constexpr int LZ = 48, NW = 8, NROWS = LZ / NW, H = 6;
+    static_assert(S <= H, "the halo must cover the steps of one launch");
+    __shared__ __attribute__((aligned(16))) double2 xch[2][NW][2][64];  // [step parity][wave][first / last row][lane]
+    int bx_, by_, b;
     {
         const unsigned gx = gridDim.x, gy = gridDim.y;
         const unsigned lin = xcd_contiguous(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
@@ -1521,67 +1526,75 @@ __global__ void __launch_bounds__(256) k_jacobi_tile(Fld outF, Fld psiF, Fld src
         by_ = (int)((lin / gx) % gy);
         b = (int)(lin / (gx * gy));
     }
-    if (active && !active[b]) return;
-    const double* psi = psiF.at(b);
-    const double* src = srcF.at(b);
+    const int act_w = *(active ? active + b : &g_const_i32[1]);
+    const int k_in = *psiF.slot_ptr(b), k_out = *outF.slot_ptr(b), k_src = *srcF.slot_ptr(b);
+    if (!act_w) return;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lzb = w * NROWS;
     const int nz = L.nz, nr = L.nr, ld = L.ld;
-    const int z0 = by_ * JT_Z - S, r0 = bx_ * JT_R - S;
-    // kind: 0 outside the domain / tile rim (never updated), 1 Dirichlet ring, 2 interior
-    int lidx[NPT];
-    double ae[NPT], aw[NPT], svr[NPT];  // coefficients and source of the thread's points stay in registers
-    unsigned kind = 0;  // 2 bits per point
+    const int z0 = by_ * (LZ - 2 * H) - H, r0 = bx_ * (128 - 2 * H) - H;  // both even
+    const int c0 = r0 + 2 * lane;
+    const bool in0 = c0 >= 1 && c0 <= nr - 2, in1 = c0 + 1 >= 1 && c0 + 1 <= nr - 2;
+    const double ae0 = *(in0 ? L.a_e + c0 : &g_const_f64[0]), aw0 = *(in0 ? L.a_w + c0 : &g_const_f64[0]);
+    const double ae1 = *(in1 ? L.a_e + c0 + 1 : &g_const_f64[0]), aw1 = *(in1 ? L.a_w + c0 + 1 : &g_const_f64[0]);
+    const char* const in_b = reinterpret_cast<const char*>(psiF.at_slot(b, k_in));
+    const char* const src_b = reinterpret_cast<const char*>(srcF.at_slot(b, k_src));
+    double* const out = outF.at_slot(b, k_out);
+    const unsigned ld8 = (unsigned)ld * 8u;
+    const unsigned lane_off = (unsigned)min(max(c0, 0), ld - 2) * 8u;
+    double2 v[NROWS], sv[NROWS];
 #pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int i = threadIdx.x + 256 * j;
-        lidx[j] = -1;
-        ae[j] = aw[j] = svr[j] = 0.0;
-        if (i < WZ * WR) {
-            const int lz = i / WR, lr = i - lz * WR;
-            const int gz = z0 + lz, gr = r0 + lr;
-            const int li = lz * LDW + lr;
-            lidx[j] = li;
-            double v = 0.0, sv = 0.0;
-            unsigned kd = 0;
-            if (gz >= 0 && gz < nz && gr >= 0 && gr < nr) {
-                const long c = (long)gz * ld + gr;
-                v = sanitize1(psi[c]);
-                sv = sanitize1(src[c]);
-                const bool ring = gz == 0 || gz == nz - 1 || gr == 0 || gr == nr - 1;
-                const bool rim = lz == 0 || lz == WZ - 1 || lr == 0 || lr == WR - 1;
-                kd = ring ? 1u : (rim ? 0u : 2u);
-                if (!ring) { ae[j] = L.a_e[gr]; aw[j] = L.a_w[gr]; }
-            }
-            kind |= kd << (2 * j);
-            bufA[li] = v;
-            bufB[li] = v;
-            svr[j] = sv;
-        }
+    for (int i = 0; i < NROWS; ++i) {
+        const int gzc = min(max(z0 + lzb + i, 0), nz - 1);  // scalar
+        const unsigned vo = (unsigned)gzc * ld8 + lane_off;
+        v[i] = *reinterpret_cast<const double2*>(in_b + vo);
+        sv[i] = *reinterpret_cast<const double2*>(src_b + vo);
     }
-    __syncthreads();
-    double* cur = bufA;
-    double* nxt = bufB;
+#pragma unroll
+    for (int i = 0; i < NROWS; ++i) {
+        v[i].x = sanitize1(v[i].x); v[i].y = sanitize1(v[i].y);
+        sv[i].x = sanitize1(sv[i].x); sv[i].y = sanitize1(sv[i].y);
+    }
+    // a cell is updated iff it is an interior grid point and not on the tile's rim (rows: wave-uniform tests)
+    const bool colok0 = lane >= 1 && in0, colok1 = lane <= 62 && in1;
+    bool rowok[NROWS];
+#pragma unroll
+    for (int i = 0; i < NROWS; ++i) {
+        const int lz = lzb + i, gz = z0 + lz;
+        rowok[i] = gz >= 1 && gz <= nz - 2 && lz >= 1 && lz <= LZ - 2;
+    }
+    const double a_ns = L.a_ns, a_c = L.a_c, inv_a_c = L.inv_a_c, lo_a_c = L.lo_a_c;
+    const int w_s = w > 0 ? w - 1 : 0, w_n = w < NW - 1 ? w + 1 : NW - 1;  // (the tile's first / last row is never updated)
 #pragma unroll 1
     for (int s = 0; s < S; ++s) {
-#pragma unroll
-        for (int j = 0; j < NPT; ++j) {
-            if (((kind >> (2 * j)) & 3u) == 2u) {
-                const int li = lidx[j];
-                double v = divc(ae[j] * cur[li + 1] + aw[j] * cur[li - 1] + L.a_ns * cur[li - LDW] + L.a_ns * cur[li + LDW] - svr[j],
-                                L.a_c, L.inv_a_c);
-                nxt[li] = fmin(fmax(v, -CAP), CAP);
-            }
-        }
+        const int pb = s & 1;
+        xch[pb][w][0][lane] = v[0];
+        xch[pb][w][1][lane] = v[NROWS - 1];
         __syncthreads();
-        double* t = cur; cur = nxt; nxt = t;
-    }
-    double* out = outF.at(b);
+        double2 old_m1 = xch[pb][w_s][1][lane];           // last row of the wave above in the tile (row index - 1)
+        const double2 nb = xch[pb][w_n][0][lane];         // first row of the wave below
 #pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int i = threadIdx.x + 256 * j;
-        if (i < WZ * WR) {
-            const int lz = i / WR, lr = i - lz * WR;
-            const int gz = z0 + lz, gr = r0 + lr;
-            if (lz >= S && lz < S + JT_Z && lr >= S && lr < S + JT_R && gz < nz && gr < nr) out[(long)gz * ld + gr] = cur[lidx[j]];
+        for (int i = 0; i < NROWS; ++i) {
+            const double2 o = v[i];
+            const double2 up = i < NROWS - 1 ? v[i < NROWS - 1 ? i + 1 : 0] : nb;
+            const double Wx = wave_shift<0x138>(o.y), Ey = wave_shift<0x130>(o.x);
+            const double nx = divc4(ae0 * o.y + aw0 * Wx + a_ns * old_m1.x + a_ns * up.x - sv[i].x, a_c, inv_a_c, lo_a_c);
+            const double ny = divc4(ae1 * Ey + aw1 * o.x + a_ns * old_m1.y + a_ns * up.y - sv[i].y, a_c, inv_a_c, lo_a_c);
+            const double cx = fmin(fmax(nx, -CAP), CAP), cy = fmin(fmax(ny, -CAP), CAP);
+            v[i].x = (rowok[i] & colok0) ? cx : o.x;
+            v[i].y = (rowok[i] & colok1) ? cy : o.y;
+            old_m1 = o;
+        }
+    }
+    const bool pair_own = lane >= H / 2 && lane < 64 - H / 2 && c0 < nr;
+    const bool pair_full = c0 + 1 < nr;
+#pragma unroll
+    for (int i = 0; i < NROWS; ++i) {
+        const int lz = lzb + i, gz = z0 + lz;
+        if (lz >= H && lz < LZ - H && gz < nz && pair_own) {  // (row test wave-uniform)
+            char* const o = reinterpret_cast<char*>(out) + ((unsigned)gz * ld8 + (unsigned)c0 * 8u);
+            if (pair_full) *reinterpret_cast<double2*>(o) = v[i];
+            else *reinterpret_cast<double*>(o) = v[i].x;
         }
     }
 }

@@ -916,10 +916,10 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         SCPN_LAUNCH(k_source_from_j, g2, BLK2D, 0, st, srcF, jF, nz, nr, ld, (const double*)h->d_neg_mu0R.p, (const int*)d_sa.p);
         if (h->use_fused && nz >= 16 && nr >= 16) {  // 50 steps = 10 launches of 5 temporally blocked steps
             ProfScope ps(h, "seed_jacobi", 10);
-            const dim3 gj(cdiv(nr, JT_R), cdiv(nz, JT_Z), B);
+            const dim3 gj(cdiv(nr, 116), cdiv(nz, 36), B);  // (window 36 x 116 of a 48 x 128 register tile)
             for (int s = 0; s < 5; ++s) {
-                SCPN_LAUNCH(k_jacobi_tile<5>, gj, dim3(256), 0, st, WF, curF, srcF, L0, (const int*)d_sa.p);
-                SCPN_LAUNCH(k_jacobi_tile<5>, gj, dim3(256), 0, st, curF, WF, srcF, L0, (const int*)d_sa.p);
+                SCPN_LAUNCH(k_jacobi_reg<5>, gj, dim3(512), 0, st, WF, curF, srcF, L0, (const int*)d_sa.p);
+                SCPN_LAUNCH(k_jacobi_reg<5>, gj, dim3(512), 0, st, curF, WF, srcF, L0, (const int*)d_sa.p);
             }
         } else {
             ProfScope ps(h, "seed_jacobi", 50);
