@@ -184,6 +184,7 @@ struct Solver {
     double seed_rc = NAN, seed_integral = 0.0;
     double mu0_tables = NAN;
 
+    std::vector<int> h_seed_act;  // host image of d_scr_sa (uploaded asynchronously by the seed phase)
     // profiling
     bool prof_on = false;
     std::vector<ProfEntry> prof;
@@ -908,7 +909,8 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         SCPN_LAUNCH(k_seed_j, g2, BLK2D, 0, st, jF, (const double*)h->d_seed.p, (const Member*)h->d_st.p, i_seed, nz, nr, ld,
                            (const int*)d_part.p);
         // members with |I_target| < 1e-12 keep psi untouched (their J is zero)
-        std::vector<int> seed_act(B);
+        std::vector<int>& seed_act = h->h_seed_act;  // (lives in the handle: its upload is not waited for here)
+        seed_act.assign(B, 0);
         for (int b = 0; b < B; ++b) seed_act[b] = part[b] && std::fabs(ms[b].i_target) >= 1e-12;
         DBuf<int>& d_sa = h->d_scr_sa;
         d_sa.alloc(B);
@@ -928,7 +930,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
                 SCPN_LAUNCH(k_jacobi, g2, BLK2D, 0, st, curF, WF, srcF, L0, (const int*)d_sa.p);
             }
         }
-        HIP_TRY(hipStreamSynchronize(st));
+        // (the relaxation stays in the stream: the host needs nothing from it; seed_act / d_sa are per-handle buffers)
     }
     if (p->external_profile_mode) {
         SCPN_LAUNCH(k_source_from_j, g2, BLK2D, 0, st, srcF, jF, nz, nr, ld, (const double*)h->d_neg_mu0R.p, (const int*)h->d_active.p);
@@ -1139,7 +1141,8 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             if (lazy)  // the source field held J_raw during the iterations: leave the last source in it, as the eager path does
                 SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, srcF, jF, 0, prevF, (const Member*)d_tmp.p, nz, nr, ld, (const double*)h->d_r.p,
                                    (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
-            HIP_TRY(hipStreamSynchronize(st));
+            // (`tmp` is a pageable host vector: its upload above was staged by the runtime before hipMemcpyAsync returned; the
+            //  results read-back below waits for these launches)
         }
         for (int b = 0; b < B; ++b)
             if (zero_current[b]) {
@@ -1772,7 +1775,7 @@ static int S_free_boundary_solve(Solver* h, const scpn_picard_params* p, int n_c
         Fld curF = h->slot_fld(h->d_cur.p);
         SCPN_LAUNCH(k_apply_bc, gring, dim3(256), 0, st, curF, extF, nz, nr, ld, (const int*)d_mask.p);
         SCPN_LAUNCH(k_copy, g2, BLK2D, 0, st, oldF, curF, nz, nr, ld, (const int*)d_mask.p);
-        HIP_TRY(hipStreamSynchronize(st));
+        // (no host wait here: the inner solve starts with a read-back on the same stream)
         if (newton) {  // inner solve = Newton-Kantorovich (solver_method "newton"): same outer loop, same Dirichlet data
             std::vector<scpn_newton_result> nres(B);
             newton_solve_impl(h, &q, newton, nres.data(), nullptr, nullptr, &mask);
