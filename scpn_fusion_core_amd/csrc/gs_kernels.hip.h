@@ -123,31 +123,8 @@ __device__ __forceinline__ double nan_to_num300(double x) {  // fusion_kernel.py
 }
 __device__ __forceinline__ bool finite_d(double x) { return fabs(x) <= 1.7976931348623157e308; }
 
-// ---------------------------------------------------------------- "last workgroup finishes" hand-off
-// A kernel whose workgroups each leave a few partials for a per-member final reduction can let the workgroup that ARRIVES LAST do
-// that reduction itself instead of ending and paying a dependent launch for it (k_jsum -> k_jsum_final, k_blend_tile ->
-// k_picard_final: two launches and two kernel boundaries off the ~11-launch chain of a Picard iteration).  Protocol
-// (MI355X_MICROARCH.md, "Valid forms", first row of the sc1 table, with the acquire kept):
-//   producer: thread 0 writes the workgroup's partials with agent-scope (sc1, write-through) stores, drains them
-//             (s_waitcnt vmcnt(0)) and takes a ticket with a relaxed agent-scope atomic add on the member's counter;
-//   consumer: the workgroup whose ticket is count-1 -- told through LDS + barrier to all its waves -- issues ONE agent-scope
-//             acquire (invalidates its L1) and reads every partial with agent-scope (sc1) loads.
-// No release fence anywhere: a buffer_wbl2 per workgroup writes back the whole XCD L2 each time and made this pattern 16x
-// slower in round 2.  The partials are combined in index order, so the result does not depend on which workgroup
-// came last.  The last workgroup resets the counter; the next launch sees that behind the kernel boundary.
-__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(long* p, long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool AGENT, typename T>
-__device__ __forceinline__ T ld_part(const T* p) {
-    if (AGENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-// thread 0 of every arriving workgroup, after its partial stores: true for the last of `count` arrivals
-__device__ __forceinline__ bool take_ticket(unsigned* counter, unsigned count) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partials have left this CU before the ticket is taken
-    return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == count - 1u;
-}
+template <typename T>
+__device__ __forceinline__ T ld_val(const T* p) { return *p; }
 
 // ---------------------------------------------------------------- block reductions (256 thr)
 // Wave reductions on the DPP cross-lane network (row_shr within the 16-lane rows, then row_bcast:15 / row_bcast:31 across
@@ -1805,12 +1782,11 @@ __global__ void __launch_bounds__(1024) k_xpoint_saddle(Fld psiF, Member* st, in
 #endif
 constexpr int JS_ROWS = JS_ROWS_N;  // rows per workgroup of the column-pair kernels (k_jsum, k_source)
 // finishes the J_raw sum of member b: I = (sum * dr) * dz, scale = I_target / I  (core/fusion_kernel.py:436-438); all 256 threads
-template <bool AGENT>
 __device__ __forceinline__ void jsum_final_body(int b, Member* st, const double* part, int nblk, double dr, double dz, double* sh,
                                                 bool commit = true) {
     const double itg = st[b].i_target;
     double s = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 256) s += ld_part<AGENT>(part + (long)b * nblk + i);
+    for (int i = threadIdx.x; i < nblk; i += 256) s += ld_val(part + (long)b * nblk + i);
     double tot = block_sum<256>(s, sh);
     if (threadIdx.x == 0 && commit) {
         double ic = (tot * dr) * dz;
@@ -1818,17 +1794,11 @@ __device__ __forceinline__ void jsum_final_body(int b, Member* st, const double*
         st[b].jscale = fabs(ic) > 1e-9 ? itg / ic : 0.0;
     }
 }
-struct JsumTail {  // counters != nullptr: the last workgroup of a member runs jsum_final_body (no k_jsum_final launch)
-    unsigned* counters = nullptr;
-    Member* st = nullptr;
-    double dr = 0, dz = 0;
-};
 template <int HM>
 __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz, int nr, int ld,
                                               const double* r_axis, const double* inv_mu0R, Prof pf,
-                                              double* part, int nblk, Fld rawF, JsumTail tail) {
+                                              double* part, int nblk, Fld rawF) {
     __shared__ double sh[4];
-    __shared__ int sh_last;
     int b = blockIdx.z;
     // the member's words in one round trip (activity, slots, normalisation), as in the tile kernels
     const int act_w = st[b].active;
@@ -1872,27 +1842,14 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
         }
     }
     double bs = block_sum<256>(s, sh);
-    double* mine = part + (long)b * nblk + (long)blockIdx.y * gridDim.x + blockIdx.x;
-    if (!tail.counters) {
-        if (threadIdx.x == 0) *mine = bs;
-        return;
-    }
-    if (threadIdx.x == 0) {
-        st_agent(mine, bs);
-        sh_last = take_ticket(tail.counters + b, (unsigned)nblk) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!sh_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    jsum_final_body<true>(b, tail.st, part, nblk, tail.dr, tail.dz, sh);
-    if (threadIdx.x == 0) __hip_atomic_store(tail.counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) part[(long)b * nblk + (long)blockIdx.y * gridDim.x + blockIdx.x] = bs;
 }
 __global__ void __launch_bounds__(256) k_jsum_final(Member* st, const double* part, int nblk, double dr,
                                                     double dz) {
     __shared__ double sh[4];
     const int b = blockIdx.x;
     // (a frozen member's sum is formed and dropped: the activity word travels with the partial sums instead of in front of them)
-    jsum_final_body<false>(b, st, part, nblk, dr, dz, sh, st[b].active != 0);
+    jsum_final_body(b, st, part, nblk, dr, dz, sh, st[b].active != 0);
 }
 // Source = (-mu0*R) * (J_raw * scale)  (core/fusion_kernel.py:440, newton_solver.py:513); optionally stores J_phi.
 // Column pair per thread (16-B loads / stores); grid (ceil(nr/128), ceil(nz/16), B), 256 threads
@@ -2007,7 +1964,7 @@ struct PicardCtl {
     int require_gs, max_iter, iter, pad;
     long n_total, n_interior;
 };
-// everything k_picard_final needs besides the member index (also handed to k_blend_tile, whose last workgroup per member can run it)
+// everything k_picard_final needs besides the member index
 struct PicardTail {
     Member* st = nullptr;
     const double* psum = nullptr;
@@ -2030,8 +1987,6 @@ struct PicardTail {
     int nr = 0;
     const double* r_axis = nullptr;
     const double* z_axis = nullptr;
-    unsigned* counters = nullptr;  // per-member arrival counters of the fused form (k_blend_tile)
-    int xcd_remap = 1;             // k_blend_tile: XCD-contiguous tile order (SCPN_HIP_XCD_BLEND=0: dispatch order)
 };
 // shared scratch of picard_final_body (declared by the calling kernel)
 struct PicardShared {
@@ -2040,10 +1995,8 @@ struct PicardShared {
     VI shx[4], shn[4];
 };
 // One 256-thread workgroup finishes member b: diff / GS RMS, best / ping-pong slots, convergence
-// (core/fusion_kernel_newton_solver.py:518-571) and, with t.topo, the axis / X-point of the next iterate.  AGENT: the partials
-// were written by other workgroups of the SAME launch (agent-scope loads); the partial of index i is combined by thread i % 256
-// in ascending i, then lanes, then waves 0..3 -- independent of who runs it.
-template <bool AGENT>
+// (core/fusion_kernel_newton_solver.py:518-571) and, with t.topo, the axis / X-point of the next iterate.  The partial of index i is
+// combined by thread i % 256 in ascending i, then lanes, then waves 0..3.
 __device__ __forceinline__ void picard_final_body(const int b, const PicardTail& t, PicardShared& S) {
     Member* st = t.st;
     const int nblk = t.nblk, nblk_r = t.nblk_r, ntopo = t.ntopo;
@@ -2059,22 +2012,22 @@ __device__ __forceinline__ void picard_final_body(const int b, const PicardTail&
     // (sum / flags, maximum, rescaled squares behind the maximum's barrier, topology candidates).  Absent entries read a constant.
     const int i0 = threadIdx.x;
     const bool in_d = i0 < nblk, in_r = i0 < nblk_r, in_t = t.topo != nullptr && i0 < ntopo;
-    const double f_ps = ld_part<AGENT>(in_d ? t.psum + (long)b * nblk + i0 : &g_const_f64[0]);
-    const int f_pb = ld_part<AGENT>(in_d ? t.pbad + (long)b * nblk + i0 : &g_const_i32[0]);
-    const double f_rm = ld_part<AGENT>(in_r ? t.rmax + (long)b * nblk_r + i0 : &g_const_f64[0]);
-    const double f_rs = ld_part<AGENT>(in_r ? t.rsum + (long)b * nblk_r + i0 : &g_const_f64[0]);
+    const double f_ps = ld_val(in_d ? t.psum + (long)b * nblk + i0 : &g_const_f64[0]);
+    const int f_pb = ld_val(in_d ? t.pbad + (long)b * nblk + i0 : &g_const_i32[0]);
+    const double f_rm = ld_val(in_r ? t.rmax + (long)b * nblk_r + i0 : &g_const_f64[0]);
+    const double f_rs = ld_val(in_r ? t.rsum + (long)b * nblk_r + i0 : &g_const_f64[0]);
     const TopoPart* const q0 = in_t ? t.topo + (long)b * ntopo + i0 : nullptr;
-    const double f_maxv = in_t ? ld_part<AGENT>(&q0->maxv) : 0.0, f_minb = in_t ? ld_part<AGENT>(&q0->minb) : 0.0;
-    const long f_maxi = in_t ? ld_part<AGENT>(&q0->maxi) : -1L, f_mini = in_t ? ld_part<AGENT>(&q0->mini) : -1L;
-    const double f_minpsi = in_t ? ld_part<AGENT>(&q0->minpsi) : INFINITY, f_pam = in_t ? ld_part<AGENT>(&q0->psi_at_min) : 0.0;
+    const double f_maxv = in_t ? ld_val(&q0->maxv) : 0.0, f_minb = in_t ? ld_val(&q0->minb) : 0.0;
+    const long f_maxi = in_t ? ld_val(&q0->maxi) : -1L, f_mini = in_t ? ld_val(&q0->mini) : -1L;
+    const double f_minpsi = in_t ? ld_val(&q0->minpsi) : INFINITY, f_pam = in_t ? ld_val(&q0->psi_at_min) : 0.0;
     s += f_ps;
     bad |= f_pb;
     for (int i = threadIdx.x + 256; i < nblk; i += 256) {
-        s += ld_part<AGENT>(t.psum + (long)b * nblk + i);
-        bad |= ld_part<AGENT>(t.pbad + (long)b * nblk + i);
+        s += ld_val(t.psum + (long)b * nblk + i);
+        bad |= ld_val(t.pbad + (long)b * nblk + i);
     }
     rm = fmax(rm, f_rm);
-    for (int i = threadIdx.x + 256; i < nblk_r; i += 256) rm = fmax(rm, ld_part<AGENT>(t.rmax + (long)b * nblk_r + i));
+    for (int i = threadIdx.x + 256; i < nblk_r; i += 256) rm = fmax(rm, ld_val(t.rmax + (long)b * nblk_r + i));
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wbad = __any(bad) ? 1 : 0;
     if (lane == 0) S.shbad[w] = wbad;
@@ -2082,8 +2035,8 @@ __device__ __forceinline__ void picard_final_body(const int b, const PicardTail&
     if (rmx_all > 0.0) {
         { const double f = f_rm / rmx_all; rs += f_rs * (f * f); }
         for (int i = threadIdx.x + 256; i < nblk_r; i += 256) {
-            const double f = ld_part<AGENT>(t.rmax + (long)b * nblk_r + i) / rmx_all;
-            rs += ld_part<AGENT>(t.rsum + (long)b * nblk_r + i) * (f * f);
+            const double f = ld_val(t.rmax + (long)b * nblk_r + i) / rmx_all;
+            rs += ld_val(t.rsum + (long)b * nblk_r + i) * (f * f);
         }
     }
     if (t.topo) {
@@ -2097,8 +2050,8 @@ __device__ __forceinline__ void picard_final_body(const int b, const PicardTail&
         if (in_t) take(VI{f_maxv, f_maxi}, VI{f_minb, f_mini}, f_pam, f_minpsi);
         for (int i = threadIdx.x + 256; i < ntopo; i += 256) {
             const TopoPart* q = t.topo + (long)b * ntopo + i;
-            take(VI{ld_part<AGENT>(&q->maxv), ld_part<AGENT>(&q->maxi)}, VI{ld_part<AGENT>(&q->minb), ld_part<AGENT>(&q->mini)},
-                 ld_part<AGENT>(&q->psi_at_min), ld_part<AGENT>(&q->minpsi));
+            take(VI{ld_val(&q->maxv), ld_val(&q->maxi)}, VI{ld_val(&q->minb), ld_val(&q->mini)},
+                 ld_val(&q->psi_at_min), ld_val(&q->minpsi));
         }
         const VI own = tmn;
         tmx = wave_vi<true>(tmx);
@@ -2197,7 +2150,7 @@ __global__ void __launch_bounds__(256) k_picard_final(PicardTail t) {
     __shared__ PicardShared S;
     const int b = blockIdx.x;
     if (!t.st[b].active) return;
-    picard_final_body<false>(b, t, S);
+    picard_final_body(b, t, S);
 }
 // reciprocals (two words) of dz, 2 dz, dr for the exact divisions of the divertor-row gradient (host IEEE division)
 struct GradRecip { double dz, inv_dz, lo_dz, two_dz, inv_two_dz, lo_two_dz, dr, inv_dr, lo_dr; };
@@ -2243,9 +2196,8 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {  // result in eve
 __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
                                                              double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
                                                              double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm,
-                                                             GradRecip gq, PicardTail tail) {
+                                                             GradRecip gq, int xcd_remap) {
     __shared__ __attribute__((aligned(16))) double t[BL_LB][128];
-    __shared__ int sh_last;
     __shared__ VI sh_mx[BL_NW], sh_mn[BL_NW];
     __shared__ double sh_dsum[BL_NW], sh_p2[BL_NW], sh_minp[BL_NW], sh_s2[BL_NW];
     __shared__ double sh_coef[2 * BL_NW][64];  // r_safe, 1/r_safe (two words), -mu0 R of the lane's two columns: loaded by one wave each
@@ -2253,7 +2205,7 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
     {
         const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
         unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        if (tail.xcd_remap) lin = xcd_contiguous(lin, total);
+        if (xcd_remap) lin = xcd_contiguous(lin, total);
         bx_ = (int)(lin % gx);
         const unsigned t_ = lin / gx;
         by_ = (int)(t_ % gy);
@@ -2474,33 +2426,15 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
         }
     }
     BLEND_STAMP(5);
-    if (!tail.counters) {
-        if (tid == 0) {
-            psum[o] = bsum;
-            pbad[o] = finite_d(bsum) ? 0 : 1;  // (a non-finite psi_new somewhere in the tile: see the header)
-            rmax[o] = bp2;
-            rsum[o] = bs2;
-            TopoPart tp;
-            tp.maxv = rmx.v; tp.maxi = rmx.i; tp.minb = rmn.v; tp.mini = rmn.i; tp.minpsi = bminp; tp.psi_at_min = pmin;
-            topo[o] = tp;
-        }
-        return;
+    if (tid == 0) {
+        psum[o] = bsum;
+        pbad[o] = finite_d(bsum) ? 0 : 1;  // (a non-finite psi_new somewhere in the tile: see the header)
+        rmax[o] = bp2;
+        rsum[o] = bs2;
+        TopoPart tp;
+        tp.maxv = rmx.v; tp.maxi = rmx.i; tp.minb = rmn.v; tp.mini = rmn.i; tp.minpsi = bminp; tp.psi_at_min = pmin;
+        topo[o] = tp;
     }
-    if (tid == 0) {  // fused tail: see "last workgroup finishes"
-        st_agent(psum + o, bsum);
-        st_agent(pbad + o, finite_d(bsum) ? 0 : 1);
-        st_agent(rmax + o, bp2);
-        st_agent(rsum + o, bs2);
-        st_agent(&topo[o].maxv, rmx.v); st_agent(&topo[o].maxi, rmx.i); st_agent(&topo[o].minb, rmn.v); st_agent(&topo[o].mini, rmn.i);
-        st_agent(&topo[o].minpsi, bminp); st_agent(&topo[o].psi_at_min, pmin);
-        sh_last = take_ticket(tail.counters + b, (unsigned)nblk) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!sh_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    PicardShared& S = *reinterpret_cast<PicardShared*>(&t[0][0]);  // the tile is dead: every wave passed the barrier above
-    picard_final_body<true>(b, tail, S);
-    if (tid == 0) __hip_atomic_store(tail.counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // ---------------------------------------------------------------- Anderson mixing (a10, method "anderson")
 // core/fusion_kernel_newton_solver.py:540-550 and core/fusion_kernel_iterative_solver.py:248-314

@@ -164,7 +164,6 @@ struct Solver {
     DBuf<Member> d_st;
     DBuf<MgMember> d_mg;
     DBuf<int> d_cur, d_nxt, d_best, d_prev, d_active, d_nactive, d_pbad;
-    DBuf<unsigned> d_tickets;  // [2][B] arrival counters of the "last workgroup finishes" kernels (k_jsum, k_blend_tile); zero between launches
     DBuf<int> d_scr_part, d_scr_zc, d_scr_sa, d_scr_mask;  // per-call masks of the Picard / free-boundary drivers
     DBuf<double> d_scr_diff;
     DBuf<Member> d_scr_st;
@@ -711,8 +710,6 @@ static Solver* create_impl(int nr, int nz, int batch, const double* r_axis, cons
         h->d_cur.alloc(batch); h->d_nxt.alloc(batch); h->d_best.alloc(batch); h->d_prev.alloc(batch);
         h->d_active.alloc(batch);
         h->d_nactive.alloc(1);
-        h->d_tickets.alloc(2 * (size_t)batch);
-        HIP_TRY(hipMemset(h->d_tickets.p, 0, sizeof(unsigned) * 2 * batch));
         HIP_TRY(hipMemset(h->d_cur.p, 0, sizeof(int) * batch));
         HIP_TRY(hipMemset(h->d_nxt.p, 0, sizeof(int) * batch));
         HIP_TRY(hipMemset(h->d_best.p, 0, sizeof(int) * batch));
@@ -975,22 +972,15 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     // the fused tail (k_blend_tile) leaves the topology partials of the next iterate, and k_picard_final finishes them for the
     // members that stay active: from the second iteration on there is no topology launch at all
     const bool topo_in_final = h->use_fused && p->method != 3 && !p->xpoint_saddle;
-    // "last workgroup finishes": k_jsum and k_blend_tile end with the per-member final reductions that used to be the launches
-    // k_jsum_final and k_picard_final (two launches and two kernel boundaries off the dependent chain of an iteration).
-    // Bit-identical, and MEASURED SLOWER on MI355X (32 x 513^2, fixed 200 iterations, same box: 345.4 / 346.6 us per iteration with
-    // the separate launches, 349.7 / 350.8 fused -- profiles/r03_experiments.md): a dependent launch costs ~2 us, while the ticket
-    // (drain + atomic round trip) lengthens every workgroup and the last one runs a serial reduction chain at the end of a
-    // kernel the next launch waits for.  Opt-in: SCPN_HIP_TAILFUSE=1.
-    static const bool tailfuse_env = [] { const char* e = std::getenv("SCPN_HIP_TAILFUSE"); return e && e[0] == '1'; }();
-    const bool tail_fuse = tailfuse_env && topo_in_final;
     // The J_raw sum finished by its first consumer: in lazy-source mode the V-cycle's first level-0 tile launch adds the per-
     // workgroup partial sums itself (every wave, redundantly: <= 256 values) and forms the scale, so k_jsum_final and its kernel
-    // boundary leave the chain -- no ticket, no atomics (contrast SCPN_HIP_TAILFUSE).  Measured (same box): ONE 513^2 equilibrium
+    // boundary leave the chain -- no ticket, no atomics (the "last workgroup finishes" form of rounds 3-4 is archived in
+    // profiles/r04_negative/last_workgroup_finishes.md: slower every time it was measured).  Measured (same box): ONE 513^2 equilibrium
     // 122.7 -> 121.1 us per iteration, 2 x 16 members 347.6 -> 349.4: like every fused scalar tail before it, it pays only where
     // the iteration is a chain of short launches -- default for stream groups of up to 14 members (the register-tile rule);
     // SCPN_HIP_SUMFUSE=0 / 1 forces it off / on.
     static const int sumfuse_env = [] { const char* e = std::getenv("SCPN_HIP_SUMFUSE"); return e ? std::atoi(e) : -1; }();
-    const bool sum_fuse = (sumfuse_env == 1 || (sumfuse_env < 0 && B <= 14)) && lazy && !tail_fuse && nblkj <= 256;
+    const bool sum_fuse = (sumfuse_env == 1 || (sumfuse_env < 0 && B <= 14)) && lazy && nblkj <= 256;
     auto iteration = [&](bool first) {
         if (first || !topo_in_final) {
             ProfScope ps(h, "topology", first || !h->use_fused || p->method == 3 || p->xpoint_saddle ? 2 : 1);
@@ -1007,13 +997,11 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
                                    (const double*)h->d_r.p, (const double*)h->d_z.p);
         }
         if (!p->external_profile_mode) {
-            ProfScope ps(h, "source", (lazy ? 2 : 3) - ((tail_fuse || sum_fuse) ? 1 : 0));
-            JsumTail jt;
-            if (tail_fuse) { jt.counters = h->d_tickets.p; jt.st = h->d_st.p; jt.dr = h->dr; jt.dz = h->dz; }
+            ProfScope ps(h, "source", (lazy ? 2 : 3) - (sum_fuse ? 1 : 0));
             SCPN_LAUNCH((pf.hmode ? k_jsum<1> : k_jsum<0>), gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
-                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, lazy ? srcF : Fld{nullptr, nullptr, 0, 0}, jt);
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, lazy ? srcF : Fld{nullptr, nullptr, 0, 0});
             if (sum_fuse) { h->jsum_part = h->d_jpart.p; h->jsum_nblk = nblkj; }  // (the V-cycle's first level-0 launch finishes the sum)
-            else if (!tail_fuse)  // (tail_fuse: the last workgroup of each member finished the sum inside k_jsum)
+            else
                 SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
             if (!lazy)  // (lazy: the V-cycle's level-0 tiles and the fused tail form the source from J_raw on load)
                 SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, srcF, jF, 0, curF, (const Member*)h->d_st.p, nz, nr, ld,
@@ -1041,7 +1029,6 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         pt.ctl = ctl; pt.hist_diff = d_hist_diff.p; pt.hist_gs = d_hist_gs.p; pt.trace = d_trace.p; pt.n_active = h->d_nactive.p;
         pt.f_cur = h->d_cur.p; pt.f_nxt = h->d_nxt.p; pt.f_best = h->d_best.p; pt.f_prev = h->d_prev.p; pt.f_active = h->d_active.p;
         pt.nr = nr; pt.r_axis = h->d_r.p; pt.z_axis = h->d_z.p;
-        bool final_done = false;
         if (h->use_fused && p->method != 3) {
             ProfScope ps(h, "blend_fused", 1);
             nb_d = nb_r = nblk2;
@@ -1050,20 +1037,10 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             gq.dz = L0.dz; gq.inv_dz = 1.0 / L0.dz; gq.lo_dz = recip_lo(L0.dz);
             gq.two_dz = 2.0 * L0.dz; gq.inv_two_dz = 1.0 / gq.two_dz; gq.lo_two_dz = recip_lo(gq.two_dz);
             gq.dr = L0.dr; gq.inv_dr = 1.0 / L0.dr; gq.lo_dr = recip_lo(L0.dr);
-            PicardTail bt;  // counters == nullptr: the kernel only leaves its partials
             static const int xcd_blend = [] { const char* e = std::getenv("SCPN_HIP_XCD_BLEND"); return e ? std::atoi(e) : 1; }();
-            bt.xcd_remap = xcd_blend;
-            if (tail_fuse) {
-                bt = pt;
-                bt.xcd_remap = xcd_blend;
-                bt.nblk = bt.nblk_r = bt.ntopo = nblk2;
-                bt.topo = h->d_topo.p;
-                bt.counters = h->d_tickets.p + B;
-                final_done = true;
-            }
             SCPN_LAUNCH(k_blend_tile, dim3(cdiv(nr, BL_WR), cdiv(nz, BL_WZ), B), dim3(64 * BL_NW), 0, st, nxtF, curF, newF, bcF, srcF,
                                (const Member*)h->d_st.p, L0, p->alpha, om_alpha, n_mask_rows, h->d_part1.p, h->d_pbad.p, h->d_part2.p,
-                               h->d_part3.p, h->d_topo.p, nblk2, lazy ? (const double*)h->d_neg_mu0R.p : (const double*)nullptr, gq, bt);
+                               h->d_part3.p, h->d_topo.p, nblk2, lazy ? (const double*)h->d_neg_mu0R.p : (const double*)nullptr, gq, xcd_blend);
         } else {
             ProfScope ps(h, "blend_norms", 2);
             SCPN_LAUNCH(k_blend, dim3(nblk1, B), dim3(256), 0, st, nxtF, curF, newF, bcF, (const Member*)h->d_st.p, nz, nr, ld, p->alpha,
@@ -1099,7 +1076,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             SCPN_LAUNCH(k_resid_norms, dim3(nblk_r, B), dim3(256), 0, st, nxtF, srcF, L0, h->d_part2.p, h->d_part3.p, nblk_r, act);
         }
         topo_count = nb_d;
-        if (!final_done) {
+        {
             ProfScope ps(h, "picard_final", 1);
             pt.nblk = nb_d; pt.nblk_r = nb_r; pt.ntopo = nb_d;
             pt.topo = topo_in_final ? (const TopoPart*)h->d_topo.p : (const TopoPart*)nullptr;
@@ -1290,7 +1267,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         if (!p->external_profile_mode) {
             ProfScope ps(h, "source", 3);
             SCPN_LAUNCH((pf.hmode ? k_jsum<1> : k_jsum<0>), gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
-                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0}, JsumTail{});
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0});
             SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
             SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, dstSrc, jF, 1, curF, (const Member*)h->d_st.p, nz, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
@@ -1350,7 +1327,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
             SCPN_LAUNCH(k_topology_final, dim3(B), dim3(256), 0, st, pF, scr.p, (const TopoPart*)h->d_topo.p, nblk1, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_z.p);
             SCPN_LAUNCH((pf.hmode ? k_jsum<1> : k_jsum<0>), gjs, dim3(256), 0, st, pF, (const Member*)scr.p, nz, nr, ld, (const double*)h->d_r.p,
-                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0}, JsumTail{});
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0});
             SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, scr.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
             SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, src2F, jF, 0, pF, (const Member*)scr.p, nz, nr, ld, (const double*)h->d_r.p,
                                (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);

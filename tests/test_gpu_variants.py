@@ -17,7 +17,6 @@ SWITCHES = [
     {"SCPN_HIP_LAZYSRC": "0"},
     {"SCPN_HIP_GROUPS": "2"},
     {"SCPN_HIP_DEFECT_MINLVL": "9"},
-    {"SCPN_HIP_TAILFUSE": "1"},
     {"SCPN_HIP_POLL": "memcpy"},
     {"SCPN_HIP_XCD_BLEND": "0"},
     {"SCPN_HIP_SUMFUSE": "0"},                                  # separate k_jsum_final launch instead of the sum in its first consumer
