@@ -1,0 +1,20 @@
+import sys, numpy as np
+sys.path.insert(0, ".")
+from scpn_fusion_core_amd.cases import iter_like_cfg, scan_member_table
+from scpn_fusion_core_amd.ensemble import EnsembleSolver
+cfg = iter_like_cfg(513, tol=1e-8, max_iter=1000)
+cur, tgt = scan_member_table(cfg, 4)
+with EnsembleSolver(cfg, batch=4, coil_currents=cur, current_targets=tgt) as es:
+    es.fill_psi(0.0)
+    res = es.solve_free_boundary(max_outer_iter=20, tol=1e-4)
+    j = es.get_jphi()
+for b in range(2):
+    nzf = (j[b] != 0).mean()
+    seg = [(j[b][:, k*128:(k+1)*128] != 0).any(axis=1) for k in range(5)]
+    segf = np.mean([s.mean() for s in seg])
+    print("member", b, "nonzero J fraction", round(float(nzf), 3), "flagged segment fraction", round(float(segf), 3), "iters", res[b]["picard_iterations"])
+cfg2 = iter_like_cfg(513, tol=1e-300, max_iter=200)
+with EnsembleSolver(cfg2, batch=2) as es:
+    es.solve_equilibrium()
+    j = es.get_jphi()
+    print("fixed-iters workload: nonzero fraction", round(float((j[0] != 0).mean()), 3), "segments", round(float(np.mean([(j[0][:, k*128:(k+1)*128] != 0).any(axis=1).mean() for k in range(5)])), 3))
