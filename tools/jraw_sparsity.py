@@ -1,3 +1,5 @@
+"""Fraction of grid points / of 128-column row segments at which J_phi is not exactly 0 at the end of a solve of the bench ensemble
+(is a sparse source field worth anything?  profiles/r04_experiments.md: no -- 99.9 % of the points are non-zero).  GPU box, repo root."""
 import sys, numpy as np
 sys.path.insert(0, ".")
 from scpn_fusion_core_amd.cases import iter_like_cfg, scan_member_table
