@@ -121,8 +121,8 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
             "limiter": {"class": "tiles in flight x tile lifetime on a chip where neither VALU (see counters) nor HBM (counter traffic = compulsory bytes) is "
                                  "saturated; what shortens a tile's life is memory round trips in its load phase (post-smoother six -> one by LDS-DMA: -5 % per "
                                  "iteration) and vector work outside the stencil (Picard tail -31 % VALU: -2 %); bytes alone do not (a tail with 25 % less traffic and "
-                                 "8 % more arithmetic is slower), larger tiles pack worse than the arithmetic they save, and the launch chain below level 0 is not "
-                                 "what the two-group iteration waits for (129^2 launches removed + their work added to the coarse kernel: unchanged)",
+                                 "8 % more arithmetic is slower), larger tiles pack worse than the arithmetic they save; the iteration time is the length of one stream "
+                                 "group's serial chain of eleven kernels (a 10 us sleep in the coarse V-cycle arrives as +11.5 us), stretched x1.3 by the other group",
                         "counters": ctr, "evidence": "profiles/r04_experiments.md, profiles/r03_experiments.md, DESIGN.md section 6"},
             "per_level": per_level, "families_ms": fam}
 
