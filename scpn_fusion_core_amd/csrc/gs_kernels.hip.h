@@ -902,7 +902,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
                 //  domain take some other in-domain coarse value -- never used)
                 ca0[j] = cr0[i >> 1];
                 ca1[j] = cr1[i >> 1];
-                if (i & 1) { cb0[j] = cr0[(i >> 1) + (PWIDE ? 1 : 0)]; cb1[j] = cr1[(i >> 1) + (PWIDE ? 1 : 0)]; }
+                if (i & 1) { cb0[j] = cr0[(i >> 1) + 1]; cb1[j] = cr1[(i >> 1) + 1]; }
             } else if (PROLONG) {
                 // (the parity of an in-domain row is that of its index i: even rows need one coarse row, odd rows two; a clamped
                 //  out-of-domain row may take the other form -- its value is never used)
@@ -940,8 +940,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
                 vy = vy + py;
             }
             if (i & 1) { v1[i] = vx; v0[i] = vy; } else { v0[i] = vx; v1[i] = vy; }
-            constexpr bool dma_row_possible = GLDS;
-            const bool dma_row = dma_row_possible && i > 0 && i < NROWS - 1;
+            const bool dma_row = GLDS && i > 0 && i < NROWS - 1;
             double2* const pr = dma_row ? reinterpret_cast<double2*>(pair_base(i)) + lane : nullptr;
             if (dma_row) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's DMA has landed; everything else is needed by now anyway)
             double sx = dma_row ? pr->x : sv2[j].x, sy = dma_row ? pr->y : sv2[j].y;  // source of the even / odd column
