@@ -424,14 +424,15 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
 template <int S, bool PROLONG, bool DEFECT>
 static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
                         const DefectOut* dfo) {
-    // Which tile geometry: by the members the chip works on at once (all stream groups of the ensemble).  More than 16: 48 rows x
-    // 8 waves (the least halo redundancy that fits three workgroups per CU); up to 16 (measured at 129^2 ... 1025^2: the launches
+    // Which tile geometry: by the members the chip works on at once (all stream groups of the ensemble).  More than 12: 48 rows x
+    // 8 waves (the least halo redundancy that fits three workgroups per CU; with round 4's one-round-trip load phase it wins from 16
+    // members on: 178.8 vs 186.3 us per iteration, and ties at 12 and 8); up to 12 (measured at 129^2 ... 1025^2: the launches
     // are then short chains of workgroup lifetimes whatever the grid): 32 x 8, and 24 x 12 (two rows per wave: the shortest
     // lifetime) while a level-0 launch has at most TILE_TINY tiles (two members at 513^2).  One- and two-sweep launches (sweep
     // counts that are not multiples of three) always take 32 x 8.  SCPN_HIP_TILEGEO=24 / 32 / 48 forces a geometry,
     // SCPN_HIP_TILE_MAXB / SCPN_HIP_TILE_TINY move the limits.
     static const int geo_env = [] { const char* e = std::getenv("SCPN_HIP_TILEGEO"); return e ? std::atoi(e) : 0; }();
-    static const int mid_maxb = [] { const char* e = std::getenv("SCPN_HIP_TILE_MAXB"); return e ? std::atoi(e) : 16; }();
+    static const int mid_maxb = [] { const char* e = std::getenv("SCPN_HIP_TILE_MAXB"); return e ? std::atoi(e) : 12; }();
     static const long tiny_max = [] { const char* e = std::getenv("SCPN_HIP_TILE_TINY"); return e ? std::atol(e) : 220L; }();
     if constexpr (S == 3) {
         const int members = h->ensemble_B > 0 ? h->ensemble_B : h->B;
