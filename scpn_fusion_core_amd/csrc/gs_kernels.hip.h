@@ -642,7 +642,7 @@ __device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (d
 #endif
 // Tile geometries (rows x waves; rows / waves = an even number of consecutive rows per wave), chosen per launch by the size of
 // the ensemble (scpn_hip.hip, launch_tile): BIG for ensembles that fill the chip (six rows per wave, the sources of a wave's
-// inner rows in LDS slots), MID for ensembles of up to 16 members (four rows per wave), TINY while a level-0 launch has at most ~220 tiles
+// inner rows in LDS slots), MID for ensembles of up to 12 members (four rows per wave), TINY while a level-0 launch has at most ~220 tiles
 // (two rows per wave: the shortest workgroup lifetime).  -D overrides build other geometries for experiments.
 #ifndef TILE_BIG_LZ
 #define TILE_BIG_LZ 48

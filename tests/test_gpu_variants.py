@@ -21,7 +21,7 @@ SWITCHES = [
     {"SCPN_HIP_XCD_BLEND": "0"},
     {"SCPN_HIP_SUMFUSE": "0"},                                  # separate k_jsum_final launch instead of the sum in its first consumer
     {"SCPN_HIP_TILEGEO": "32"},                                 # tile geometries: the default of this 2-member run is 24 rows x 12 waves
-    {"SCPN_HIP_TILEGEO": "48"},                                 # 48 rows x 8 waves (six rows per wave, inner sources in LDS slots): ensembles of more than 16 members
+    {"SCPN_HIP_TILEGEO": "48"},                                 # 48 rows x 8 waves (six rows per wave, inner sources in LDS slots): ensembles of more than 12 members
     {"SCPN_HIP_TILEGEO": "48", "SCPN_HIP_SUMFUSE": "0"},
 ]
 # experiment builds (never shipped: `_lib.build(variant=...)` makes libscpn_hip.<variant>.so next to the product library)
