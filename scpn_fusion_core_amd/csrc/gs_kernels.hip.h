@@ -1776,8 +1776,10 @@ __global__ void __launch_bounds__(1024) k_xpoint_saddle(Fld psiF, Member* st, in
 // ---------------------------------------------------------------- Picard: source (a9)
 // partial sums of J_raw.  Each thread owns a column pair (16-B loads) of 4 rows: block = 64 pairs x 4 row-lanes,
 // 16 rows per block.  grid (ceil(nr/128), ceil(nz/16), B); partial index = blockIdx.y * gridDim.x + blockIdx.x
+// (round 4: 16 rows -- four per wave, all loads of a wave in one batch -- instead of 64: equal for the 32-member ensemble,
+//  -1.6 % per iteration for ONE equilibrium, whose launch is a fraction of a round of workgroups)
 #ifndef JS_ROWS_N
-#define JS_ROWS_N 64
+#define JS_ROWS_N 16
 #endif
 constexpr int JS_ROWS = JS_ROWS_N;  // rows per workgroup of the column-pair kernels (k_jsum, k_source)
 // finishes the J_raw sum of member b: I = (sum * dr) * dz, scale = I_target / I  (core/fusion_kernel.py:436-438); all 256 threads
@@ -1815,7 +1817,7 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
         const double m0 = inv_mu0R[c0], m1 = two ? inv_mu0R[c0 + 1] : 0.0;
         // rows in batches of JS_BATCH: all loads of a batch are issued before the first J_raw store (the compiler may not move
         // a load above a store through another pointer, so load / compute / store per row would serialise the memory round trips)
-        constexpr int JS_BATCH = 8;
+        constexpr int JS_BATCH = JS_ROWS / 4 < 8 ? JS_ROWS / 4 : 8;
 #pragma unroll
         for (int k0 = 0; k0 < JS_ROWS / 4; k0 += JS_BATCH) {
             double2 v[JS_BATCH];
