@@ -1776,10 +1776,11 @@ __global__ void __launch_bounds__(1024) k_xpoint_saddle(Fld psiF, Member* st, in
 // ---------------------------------------------------------------- Picard: source (a9)
 // partial sums of J_raw.  Each thread owns a column pair (16-B loads) of 4 rows: block = 64 pairs x 4 row-lanes,
 // 16 rows per block.  grid (ceil(nr/128), ceil(nz/16), B); partial index = blockIdx.y * gridDim.x + blockIdx.x
-// (round 4: 16 rows -- four per wave, all loads of a wave in one batch -- instead of 64: equal for the 32-member ensemble,
-//  -1.6 % per iteration for ONE equilibrium, whose launch is a fraction of a round of workgroups)
+// (16 rows -- four per wave -- are equal for the 32-member ensemble and -1.6 % per Picard iteration for ONE equilibrium, but regroup
+//  the partial sums of J_raw: the last bits of the current integral move and the finite-difference Newton lane, which is sensitive to
+//  them, takes 33 instead of 22 inner iterations on the DIII-D-like case; 64 stays: profiles/r04_experiments.md)
 #ifndef JS_ROWS_N
-#define JS_ROWS_N 16
+#define JS_ROWS_N 64
 #endif
 constexpr int JS_ROWS = JS_ROWS_N;  // rows per workgroup of the column-pair kernels (k_jsum, k_source)
 // finishes the J_raw sum of member b: I = (sum * dr) * dz, scale = I_target / I  (core/fusion_kernel.py:436-438); all 256 threads
