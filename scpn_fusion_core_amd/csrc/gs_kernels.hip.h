@@ -730,7 +730,7 @@ __device__ __forceinline__ double wave_shift(double x) {  // 0x138: wave_shr:1 =
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT, int WPEU, bool SUMF = false>
+template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT, int WPEU, bool SUMF = false, bool GS1T = false>
 __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
                                                     const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, LazySrc lzs,
                                                     DefectDst dd, int xcd_remap) {
@@ -980,9 +980,13 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
 #pragma unroll
     for (int i = 1; i < NROWS; ++i) hmax_low = min(hmax_low, hmax[i]);
     // one update of row i, colour c (both compile-time): mine / oth are the register rows of colour c / 1 - c
-    auto update = [&](auto colour, auto row, const int hs, double (&mine)[NROWS], const double (&oth)[NROWS], const double Sb,
-                      const double Nb) {
+    // gauss_seidel (compile-time): omega == 1.0, i.e. om1 == 0.0 -- the relaxed value (1 - omega) * old + omega * gs is then
+    // fma(0.0, old, gs) in EVERY case (the product 0 * old is exact: +-0, or NaN for a non-finite old, and 1.0 * gs is gs), one
+    // instruction instead of three and a dependent chain of 10 instead of 11
+    auto update = [&](auto gauss_seidel, auto colour, auto row, const int hs, double (&mine)[NROWS], const double (&oth)[NROWS],
+                      const double Sb, const double Nb) {
         constexpr int c = decltype(colour)::value, i = decltype(row)::value, p = (c + i) & 1;
+        constexpr bool GS1 = decltype(gauss_seidel)::value;
         // The row test (wave-uniform: hs <= hmax[i]) is NOT a branch: the update is evaluated for every row and kept under
         // (row test & column predicate), so the dependent 11-instruction chains of the wave's rows are independent straight-line
         // code the scheduler interleaves (a lone chain issues one fp64 instruction every ~13 cycles).  A row outside keeps its value.
@@ -993,12 +997,12 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         const double sv = (GLDS && i > 0 && i < NROWS - 1) ? pair_base(i)[2 * lane + p]
                           : ((SRCL && i > 0 && i < NROWS - 1) ? (c ? b1 : b0)[i * 64] : (c ? s1[i] : s0[i]));
         const double gsv = divc4(ae * E + aw * W + a_ns * Sv + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
-        double nw = om1 * mine[i] + omega * gsv;
+        double nw = GS1 ? __builtin_fma(om1, mine[i], gsv) : om1 * mine[i] + omega * gsv;
         asm volatile("" : "+v"(nw));  // (an opaque use: keeps the compiler from sinking the chain into an exec-masked branch)
         const bool keep = (hs <= hmax[i]) & (p ? colok1 : colok0);
         mine[i] = keep ? nw : mine[i];
     };
-    auto half_sweep = [&](auto colour, const int hs) {
+    auto half_sweep = [&](auto gauss_seidel, auto colour, const int hs) {
         constexpr int c = decltype(colour)::value;
         double(&mine)[NROWS] = c ? v1 : v0;
         const double(&oth)[NROWS] = c ? v0 : v1;
@@ -1009,29 +1013,32 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             // by the last pass) and waves that overhang the grid: a row is SKIPPED under its wave-uniform test -- 15-20 % of a
             // six-row tile's pass arithmetic; the rows left are short of the other waves' six interleaved chains anyway
             [&]<int... I>(std::integer_sequence<int, I...>) {
-                ((hs <= hmax[I] ? update(colour, std::integral_constant<int, I>{}, hs, mine, oth, Sb, Nb) : (void)0), ...);
+                ((hs <= hmax[I] ? update(gauss_seidel, colour, std::integral_constant<int, I>{}, hs, mine, oth, Sb, Nb) : (void)0), ...);
             }(std::make_integer_sequence<int, NROWS>{});
         } else {
             // rows that need no LDS value first
             [&]<int... I>(std::integer_sequence<int, I...>) {
-                (update(colour, std::integral_constant<int, I + 1>{}, hs, mine, oth, Sb, Nb), ...);
+                (update(gauss_seidel, colour, std::integral_constant<int, I + 1>{}, hs, mine, oth, Sb, Nb), ...);
             }(std::make_integer_sequence<int, NROWS - 2>{});
-            update(colour, std::integral_constant<int, 0>{}, hs, mine, oth, Sb, Nb);
-            update(colour, std::integral_constant<int, NROWS - 1>{}, hs, mine, oth, Sb, Nb);
+            update(gauss_seidel, colour, std::integral_constant<int, 0>{}, hs, mine, oth, Sb, Nb);
+            update(gauss_seidel, colour, std::integral_constant<int, NROWS - 1>{}, hs, mine, oth, Sb, Nb);
         }
         double* const mb = c ? b1 : b0;
         mb[0] = mine[0];
         mb[(NROWS - 1) * 64] = mine[NROWS - 1];
     };
+    auto sweeps = [&](auto gauss_seidel) {
 #pragma unroll 1
-    for (int sw = 0; sw < S; ++sw) {
-        half_sweep(std::integral_constant<int, 0>{}, 2 * sw);
-        __syncthreads();
-        TILE_STAMP(2 + 2 * sw);
-        half_sweep(std::integral_constant<int, 1>{}, 2 * sw + 1);
-        __syncthreads();
-        TILE_STAMP(3 + 2 * sw);
-    }
+        for (int sw = 0; sw < S; ++sw) {
+            half_sweep(gauss_seidel, std::integral_constant<int, 0>{}, 2 * sw);
+            __syncthreads();
+            TILE_STAMP(2 + 2 * sw);
+            half_sweep(gauss_seidel, std::integral_constant<int, 1>{}, 2 * sw + 1);
+            __syncthreads();
+            TILE_STAMP(3 + 2 * sw);
+        }
+    };
+    sweeps(std::integral_constant<bool, GS1T>{});
     // ---- store the window
 #pragma unroll
     for (int i = 0; i < NROWS; ++i) {
@@ -1150,6 +1157,13 @@ __device__ __forceinline__ double dpp_f64(double x) {
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+// the relaxed value (1 - omega) * old + omega * gs; GS1 (omega == 1.0, om1 == 0.0): fma(0.0, old, gs), the same value in every case
+// (the product is exact; see k_smooth_tile) in one instruction instead of three
+template <bool GS1>
+__device__ __forceinline__ double relaxed(double om1, double old, double omega, double gs) {
+    return GS1 ? __builtin_fma(om1, old, gs) : om1 * old + omega * gs;
+}
+template <bool GS1>
 __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const double* tab, int nz, int nr, double a_ns,
                                           double a_c, double inv_a_c, double lo_a_c, double omega, double om1, int n_sweeps) {
     const int hw = (nr - 2 + 1) / 2, tot = (nz - 2) * hw;
@@ -1182,7 +1196,7 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     const double Nd = dpp_f64<0x104>(v), Sd = dpp_f64<0x114>(v);  // row_shl:4 / row_shr:4
                     const double E = hasE ? Ed : rE, W = hasW ? Wd : rW, N = hasN ? Nd : rN, S = hasS ? Sd : rS;
                     const double gs = divc4(ae * E + aw * W + a_ns * S + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
-                    const double nw = om1 * v + omega * gs;
+                    const double nw = relaxed<GS1>(om1, v, omega, gs);
                     if (in && par == (s & 1)) v = nw;
                 }
             } else {
@@ -1191,7 +1205,7 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     const double Ns = __shfl(v, lane + lw, 64), Ss = __shfl(v, lane - lw, 64);
                     const double E = hasE ? Es : rE, W = hasW ? Ws : rW, N = hasN ? Ns : rN, S = hasS ? Ss : rS;
                     const double gs = divc4(ae * E + aw * W + a_ns * S + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
-                    const double nw = om1 * v + omega * gs;
+                    const double nw = relaxed<GS1>(om1, v, omega, gs);
                     if (in && par == (s & 1)) v = nw;
                 }
             }
@@ -1240,14 +1254,14 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                 if (m1 == 0) {  // the wave updates the first column of its pairs: E is the lane's own second column
                     if (ok0[j]) {
                         const double gs = divc4(ae0[j] * v1[j] + aw0[j] * p[-1] + a_ns * p[-nr] + a_ns * p[nr] - s0[j], a_c, inv_a_c, lo_a_c);
-                        const double nw = om1 * v0[j] + omega * gs;
+                        const double nw = relaxed<GS1>(om1, v0[j], omega, gs);
                         v0[j] = nw;
                         p[0] = nw;
                     }
                 } else if (m1 == mv) {  // the second column: W is the lane's own first column
                     if (ok1[j]) {
                         const double gs = divc4(ae1[j] * p[2] + aw1[j] * v0[j] + a_ns * p[1 - nr] + a_ns * p[1 + nr] - s1[j], a_c, inv_a_c, lo_a_c);
-                        const double nw = om1 * v1[j] + omega * gs;
+                        const double nw = relaxed<GS1>(om1, v1[j], omega, gs);
                         v1[j] = nw;
                         p[1] = nw;
                     }
@@ -1257,7 +1271,7 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     const double E = e ? oth : v1[j], W = e ? v0[j] : oth, C = e ? v1[j] : v0[j];
                     const double gs = divc4((e ? ae1[j] : ae0[j]) * E + (e ? aw1[j] : aw0[j]) * W + a_ns * Sv + a_ns * Nv - (e ? s1[j] : s0[j]),
                                             a_c, inv_a_c, lo_a_c);
-                    const double nw = om1 * C + omega * gs;
+                    const double nw = relaxed<GS1>(om1, C, omega, gs);
                     if (e) v1[j] = nw; else v0[j] = nw;
                     p[e] = nw;
                 }
@@ -1292,7 +1306,7 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     if (ir <= nr - 2) {
                         const int c = cbase[j] + off;
                         double gs = divc(a_e[ir] * psi[c + 1] + a_w[ir] * psi[c - 1] + a_ns * psi[c - nr] + a_ns * psi[c + nr] - rhs[c], a_c, inv_a_c);
-                        psi[c] = om1 * psi[c] + omega * gs;
+                        psi[c] = relaxed<GS1>(om1, psi[c], omega, gs);
                     }
                 }
             }
@@ -1308,7 +1322,7 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
             if (ir <= nr - 2) {
                 int c = iz * nr + ir;
                 double gs = divc(a_e[ir] * psi[c + 1] + a_w[ir] * psi[c - 1] + a_ns * psi[c - nr] + a_ns * psi[c + nr] - rhs[c], a_c, inv_a_c);
-                psi[c] = om1 * psi[c] + omega * gs;
+                psi[c] = relaxed<GS1>(om1, psi[c], omega, gs);
             }
         }
         __syncthreads();
@@ -1325,6 +1339,7 @@ __device__ __forceinline__ double cv_resid(const double* psi, const double* rhs,
     double lpsi = d2r - divc(d1r, rs[ir], rs[nr + ir]) + d2z;
     return lpsi - rhs[c];
 }
+template <bool GS1>
 __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, CoarseV V, double omega, double om1, int pre,
                                                         int post, const int* active) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1366,7 +1381,7 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
         double* psi = lds + V.off_psi[l];
         const double* rhs = lds + V.off_rhs[l];
         const double* tab = lds + V.off_tab[l];
-        cv_smooth(psi, rhs, tab, V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, pre);
+        cv_smooth<GS1>(psi, rhs, tab, V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, pre);
         CV_STAMP(2 + 2 * l);
         // coarse rhs = restrict_full_weight(-(L*psi - rhs)); coarse e = 0
         double* rc = lds + V.off_rhs[l + 1];
@@ -1404,7 +1419,7 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
     }
     {
         const int l = V.n - 1;  // base case: 50 sweeps (multigrid_solve.py:293)
-        cv_smooth(lds + V.off_psi[l], lds + V.off_rhs[l], lds + V.off_tab[l], V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, 50);
+        cv_smooth<GS1>(lds + V.off_psi[l], lds + V.off_rhs[l], lds + V.off_tab[l], V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, 50);
         CV_STAMP(20);
     }
     for (int l = V.n - 2; l >= 0; --l) {
@@ -1432,7 +1447,7 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
         }
         __syncthreads();
         CV_STAMP(21 + 2 * l);
-        cv_smooth(psi, lds + V.off_rhs[l], lds + V.off_tab[l], nzf, nrf, V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, post);
+        cv_smooth<GS1>(psi, lds + V.off_rhs[l], lds + V.off_tab[l], nzf, nrf, V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, post);
         CV_STAMP(22 + 2 * l);
     }
     {

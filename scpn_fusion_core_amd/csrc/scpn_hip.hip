@@ -374,6 +374,10 @@ struct DefectOut {  // coarse rhs / coarse correction produced by the fused defe
     Fld rhs{nullptr, nullptr, 0, 0}, e{nullptr, nullptr, 0, 0};
     int nz_c = 0, nr_c = 0, ld_c = 0;
 };
+static bool gauss_seidel_forms() {
+    static const bool on = [] { const char* e = std::getenv("SCPN_HIP_GS1"); return e ? std::atoi(e) != 0 : true; }();
+    return on;
+}
 template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT>
 static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
                           const DefectOut* dfo) {
@@ -381,17 +385,31 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
     // (+ 3 KiB behind the planes: the residual coefficients the waves of a six-row DEFECT tile share, see SHARE_D in the kernel)
     constexpr bool share_d = DEFECT && LZT / NWT >= 6 && NWT >= 6 && (TILE_SHARE_D != 0);
     constexpr size_t lds = (size_t)LZT * 128 * sizeof(double) + (share_d ? 6 * 64 * sizeof(double) : 0);
-    auto kern = &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE>;
+    auto kern_any = &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE>;
     // the instantiation that also finishes the J_raw sum (LazySrc::part) exists for the V-cycle's first level-0 launch only
     constexpr bool HAS_SUMF = S == 3 && DEFECT && !PROLONG;
-    auto kern_sum = [] {
-        if constexpr (!HAS_SUMF) return (decltype(kern))nullptr;
+    auto kern_sum_any = [] {
+        if constexpr (!HAS_SUMF) return (decltype(kern_any))nullptr;
         else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE, true>;
     }();
+    // omega == 1.0 (plain Gauss-Seidel: the multigrid default and the bench's setting): the instantiations whose relaxation step is
+    // one fma, for the three-sweep launches of the V-cycle (SCPN_HIP_GS1=0: the general instantiations whatever omega is)
+    constexpr bool HAS_GS1 = S == 3;
+    auto kern_gs1 = [] {
+        if constexpr (!HAS_GS1) return (decltype(kern_any))nullptr;
+        else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE, false, true>;
+    }();
+    auto kern_sum_gs1 = [] {
+        if constexpr (!(HAS_GS1 && HAS_SUMF)) return (decltype(kern_any))nullptr;
+        else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE, true, true>;
+    }();
     std::call_once(attr_once, [&] {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (kern_sum) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_sum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (auto k : {kern_any, kern_sum_any, kern_gs1, kern_sum_gs1})
+            if (k) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
+    const bool gs1 = HAS_GS1 && omega == 1.0 && gauss_seidel_forms();
+    auto kern = gs1 ? kern_gs1 : kern_any;
+    auto kern_sum = gs1 ? kern_sum_gs1 : kern_sum_any;
     constexpr int H = 2 * S + (DEFECT ? 2 : 0);
     static_assert(LZT - 2 * H >= 2, "tile too short for its halo");
     dim3 g(cdiv(L.nr, 128 - 2 * H), cdiv(L.nz, LZT - 2 * H), h->B);
@@ -575,10 +593,13 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
     if (lc <= k) {
         static std::once_flag attr_once;
         std::call_once(attr_once, [] {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vcycle_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vcycle_coarse<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vcycle_coarse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         });
         ProfScope ps(h, "vcycle_coarse", 1);
-        SCPN_LAUNCH(k_vcycle_coarse, dim3(B), dim3(1024), H.cv_lds, h->stream, cur[lc], rhs_of(lc), H.cv, omega, 1.0 - omega, pre, post, active);
+        // (omega == 1.0: the instantiation whose relaxation steps are single fmas, as in the tile smoother)
+        auto kern = (omega == 1.0 && gauss_seidel_forms()) ? &k_vcycle_coarse<true> : &k_vcycle_coarse<false>;
+        SCPN_LAUNCH(kern, dim3(B), dim3(1024), H.cv_lds, h->stream, cur[lc], rhs_of(lc), H.cv, omega, 1.0 - omega, pre, post, active);
         top = lc;
     } else {
         cur[k] = smooth(h, lv[k]->dev, cur[k], other_of(k, cur[k]), rhs_of(k), omega, 50, active, false, k);

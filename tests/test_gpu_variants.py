@@ -23,6 +23,10 @@ SWITCHES = [
     {"SCPN_HIP_TILEGEO": "32"},                                 # tile geometries: the default of this 2-member run is 24 rows x 12 waves
     {"SCPN_HIP_TILEGEO": "48"},                                 # 48 rows x 8 waves (six rows per wave, inner sources in LDS slots): ensembles of more than 12 members
     {"SCPN_HIP_TILEGEO": "48", "SCPN_HIP_SUMFUSE": "0"},
+    # the run's omega is 1.0, so its smoothers are the Gauss-Seidel instantiations (relaxation step = one fma): the general ones, each geometry
+    {"SCPN_HIP_GS1": "0"},
+    {"SCPN_HIP_GS1": "0", "SCPN_HIP_TILEGEO": "32"},
+    {"SCPN_HIP_GS1": "0", "SCPN_HIP_TILEGEO": "48"},
 ]
 # experiment builds (never shipped: `_lib.build(variant=...)` makes libscpn_hip.<variant>.so next to the product library)
 # name -> (defines, tile geometry the run forces)
@@ -54,7 +58,7 @@ def test_switches_are_bit_identical():
     for sw in SWITCHES:
         got = run(sw)
         # fields bit-identical; the mean |dpsi| reduction groups its partial sums by tile, so it may differ in the last ulp
-        assert (got["psi"], got["jphi"], got["iterations"]) == (base["psi"], base["jphi"], base["iterations"]), (sw, got, base)
+        assert (got["psi"], got["jphi"], got["iterations"], got["special"]) == (base["psi"], base["jphi"], base["iterations"], base["special"]), (sw, got, base)
         assert got["residual"] == pytest.approx(base["residual"], rel=1e-13), sw
 
 
@@ -66,7 +70,7 @@ def test_experiment_builds_are_bit_identical():
     for name, (defines, geo) in EXPERIMENT_BUILDS.items():
         lib = _lib.build(variant=name, defines=defines)
         got = run({"SCPN_HIP_LIB": str(lib), "SCPN_HIP_TILEGEO": geo})
-        assert (got["psi"], got["jphi"], got["iterations"]) == (base["psi"], base["jphi"], base["iterations"]), (name, got, base)
+        assert (got["psi"], got["jphi"], got["iterations"], got["special"]) == (base["psi"], base["jphi"], base["iterations"], base["special"]), (name, got, base)
 
 
 @pytest.mark.parametrize("env", [{"SCPN_HIP_TILEGEO": "32"}, {"SCPN_HIP_TILEGEO": "48"}], ids=["tile_32_rows", "tile_48_rows"])
