@@ -1136,6 +1136,9 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
 // One 1024-thread workgroup per member runs the complete recursion from level `lc` down to the base
 // case and back (core/multigrid_solve.py:289-335) with every level resident in LDS: e_lc = Vcycle(0, rhs_lc).
 constexpr int CV_MAX = 8;
+#ifndef CV_BLOCKS
+#define CV_BLOCKS 1  // 17^2 .. 65^2 levels of the coarse kernel: 2x2 register blocks per lane (1) or column pairs with three LDS reads per update (0)
+#endif
 struct CoarseV {
     int n;                 // number of levels held (last one is the base case)
     int nz[CV_MAX], nr[CV_MAX];
@@ -1213,6 +1216,66 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
         }
         __syncthreads();
         return;
+    }
+    // 2^k+1 levels from 17x17 to 65x65 (CV_BLOCKS): a lane owns the 2x2 BLOCK of points (2by..2by+1, 2bx..2bx+1), values, right-hand
+    // sides and column coefficients in registers for all passes.  Block origins are even/even, so a colour pass updates the same two
+    // points of every block -- top-left + bottom-right, then top-right + bottom-left: two INDEPENDENT chains per lane, compiled per
+    // colour without selects on the operands.  Of a point's four neighbours two are the lane's own registers, one is the
+    // neighbouring lane's (a block row is nbx <= 32 consecutive lanes of one wave: wave_shr / wave_shl moves) and one comes from
+    // the level's plane in LDS, where every updated value is also written for the rows above / below, the defect and the
+    // prolongation: 1 LDS read + 1 write per update instead of 3 + 1, and a pass is one chain deep on 65x65 instead of two.
+    // The ring is +0.0 in every use (the levels of k_vcycle_coarse start from e = 0 and the ring is never updated): the lane move
+    // across the end of a block row (last block's E neighbour = ring column nr-1) delivers the next row's ring column 0, or the
+    // move's 0 fill at the wave's end -- the same +0.0.  17x17 is one wave: no workgroup barrier in its passes.
+    {
+        const int nbx = (nr - 1) >> 1, nby = (nz - 1) >> 1, nblk = nbx * nby;
+        if (CV_BLOCKS && (nr & 1) && (nz & 1) && nbx >= 8 && nbx <= 32 && (nbx & (nbx - 1)) == 0 && nblk <= (int)blockDim.x && (nblk & 63) == 0) {
+            const int t = threadIdx.x;
+            const bool part = t < nblk;  // (wave-uniform: nblk is a multiple of 64)
+            const bool one_wave = nblk == 64;
+            if (part) {
+                const int by = t / nbx, bx = t - by * nbx;
+                double* const p = psi + (2 * by) * nr + 2 * bx;  // block origin
+                const double* const pS = by >= 1 ? p - nr : p;    // row above the block (first block row: never used)
+                const double* const q = rhs + (2 * by) * nr + 2 * bx;
+                double v00 = p[0], v01 = p[1], v10 = p[nr], v11 = p[nr + 1];
+                const double s00 = q[0], s01 = q[1], s10 = q[nr], s11 = q[nr + 1];
+                const double ae0 = a_e[2 * bx], aw0 = a_w[2 * bx], ae1 = a_e[2 * bx + 1], aw1 = a_w[2 * bx + 1];
+                const bool k_tl = by >= 1 && bx >= 1, k_tr = by >= 1, k_bl = bx >= 1;  // (the bottom-right point is always interior)
+                for (int s = 0; s < n_sweeps; ++s) {
+                    {  // colour 0, (row + column) even: top-left (2by, 2bx) and bottom-right (2by+1, 2bx+1)
+                        const double S_tl = pS[0], N_br = p[2 * nr + 1];
+                        const double W_tl = wave_shift<0x138>(v01), E_br = wave_shift<0x130>(v10);
+                        const double g0 = divc4(ae0 * v01 + aw0 * W_tl + a_ns * S_tl + a_ns * v10 - s00, a_c, inv_a_c, lo_a_c);
+                        const double g1 = divc4(ae1 * E_br + aw1 * v10 + a_ns * v01 + a_ns * N_br - s11, a_c, inv_a_c, lo_a_c);
+                        const double n0 = relaxed<GS1>(om1, v00, omega, g0), n1 = relaxed<GS1>(om1, v11, omega, g1);
+                        v00 = k_tl ? n0 : v00;
+                        v11 = n1;
+                        p[0] = v00;
+                        p[nr + 1] = v11;
+                    }
+                    if (one_wave) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (the wave's own LDS writes before its reads)
+                    else __syncthreads();
+                    {  // colour 1: top-right (2by, 2bx+1) and bottom-left (2by+1, 2bx)
+                        const double S_tr = pS[1], N_bl = p[2 * nr];
+                        const double E_tr = wave_shift<0x130>(v00), W_bl = wave_shift<0x138>(v11);
+                        const double g0 = divc4(ae1 * E_tr + aw1 * v00 + a_ns * S_tr + a_ns * v11 - s01, a_c, inv_a_c, lo_a_c);
+                        const double g1 = divc4(ae0 * v11 + aw0 * W_bl + a_ns * v00 + a_ns * N_bl - s10, a_c, inv_a_c, lo_a_c);
+                        const double n0 = relaxed<GS1>(om1, v01, omega, g0), n1 = relaxed<GS1>(om1, v10, omega, g1);
+                        v01 = k_tr ? n0 : v01;
+                        v10 = k_bl ? n1 : v10;
+                        p[1] = v01;
+                        p[nr] = v10;
+                    }
+                    if (one_wave) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    else __syncthreads();
+                }
+            } else if (!one_wave) {
+                for (int s = 0; s < 2 * n_sweeps; ++s) __syncthreads();  // (the waves without blocks keep the barrier count)
+            }
+            if (one_wave) __syncthreads();
+            return;
+        }
     }
     // Up to 2 column pairs per thread (65x65 on 1024 threads): the pair's coefficients, right-hand sides and OWN values stay in
     // registers for all passes.  A pass updates one column of the pair, whose E or W neighbour is the thread's other column, so
