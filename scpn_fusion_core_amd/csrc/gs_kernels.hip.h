@@ -1166,9 +1166,27 @@ template <bool GS1>
 __device__ __forceinline__ double relaxed(double om1, double old, double omega, double gs) {
     return GS1 ? __builtin_fma(om1, old, gs) : om1 * old + omega * gs;
 }
+struct CvC { double dr2, dz2, two_dr, inv_dr2, inv_dz2, inv_two_dr; };
+// L*psi - rhs at one point from its five values (core/multigrid_solve.py:211-249, the expression of cv_resid / mg_residual)
+__device__ __forceinline__ double cv_resid_pt(double p, double e, double w, double n, double s, double rhs_c, double r_safe, double r_inv,
+                                              const CvC& k) {
+    const double d2r = divc(e - 2.0 * p + w, k.dr2, k.inv_dr2);
+    const double d1r = divc(e - w, k.two_dr, k.inv_two_dr);
+    const double d2z = divc(n - 2.0 * p + s, k.dz2, k.inv_dz2);
+    const double lpsi = d2r - divc(d1r, r_safe, r_inv) + d2z;
+    return lpsi - rhs_c;
+}
+// the levels the 2x2-block form of cv_smooth takes (uniform)
+__device__ __forceinline__ bool cv_block_level(int nz, int nr) {
+    const int nbx = (nr - 1) >> 1, nby = (nz - 1) >> 1, nblk = nbx * nby;
+    return CV_BLOCKS && (nr & 1) && (nz & 1) && nbx >= 8 && nbx <= 32 && (nbx & (nbx - 1)) == 0 && nblk <= (int)blockDim.x && (nblk & 63) == 0;
+}
+// add_c / nrc: (block levels only) the coarse-grid correction whose bilinear prolongation is added to psi while the blocks are loaded
+// (psi += P e, the loop of k_vcycle_coarse); dscr / kk: (block levels only) where the defect -(L*psi - rhs) of the smoothed level goes
 template <bool GS1>
 __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const double* tab, int nz, int nr, double a_ns,
-                                          double a_c, double inv_a_c, double lo_a_c, double omega, double om1, int n_sweeps) {
+                                          double a_c, double inv_a_c, double lo_a_c, double omega, double om1, int n_sweeps,
+                                          const double* add_c = nullptr, int nrc = 0, double* dscr = nullptr, const CvC* kk = nullptr) {
     const int hw = (nr - 2 + 1) / 2, tot = (nz - 2) * hw;
     const double* a_e = tab;
     const double* a_w = tab + nr;
@@ -1177,11 +1195,50 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
     if (wi * hi_ <= 64) {
         // The interior fits one wave (9x9 level, 5x5 base case with its 50 sweeps): one interior point per lane, its value in
         // a register for all passes, the four neighbours from the neighbouring lanes, ring neighbours as per-lane constants --
-        // no LDS round trip and no barrier per colour pass.  Interiors of at most 4x4 points sit in one 16-lane DPP row
+        // no LDS round trip and no barrier per colour pass.  Interiors of at most 4 rows x 3 columns sit in one 16-lane DPP row
         // (lane = 4 * row + column): the neighbours come by row_shr / row_shl moves instead of ds_bpermute.
+        if (CV_BLOCKS && nr == 9 && (nz & 1) && nz >= 5 && nz <= 9) {
+            // 9x9 (and 9 columns x 5 / 7 rows) as 2x2 blocks, see the 17x17 .. 65x65 form below: 4 x 4 blocks are the 16 lanes of ONE
+            // DPP row, so all four out-of-block neighbours come by row moves (row_shr / row_shl by 1 and by 4) -- no LDS and no
+            // ds_bpermute inside the passes.  Lanes without a block hold the ring's +0.0, which is also the moves' fill.
+            if (threadIdx.x < 64) {
+                const int lane = threadIdx.x, nby = (nz - 1) >> 1;
+                const bool part = lane < 4 * nby;
+                const int by = part ? lane >> 2 : 0, bx = lane & 3;
+                double* const p = psi + (2 * by) * nr + 2 * bx;
+                const double* const q = rhs + (2 * by) * nr + 2 * bx;
+                double v00 = part ? p[0] : 0.0, v01 = part ? p[1] : 0.0, v10 = part ? p[nr] : 0.0, v11 = part ? p[nr + 1] : 0.0;
+                const double s00 = part ? q[0] : 0.0, s01 = part ? q[1] : 0.0, s10 = part ? q[nr] : 0.0, s11 = part ? q[nr + 1] : 0.0;
+                const double ae0 = a_e[2 * bx], aw0 = a_w[2 * bx], ae1 = a_e[2 * bx + 1], aw1 = a_w[2 * bx + 1];
+                const bool k_tl = part && by >= 1 && bx >= 1, k_tr = part && by >= 1, k_bl = part && bx >= 1, k_br = part;
+                for (int s = 0; s < n_sweeps; ++s) {
+                    {  // top-left and bottom-right
+                        const double W_tl = dpp_f64<0x111>(v01), S_tl = dpp_f64<0x114>(v10);  // lane-1's right column, lane-4's bottom row
+                        const double E_br = dpp_f64<0x101>(v10), N_br = dpp_f64<0x104>(v01);  // lane+1's left column, lane+4's top row
+                        const double g0 = divc4(ae0 * v01 + aw0 * W_tl + a_ns * S_tl + a_ns * v10 - s00, a_c, inv_a_c, lo_a_c);
+                        const double g1 = divc4(ae1 * E_br + aw1 * v10 + a_ns * v01 + a_ns * N_br - s11, a_c, inv_a_c, lo_a_c);
+                        const double n0 = relaxed<GS1>(om1, v00, omega, g0), n1 = relaxed<GS1>(om1, v11, omega, g1);
+                        v00 = k_tl ? n0 : v00;
+                        v11 = k_br ? n1 : v11;
+                    }
+                    {  // top-right and bottom-left
+                        const double E_tr = dpp_f64<0x101>(v00), S_tr = dpp_f64<0x114>(v11);
+                        const double W_bl = dpp_f64<0x111>(v11), N_bl = dpp_f64<0x104>(v00);
+                        const double g0 = divc4(ae1 * E_tr + aw1 * v00 + a_ns * S_tr + a_ns * v11 - s01, a_c, inv_a_c, lo_a_c);
+                        const double g1 = divc4(ae0 * v11 + aw0 * W_bl + a_ns * v00 + a_ns * N_bl - s10, a_c, inv_a_c, lo_a_c);
+                        const double n0 = relaxed<GS1>(om1, v01, omega, g0), n1 = relaxed<GS1>(om1, v10, omega, g1);
+                        v01 = k_tr ? n0 : v01;
+                        v10 = k_bl ? n1 : v10;
+                    }
+                }
+                if (part) { p[0] = v00; p[1] = v01; p[nr] = v10; p[nr + 1] = v11; }
+            }
+            __syncthreads();
+            return;
+        }
         if (threadIdx.x < 64) {
             const int lane = threadIdx.x;
-            const bool dpp = wi <= 4 && hi_ <= 4;
+            const bool dpp = wi <= 3 && hi_ <= 4;  // (at most three columns: the fourth lane of a row is the spare one that holds the ring's 0)
             const int lw = dpp ? 4 : wi;  // lanes per interior row
             const int rz = lane / lw, rr = lane - rz * lw;
             const bool in = rz < hi_ && rr < wi;
@@ -1195,9 +1252,10 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
             if (dpp) {
                 for (int s = 0; s < 2 * n_sweeps; ++s) {
                     // (the moves run with every lane enabled: a DPP read from a disabled lane returns 0)
-                    const double Ed = dpp_f64<0x101>(v), Wd = dpp_f64<0x111>(v);  // row_shl:1 / row_shr:1
-                    const double Nd = dpp_f64<0x104>(v), Sd = dpp_f64<0x114>(v);  // row_shl:4 / row_shr:4
-                    const double E = hasE ? Ed : rE, W = hasW ? Wd : rW, N = hasN ? Nd : rN, S = hasS ? Sd : rS;
+                    // (the ring is +0.0 in every level of k_vcycle_coarse, and so is what the moves deliver for it: the spare lane
+                    //  of a 4-lane row, a lane without a point, or the fill outside the 16-lane row -- no select per neighbour)
+                    const double E = dpp_f64<0x101>(v), W = dpp_f64<0x111>(v);  // row_shl:1 / row_shr:1
+                    const double N = dpp_f64<0x104>(v), S = dpp_f64<0x114>(v);  // row_shl:4 / row_shr:4
                     const double gs = divc4(ae * E + aw * W + a_ns * S + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
                     const double nw = relaxed<GS1>(om1, v, omega, gs);
                     if (in && par == (s & 1)) v = nw;
@@ -1229,7 +1287,7 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
     // move's 0 fill at the wave's end -- the same +0.0.  17x17 is one wave: no workgroup barrier in its passes.
     {
         const int nbx = (nr - 1) >> 1, nby = (nz - 1) >> 1, nblk = nbx * nby;
-        if (CV_BLOCKS && (nr & 1) && (nz & 1) && nbx >= 8 && nbx <= 32 && (nbx & (nbx - 1)) == 0 && nblk <= (int)blockDim.x && (nblk & 63) == 0) {
+        if (cv_block_level(nz, nr)) {
             const int t = threadIdx.x;
             const bool part = t < nblk;  // (wave-uniform: nblk is a multiple of 64)
             const bool one_wave = nblk == 64;
@@ -1242,6 +1300,21 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                 const double s00 = q[0], s01 = q[1], s10 = q[nr], s11 = q[nr + 1];
                 const double ae0 = a_e[2 * bx], aw0 = a_w[2 * bx], ae1 = a_e[2 * bx + 1], aw1 = a_w[2 * bx + 1];
                 const bool k_tl = by >= 1 && bx >= 1, k_tr = by >= 1, k_bl = bx >= 1;  // (the bottom-right point is always interior)
+                if (add_c) {
+                    // psi += P e on load: the block (2by.., 2bx..) is exactly the fine cell of coarse cell (by, bx) -- the coincident
+                    // point, the two edge midpoints and the centre, expressions of prolong_at (core/multigrid_solve.py:117-143; on
+                    // a 2^k+1 level none of its zero fills applies inside the blocks, and the fine ring row / column outside them
+                    // would receive + 0.0: the coarse ring is +0.0)
+                    const double* const c = add_c + by * nrc + bx;
+                    const double c00 = c[0], c01 = c[1], c10 = c[nrc], c11 = c[nrc + 1];
+                    v00 = v00 + c00;
+                    v01 = v01 + 0.5 * (c00 + c01);
+                    v10 = v10 + 0.5 * (c00 + c10);
+                    v11 = v11 + 0.25 * (c00 + c10 + c01 + c11);
+                    p[0] = v00; p[1] = v01; p[nr] = v10; p[nr + 1] = v11;
+                    if (one_wave) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    else __syncthreads();
+                }
                 for (int s = 0; s < n_sweeps; ++s) {
                     {  // colour 0, (row + column) even: top-left (2by, 2bx) and bottom-right (2by+1, 2bx+1)
                         const double S_tl = pS[0], N_br = p[2 * nr + 1];
@@ -1270,8 +1343,25 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     if (one_wave) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                     else __syncthreads();
                 }
+                if (dscr) {
+                    // the defect -(L*psi - rhs) of the block's points from the registers (four independent chains; the rows above /
+                    // below from the plane, the columns left / right by lane moves), kept at interior points
+                    const double* const rs = tab + 2 * nr;  // r_safe, then its reciprocals
+                    const double rs0 = rs[2 * bx], ri0 = rs[nr + 2 * bx], rs1 = rs[2 * bx + 1], ri1 = rs[nr + 2 * bx + 1];
+                    const double S0 = pS[0], S1 = pS[1], N0 = p[2 * nr], N1 = p[2 * nr + 1];
+                    const double W0 = wave_shift<0x138>(v01), W1 = wave_shift<0x138>(v11), E0 = wave_shift<0x130>(v00), E1 = wave_shift<0x130>(v10);
+                    double* const d = dscr + (2 * by) * nr + 2 * bx;
+                    const double d00 = -cv_resid_pt(v00, v01, W0, v10, S0, s00, rs0, ri0, *kk);
+                    const double d01 = -cv_resid_pt(v01, E0, v00, v11, S1, s01, rs1, ri1, *kk);
+                    const double d10 = -cv_resid_pt(v10, v11, W1, N0, v00, s10, rs0, ri0, *kk);
+                    const double d11 = -cv_resid_pt(v11, E1, v10, N1, v01, s11, rs1, ri1, *kk);
+                    if (k_tl) d[0] = d00;
+                    if (k_tr) d[1] = d01;
+                    if (k_bl) d[nr] = d10;
+                    d[nr + 1] = d11;
+                }
             } else if (!one_wave) {
-                for (int s = 0; s < 2 * n_sweeps; ++s) __syncthreads();  // (the waves without blocks keep the barrier count)
+                for (int s = 0; s < 2 * n_sweeps + (add_c ? 1 : 0); ++s) __syncthreads();  // (the waves without blocks keep the barrier count)
             }
             if (one_wave) __syncthreads();
             return;
@@ -1391,7 +1481,6 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
         __syncthreads();
     }
 }
-struct CvC { double dr2, dz2, two_dr, inv_dr2, inv_dz2, inv_two_dr; };
 __device__ __forceinline__ double cv_resid(const double* psi, const double* rhs, const double* rs, int nr, const CvC& k, int iz,
                                            int ir) {
     int c = iz * nr + ir;  // rs = r_safe table, rs + nr = its reciprocals
@@ -1444,7 +1533,11 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
         double* psi = lds + V.off_psi[l];
         const double* rhs = lds + V.off_rhs[l];
         const double* tab = lds + V.off_tab[l];
-        cv_smooth<GS1>(psi, rhs, tab, V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, pre);
+        const CvC kk{V.dr2[l], V.dz2[l], V.two_dr[l], V.inv_dr2[l], V.inv_dz2[l], V.inv_two_dr[l]};
+        double* scr = lds + V.off_scr;
+        const bool blk = cv_block_level(V.nz[l], V.nr[l]);  // (block levels: the smoother leaves the defect in the scratch field itself)
+        cv_smooth<GS1>(psi, rhs, tab, V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, pre, nullptr, 0,
+                       blk ? scr : nullptr, &kk);
         CV_STAMP(2 + 2 * l);
         // coarse rhs = restrict_full_weight(-(L*psi - rhs)); coarse e = 0
         double* rc = lds + V.off_rhs[l + 1];
@@ -1453,9 +1546,7 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
         const double* rs = tab + 2 * nrf;
         // (1) the defect -(L*psi - rhs) of every fine interior point, once, into the scratch field (the restriction stencils of
         //     neighbouring coarse points overlap: evaluating it per coarse point costs 2.25x the arithmetic and LDS reads)
-        double* scr = lds + V.off_scr;
-        {
-            const CvC kk{V.dr2[l], V.dz2[l], V.two_dr[l], V.inv_dr2[l], V.inv_dz2[l], V.inv_two_dr[l]};
+        if (!blk) {
             const int wi = nrf - 2, ni = (V.nz[l] - 2) * wi;
             for (int i = threadIdx.x; i < ni; i += blockDim.x) {
                 const int iz = 1 + i / wi, ir = 1 + (i - (iz - 1) * wi);
@@ -1492,7 +1583,9 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
         // psi += P e, one thread per coarse cell: its four coarse corners are read once and serve the coincident fine point, the
         // two edge midpoints and the cell centre (expressions and zero fill of prolong_at, core/multigrid_solve.py:117-143)
         (void)n;
-        {
+        // (block levels: the post-smoother adds the prolonged correction while it loads its blocks)
+        const bool blk = cv_block_level(nzf, nrf) && 2 * (nrc - 1) == nrf - 1 && 2 * (nzc - 1) == nzf - 1;
+        if (!blk) {
             const int h_end = min(2 * (nrc - 1), nrf - 1), v_end = min(2 * (nzc - 1), nzf - 1);
             for (int i = threadIdx.x; i < nzc * nrc; i += blockDim.x) {
                 const int ic = i / nrc, jc = i - ic * nrc;
@@ -1507,10 +1600,11 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
                     if (fj + 1 < nrf) f[nrf + 1] = f[nrf + 1] + ((fi + 1 >= v_end || fj + 1 >= h_end) ? 0.0 : 0.25 * (c00 + c10 + c01 + c11));
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
         CV_STAMP(21 + 2 * l);
-        cv_smooth<GS1>(psi, lds + V.off_rhs[l], lds + V.off_tab[l], nzf, nrf, V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, post);
+        cv_smooth<GS1>(psi, lds + V.off_rhs[l], lds + V.off_tab[l], nzf, nrf, V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, post,
+                       blk ? pc : nullptr, nrc);
         CV_STAMP(22 + 2 * l);
     }
     {
