@@ -763,6 +763,9 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     // word, the slot words of the fields, the lazy-source scale, the column coefficients -- so that the row loads wait for ONE
     // memory round trip, not for a chain of them (absent sources point at a constant).
     const bool lazy = lzs.st != nullptr;  // uniform
+    // bit 1 of xcd_remap: `in` is the zero field (the correction of a level >= 1 before its pre-smoother: the level above leaves
+    // it unwritten, see DefectDst::e) -- the tile starts from +0.0 without loading it
+    const bool in_zero = (xcd_remap & 2) != 0;
     const int act_w = *(active ? active + b : &g_const_i32[1]);
     const int k_in = *inF.slot_ptr(b), k_out = *outF.slot_ptr(b), k_src = *srcF.slot_ptr(b);
     const int k_cc = (PROLONG || DEFECT) ? *coarseF.slot_ptr(b) : 0;  // PROLONG: the coarse correction read; DEFECT: the coarse rhs written
@@ -891,7 +894,9 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
 #else
             const unsigned vo = (unsigned)gzc * ld8 + lane_off;
 #endif
-            pv[j] = *reinterpret_cast<const double2*>(in_b + vo);
+            // (in_zero, uniform: the input is the all-zero correction a coarser level starts from -- nothing is loaded)
+            if (in_zero) pv[j] = double2{0.0, 0.0};
+            else pv[j] = *reinterpret_cast<const double2*>(in_b + vo);
             if (GLDS && i > 0 && i < NROWS - 1)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_b + vo),
                                                  (__attribute__((address_space(3))) void*)pair_base(i), 16, 0, 0);
@@ -1125,7 +1130,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
                 v = fw9(A0[q], A1[q - 64], A1[q + 64], A1[q - 1], A1[q], A0[q - 65], A0[q - 64], A0[q + 63], A0[q + 64]);
             }
             rc[(long)ic * ld_c + jcn] = v;
-            ec[(long)ic * ld_c + jcn] = 0.0;
+            if (dd.e.base) ec[(long)ic * ld_c + jcn] = 0.0;  // (nullptr: the consumer of the coarse level starts from zero by itself)
         }
     }
     TILE_STAMP(10);

@@ -380,7 +380,7 @@ static bool gauss_seidel_forms() {
 }
 template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT>
 static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                          const DefectOut* dfo) {
+                          const DefectOut* dfo, bool in_zero) {
     static std::once_flag attr_once;  // (two stream-group threads may reach a first launch at the same time)
     // (+ 3 KiB behind the planes: the residual coefficients the waves of a six-row DEFECT tile share, see SHARE_D in the kernel)
     constexpr bool share_d = DEFECT && LZT / NWT >= 6 && NWT >= 6 && (TILE_SHARE_D != 0);
@@ -437,11 +437,11 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
         }
     }
     SCPN_LAUNCH(lzs.part ? kern_sum : kern, g, dim3(64 * NWT), lds, h->stream, out, in, src, L, omega, 1.0 - omega, active, cF, nz_c, nr_c,
-                ld_c, lzs, dd, xcd_env);
+                ld_c, lzs, dd, (xcd_env & 1) | (in_zero ? 2 : 0));
 }
 template <int S, bool PROLONG, bool DEFECT>
 static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                        const DefectOut* dfo) {
+                        const DefectOut* dfo, bool in_zero) {
     // Which tile geometry: by the members the chip works on at once (all stream groups of the ensemble).  More than 12: 48 rows x
     // 8 waves (the least halo redundancy that fits three workgroups per CU; with round 4's one-round-trip load phase it wins from 16
     // members on: 178.8 vs 186.3 us per iteration, and ties at 12 and 8); up to 12 (measured at 129^2 ... 1025^2: the launches
@@ -456,25 +456,28 @@ static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, doubl
         const int members = h->ensemble_B > 0 ? h->ensemble_B : h->B;
         const long tiles0 = (long)cdiv(h->nr, 128 - 16) * cdiv(h->nz, 40 - 16) * members;  // (counted in 24-row windows of 112 columns)
         const int geo = geo_env ? geo_env : (members > mid_maxb ? 48 : (tiles0 <= tiny_max ? 24 : 32));
-        if (geo == 48) return launch_tile_g<S, PROLONG, DEFECT, TILE_BIG_LZ, TILE_BIG_NW>(h, L, out, in, src, omega, active, ps, dfo);
-        if (geo == 24) return launch_tile_g<S, PROLONG, DEFECT, TILE_TINY_LZ, TILE_TINY_NW>(h, L, out, in, src, omega, active, ps, dfo);
+        if (geo == 48) return launch_tile_g<S, PROLONG, DEFECT, TILE_BIG_LZ, TILE_BIG_NW>(h, L, out, in, src, omega, active, ps, dfo, in_zero);
+        if (geo == 24) return launch_tile_g<S, PROLONG, DEFECT, TILE_TINY_LZ, TILE_TINY_NW>(h, L, out, in, src, omega, active, ps, dfo, in_zero);
     }
-    launch_tile_g<S, PROLONG, DEFECT, TILE_MID_LZ, TILE_MID_NW>(h, L, out, in, src, omega, active, ps, dfo);
+    launch_tile_g<S, PROLONG, DEFECT, TILE_MID_LZ, TILE_MID_NW>(h, L, out, in, src, omega, active, ps, dfo, in_zero);
 }
 // the three production roles of the tile kernel: plain, + prolongation on load, + defect / restriction on store
 template <int S>
 static void launch_tile_p(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, double omega, const int* active, const ProlongSrc& ps,
-                          const DefectOut* dfo) {
-    if (dfo) launch_tile<S, false, true>(h, L, out, in, src, omega, active, ps, dfo);
-    else if (ps.c.base) launch_tile<S, true, false>(h, L, out, in, src, omega, active, ps, nullptr);
-    else launch_tile<S, false, false>(h, L, out, in, src, omega, active, ps, nullptr);
+                          const DefectOut* dfo, bool in_zero) {
+    if (dfo) launch_tile<S, false, true>(h, L, out, in, src, omega, active, ps, dfo, in_zero);
+    else if (ps.c.base) launch_tile<S, true, false>(h, L, out, in, src, omega, active, ps, nullptr, in_zero);
+    else launch_tile<S, false, false>(h, L, out, in, src, omega, active, ps, nullptr, in_zero);
 }
 
 // n_sweeps red-black SOR sweeps of (in, src).  Returns the field that holds the result: `in` itself for the
 // in-place kernels, or `in`/`alt` alternately for the out-of-place LDS-tiled kernel (`alt` must not alias `in`).
 static std::string lname(const char* kind, int lvl) { return std::string(kind) + "_L" + std::to_string(lvl); }
 static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omega, int n_sweeps, const int* active,
-                  bool clip = false, int lvl = 0, const ProlongSrc* prolong = nullptr, const DefectOut* defect = nullptr) {
+                  bool clip = false, int lvl = 0, const ProlongSrc* prolong = nullptr, const DefectOut* defect = nullptr,
+                  bool* in_zero = nullptr) {
+    const bool tile_path = !(n_sweeps <= 0 || L.nz < 3 || L.nr < 3) && !clip && (long)L.nz * L.nr > SMALL_MAX && h->use_fused && alt.base != nullptr;
+    if (in_zero && *in_zero && !tile_path) throw std::logic_error("smooth: zero-input flag on a path that reads its input");
     if (n_sweeps <= 0 || L.nz < 3 || L.nr < 3) return in;
     const double om1 = 1.0 - omega;
     if (!clip && (long)L.nz * L.nr <= SMALL_MAX) {
@@ -489,12 +492,16 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
         Fld a = in, b = alt;
         int left = n_sweeps;
         ProlongSrc pso = prolong ? *prolong : ProlongSrc{};  // only the first launch adds the coarse correction
+        // *in_zero (in / out): `in` is known to be the zero field and nobody has written it -- the first tile launch starts from
+        // +0.0 without reading it; reset to false when a path that does read `in` was taken instead
+        bool iz = in_zero && *in_zero;
         while (left > 0) {
             const int S = std::min(3, left);
             const DefectOut* dfo = (defect && left - S <= 0) ? defect : nullptr;  // the LAST launch also produces the coarse rhs
-            if (S == 3) launch_tile_p<3>(h, L, b, a, src, omega, active, pso, dfo);
-            else if (S == 2) launch_tile_p<2>(h, L, b, a, src, omega, active, pso, dfo);
-            else launch_tile_p<1>(h, L, b, a, src, omega, active, pso, dfo);
+            if (S == 3) launch_tile_p<3>(h, L, b, a, src, omega, active, pso, dfo, iz);
+            else if (S == 2) launch_tile_p<2>(h, L, b, a, src, omega, active, pso, dfo, iz);
+            else launch_tile_p<1>(h, L, b, a, src, omega, active, pso, dfo, iz);
+            iz = false;
             pso = ProlongSrc{};
             std::swap(a, b);
             left -= S;
@@ -541,9 +548,20 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
     auto defect_fusable = [&](int l) {
         return fused && pre > 0 && l < k && l >= defect_min_level && (long)lv[l]->dev.nz * lv[l]->dev.nr > SMALL_MAX;
     };
+    // The correction of level l + 1 starts as the zero field.  Whoever smooths it first need not find the zeros in memory if it
+    // starts from +0.0 by itself: the coarse kernel always does (it never reads e), and so does the first tile launch of a
+    // pre-smoother (zero-input flag).  Then the fused defect stage of level l leaves e unwritten (SCPN_HIP_ZEROIN=0: written and read).
+    static const bool zeroin_env = [] { const char* e = std::getenv("SCPN_HIP_ZEROIN"); return !(e && e[0] == '0'); }();
+    auto tile_level = [&](int l) { return fused && (long)lv[l]->dev.nz * lv[l]->dev.nr > SMALL_MAX; };
+    auto starts_from_zero = [&](int l) {  // level l (>= 1): its first consumer needs no zeros in memory
+        if (!zeroin_env) return false;
+        if (l == lc) return true;
+        return l < lc && l < k && pre > 0 && tile_level(l);
+    };
     auto defect_out = [&](int l) {
         DefectOut d;
         d.rhs = lvf(lv[l + 1]->rhs, l + 1); d.e = lvf(lv[l + 1]->psi, l + 1);
+        if (starts_from_zero(l + 1)) d.e.base = nullptr;
         d.nz_c = lv[l + 1]->dev.nz; d.nr_c = lv[l + 1]->dev.nr; d.ld_c = lv[l + 1]->dev.ld;
         return d;
     };
@@ -578,8 +596,10 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
             const bool df = defect_fusable(l);
             DefectOut dl;
             if (df) dl = defect_out(l);
+            // (the correction was left unwritten by level l - 1's fused defect stage iff that stage ran and this level starts from zero)
+            bool in_zero = defect_fusable(l - 1) && (l - 1 > 0 || defect_done0) && starts_from_zero(l);
             cur[l] = smooth(h, lv[l]->dev, cur[l], other_of(l, cur[l]), rhs_of(l), omega, pre, active, false, l, nullptr,
-                            df ? &dl : nullptr);
+                            df ? &dl : nullptr, &in_zero);
             done = df;
         }
         cur[l + 1] = lvf(lv[l + 1]->psi, l + 1);

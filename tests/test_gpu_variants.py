@@ -27,6 +27,10 @@ SWITCHES = [
     {"SCPN_HIP_GS1": "0"},
     {"SCPN_HIP_GS1": "0", "SCPN_HIP_TILEGEO": "32"},
     {"SCPN_HIP_GS1": "0", "SCPN_HIP_TILEGEO": "48"},
+    # the zero correction a coarse level starts from written by the level above and read back (default: neither), each geometry
+    {"SCPN_HIP_ZEROIN": "0"},
+    {"SCPN_HIP_ZEROIN": "0", "SCPN_HIP_TILEGEO": "32"},
+    {"SCPN_HIP_ZEROIN": "0", "SCPN_HIP_TILEGEO": "48"},
 ]
 # experiment builds (never shipped: `_lib.build(variant=...)` makes libscpn_hip.<variant>.so next to the product library)
 # name -> (defines, tile geometry the run forces)
