@@ -37,9 +37,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec; the copy bandwidth me
 
 # Bytes per grid point one launch of a kernel family must move (fp64, fused kernels: DESIGN.md section 5) and the SURVEY 8(d)
 # figure of the same work done as separate passes.  smooth_*_pre = 3 RB-SOR sweeps + defect + full-weight restriction
-# (psi, src in; psi out; coarse rhs + coarse e out = 2 x 8/4); smooth_*_post = prolong-add + 3 sweeps (coarse e in = 8/4).
-FAMILY_BYTES = {"smooth_pre": (28.0, 106.0), "smooth_post": (26.0, 90.0), "smooth": (24.0, 72.0),
+# (psi, src in; psi out; coarse rhs out = 8/4 -- the zero coarse correction is no longer written since round 4, and on levels
+# >= 1 the zero input is not read: SMOOTH_PRE_COARSE_LEVEL_BYTES); smooth_*_post = prolong-add + 3 sweeps (coarse e in = 8/4).
+FAMILY_BYTES = {"smooth_pre": (26.0, 106.0), "smooth_post": (26.0, 90.0), "smooth": (24.0, 72.0),
                 "blend_fused": (32.0, 40.0), "source": (16.0, 24.0)}
+SMOOTH_PRE_COARSE_LEVEL_BYTES = 18.0  # src in, psi out, coarse rhs out
+
+
+def family_bytes_per_point(family: str, lvl: int) -> float:
+    return SMOOTH_PRE_COARSE_LEVEL_BYTES if (family == "smooth_pre" and lvl >= 1) else FAMILY_BYTES.get(family, (16.0, 16.0))[0]
 
 
 def counters_of(kernel_symbol: str) -> dict | None:
@@ -97,7 +103,8 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
         pts = ((grid - 1) // (2 ** level(name)) + 1) ** 2 if dom.startswith("smooth") else grid * grid
         tot_ms += v["ms"]
         tot_launch += v["launches"]
-        bytes_fused += fused_pt * pts * members_per_launch * v["launches"]
+        lvl_pt = family_bytes_per_point(dom, level(name))
+        bytes_fused += lvl_pt * pts * members_per_launch * v["launches"]
         bytes_survey += survey_pt * pts * members_per_launch * v["launches"]
         per_member = (pmc["hbm_bytes_per_member_launch"].get(name) if pmc else None)
         if per_member is None:
@@ -106,7 +113,7 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
             traffic += per_member * members_per_launch * v["launches"]
         us = 1e3 * v["ms"] / v["launches"]
         per_level[name] = {"avg_launch_us": round(us, 2), "launches": v["launches"],
-                           "achieved": round(fused_pt * pts * members_per_launch / (us * 1e-6) / 1e9, 1)}
+                           "alg_bytes_per_point": lvl_pt, "achieved": round(lvl_pt * pts * members_per_launch / (us * 1e-6) / 1e9, 1)}
     ach = bytes_fused / (tot_ms * 1e-3) / 1e9
     ctr = counters_of(dom)
     return {"kernel": dom, "bound": "hbm",  # the roofline `frac` is taken against (the contract's enum); what limits it: `limiter`
@@ -323,8 +330,9 @@ def main() -> int:
                 else:
                     os.environ["SCPN_HIP_GROUPS"] = old_groups
             full = {}
-            for name, (key, bpp) in {"smooth_tile_L0_pre": ("smooth_pre", 28.0), "smooth_tile_L0_post": ("smooth_post", 26.0),
-                                     "blend_fused": ("blend_fused", 32.0)}.items():
+            for name, (key, bpp) in {"smooth_tile_L0_pre": ("smooth_pre", FAMILY_BYTES["smooth_pre"][0]),
+                                     "smooth_tile_L0_post": ("smooth_post", FAMILY_BYTES["smooth_post"][0]),
+                                     "blend_fused": ("blend_fused", FAMILY_BYTES["blend_fused"][0])}.items():
                 if name in fam1 and fam1[name]["launches"]:
                     us = 1e3 * fam1[name]["ms"] / fam1[name]["launches"]
                     gbs = bpp * n_pts * B / us / 1e3
