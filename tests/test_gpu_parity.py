@@ -140,6 +140,25 @@ def test_vcycle_random_shapes_vs_oracle_bit_exact(mgs, orc):
         assert np.array_equal(out, ref), (nz, nr, omega)
 
 
+def test_vcycle_block_levels_vs_oracle_bit_exact(mgs, orc):
+    """Every 2^k+1 level shape the coarse kernel smooths as 2x2 register blocks (17 .. 65 points per side, square and not, one wave
+    or many), below tile levels or as the cycle's top level, with omega 1.0 (one-fma relaxation) and 1.3, and with sweep counts
+    that leave the fused prolongation / defect without sweeps around them."""
+    sides = (9, 17, 33, 65)
+    shapes = [(a, b) for a in sides for b in sides if max(a, b) >= 17] + [(129, 65), (65, 129), (257, 33), (33, 257), (129, 257)]
+    for k, (nz, nr) in enumerate(shapes):
+        psi, source, rr, dr, dz = operator_problem(nz, nr)
+        for omega in (1.0, 1.3):
+            ref = orc.multigrid_vcycle(psi, source, rr, dr, dz, omega=omega)
+            out = mgs.multigrid_vcycle(psi, source, rr, dr, dz, omega=omega)
+            assert np.array_equal(out, ref), (nz, nr, omega)
+    psi, source, rr, dr, dz = operator_problem(65, 65)
+    for pre, post in ((0, 3), (3, 0), (1, 2), (5, 4)):
+        ref = orc.multigrid_vcycle(psi, source, rr, dr, dz, omega=1.0, pre_smooth=pre, post_smooth=post)
+        out = mgs.multigrid_vcycle(psi, source, rr, dr, dz, omega=1.0, pre_smooth=pre, post_smooth=post)
+        assert np.array_equal(out, ref), (pre, post)
+
+
 def test_vcycle_batched_with_frozen_members_matches_oracle(mgs, orc):
     # multigrid_solve with members that converge at different cycles exercises the pass-through of frozen members
     n = 129

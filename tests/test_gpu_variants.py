@@ -40,6 +40,7 @@ EXPERIMENT_BUILDS = {
     "pw0lg2": (("TILE_PWIDE=0", "TILE_LG=2"), "48"), # ... two rows in flight
     "glds0": (("TILE_GLDS=0",), "48"),               # six-row post-smoother: inner-row sources through registers instead of LDS-DMA
     "shd0": (("TILE_SHARE_D=0",), "48"),             # six-row pre-smoother: residual coefficients loaded by every wave at the defect stage
+    "cvb0": (("CV_BLOCKS=0",), "48"),                # coarse kernel: 17^2 .. 65^2 levels as column pairs with three LDS reads per update (rounds 2-3), separate defect / prolongation passes
 }
 
 
