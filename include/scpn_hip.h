@@ -302,6 +302,12 @@ int scpn_gs_map_profiles(scpn_gs *h, double z_min_cfg, int n_rho, const double *
 int scpn_gs_sample_psi(scpn_gs *h, int n_pts, const double *pts_r, const double *pts_z, double *out);
 
 /* psi <- value on every member, on the device (ensemble re-runs without a host upload) */
+/* Relative flux change of the transport coupling (core/integrated_transport_solver_coupling.py:131-146: psi_old = Psi.copy() ...
+ * norm(Psi - psi_old) / norm(psi_old), norm(psi_old) < 1e-30 -> 1) without a download of the fields: scpn_gs_snapshot_psi keeps a
+ * device copy of every member's current iterate, scpn_gs_flux_change returns the ratio per member (rel_change: batch doubles)
+ * for the iterate the handle holds then. */
+int scpn_gs_snapshot_psi(scpn_gs *h);
+int scpn_gs_flux_change(scpn_gs *h, double *rel_change);
 int scpn_gs_fill_psi(scpn_gs *h, double value);
 /* pack the current psi of all members into one dense device buffer [batch][nz][nr] owned by the
  * handle and return its DEVICE address (valid until the next pack / destroy): the send buffer of the

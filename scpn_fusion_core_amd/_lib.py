@@ -131,6 +131,8 @@ SIGNATURES = {
     "scpn_gs_compute_b_field": (_i, [_vp, _i, _dp, _dp]),
     "scpn_gs_sample_psi": (_i, [_vp, _i, _dp, _dp, _dp]),
     "scpn_gs_map_profiles": (_i, [_vp, _d, _i, _dp, _dp, _dp, _vp, _vp]),
+    "scpn_gs_snapshot_psi": (_i, [_vp]),
+    "scpn_gs_flux_change": (_i, [_vp, _dp]),
     "scpn_gs_fill_psi": (_i, [_vp, _d]),
     "scpn_gs_pack_psi_device": (_i, [_vp, C.POINTER(_vp)]),
     "scpn_gs_profile": (_i, [_vp, _i]),

@@ -2790,6 +2790,34 @@ __global__ void __launch_bounds__(256) k_maxabsdiff(Fld aF, Fld bF, int nz, int 
     double bm = block_max<256>(m, sh);
     if (threadIdx.x == 0) pmax[(long)b * nblk + blockIdx.x] = bm;
 }
+// per-workgroup partial sums of old^2 and (cur - old)^2 of member blockIdx.y: the two norms of the transport coupling's relative
+// flux change ||psi - psi_old|| / ||psi_old|| (core/integrated_transport_solver_coupling.py:131-146) without a download of the
+// fields.  part: [B][nblk][2]; the host adds the partials of a member in index order.
+__global__ void __launch_bounds__(256) k_flux_change(Fld curF, Fld oldF, int nz, int nr, int ld, double* part, int nblk) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y;
+    const double* a = curF.at(b);
+    const double* o = oldF.at(b);
+    const long n = (long)nz * nr;
+    double so = 0.0, sd = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long q = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (q < n) {
+            const int iz = (int)(q / nr), ir = (int)(q - (long)iz * nr);
+            const long c = (long)iz * ld + ir;
+            const double vo = o[c], d = a[c] - vo;
+            so += vo * vo;
+            sd += d * d;
+        }
+    }
+    const double bo = block_sum<256>(so, sh);
+    const double bd = block_sum<256>(sd, sh);
+    if (threadIdx.x == 0) {
+        part[((long)b * nblk + blockIdx.x) * 2] = bo;
+        part[((long)b * nblk + blockIdx.x) * 2 + 1] = bd;
+    }
+}
 __global__ void __launch_bounds__(256) k_max_final(double* out, const double* pmax, int nblk) {
     __shared__ double sh[4];
     int b = blockIdx.x;

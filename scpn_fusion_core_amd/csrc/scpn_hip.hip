@@ -146,6 +146,8 @@ struct Solver {
     // multigrid hierarchies keyed by min_grid
     std::map<int, Hier> hier;
     const double* lazy_src = nullptr;  // base of the level-0 source field while it holds J_raw (lazy-source Picard iterations)
+    DBuf<double> d_snap, d_fluxpart;    // scpn_gs_snapshot_psi's copy of the iterate / scpn_gs_flux_change's partial sums
+    bool snap_valid = false;
     const double* jsum_part = nullptr;  // != nullptr: k_jsum's partial sums wait for the first lazy tile launch to finish them (LazySrc::part)
     int jsum_nblk = 0;
     bool use_fused = true;  // SCPN_HIP_FUSED=0 selects the one-pass-per-launch kernels (A/B testing)
@@ -1931,6 +1933,37 @@ static int S_sample_psi(Solver* h, int n_pts, const double* pts_r, const double*
     HIP_TRY(hipStreamSynchronize(h->stream));
     API_END
 }
+// the transport coupling's relative flux change without field downloads: a device copy of the current iterate, and later the two
+// norms of (current, copy) from per-workgroup partial sums added on the host in index order
+static int S_snapshot_psi(Solver* h) {
+    if (!h) return fail(SCPN_E_ARG, "null handle");
+    API_BEGIN
+    h->d_snap.alloc((size_t)h->stride * h->B);
+    SCPN_LAUNCH(k_copy, grid2d(h->nr, h->nz, h->B), BLK2D, 0, h->stream, h->plain(h->d_snap.p), h->slot_fld(h->d_cur.p), h->nz, h->nr, h->ld,
+                       (const int*)nullptr);
+    h->snap_valid = true;
+    API_END
+}
+static int S_flux_change(Solver* h, double* rel_change) {
+    if (!h || !rel_change) return fail(SCPN_E_ARG, "bad arguments");
+    if (!h->snap_valid) return fail(SCPN_E_ARG, "scpn_gs_flux_change: no snapshot (call scpn_gs_snapshot_psi first)");
+    API_BEGIN
+    const int nblk = cdiv((long)h->nz * h->nr, 1024);
+    h->d_fluxpart.alloc((size_t)h->B * nblk * 2);
+    SCPN_LAUNCH(k_flux_change, dim3(nblk, h->B), dim3(256), 0, h->stream, h->slot_fld(h->d_cur.p), h->plain(h->d_snap.p), h->nz, h->nr, h->ld,
+                       h->d_fluxpart.p, nblk);
+    std::vector<double> part((size_t)h->B * nblk * 2);
+    HIP_TRY(hipMemcpyAsync(part.data(), h->d_fluxpart.p, sizeof(double) * part.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < h->B; ++b) {
+        double so = 0.0, sd = 0.0;
+        for (int i = 0; i < nblk; ++i) { so += part[((size_t)b * nblk + i) * 2]; sd += part[((size_t)b * nblk + i) * 2 + 1]; }
+        double norm_old = std::sqrt(so);
+        if (norm_old < 1e-30) norm_old = 1.0;  // integrated_transport_solver_coupling.py:133-134
+        rel_change[b] = std::sqrt(sd) / norm_old;
+    }
+    API_END
+}
 static int S_fill_psi(Solver* h, double value) {
     if (!h) return fail(SCPN_E_ARG, "null handle");
     API_BEGIN
@@ -2204,6 +2237,14 @@ int scpn_debug_cv_stamps(unsigned long long* out) {
 }
 #endif
 int scpn_gs_num_groups(scpn_gs* g) { return g ? (int)g->kids.size() : 0; }
+int scpn_gs_snapshot_psi(scpn_gs* g) {
+    if (!g) return fail(SCPN_E_ARG, "null handle");
+    return each_group(g, [&](int, Solver* k) { return S_snapshot_psi(k); });
+}
+int scpn_gs_flux_change(scpn_gs* g, double* rel_change) {
+    if (!g || !rel_change) return fail(SCPN_E_ARG, "bad arguments");
+    return each_group(g, [&](int gi, Solver* k) { return S_flux_change(k, rel_change + g->off[gi]); });
+}
 int scpn_gs_fill_psi(scpn_gs* g, double value) {
     if (!g) return fail(SCPN_E_ARG, "null handle");
     return each_group(g, [&](int, Solver* k) { return S_fill_psi(k, value); });

@@ -520,6 +520,17 @@ class EnsembleSolver:
         check(self._L.scpn_gs_compute_b_field(self._h, int(member), br, bz))
         return br, bz
 
+    def snapshot_psi(self):
+        """Keep a device copy of every member's current psi (the ``psi_old`` of the transport coupling's flux-change test)."""
+        check(self._L.scpn_gs_snapshot_psi(self._h))
+
+    def flux_change(self) -> np.ndarray:
+        """``||psi - psi_old|| / ||psi_old||`` per member against the last :meth:`snapshot_psi`, evaluated on the device
+        (core/integrated_transport_solver_coupling.py:131-146; ``||psi_old|| < 1e-30`` counts as 1)."""
+        out = np.empty(self.batch)
+        check(self._L.scpn_gs_flux_change(self._h, out))
+        return out
+
     def fill_psi(self, value: float = 0.0):
         """psi <- value on every member, on the device."""
         check(self._L.scpn_gs_fill_psi(self._h, float(value)))

@@ -153,6 +153,33 @@ def test_gs_transport_outer_step(hip, orc):
         assert resid[b] == pytest.approx(np.linalg.norm(ref["psi"] - psi0[b]) / np.linalg.norm(psi0[b]), rel=1e-6)
 
 
+def test_flux_change_on_device_matches_host_norms(hip):
+    """scpn_gs_snapshot_psi / scpn_gs_flux_change: ||psi - psi_old|| / ||psi_old|| per member without field downloads, against
+    np.linalg.norm of the downloaded fields (core/integrated_transport_solver_coupling.py:131-146), incl. the rule for a zero
+    psi_old, for a handle with two stream groups' worth of members and a grid that is no multiple of the block size."""
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    n, B = 97, 5
+    cfg = iter_like_cfg(n, tol=1e-6, max_iter=30)
+    rng = np.random.default_rng(7)
+    with EnsembleSolver(cfg, batch=B) as es:
+        with pytest.raises(ValueError):
+            es.flux_change()  # no snapshot yet
+        old = rng.standard_normal((B, n, n))
+        old[3] = 0.0  # ||psi_old|| < 1e-30 counts as 1
+        es.set_psi(old)
+        es.snapshot_psi()
+        new = old + 1e-3 * rng.standard_normal((B, n, n))
+        new[1] = old[1]  # no change: exactly 0
+        es.set_psi(new)
+        got = es.flux_change()
+    norm_old = np.linalg.norm(old.reshape(B, -1), axis=1)
+    norm_old = np.where(norm_old < 1e-30, 1.0, norm_old)
+    want = np.linalg.norm((new - old).reshape(B, -1), axis=1) / norm_old
+    assert got[1] == 0.0 and got[3] == pytest.approx(np.linalg.norm(new[3]), rel=1e-12)
+    assert np.allclose(got, want, rtol=1e-12, atol=0.0)
+
+
 def test_config4_coupled_step_513(hip, orc):
     """BASELINE config 4 at full size: one coupled transport step (map_profiles_to_2d -> external-profile re-solve -> relative
     flux change -> current-diffusion step) on the 513x513 ITER-like grid for 2 members, against the same sequence on the CPU
