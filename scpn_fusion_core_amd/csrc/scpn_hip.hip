@@ -2680,7 +2680,14 @@ int scpn_coil_flux(const double* r_axis, const double* z_axis, int nz, int nr, i
     API_BEGIN
     HIP_TRY(hipSetDevice(g_device));
     size_t n = (size_t)nz * nr, c = (size_t)std::max(n_coils, 1) * batch;
-    DBuf<double> dout, dr_, dz_, cr, cz, ci, ct;
+    // Scratch of the calling thread on this device, grown on demand and kept: the shape-optimisation loop calls this once per outer
+    // iteration, and seven hipMalloc / hipFree pairs were ~7 of the 8 ms of a 513 x 513 call.  (Never destroyed: no hipFree from a
+    // thread-exit destructor after the runtime has shut down.)
+    struct Scratch { DBuf<double> dout, dr_, dz_, cr, cz, ci, ct; };
+    static thread_local std::map<int, Scratch*>* pools = new std::map<int, Scratch*>();
+    Scratch*& sp = (*pools)[g_device];
+    if (!sp) sp = new Scratch();
+    DBuf<double>&dout = sp->dout, &dr_ = sp->dr_, &dz_ = sp->dz_, &cr = sp->cr, &cz = sp->cz, &ci = sp->ci, &ct = sp->ct;
     dout.alloc(n * batch); dr_.alloc(nr); dz_.alloc(nz); cr.alloc(c); cz.alloc(c); ci.alloc(c); ct.alloc(c);
     HIP_TRY(hipMemcpy(dr_.p, r_axis, sizeof(double) * nr, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dz_.p, z_axis, sizeof(double) * nz, hipMemcpyHostToDevice));
