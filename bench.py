@@ -96,7 +96,7 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
             pmc = None
     except (OSError, ValueError):
         pmc = None
-    tot_ms = tot_launch = bytes_fused = bytes_survey = traffic = 0.0
+    tot_ms = tot_launch = bytes_fused = bytes_survey = traffic = bytes_r3 = 0.0
     traffic_ok = pmc is not None
     per_level = {}
     for name, v in groups[dom]:
@@ -106,6 +106,7 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
         lvl_pt = family_bytes_per_point(dom, level(name))
         bytes_fused += lvl_pt * pts * members_per_launch * v["launches"]
         bytes_survey += survey_pt * pts * members_per_launch * v["launches"]
+        bytes_r3 += (28.0 if dom == "smooth_pre" else fused_pt) * pts * members_per_launch * v["launches"]  # rounds 1-3: 28 B/pt on every level
         per_member = (pmc["hbm_bytes_per_member_launch"].get(name) if pmc else None)
         if per_member is None:
             traffic_ok = False
@@ -121,6 +122,9 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
             "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": round(traffic / tot_launch) if traffic_ok else None,
             "alg_bytes_per_point": fused_pt, "alg_bytes_per_launch": round(bytes_fused / tot_launch),
+            # continuity with rounds 1-3: the same launches priced with the bytes the pre-smoother HAD to move then (the zero coarse
+            # correction written by it and read back by the level below); round 4 removed that traffic, so `frac` prices fewer bytes
+            "frac_with_round3_byte_count": round(bytes_r3 / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "survey_8d_equivalent": {"bytes_per_point_unfused": survey_pt,
                                      "gbs_equivalent": round(bytes_survey / (tot_ms * 1e-3) / 1e9, 1)},
             "avg_launch_us": round(1e3 * tot_ms / tot_launch, 2), "launches": int(tot_launch),
