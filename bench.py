@@ -117,7 +117,13 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
                            "alg_bytes_per_point": lvl_pt, "achieved": round(lvl_pt * pts * members_per_launch / (us * 1e-6) / 1e9, 1)}
     ach = bytes_fused / (tot_ms * 1e-3) / 1e9
     ctr = counters_of(dom)
-    return {"kernel": dom, "bound": "hbm",  # the roofline `frac` is taken against (the contract's enum); what limits it: `limiter`
+    # `bound` = the roofline `frac` is taken against (the contract's enum: this kernel has no MFMA work, its ceiling is the HBM stream of
+    # its compulsory bytes); `bound_observed` = what the committed SQ / traffic counters of the same kernel say holds it back
+    observed = None
+    if ctr is not None and "valu_busy" in ctr:
+        observed = ("valu" if ctr["valu_busy"] >= 0.85 else
+                    "latency (tiles in flight x tile lifetime): neither VALU nor HBM saturated" if ach / HBM_PEAK_GBS < 0.6 else "hbm")
+    return {"kernel": dom, "bound": "hbm", "bound_observed": observed,
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": round(traffic / tot_launch) if traffic_ok else None,
@@ -164,7 +170,10 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="ensemble members per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="ensemble members per GPU (weak scaling: the global ensemble is batch x gpus)")
+    ap.add_argument("--total-members", type=int, default=0,
+                    help="STRONG scaling: a fixed global ensemble of this many members (BASELINE config 5: 256) sharded as "
+                         "ceil(total/gpus) per rank; overrides --batch and reports \"scaling\": \"strong\"")
     ap.add_argument("--grid", type=int, default=513)
     ap.add_argument("--check-every", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -218,7 +227,7 @@ def main() -> int:
             comm_error = f"{type(exc).__name__}: {exc}"  # solve their shards, the line says the gather did not run and is marked invalid
 
     from scpn_fusion_core_amd import _lib
-    from scpn_fusion_core_amd.cases import member_cfg, scan_member_table
+    from scpn_fusion_core_amd.cases import member_cfg, shape_scan_member_table
     from scpn_fusion_core_amd.ensemble import EnsembleSolver
 
     if comm is None and world > 1:
@@ -236,13 +245,19 @@ def main() -> int:
             return 3
     _lib.require_gpu()
     cfg = make_cfg(args.grid)
-    B = args.batch
-    from scpn_fusion_core_amd.distributed import shard_range
+    from scpn_fusion_core_amd.distributed import plan_ensemble
 
-    lo, hi = shard_range(B * world, rank, world)
-    all_currents, all_targets = scan_member_table(cfg, B * world)
-    currents, targets = all_currents[lo:hi], all_targets[lo:hi]
-    es = EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, device=local_rank)
+    try:  # weak: --batch members on every rank; strong (--total-members): contiguous blocks of ceil(total / world), the last may be short
+        plan = plan_ensemble(rank, world, members_per_rank=args.batch, total_members=args.total_members)
+    except ValueError as exc:
+        print(f"bench.py: {exc}", file=sys.stderr)
+        return 2
+    strong, total, lo, hi = plan["scaling"] == "strong", plan["total"], plan["start"], plan["stop"]
+    B, per_rank = plan["members"], plan["block"]  # members resident on THIS rank; the block every rank sends into the gather
+    table = shape_scan_member_table(cfg, total)  # config-5 scan: coil currents, I_p and kappa (coil heights) per member
+    currents, targets = table["currents"][lo:hi], table["targets"][lo:hi]
+    coil_r, coil_z = table["coil_r"][lo:hi], table["coil_z"][lo:hi]
+    es = EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, coil_r=coil_r, coil_z=coil_z, device=local_rank)
     n_pts = args.grid * args.grid
 
     if comm is None and world > 1:
@@ -263,7 +278,7 @@ def main() -> int:
         res = es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
         if comm is not None:  # ensemble gather of the psi blocks over RCCL/xGMI (the path's only exchange step): launched
             comm.wait()       # asynchronously, it runs while the next step solves; every gather ends inside the timed region
-            comm.allgather_psi(es, total=B * world)
+            comm.allgather_psi(es, total=total)
         return res
 
     for _ in range(args.warmup):
@@ -280,12 +295,13 @@ def main() -> int:
         elapsed = host_sync.allreduce_max(elapsed)
 
     # member 0 of the last timed solve, kept for the full-size parity figure reported with the CPU baseline
-    psi_gpu0 = es.get_psi(0) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
-    picard_gpu0 = list(res[0]["picard_iterations"]) if res else None
+    n_cpu = max(1, min(16, os.cpu_count() or 1, B))  # members the CPU leg solves (one per host core): ALL of them are compared
+    psi_gpu_cmp = [es.get_psi(m) for m in range(n_cpu)] if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    picard_gpu = [list(r["picard_iterations"]) for r in res]
     n_conv = sum(int(r["converged"]) for r in res)
     picard_total = [sum(r["picard_iterations"]) for r in res]
     outer = [r["outer_iterations"] for r in res]
-    value = args.steps * B * world / elapsed
+    value = args.steps * total / elapsed  # whole-job equilibria per second: every rank's members / the slowest rank's time
 
     # ---- roofline of the dominant kernel: HIP events on the solver's own stream, in a separate pass (event records would
     #      perturb the timed region); the two stream groups run one after the other while timing, so a kernel is alone on
@@ -320,7 +336,7 @@ def main() -> int:
             old_groups = os.environ.get("SCPN_HIP_GROUPS")
             os.environ["SCPN_HIP_GROUPS"] = "1"
             try:
-                with EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, device=local_rank) as one:
+                with EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, coil_r=coil_r, coil_z=coil_z, device=local_rank) as one:
                     one.fill_psi(0.0)
                     one.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
                     one.fill_psi(0.0)
@@ -355,10 +371,10 @@ def main() -> int:
         from oracle import oracle as orc
 
         orc.lib()  # build / load once, outside the timed region
-        cores = max(1, min(16, os.cpu_count() or 1, B))
+        cores = n_cpu
 
         def cpu_member(m):
-            cm = member_cfg(cfg, currents[m], targets[m])
+            cm = member_cfg(cfg, currents[m], targets[m], coil_r[m], coil_z[m])
             co = cm["coils"]
             t = time.perf_counter()
             r = orc.free_boundary_solve(cm, [c["r"] for c in co], [c["z"] for c in co], [c["current"] for c in co],
@@ -370,8 +386,7 @@ def main() -> int:
             outs = list(pool.map(cpu_member, range(cores)))
         dt = time.perf_counter() - tc
         ref, dt0 = outs[0]
-        psi0 = psi_gpu0
-        cpu = {"value": round(cores / dt, 5), "unit": "equilibria/s", "cores": cores, "kind": "port",
+        cpu = {"value": round(cores / dt, 5), "unit": "equilibria/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
                "sample": f"{cores} full {args.grid}x{args.grid} free-boundary solves (ensemble members 0..{cores - 1}, one per host core, "
                          f"concurrently; member 0: {ref['outer_iterations']} outer, {sum(ref['picard_iterations'])} Picard iterations, "
                          f"{dt0:.1f} s on its core; wall {dt:.1f} s) by oracle/gs_oracle.c",
@@ -400,9 +415,17 @@ def main() -> int:
                                            "by oracle/numpy_lane.py, extrapolated to member 0's iteration count"}
         except Exception as exc:  # the baseline line must not be lost to the optional lane
             cpu["numpy_lane"] = {"error": str(exc)}
-        if psi0 is not None:  # the oracle's psi of member 0 against the device's (same inputs, full size)
-            cpu["psi_rel_linf_vs_gpu"] = float(np.abs(psi0 - ref["psi"]).max() / np.abs(ref["psi"]).max())
-            cpu["picard_iterations_gpu_member0"] = picard_gpu0
+        if psi_gpu_cmp is not None:  # EVERY member the CPU leg solved against the device's result of the timed run (same inputs, full size)
+            errs = [float(np.abs(psi_gpu_cmp[m] - outs[m][0]["psi"]).max() / np.abs(outs[m][0]["psi"]).max()) for m in range(cores)]
+            same = [list(outs[m][0]["picard_iterations"]) == picard_gpu[m] for m in range(cores)]
+            cpu["psi_rel_linf_vs_gpu"] = max(errs)  # the worst of the compared members
+            cpu["members_compared"] = cores
+            cpu["psi_rel_linf_vs_gpu_per_member"] = [float(f"{e:.3e}") for e in errs]
+            cpu["picard_iterations_equal_on_all_compared_members"] = bool(all(same))
+            cpu["picard_iterations_gpu_member0"] = picard_gpu[0]
+            if not all(same):
+                cpu["picard_iterations_mismatch"] = {str(m): {"cpu": list(outs[m][0]["picard_iterations"]), "gpu": picard_gpu[m]}
+                                                     for m in range(cores) if not same[m]}
 
     # ---- beside the Picard figure: the same ensemble with the Newton inner solver of this package (finite-difference Jacobian
     #      action, V-cycle-preconditioned GMRES, full steps).  Not the metric -- the metric is the reference's
@@ -415,7 +438,7 @@ def main() -> int:
                                       "newton_warmup_steps": 2}}
             psi_picard = es.get_psi()
             es.close()  # (done with the Picard handle; keeps this lane's two group streams on hardware queues of their own)
-            with EnsembleSolver(ncfg, batch=B, coil_currents=currents, current_targets=targets, device=local_rank) as nes:
+            with EnsembleSolver(ncfg, batch=B, coil_currents=currents, current_targets=targets, coil_r=coil_r, coil_z=coil_z, device=local_rank) as nes:
                 def nstep():
                     nes.fill_psi(0.0)
                     return nes.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
@@ -436,33 +459,49 @@ def main() -> int:
         except Exception as exc:
             newton = {"error": str(exc)}
 
-    # ---- strict-parity gate (outside the timed region): the HIP free-boundary solve of the DIII-D-like case at 129^2 against the
-    #      reference's own NumPy-lane flux map (data file scpn_fusion_core_amd/data/d3d129_reference_lane.npz, made from the imported reference), with the
-    #      metrics and thresholds of validation/benchmark_freegs_public_example_reconstruction.py:491-497
+    # ---- strict-parity gate (outside the timed region), all FIVE thresholds of
+    #      validation/benchmark_freegs_public_example_reconstruction.py:491-497:
+    #      (1) the harness's own native lane (:275-315: a supplied current density inside a supplied Dirichlet ring) solved on the device
+    #          on both public-example grids, compared with the flux map the imported reference function produced (data file
+    #          scpn_fusion_core_amd/data/freegs_native_lane.npz = tests/golden/freegs_native.npz, written by tests/golden/make_golden.py);
+    #      (2) the HIP free-boundary solve of the DIII-D-like case at 129^2 against the reference's own NumPy-lane flux map
+    #          (scpn_fusion_core_amd/data/d3d129_reference_lane.npz), current closure from the device's J_phi.
     parity = None
     if rank == 0:
         try:
-            from scpn_fusion_core_amd.parity_gate import strict_parity_metrics
-
             from scpn_fusion_core_amd.cases import diiid_like_cfg
+            from scpn_fusion_core_amd.parity_gate import (GATE_THRESHOLDS, native_profile_source_reconstruction,
+                                                          same_case_profile_source_comparison, strict_parity_metrics)
 
+            gated = ("psi_n_rmse", "axis_error_m", "boundary_max_abs_error_wb", "current_closure_relative_error", "xpoint_psi_n_error_max")
+            fn = np.load(ROOT / "scpn_fusion_core_amd" / "data" / "freegs_native_lane.npz")
+            native = {}
+            for cid in ("freegs_01_test_tokamak_freeboundary", "freegs_16_diiid_public_example"):
+                spec = json.loads(str(fn[f"{cid}_spec"]))
+                vac, ext = fn[f"{cid}_vacuum_psi"], fn[f"{cid}_native_plasma_psi"] + fn[f"{cid}_vacuum_psi"]  # "external" = the reference lane's own total flux
+                dev = native_profile_source_reconstruction(fn[f"{cid}_r"], fn[f"{cid}_z"], fn[f"{cid}_boundary_psi"], fn[f"{cid}_jtor"])
+                rec = same_case_profile_source_comparison(fn[f"{cid}_r"], fn[f"{cid}_z"], ext, fn[f"{cid}_boundary_psi"], fn[f"{cid}_jtor"],
+                                                          spec["plasma_current_a"], spec["xpoints"], native_plasma_psi=dev)
+                native[cid] = {**{k: rec[k] for k in gated}, "psi_max_abs_error_wb": float(np.abs(dev - fn[f"{cid}_native_plasma_psi"]).max()),
+                               "checks": rec["checks"], "pass": bool(rec["pass"] and len(rec["checks"]) == 5)}
             g = np.load(ROOT / "scpn_fusion_core_amd" / "data" / "d3d129_reference_lane.npz")  # data only: the reference lane's flux map
             gcfg = diiid_like_cfg(129)
             with EnsembleSolver(gcfg, batch=2, device=local_rank) as ges:
                 ges.solve_free_boundary(max_outer_iter=20, tol=1e-4)
-                gpsi = ges.get_psi(0)
+                gpsi, gj = ges.get_psi(0), ges.get_jphi(0)
             gd, gax = gcfg["dimensions"], g["axis_x"]
-            m = strict_parity_metrics(gpsi, g["psi"], np.linspace(gd["R_min"], gd["R_max"], 129),
-                                      np.linspace(gd["Z_min"], gd["Z_max"], 129), x_points=[(gax[2], gax[3])])
-            parity = {"case": "DIII-D-like free-boundary 129x129 (validation/diiid_config.json) vs the reference NumPy lane",
-                      "psi_rmse_wb": m["psi_rmse"], "psi_n_rmse": m["psi_n_rmse"], "axis_error_m": m["axis_error_m"],
-                      "boundary_max_abs_error_wb": m["boundary_max_abs_error_wb"], "xpoint_psi_n_error_max": m["xpoint_psi_n_error_max"],
-                      "thresholds": {"psi_n_rmse": 0.05, "axis_error_m": 0.025, "boundary_max_abs_error_wb": 1e-10, "xpoint_psi_n_error": 0.05},
-                      "pass": m["pass"],
-                      "freegs": "live FreeGS absent (unpinned); FreeGS 0.8.2 vacuum-psi samples held by the reference reproduced by the "
-                                "device Green's function to 2e-9 Wb (tests/test_gpu_freegs_gate.py)"}
+            m = strict_parity_metrics(gpsi, g["psi"], np.linspace(gd["R_min"], gd["R_max"], 129), np.linspace(gd["Z_min"], gd["Z_max"], 129),
+                                      x_points=[(gax[2], gax[3])], jtor=gj, plasma_current_a=gcfg["physics"]["plasma_current_target"])
+            parity = {"thresholds": dict(GATE_THRESHOLDS),
+                      "native_profile_source_lane": {"what": "device solve of _native_profile_source_reconstruction's system (65x65, FreeGS public-example grids) vs the "
+                                                             "imported reference function's flux map; synthetic J_tor 0.2 % off I_p by construction", "cases": native},
+                      "free_boundary_lane": {"case": "DIII-D-like free-boundary 129x129 (validation/diiid_config.json) vs the reference NumPy lane",
+                                             "psi_rmse_wb": m["psi_rmse"], **{k: m[k] for k in gated}, "checks": m["checks"], "pass": m["pass"]},
+                      "pass": bool(m["pass"] and all(c["pass"] for c in native.values()) and len(m["checks"]) == 5),
+                      "freegs": "live FreeGS absent; the FreeGS 0.8.2 vacuum-psi samples the reference holds are reproduced by the device Green's "
+                                "function inside the artifact's own 1e-12 Wb threshold (tests/test_gpu_freegs_gate.py)"}
         except Exception as exc:  # the gate must not cost the bench line
-            parity = {"error": str(exc)}
+            parity = {"error": f"{type(exc).__name__}: {exc}"}
 
     # ---- one figure per BASELINE config (outside the timed region)
     configs = None
@@ -474,15 +513,44 @@ def main() -> int:
         except Exception as exc:
             configs = {"error": f"{type(exc).__name__}: {exc}"}
 
+    # ---- the OTHER scaling label's N = 1 value (outside the timed region): a weak-scaling run also times the fixed 256-member
+    #      ensemble of BASELINE config 5 on this one GPU (what `--total-members 256 --gpus 1` reports as `value`)
+    strong_n1 = None
+    if rank == 0 and world == 1 and not strong and not args.no_configs:
+        try:
+            es.close()
+            t256 = shape_scan_member_table(cfg, 256)
+            with EnsembleSolver(cfg, batch=256, coil_currents=t256["currents"], current_targets=t256["targets"], coil_r=t256["coil_r"],
+                                coil_z=t256["coil_z"], device=local_rank) as big:
+                def bstep():
+                    big.fill_psi(0.0)
+                    return big.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
+                bstep()
+                big.sync()
+                tb = time.perf_counter()
+                bres = bstep()
+                big.sync()
+                dtb = time.perf_counter() - tb
+            its = [sum(r["picard_iterations"]) for r in bres]
+            strong_n1 = {"value": round(256 / dtb, 3), "unit": "equilibria/s", "scaling": "strong", "n_gpus": 1, "total_members": 256,
+                         "ms_per_step": round(dtb * 1e3, 2), "converged_members": sum(int(r["converged"]) for r in bres),
+                         "picard_iterations_per_member": [min(its), max(its)],
+                         "command": "python bench.py --gpus N --total-members 256"}
+        except Exception as exc:
+            strong_n1 = {"error": f"{type(exc).__name__}: {exc}"}
+
     if rank == 0:
         line = {
             "metric": "converged equilibria/s (513x513 free-boundary, Picard tol 1e-8)",
             "value": round(value, 3), "unit": "equilibria/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"ensemble of {B} ITER-like free-boundary equilibria per GPU, {args.grid}x{args.grid}, "
-                                   "PF-coil Green's-function boundary, Picard+V-cycle tol 1e-8 (BASELINE configs[2]/[4])",
-                       "grid": args.grid, "members_per_gpu": B, "global_members": B * world,
+            "config": {"workload": (f"fixed ensemble of {total} ITER-like free-boundary equilibria sharded over {world} GPU(s) ({per_rank} per rank), "
+                                    if strong else f"ensemble of {B} ITER-like free-boundary equilibria per GPU, ")
+                                   + f"{args.grid}x{args.grid}, coil/shape scan (coil currents and I_p +-10 %, kappa in [1.5, 1.9] through the coil heights), "
+                                     "PF-coil Green's-function boundary, Picard+V-cycle tol 1e-8 (BASELINE configs[4] = configs[2]'s solve x 256)",
+                       "grid": args.grid, "members_per_gpu": per_rank, "members_rank0": B, "global_members": total,
+                       "kappa_range_rank0": [round(float(table["kappa"][lo:hi].min()), 4), round(float(table["kappa"][lo:hi].max()), 4)],
                        "parallelism": f"ensemble-sharded x{world}", "rccl": comm.info() if comm is not None else ({"error": comm_error, "gather": "not run"} if comm_error else None),
                        "converged_members_rank0": n_conv, "outer_iterations": [min(outer), max(outer)],
                        "picard_iterations_per_member": [min(picard_total), max(picard_total)]},
@@ -497,6 +565,8 @@ def main() -> int:
             line["newton_fd_mg"] = newton
         if configs is not None:
             line["configs"] = configs
+        if strong_n1 is not None:
+            line["strong_scaling_n1"] = strong_n1
         if world > 1 and comm is None:  # the N>1 metric includes the ensemble gather: without it the line is not a scaling point
             line["valid"] = False
             line["n_gpus_gathered"] = 0

@@ -211,6 +211,24 @@ def multigrid_solve(source, psi_bc, r_min, r_max, z_min, z_max, nr, nz, *, tol=1
     return psi, res.value, ncy.value, bool(conv.value)
 
 
+def native_profile_source_reconstruction(r_axis, z_axis, boundary_psi, jtor, rel_tol=1e-13, max_cycles=40):
+    """CPU counterpart of the strict-parity harness's native lane (validation/benchmark_freegs_public_example_reconstruction.py:275-315):
+    the linear system the reference factorises with SuperLU -- rows 1/dZ^2, 1/dR^2 +- 1/(2 R dR), -2(1/dR^2 + 1/dZ^2), right-hand side
+    -mu0 R J inside the ring of ``boundary_psi`` (R-slow (len(R), len(Z)) arrays) -- relaxed to round-off by ``orc_multigrid_solve``
+    on linspace axes.  Test infrastructure: checked against the reference's own output in tests/test_oracle_golden.py."""
+    r_axis, z_axis = np.asarray(r_axis, dtype=np.float64), np.asarray(z_axis, dtype=np.float64)
+    src = np.ascontiguousarray((-(4.0e-7 * np.pi) * r_axis[:, None] * np.asarray(jtor, dtype=np.float64)).T)
+    ring = np.asarray(boundary_psi, dtype=np.float64).T
+    start = np.zeros_like(src)
+    start[0, :], start[-1, :], start[:, 0], start[:, -1] = ring[0, :], ring[-1, :], ring[:, 0], ring[:, -1]
+    scale = float(np.abs(src).max())
+    psi, res, _, _ = multigrid_solve(src, start, r_axis[0], r_axis[-1], z_axis[0], z_axis[-1], r_axis.size, z_axis.size,
+                                     tol=rel_tol * scale, max_cycles=max_cycles)
+    if res > 1e-10 * scale:
+        raise RuntimeError(f"residual {res:.3e} did not reach round-off")
+    return np.ascontiguousarray(psi.T)
+
+
 def jacobi_step(psi, source, r_grid, dr, dz):
     psi = _c(psi)
     nz, nr = psi.shape

@@ -25,23 +25,30 @@ def bench_problem(nz, nr, seed=2026):
     return psi0, source, rr, r, z
 
 
+ITER_LIKE = {"R0": 6.2, "a": 2.0, "kappa": 1.7, "Ip": 15.0}  # validation/benchmark_vs_freegs.py:157
+
+
+def iter_like_coil_positions(kappa: float = ITER_LIKE["kappa"]) -> tuple[list[float], list[float]]:
+    """(r, z) of the five PF coils of ``build_config`` (validation/benchmark_vs_freegs.py:424-432) for an elongation ``kappa``:
+    the coils sit at Z = +-1.2 kappa a (PF1/PF2) and +-1.1 * 1.2 kappa a (PF3/PF4) -- the shape knob of the config-5 scan."""
+    R0, a = ITER_LIKE["R0"], ITER_LIKE["a"]
+    coil_R, coil_Z = R0 + 1.5 * a, 1.2 * kappa * a
+    return ([coil_R, coil_R, R0 - 0.5 * a, R0 - 0.5 * a, max(R0 - 2 * a + 0.05, 0.3)],
+            [coil_Z, -coil_Z, coil_Z * 1.1, -coil_Z * 1.1, 0.0])
+
+
 def iter_like_cfg(n, method="multigrid", omega=1.0, tol=1e-8, max_iter=1000, alpha=0.12):
     """ITER-like case of validation/benchmark_vs_freegs.py:157,412-456 (values restated)."""
-    R0, a, kappa, Ip = 6.2, 2.0, 1.7, 15.0
-    coil_R, coil_Z = R0 + 1.5 * a, 1.2 * kappa * a
+    R0, a, kappa, Ip = (ITER_LIKE[k] for k in ("R0", "a", "kappa", "Ip"))
+    cr, cz = iter_like_coil_positions(kappa)
     return {
         "reactor_name": "ITER-like",
         "grid_resolution": [n, n],
         "dimensions": {"R_min": round(R0 - 2 * a, 4), "R_max": round(R0 + 2 * a, 4),
                        "Z_min": round(-2 * kappa * a, 4), "Z_max": round(2 * kappa * a, 4)},
         "physics": {"plasma_current_target": Ip, "vacuum_permeability": 1.0},
-        "coils": [
-            {"name": "PF1", "r": coil_R, "z": coil_Z, "current": 2.0},
-            {"name": "PF2", "r": coil_R, "z": -coil_Z, "current": 2.0},
-            {"name": "PF3", "r": R0 - 0.5 * a, "z": coil_Z * 1.1, "current": -1.0},
-            {"name": "PF4", "r": R0 - 0.5 * a, "z": -coil_Z * 1.1, "current": -1.0},
-            {"name": "CS", "r": max(R0 - 2 * a + 0.05, 0.3), "z": 0.0, "current": 0.15},
-        ],
+        "coils": [{"name": nm, "r": cr[k], "z": cz[k], "current": cur}
+                  for k, (nm, cur) in enumerate((("PF1", 2.0), ("PF2", 2.0), ("PF3", -1.0), ("PF4", -1.0), ("CS", 0.15)))],
         "solver": {"max_iterations": max_iter, "convergence_threshold": tol, "relaxation_factor": alpha,
                    "solver_method": method, "sor_omega": omega},
     }
@@ -66,7 +73,7 @@ def diiid_like_cfg(n, tol=1e-8, max_iter=1000, alpha=0.12):
 
 
 def scan_member_table(cfg: dict, total: int, seed: int = 2026) -> tuple[np.ndarray, np.ndarray]:
-    """Coil/shape scan of BASELINE config 5: coil currents I_k*(1+0.1u) and plasma current Ip*(1+0.1u),
+    """The coil-current half of the config-5 scan: coil currents I_k*(1+0.1u) and plasma current Ip*(1+0.1u),
     u ~ U(-1, 1) from ``np.random.default_rng(seed)``; returns (currents [total, n_coils], I_p targets [total])."""
     base = np.array([c["current"] for c in cfg["coils"]], dtype=np.float64)
     rng = np.random.default_rng(seed)
@@ -75,7 +82,30 @@ def scan_member_table(cfg: dict, total: int, seed: int = 2026) -> tuple[np.ndarr
     return currents, targets
 
 
-def member_cfg(cfg: dict, currents_row, target) -> dict:
+def shape_scan_member_table(cfg: dict, total: int, seed: int = 2026, kappa_range: tuple[float, float] = (1.5, 1.9)) -> dict:
+    """Coil/shape scan of BASELINE config 5 (SURVEY 8d cfg 5): per member, coil currents I_k*(1+0.1u), plasma current Ip*(1+0.1u),
+    u ~ U(-1, 1), and an elongation kappa ~ U(kappa_range) realised through the coil heights Z = 1.2 kappa a of the ITER-like
+    coil set (validation/benchmark_vs_freegs.py:424-432); grid and domain are the config's for every member.  Currents and targets
+    are ``scan_member_table``'s (the rounds 1-4 table), kappa comes from ``np.random.default_rng([seed, 5])``.
+    Returns ``{"currents": [total, n], "targets": [total], "kappa": [total], "coil_r": [total, n], "coil_z": [total, n]}``."""
+    if len(cfg["coils"]) != 5 or cfg.get("reactor_name") != "ITER-like":
+        raise ValueError("the shape scan is defined on the ITER-like five-coil set")
+    currents, targets = scan_member_table(cfg, total, seed)
+    kappa = np.random.default_rng([seed, 5]).uniform(kappa_range[0], kappa_range[1], size=total)  # (own stream: member m's kappa does not depend on `total`)
+    pos = [iter_like_coil_positions(float(k)) for k in kappa]
+    return {"currents": currents, "targets": targets, "kappa": kappa,
+            "coil_r": np.array([p[0] for p in pos], dtype=np.float64).reshape(total, 5),
+            "coil_z": np.array([p[1] for p in pos], dtype=np.float64).reshape(total, 5)}
+
+
+def member_cfg(cfg: dict, currents_row, target, coil_r_row=None, coil_z_row=None) -> dict:
     """The config of one scan member on its own (what a single-equilibrium solver would be handed for it)."""
-    return {**cfg, "coils": [dict(co, current=float(currents_row[i])) for i, co in enumerate(cfg["coils"])],
-            "physics": dict(cfg["physics"], plasma_current_target=float(target))}
+    coils = []
+    for i, co in enumerate(cfg["coils"]):
+        c = dict(co, current=float(currents_row[i]))
+        if coil_r_row is not None:
+            c["r"] = float(coil_r_row[i])
+        if coil_z_row is not None:
+            c["z"] = float(coil_z_row[i])
+        coils.append(c)
+    return {**cfg, "coils": coils, "physics": dict(cfg["physics"], plasma_current_target=float(target))}

@@ -721,6 +721,25 @@ static void set_tables_mu0(Solver* h, double mu0) {
 }
 
 // ------------------------------------------------------------------------------------------ creation
+// Which stream group of an ensemble handle the next create_impl() call builds (set by scpn_gs_create around S_create).
+static thread_local int t_group_index = 0, t_group_count = 1;
+// Stream of one group.  Experiment switch SCPN_HIP_CURESERVE=n (two-group handles only): each group keeps n compute units the OTHER
+// group's stream may not use (hipExtStreamCreateWithCUMask), so a group's one-workgroup-per-member coarse V-cycle kernel -- which
+// needs a whole CU (150 KiB of LDS) -- finds CUs that the other group's tile kernels are not refilling.  Mask bit i addresses
+// XCD i % 8, shader engine (i / 8) % 4, CU i / 32 of that engine (the driver deals the bits round-robin), so bits [0, 16) are two
+// CUs of every XCD and bits [16, 32) two others.
+static void create_group_stream(hipStream_t* st) {
+    static const int reserve = [] { const char* e = std::getenv("SCPN_HIP_CURESERVE"); return e ? std::atoi(e) : 0; }();
+    if (reserve <= 0 || t_group_count != 2) { HIP_TRY(hipStreamCreate(st)); return; }
+    hipDeviceProp_t pr;
+    HIP_TRY(hipGetDeviceProperties(&pr, g_device));
+    const int ncu = pr.multiProcessorCount, nres = std::min(reserve, ncu / 4);
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int i = 0; i < ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    const int lo = (1 - t_group_index) * nres;  // the other group's reserve: not for this stream
+    for (int i = lo; i < lo + nres; ++i) mask[(size_t)i / 32] &= ~(1u << (i % 32));
+    HIP_TRY(hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()));
+}
 static Solver* create_impl(int nr, int nz, int batch, const double* r_axis, const double* z_axis, double dr, double dz) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available");
@@ -734,7 +753,7 @@ static Solver* create_impl(int nr, int nz, int batch, const double* r_axis, cons
         h->r_axis.assign(r_axis, r_axis + nr);
         if (z_axis) h->z_axis.assign(z_axis, z_axis + nz);
         else { h->z_axis.assign(nz, 0.0); for (int i = 0; i < nz; ++i) h->z_axis[i] = i * dz; }
-        HIP_TRY(hipStreamCreate(&h->stream));
+        create_group_stream(&h->stream);
         size_t n = (size_t)h->stride * batch;
         h->psi_slots.alloc(3 * n);
         h->W.alloc(n);
@@ -2098,7 +2117,9 @@ int scpn_gs_create(scpn_gs** out, int nr, int nz, int batch, const double* r_axi
     for (int gi = 0; gi < ng; ++gi) {
         int cnt = (batch - done + (ng - gi) - 1) / (ng - gi);
         Solver* k = nullptr;
+        t_group_index = gi; t_group_count = ng;
         int rc = S_create(&k, nr, nz, cnt, r_axis, z_axis, dr, dz);
+        t_group_index = 0; t_group_count = 1;
         if (rc) { delete g; return rc; }
         k->ensemble_B = batch;
         g->kids.push_back(k);

@@ -39,6 +39,23 @@ def shard_sizes(total: int, world: int) -> list[int]:
     return [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
 
 
+def plan_ensemble(rank: int, world: int, *, members_per_rank: int = 0, total_members: int = 0) -> dict:
+    """How a job of ``world`` ranks splits an ensemble, for this ``rank``.
+
+    ``total_members > 0``: STRONG scaling -- a fixed global ensemble cut into contiguous blocks of ceil(total / world) (the last
+    rank may hold fewer, never none).  Otherwise WEAK scaling: ``members_per_rank`` on every rank.  Returns ``{"scaling", "total",
+    "start", "stop", "members" (this rank's), "block" (what every rank sends into the gather: short blocks are padded)}``."""
+    strong = total_members > 0
+    total = int(total_members) if strong else int(members_per_rank) * world
+    if total < 1:
+        raise ValueError("the ensemble needs at least one member")
+    if min(shard_sizes(total, world)) < 1:
+        raise ValueError(f"{total} members cannot be cut into {world} non-empty blocks of {-(-total // world)}")
+    start, stop = shard_range(total, rank, world)
+    return {"scaling": "strong" if strong else "weak", "total": total, "start": start, "stop": stop, "members": stop - start,
+            "block": -(-total // world)}
+
+
 # ------------------------------------------------------------------------------------------------- TCP plumbing (host data)
 def rendezvous_port(env=None) -> int:
     env = os.environ if env is None else env

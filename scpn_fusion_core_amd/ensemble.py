@@ -170,10 +170,13 @@ class EnsembleSolver:
         Per-member currents of ``cfg["coils"]`` (default: the config's currents for every member).
     current_targets : array (batch,), optional
         Per-member ``plasma_current_target``.
+    coil_r, coil_z : array (batch, n_coils), optional
+        Per-member positions of ``cfg["coils"]`` (a shape scan: every member its own coil geometry on the shared grid); they
+        feed the vacuum field of the seed and are the default coil set of ``solve_free_boundary``.
     """
 
     def __init__(self, cfg: dict, batch: int = 1, coil_currents=None, current_targets=None, device: int | None = None,
-                 r_axis=None, z_axis=None):
+                 r_axis=None, z_axis=None, coil_r=None, coil_z=None):
         self._L = _lib.require_gpu()
         if device is not None:
             check(self._L.scpn_set_device(int(device)))
@@ -195,8 +198,10 @@ class EnsembleSolver:
         _note_live_handle(+1, self._L.scpn_gs_num_groups(h))
         coils = cfg.get("coils", [])
         self.n_coils = len(coils)
-        self.coil_r = np.tile(np.array([c["r"] for c in coils], dtype=np.float64), (self.batch, 1))
-        self.coil_z = np.tile(np.array([c["z"] for c in coils], dtype=np.float64), (self.batch, 1))
+        self.coil_r = np.tile(np.array([c["r"] for c in coils], dtype=np.float64), (self.batch, 1)) if coil_r is None else as_f64(coil_r).reshape(self.batch, -1)
+        self.coil_z = np.tile(np.array([c["z"] for c in coils], dtype=np.float64), (self.batch, 1)) if coil_z is None else as_f64(coil_z).reshape(self.batch, -1)
+        if self.coil_r.shape != (self.batch, self.n_coils) or self.coil_z.shape != (self.batch, self.n_coils):
+            raise ValueError("coil_r / coil_z must have shape (batch, n_coils)")
         base_i = np.array([c["current"] for c in coils], dtype=np.float64)
         self.coil_i = np.tile(base_i, (self.batch, 1)) if coil_currents is None else as_f64(coil_currents).reshape(self.batch, -1)
         if self.coil_i.shape != (self.batch, self.n_coils):

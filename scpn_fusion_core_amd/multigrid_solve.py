@@ -161,11 +161,27 @@ def multigrid_solve(source, psi_bc, r_min, r_max, z_min, z_max, nr, nz, *, tol=1
     if max_cycles < 1:
         raise ValueError("max_cycles must be >= 1.")
     validate_sor_omega(omega)
+    return multigrid_solve_on_axes(source_arr, psi, np.linspace(r_min, r_max, nr), np.linspace(z_min, z_max, nz), tol=tol,
+                                   max_cycles=max_cycles, omega=omega, pre_smooth=pre_smooth, post_smooth=post_smooth, min_grid=min_grid)
+
+
+def multigrid_solve_on_axes(source, psi_bc, r_axis, z_axis, *, tol=1e-6, max_cycles=500, omega=1.0, pre_smooth=3, post_smooth=3,
+                            min_grid=5):
+    """``multigrid_solve`` for callers that hold the 1-D axes themselves (an external code's grid): R at every column is
+    ``r_axis[i]``, the spacings are ``r_axis[1] - r_axis[0]`` / ``z_axis[1] - z_axis[0]`` (core/multigrid_solve.py:429-432)."""
+    source_arr, psi = as_f64(source), np.array(psi_bc, dtype=np.float64)
+    r_axis, z_axis = np.ascontiguousarray(r_axis, dtype=np.float64), np.ascontiguousarray(z_axis, dtype=np.float64)
+    nr, nz = r_axis.size, z_axis.size
+    if source_arr.shape[-2:] != (nz, nr) or psi.shape != source_arr.shape or psi.ndim not in (2, 3):
+        raise ValueError(f"source and psi_bc must have shape (nz, nr) = ({nz}, {nr}); got source={source_arr.shape}, psi_bc={psi.shape}.")
+    if not (np.isfinite(tol) and tol > 0.0):
+        raise ValueError("tol must be finite and > 0.")
+    if max_cycles < 1:
+        raise ValueError("max_cycles must be >= 1.")
+    validate_sor_omega(omega)
     L = _lib.require_gpu()
     batched = psi.ndim == 3
     B = psi.shape[0] if batched else 1
-    r_axis = np.linspace(r_min, r_max, nr)
-    z_axis = np.linspace(z_min, z_max, nz)
     psi = np.ascontiguousarray(psi)
     res = np.empty(B)
     ncy = np.empty(B, dtype=np.int32)
@@ -204,4 +220,4 @@ def sor_step(psi, source, r_grid, dr, dz, omega=1.6):
 
 
 __all__ = ["validate_sor_omega", "mg_smooth", "mg_residual", "residual_linf", "gs_residual_rms", "restrict_full_weight",
-           "prolongate_bilinear", "multigrid_vcycle", "multigrid_solve", "jacobi_step", "sor_step"]
+           "prolongate_bilinear", "multigrid_vcycle", "multigrid_solve", "multigrid_solve_on_axes", "jacobi_step", "sor_step"]

@@ -5,9 +5,11 @@ neither vendored under /root/reference nor installed, so the machine is restated
 (freegs/machine.py ``TestTokamak``: shaped coils P1L / P1U = the unit squares of side 0.1 m centred at (1.0, -1.1) / (1.0, +1.1),
 point coils P2L / P2U at (1.75, -0.6) / (1.75, +0.6); freegs/quadrature.py: a shaped coil is represented by the six-point
 degree-4 Gauss rule on each triangle of its polygon, weights scaled by the triangles' area shares -- 12 filaments per square,
-as the artifact's ``filament_count`` records).  With the coil currents stored in the artifact this reproduces the nine
-``freegs_vacuum_psi_sample`` values to 4e-10 Wb (1e-9 relative); the remainder is the part of FreeGS's quadrature constants
-that could not be recovered without its source, so the pin is asserted at 2e-9, not at the artifact's 1e-12.
+as the artifact's ``filament_count`` records).  A square has two triangulations; which diagonal FreeGS's ear clipping cuts
+depends on the polygon's winding, and the two squares are mirror images: P1L is fanned from its vertex 1, P1U from its vertex 0.
+With the coil currents stored in the artifact this reproduces the nine ``freegs_vacuum_psi_sample`` values to 6e-16 Wb -- inside
+the artifact's own 1e-12 thresholds (rounds 1-4 fanned both squares from vertex 1 and stopped at 3.75e-10; the other three
+combinations of diagonals give 3.75e-10 ... 6.96e-10, a degree-3 six-point rule 1e-7).
 """
 import numpy as np
 
@@ -22,10 +24,10 @@ def _rule():
     return pts
 
 
-def _shaped(polygon):
-    """Filaments (r, z, weight) of a convex polygon: fan triangulation from vertex 1, six Gauss points per triangle."""
+def _shaped(polygon, apex=1):
+    """Filaments (r, z, weight) of a convex polygon: fan triangulation from vertex ``apex``, six Gauss points per triangle."""
     n = len(polygon)
-    tris = [(polygon[1], polygon[(1 + i) % n], polygon[(2 + i) % n]) for i in range(1, n - 1)]
+    tris = [(polygon[apex], polygon[(apex + i) % n], polygon[(apex + 1 + i) % n]) for i in range(1, n - 1)]
     area = [0.5 * abs((t[1][0] - t[0][0]) * (t[2][1] - t[0][1]) - (t[2][0] - t[0][0]) * (t[1][1] - t[0][1])) for t in tris]
     out = []
     for t, a in zip(tris, area):
@@ -38,6 +40,6 @@ def tokamak_filaments(currents: dict) -> np.ndarray:
     """(n, 3) array of (R, Z, current) filaments of TestTokamak for the given coil currents {"P1L": ..., ...}."""
     p1l = [(0.95, -1.15), (0.95, -1.05), (1.05, -1.05), (1.05, -1.15)]
     p1u = [(0.95, 1.15), (0.95, 1.05), (1.05, 1.05), (1.05, 1.15)]
-    fil = [(r, z, currents["P1L"] * w) for r, z, w in _shaped(p1l)] + [(r, z, currents["P1U"] * w) for r, z, w in _shaped(p1u)]
+    fil = [(r, z, currents["P1L"] * w) for r, z, w in _shaped(p1l, 1)] + [(r, z, currents["P1U"] * w) for r, z, w in _shaped(p1u, 0)]
     fil += [(1.75, -0.6, currents["P2L"]), (1.75, 0.6, currents["P2U"])]
     return np.asarray(fil, dtype=np.float64)

@@ -771,10 +771,96 @@ def gen_freegs():
         print("native lane", n, r["outer_iterations"], r["final_diff"], (k.R[ir], k.Z[iz]), (xr, xz))
     out["_configs"] = np.array(json.dumps(cfgs))
     save("freegs.npz", **out)
+    gen_freegs_native()
+
+
+def _synthetic_same_case(spec, fg):
+    """Inputs of the harness's native lane on one public FreeGS example grid, built WITHOUT FreeGS (not installed): a synthetic
+    toroidal current density (Gaussian core + pedestal shoulder, sign and total of the case's plasma current up to a known
+    0.2 % closure error), its own free-space flux on the grid's ring from the reference's ``green_function`` (what FreeGS's
+    von-Hagenow boundary delivers as ``plasma_psi`` there) and a vacuum flux of four point coils outside the domain.  Layout
+    is the harness's: arrays are (len(R), len(Z)), R slow."""
+    r = np.linspace(spec.r_min, spec.r_max, spec.nx)
+    z = np.linspace(spec.z_min, spec.z_max, spec.ny)
+    rc, zc = 0.5 * (spec.xpoints[0][0] + spec.xpoints[1][0]) + 0.12, 0.5 * (spec.xpoints[0][1] + spec.xpoints[1][1])
+    a, kappa = 0.30 * (spec.r_max - spec.r_min) / 1.9 * 1.6, 1.35
+    rr, zz = np.meshgrid(r, z, indexing="ij")
+    rho = np.sqrt(((rr - rc) / a) ** 2 + ((zz - zc) / (kappa * a)) ** 2)
+    shape = np.exp(-rho**2 / 0.18) + 0.25 * 0.5 * (1.0 - np.tanh((rho - 0.85) / 0.06))
+    shape[rho > 1.25] = 0.0
+    shape[0, :] = shape[-1, :] = 0.0
+    shape[:, 0] = shape[:, -1] = 0.0
+    jtor = shape * (spec.plasma_current_a * (1.0 + 2.0e-3) / fg._integrate_current(r, z, shape))
+    d_r, d_z = r[1] - r[0], z[1] - z[0]
+    src = [(i, j) for i in range(spec.nx) for j in range(spec.ny) if jtor[i, j] != 0.0]
+    plasma = 0.37 * np.sin(3.0 * rr) * np.cos(2.0 * zz)  # interior values: the lane must ignore them
+    ring = [(i, j) for i in range(spec.nx) for j in range(spec.ny) if i in (0, spec.nx - 1) or j in (0, spec.ny - 1)]
+    for i, j in ring:
+        plasma[i, j] = sum(jtor[a_, b_] * green_function(r[a_], z[b_], r[i], z[j]) for a_, b_ in src) * d_r * d_z
+    span_r, span_z = spec.r_max - spec.r_min, spec.z_max - spec.z_min
+    coils = [(spec.r_min + 0.45 * span_r, spec.z_max + 0.15 * span_z, 0.35), (spec.r_min + 0.45 * span_r, spec.z_min - 0.15 * span_z, 0.35),
+             (spec.r_max + 0.12 * span_r, 0.35 * spec.z_max, -0.2), (spec.r_max + 0.12 * span_r, 0.35 * spec.z_min, -0.2)]
+    vacuum = np.zeros_like(plasma)
+    for cr, cz, frac in coils:
+        cur = frac * spec.plasma_current_a
+        for i in range(spec.nx):
+            for j in range(spec.ny):
+                vacuum[i, j] += cur * green_function(cr, cz, r[i], z[j])
+    return r, z, jtor, plasma, vacuum
+
+
+# validation/benchmark_freegs_public_example_reconstruction.py:275-315 (native lane), :318-378 (metric helpers), :431-497 (comparison)
+def gen_freegs_native():
+    """The strict-parity harness's OWN native lane, called as the harness calls it, on both public-example grids (65 x 65, the
+    artifact's domains).  Stored: inputs, ``_native_profile_source_reconstruction``'s flux, and the full metric record of
+    ``_native_same_case_profile_source_comparison`` against an "external" flux map = that lane's total flux + a smooth 1e-3
+    perturbation + 3e-12 Wb on the ring, so every one of the five gated metrics is non-zero in the fixture."""
+    from types import SimpleNamespace
+
+    import validation.benchmark_freegs_public_example_reconstruction as fg
+
+    out = {}
+    for spec in fg.PUBLIC_CASES:
+        cid = spec.case_id
+        r, z, jtor, plasma, vacuum = _synthetic_same_case(spec, fg)
+        native_plasma = fg._native_profile_source_reconstruction(r, z, plasma, jtor)
+        rr, zz = np.meshgrid(r, z, indexing="ij")
+        bump = np.sin(np.pi * (rr - r[0]) / (r[-1] - r[0])) * np.sin(np.pi * (zz - z[0]) / (z[-1] - z[0]))
+        total = native_plasma + vacuum
+        external = total + 1.0e-3 * (total.max() - total.min()) * bump * np.cos(2.0 * rr)
+        for edge in (external[0, :], external[-1, :], external[:, 0], external[:, -1]):
+            edge += 3.0e-12
+        # the harness takes R_1D / Z_1D / Jtor / plasma_psi from a FreeGS equilibrium object; here they are plain arrays
+        eq = SimpleNamespace(R_1D=r, Z_1D=z, Jtor=jtor, plasma_psi=external - vacuum)
+        rec = fg._native_same_case_profile_source_comparison(eq, None, spec, external)
+        rec.pop("q_profile_sanity")  # FreeGS-only (eq.q)
+        out[f"{cid}_r"], out[f"{cid}_z"], out[f"{cid}_jtor"] = r, z, jtor
+        out[f"{cid}_boundary_psi"], out[f"{cid}_vacuum_psi"], out[f"{cid}_external_psi"] = plasma, vacuum, external
+        out[f"{cid}_native_plasma_psi"] = native_plasma
+        # the comparison solves with eq.plasma_psi (= external - vacuum) on the ring: its own solution is stored too
+        out[f"{cid}_native_plasma_psi_cmp"] = fg._native_profile_source_reconstruction(r, z, external - vacuum, jtor)
+        out[f"{cid}_record"] = np.array(json.dumps(rec))
+        # a second "external" map far enough away (6 % of the flux range, skewed in R) that the axis moves and thresholds fail
+        ia, ja = np.unravel_index(int(np.argmax(total)), total.shape)
+        hill = np.exp(-(((rr - r[min(ia + 4, spec.nx - 2)]) / (3.0 * (r[1] - r[0]))) ** 2 + ((zz - z[min(ja + 3, spec.ny - 2)]) / (3.0 * (z[1] - z[0]))) ** 2))
+        far = total + (total.max() - total.min()) * (6.0e-2 * bump * (rr - r[0]) / (r[-1] - r[0]) + 0.15 * hill * bump)
+        rec_far = fg._native_same_case_profile_source_comparison(
+            SimpleNamespace(R_1D=r, Z_1D=z, Jtor=jtor, plasma_psi=far - vacuum), None, spec, far)
+        rec_far.pop("q_profile_sanity")
+        out[f"{cid}_external_psi_far"], out[f"{cid}_record_far"] = far, np.array(json.dumps(rec_far))
+        out[f"{cid}_native_plasma_psi_far"] = fg._native_profile_source_reconstruction(r, z, far - vacuum, jtor)
+        print("  far:", {k: rec_far[k] for k in ("psi_n_rmse", "axis_error_m", "xpoint_psi_n_error_max")})
+        out[f"{cid}_spec"] = np.array(json.dumps({"plasma_current_a": spec.plasma_current_a, "xpoints": spec.xpoints}))
+        print(cid, {k: rec[k] for k in ("psi_n_rmse", "axis_error_m", "boundary_max_abs_error_wb", "current_closure_relative_error",
+                                        "xpoint_psi_n_error_max", "native_plasma_psi_rmse")})
+    save("freegs_native.npz", **out)
+    # the same data file beside the package: bench.py's parity block reads it from there (it does not read tests/)
+    import shutil
+    shutil.copyfile(OUT / "freegs_native.npz", OUT.parents[1] / "scpn_fusion_core_amd" / "data" / "freegs_native_lane.npz")
 
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["smooth", "operators", "mgsolve", "polyglot", "picard", "pieces", "green",
-                             "free_boundary", "fastsolver", "anderson", "shape", "shape_d3d", "eqdsk", "newton", "products", "transport", "saddle", "freegs"]
+                             "free_boundary", "fastsolver", "anderson", "shape", "shape_d3d", "eqdsk", "newton", "products", "transport", "saddle", "freegs"]  # "freegs" also writes freegs_native.npz
     for w in which:
         globals()[f"gen_{w}"]()

@@ -247,3 +247,79 @@ def test_bench_ends_at_once_when_a_rank_has_no_gpu_and_no_communicator():
 
         pytest.skip("GPUs are visible to this process")
     assert r.returncode == 3 and not r.stdout.strip() and time.monotonic() - t0 < 60.0
+
+
+# ---- strong scaling (bench.py --total-members): a FIXED shape-scan ensemble cut over the ranks
+STRONG_TOTAL = 5  # odd: rank 1's block is one member short and is padded in the gather
+
+
+def _scan_solve(start, stop):
+    """Members [start, stop) of the config-5 coil/shape scan (currents, I_p AND kappa through the coil heights) on a 17 x 17 grid,
+    solved by the CPU oracle's free-boundary loop (what each rank's device solve is checked against on the GPU box)."""
+    from oracle import oracle as orc
+    from scpn_fusion_core_amd.cases import member_cfg as scan_cfg, shape_scan_member_table
+
+    cfg = iter_like_cfg(17, tol=1e-5, max_iter=80)
+    t = shape_scan_member_table(cfg, STRONG_TOTAL)
+    psi = []
+    for m in range(start, stop):
+        cm = scan_cfg(cfg, t["currents"][m], t["targets"][m], t["coil_r"][m], t["coil_z"][m])
+        co = cm["coils"]
+        r = orc.free_boundary_solve(cm, [c["r"] for c in co], [c["z"] for c in co], [c["current"] for c in co], [1.0] * len(co),
+                                    max_outer=3, tol=1e-4)
+        psi.append(r["psi"])
+    return np.array(psi).reshape(-1, 17 * 17)
+
+
+def _strong_worker(rank, world, port, out_dir):
+    from scpn_fusion_core_amd.distributed import EnsembleComm, exchange, plan_ensemble
+
+    plan = plan_ensemble(rank, world, members_per_rank=32, total_members=STRONG_TOTAL)
+    psi = _scan_solve(plan["start"], plan["stop"])
+    block = np.zeros((plan["block"], 17 * 17))
+    block[: plan["members"]] = psi
+    parts = exchange(rank, world, block.tobytes(), addr="127.0.0.1", port=port)
+    gathered = np.stack([np.frombuffer(p, dtype=np.float64).reshape(plan["block"], 17 * 17) for p in parts])
+    np.savez(os.path.join(out_dir, f"strong{rank}.npz"), psi=EnsembleComm.unpad(gathered, STRONG_TOTAL), plan=np.array(
+        [plan["total"], plan["start"], plan["stop"], plan["members"], plan["block"]]), scaling=np.array(plan["scaling"]))
+
+
+def test_strong_scaling_plan_and_two_rank_shape_scan(tmp_path):
+    import pytest
+
+    from scpn_fusion_core_amd.cases import shape_scan_member_table
+    from scpn_fusion_core_amd.distributed import plan_ensemble
+
+    # the plan itself: 256 members over 1 / 2 / 4 / 8 ranks are even blocks; weak mode multiplies; empty blocks are refused
+    for world in (1, 2, 4, 8):
+        plans = [plan_ensemble(r, world, members_per_rank=32, total_members=256) for r in range(world)]
+        assert [p["members"] for p in plans] == [256 // world] * world and plans[-1]["stop"] == 256 and plans[0]["scaling"] == "strong"
+        weak = plan_ensemble(world - 1, world, members_per_rank=32)
+        assert weak["scaling"] == "weak" and weak["total"] == 32 * world and weak["members"] == weak["block"] == 32
+    with pytest.raises(ValueError, match="non-empty"):
+        plan_ensemble(0, 4, total_members=5)  # blocks of 2: the fourth rank would hold nothing
+    # the scan table: member m does not depend on the ensemble's size in its coil geometry, kappa spans [1.5, 1.9]
+    cfg = iter_like_cfg(17)
+    t5, t256 = shape_scan_member_table(cfg, STRONG_TOTAL), shape_scan_member_table(cfg, 256)
+    assert np.array_equal(t5["coil_z"], t256["coil_z"][:STRONG_TOTAL]) and np.array_equal(t5["currents"], t256["currents"][:STRONG_TOTAL])
+    assert 1.5 <= t256["kappa"].min() < 1.52 and 1.88 < t256["kappa"].max() <= 1.9
+    assert np.allclose(t256["coil_z"][:, 0], 1.2 * t256["kappa"] * 2.0) and np.allclose(t256["coil_z"][:, 3], -1.1 * 1.2 * t256["kappa"] * 2.0)
+    assert np.array_equal(t256["coil_z"][:, 4], np.zeros(256)) and np.array_equal(t256["coil_r"], np.tile(t256["coil_r"][0], (256, 1)))
+    # two ranks solve their blocks of the 5-member scan and gather them (padded block of rank 1): equal to the serial solve
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_strong_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    serial = _scan_solve(0, STRONG_TOTAL)
+    assert len({serial[m].tobytes() for m in range(STRONG_TOTAL)}) == STRONG_TOTAL  # (the members really differ)
+    for rank, (a, b) in enumerate(((0, 3), (3, 5))):
+        got = np.load(tmp_path / f"strong{rank}.npz")
+        assert list(got["plan"]) == [STRONG_TOTAL, a, b, b - a, 3] and str(got["scaling"]) == "strong"
+        assert np.array_equal(got["psi"], serial)

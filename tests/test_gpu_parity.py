@@ -571,27 +571,42 @@ def test_legacy_abi_golden_bit_exact(hip, golden):
 
 
 def test_config5_scan_256_members_on_one_gpu(hip, orc):
-    """BASELINE config 5 on ONE device: the 256-member 513x513 coil / I_p scan (rng 2026, +-10 %), free-boundary solve of every
-    member (2 outer x ~240 / 175 Picard iterations).  All 256 converge; members 0 and 255 are solved by the CPU oracle too
-    (~4 s each) and agree in iteration counts and psi."""
-    from scpn_fusion_core_amd.cases import member_cfg, scan_member_table
+    """BASELINE config 5 on ONE device: the 256-member 513x513 coil / shape scan of SURVEY 8(d) cfg 5 -- coil currents and I_p
+    +-10 % (rng 2026) AND kappa in [1.5, 1.9] through the coil heights Z = 1.2 kappa a (validation/benchmark_vs_freegs.py:424-432),
+    every member its own coil geometry -- free-boundary solve of every member.  All 256 converge; eight seeded members (first,
+    last, lowest and highest kappa, four drawn) are solved by the CPU oracle too, one per host core (~4 s each), and agree in
+    iteration counts and psi."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from scpn_fusion_core_amd.cases import member_cfg, shape_scan_member_table
     from scpn_fusion_core_amd.ensemble import EnsembleSolver
 
     n, total = 513, 256
     cfg = iter_like_cfg(n, method="multigrid", omega=1.0, tol=1e-8, max_iter=1000, alpha=0.12)
-    currents, targets = scan_member_table(cfg, total)
-    with EnsembleSolver(cfg, batch=total, coil_currents=currents, current_targets=targets) as es:
+    t = shape_scan_member_table(cfg, total)
+    assert 1.5 <= t["kappa"].min() and t["kappa"].max() <= 1.9 and np.ptp(t["coil_z"][:, 0]) > 1.4  # the coil heights really move
+    check = sorted({0, total - 1, int(np.argmin(t["kappa"])), int(np.argmax(t["kappa"])),
+                    *(int(m) for m in np.random.default_rng(5).choice(total, size=4, replace=False))})
+    assert len(check) >= 8
+    with EnsembleSolver(cfg, batch=total, coil_currents=t["currents"], current_targets=t["targets"], coil_r=t["coil_r"], coil_z=t["coil_z"]) as es:
         res = es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=8)
-        picked = {m: es.get_psi(m) for m in (0, total - 1)}
+        picked = {m: es.get_psi(m) for m in check}
     assert len(res) == total and all(r["converged"] for r in res)
     assert all(r["outer_iterations"] == 2 for r in res)
-    for m, psi in picked.items():
-        cm = member_cfg(cfg, currents[m], targets[m])
+
+    def cpu(m):
+        cm = member_cfg(cfg, t["currents"][m], t["targets"][m], t["coil_r"][m], t["coil_z"][m])
         co = cm["coils"]
-        ref = orc.free_boundary_solve(cm, [c["r"] for c in co], [c["z"] for c in co], [c["current"] for c in co], [1.0] * len(co),
-                                      max_outer=20, tol=1e-4)
+        return orc.free_boundary_solve(cm, [c["r"] for c in co], [c["z"] for c in co], [c["current"] for c in co], [1.0] * len(co),
+                                       max_outer=20, tol=1e-4)
+
+    with ThreadPoolExecutor(max_workers=8) as pool:  # (ctypes releases the GIL inside the C solve)
+        refs = dict(zip(check, pool.map(cpu, check)))
+    for m, psi in picked.items():
+        ref = refs[m]
         assert res[m]["outer_iterations"] == ref["outer_iterations"] and res[m]["picard_iterations"] == ref["picard_iterations"], m
         assert np.abs(psi - ref["psi"]).max() <= 1e-10 * np.abs(ref["psi"]).max(), m
+    assert len({tuple(r["picard_iterations"]) for r in res}) > 1  # (members differ in their iteration counts: a real scan)
 
 
 def test_picard_on_a_tall_grid_with_more_than_256_tail_tiles_per_member(hip, orc):

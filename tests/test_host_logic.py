@@ -249,3 +249,48 @@ def test_second_handle_without_hardware_queues_warns_once(monkeypatch):
         for _ in range(4):
             ensemble._note_live_handle(+1, 2)
         assert not seen
+
+
+# ---- strict-parity gate, host side (validation/benchmark_freegs_public_example_reconstruction.py:318-378,431-497)
+@pytest.mark.parametrize("cid", ["freegs_01_test_tokamak_freeboundary", "freegs_16_diiid_public_example"])
+@pytest.mark.parametrize("which", ["", "_far"])
+def test_same_case_comparison_record_equals_the_reference_record(golden, cid, which):
+    """The five gated metrics (and every other numeric entry) of the comparison record, from the reference's own native-lane flux,
+    against the record the reference function wrote into the fixture: equal to the last bit or two."""
+    import json
+
+    from scpn_fusion_core_amd import parity_gate as pg
+
+    g = golden("freegs_native.npz")
+    spec, want = json.loads(str(g[f"{cid}_spec"])), json.loads(str(g[f"{cid}_record{which}"]))
+    ext, vac = g[f"{cid}_external_psi{which}"], g[f"{cid}_vacuum_psi"]
+    native = g[f"{cid}_native_plasma_psi{which or '_cmp'}"]
+    rec = pg.same_case_profile_source_comparison(g[f"{cid}_r"], g[f"{cid}_z"], ext, ext - vac, g[f"{cid}_jtor"], spec["plasma_current_a"],
+                                                 spec["xpoints"], native_plasma_psi=native)
+    assert rec["thresholds"] == want["thresholds"] == pg.GATE_THRESHOLDS and len(pg.GATE_THRESHOLDS) == 5
+    for key, val in want.items():
+        if key == "thresholds":
+            continue
+        if isinstance(val, float):
+            assert rec[key] == pytest.approx(val, rel=1e-14, abs=1e-300), key
+        else:
+            assert rec[key] == val, key
+    assert set(rec["checks"]) == set(pg.GATE_THRESHOLDS)
+    far_axis_moved = which == "_far" and cid.startswith("freegs_01")
+    assert rec["pass"] is (not far_axis_moved) and rec["checks"]["axis_error_m"] is (not far_axis_moved)
+    assert want["current_closure_relative_error"] == pytest.approx(2e-3, rel=1e-9)  # (the fixture's current density is 0.2 % off I_p by construction)
+
+
+def test_native_lane_validation_precedes_the_device():
+    """The ValueErrors of _native_profile_source_reconstruction (:282-291), raised before any device call."""
+    from scpn_fusion_core_amd.parity_gate import native_profile_source_reconstruction as lane, strict_parity_metrics
+
+    r, z = np.linspace(1.0, 2.0, 9), np.linspace(-1.0, 1.0, 7)
+    ok = np.zeros((9, 7))
+    for args, msg in (((r, z, ok, np.zeros((9, 6))), "matching shapes"), ((r, z, ok.T, ok.T), "len\\(R\\) x len\\(Z\\)"),
+                      ((r[:2], z, ok[:2], ok[:2]), "at least 3x3"), ((r, z, np.full((9, 7), np.nan), ok), "must be finite"),
+                      ((r[::-1], z, ok, ok), "strictly increasing")):
+        with pytest.raises(ValueError, match=msg):
+            lane(*args)
+    with pytest.raises(ValueError, match="plasma_current_a"):
+        strict_parity_metrics(ok.T, ok.T, r, z, jtor=ok.T)

@@ -436,7 +436,7 @@ def test_green_function_against_freegs_vacuum_samples(golden):
     assert fil.shape == (26, 3)  # the artifact's filament_count
     psi = np.array([sum(i * orc.green_function(rc, zc, r, z) for rc, zc, i in fil) for r, z in g[f"{cid}_points"]])
     want = g[f"{cid}_freegs_vacuum_psi"]
-    assert np.abs(psi - want).max() <= 2e-9  # restated FreeGS quadrature, see tests/_freegs_machines.py
+    assert np.abs(psi - want).max() <= float(g[f"{cid}_thresholds"][0]) == 1e-12  # the artifact's own threshold (tests/_freegs_machines.py)
     for case in (cid, "freegs_16_diiid_public_example"):  # the reference's own acceptance, on the data it stores
         assert np.abs(g[f"{case}_native_vacuum_psi"] - g[f"{case}_freegs_vacuum_psi"]).max() <= float(g[f"{case}_thresholds"][0])
 
@@ -480,3 +480,23 @@ def test_newton_mg_fd_oracle_reaches_the_pinned_picard_fixed_point(n, warm):
     assert h[-1] < 1e-8 and h[-1] < 1e-6 * h[0]
     fast = h[1:][h[:-1] < 1.0]  # once inside the basin: at least a decade per step down to the finite-difference noise floor (~1e-8)
     assert np.all(fast[fast > 1e-7] < 0.1 * h[:-1][h[:-1] < 1.0][fast > 1e-7])
+
+
+# ---- the strict-parity harness's own native lane (tests/golden/freegs_native.npz <- the imported reference function, both public-example grids)
+NATIVE_CASES = ("freegs_01_test_tokamak_freeboundary", "freegs_16_diiid_public_example")
+
+
+@pytest.mark.parametrize("cid", NATIVE_CASES)
+def test_native_profile_source_lane_against_the_reference_function(golden, cid):
+    """validation/benchmark_freegs_public_example_reconstruction.py:275-315: sparse-LU solution of the reference vs V-cycles of the
+    same 5-point system, to the gate's own boundary threshold (1e-10 Wb) everywhere; three different Dirichlet rings per grid."""
+    g = golden("freegs_native.npz")
+    r, z, jt, vac = g[f"{cid}_r"], g[f"{cid}_z"], g[f"{cid}_jtor"], g[f"{cid}_vacuum_psi"]
+    for ring, want in ((g[f"{cid}_boundary_psi"], g[f"{cid}_native_plasma_psi"]),
+                       (g[f"{cid}_external_psi"] - vac, g[f"{cid}_native_plasma_psi_cmp"]),
+                       (g[f"{cid}_external_psi_far"] - vac, g[f"{cid}_native_plasma_psi_far"])):
+        got = orc.native_profile_source_reconstruction(r, z, ring, jt)
+        assert got.shape == want.shape == (r.size, z.size)
+        assert np.abs(got - want).max() <= 1e-10, np.abs(got - want).max()
+        assert np.abs(got - want).max() <= 2e-11 * np.abs(want).max()
+        assert np.array_equal(got[0, :], ring[0, :]) and np.array_equal(got[:, -1], ring[:, -1])  # the ring is Dirichlet data, untouched
