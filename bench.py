@@ -478,9 +478,10 @@ def main() -> int:
             native = {}
             for cid in ("freegs_01_test_tokamak_freeboundary", "freegs_16_diiid_public_example"):
                 spec = json.loads(str(fn[f"{cid}_spec"]))
-                vac, ext = fn[f"{cid}_vacuum_psi"], fn[f"{cid}_native_plasma_psi"] + fn[f"{cid}_vacuum_psi"]  # "external" = the reference lane's own total flux
+                ref_plasma = fn[f"{cid}_native_plasma_psi"]                     # the imported reference function's solution
+                ext = ref_plasma + fn[f"{cid}_vacuum_psi"]                      # "external" map = the reference lane's own total flux
                 dev = native_profile_source_reconstruction(fn[f"{cid}_r"], fn[f"{cid}_z"], fn[f"{cid}_boundary_psi"], fn[f"{cid}_jtor"])
-                rec = same_case_profile_source_comparison(fn[f"{cid}_r"], fn[f"{cid}_z"], ext, fn[f"{cid}_boundary_psi"], fn[f"{cid}_jtor"],
+                rec = same_case_profile_source_comparison(fn[f"{cid}_r"], fn[f"{cid}_z"], ext, ref_plasma, fn[f"{cid}_jtor"],
                                                           spec["plasma_current_a"], spec["xpoints"], native_plasma_psi=dev)
                 native[cid] = {**{k: rec[k] for k in gated}, "psi_max_abs_error_wb": float(np.abs(dev - fn[f"{cid}_native_plasma_psi"]).max()),
                                "checks": rec["checks"], "pass": bool(rec["pass"] and len(rec["checks"]) == 5)}

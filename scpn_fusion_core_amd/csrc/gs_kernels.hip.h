@@ -669,22 +669,10 @@ __device__ unsigned long long g_tile_stamps[8 * 16];  // 8 sampled workgroups (d
 #ifndef TILE_SKIP_MIN_ROWS
 #define TILE_SKIP_MIN_ROWS 4
 #endif
-// rows whose psi / source / coarse loads are in flight together in the PROLONG variant (register budget)
-#ifndef TILE_LG
-#define TILE_LG 1
-#endif
-// PROLONG: distinct coarse rows fetched once in front of the row loads (1) or per fine row (0); rows in flight together in the wide form
-// DEFECT, six rows per wave: residual coefficients shared through LDS (1) or loaded by every wave at the defect stage (0)
-#ifndef TILE_SHARE_D
-#define TILE_SHARE_D 1
-#endif
-#ifndef TILE_PWIDE
-#define TILE_PWIDE 1
-#endif
-// PROLONG, six rows per wave: inner-row sources by LDS-DMA into the lane's slots (1) or through registers (0)
-#ifndef TILE_GLDS
-#define TILE_GLDS 1
-#endif
+// PROLONG with fewer than six rows per wave: fine rows whose psi / source loads are in flight together behind the coarse rows
+// (register budget; with six rows per wave the inner-row sources travel by LDS-DMA and all rows are in flight at once).
+// (Round 4's A/B switches of the load phase -- TILE_PWIDE, TILE_LG, TILE_GLDS, TILE_SHARE_D -- are retired: the forms they
+// switched back to are archived as diffs under profiles/r04_negative/ and profiles/r05_negative/retired_tile_switches.md.)
 #ifndef TILE_LG_WIDE
 #define TILE_LG_WIDE 2
 #endif
@@ -779,7 +767,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     double lz_n1 = *(lazy ? lzs.neg_mu0R + min(max(c0 + 1, 0), nr - 1) : &g_const_f64[1]);
     // (PROLONG, wide load: the stencil coefficients are first used by the sweeps -- they are requested behind the LAST group of row
     //  loads, so that they hold no registers while the earlier groups are in flight)
-    constexpr bool COEF_LATE = PROLONG && (TILE_PWIDE != 0);
+    constexpr bool COEF_LATE = PROLONG;
     const double* const pe0 = in0 ? L.a_e + c0 : &g_const_f64[0];
     const double* const pw0 = in0 ? L.a_w + c0 : &g_const_f64[0];
     const double* const pe1 = in1 ? L.a_e + c0 + 1 : &g_const_f64[0];
@@ -793,7 +781,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     // Six rows per wave: the six values are the same for all waves of the tile (same columns), so wave k requests the k-th of them
     // here -- one double in flight per lane -- parks it in LDS behind the tile's planes, and the defect stage reads all six from
     // there (an LDS access instead of a memory round trip in the middle of the tile's life).
-    constexpr bool SHARE_D = DEFECT && !EARLY_D && NW >= 6 && (TILE_SHARE_D != 0);
+    constexpr bool SHARE_D = DEFECT && !EARLY_D && NW >= 6;
     double* const CO = lds + LZ * 128;  // [6][64] doubles (allocated by the launcher for SHARE_D instantiations)
     double co_x = 0.0;
     if (SHARE_D) {
@@ -846,15 +834,15 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     // 2k and 2k + 1 both start from coarse row k, odd rows add coarse row k + 1 -- so the coarse correction is fetched once per
     // distinct row (two 8-B loads: columns jc, jc + 1) IN FRONT of the row loads instead of two / four loads per fine row inside a
     // row-at-a-time loop: 8 instead of 18 coarse loads per lane at six rows per wave, and the tile's load phase is one memory
-    // round trip instead of a chain of NROWS / TILE_LG of them (TILE_PWIDE=0 restores the per-row form).
-    constexpr bool PWIDE = PROLONG && (TILE_PWIDE != 0);
+    // round trip instead of a chain of NROWS of them (rounds 1-3 loaded per fine row: profiles/r05_negative/retired_tile_switches.md).
+    constexpr bool PWIDE = PROLONG;
     // PROLONG with six or more rows per wave: the sources of the wave's INNER rows never need registers -- they go straight to
     // the lane's LDS slots by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per row, lane-linear: the slot layout of
     // these rows is the lane's (even column, odd column) PAIR here, two rows per KiB-pair of the wave's own inner plane rows), and
     // with them out of the register budget ALL rows of the wave are in flight at once: one memory round trip per tile.
     // The lazy-source factors are applied in place once the data has landed (the issuing wave's own vmcnt orders its reads).
-    constexpr bool GLDS = PWIDE && SRCL && (TILE_GLDS != 0);
-    constexpr int LG = PROLONG ? (GLDS ? NROWS : (PWIDE ? (TILE_LG_WIDE < NROWS ? TILE_LG_WIDE : NROWS) : TILE_LG)) : NROWS;
+    constexpr bool GLDS = PWIDE && SRCL;
+    constexpr int LG = PROLONG ? (GLDS ? NROWS : (TILE_LG_WIDE < NROWS ? TILE_LG_WIDE : NROWS)) : NROWS;
     constexpr int GHALF = (NROWS - 2) / 2 > 0 ? (NROWS - 2) / 2 : 1;  // inner rows per plane chunk (GLDS)
     // wave-uniform base (doubles) of the pair row of inner row i: rows 1 .. GHALF in the wave's inner rows of plane 0, the rest in plane 1
     auto pair_base = [&](int i) { return (i - 1 < GHALF ? A0 : A1) + (lzb + 1) * 64 + ((i - 1) % GHALF) * 128; };
@@ -908,18 +896,6 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
                 ca0[j] = cr0[i >> 1];
                 ca1[j] = cr1[i >> 1];
                 if (i & 1) { cb0[j] = cr0[(i >> 1) + 1]; cb1[j] = cr1[(i >> 1) + 1]; }
-            } else if (PROLONG) {
-                // (the parity of an in-domain row is that of its index i: even rows need one coarse row, odd rows two; a clamped
-                //  out-of-domain row may take the other form -- its value is never used)
-                const int ic = gzc >> 1, icc = min(ic, nz_c - 1);
-                const unsigned ra = (unsigned)icc * ldc8;
-                ca0[j] = *reinterpret_cast<const double*>(cc_b + (ra + jc_off0));
-                ca1[j] = *reinterpret_cast<const double*>(cc_b + (ra + jc_off1));
-                if (i & 1) {
-                    const unsigned rbp = (unsigned)min(ic + 1, nz_c - 1) * ldc8;
-                    cb0[j] = *reinterpret_cast<const double*>(cc_b + (rbp + jc_off0));
-                    cb1[j] = *reinterpret_cast<const double*>(cc_b + (rbp + jc_off1));
-                }
             }
         }
         if (COEF_LATE && g0 + LG >= NROWS) { ae0 = *pe0; aw0 = *pw0; ae1 = *pe1; aw1 = *pw1; }
@@ -2156,6 +2132,15 @@ struct PicardTail {
     double* hist_gs = nullptr;
     double* trace = nullptr;
     int* n_active = nullptr;
+    // run-ahead control of the host loop (scpn_hip.hip, picard_solve_impl): two host-mapped words, each written by ONE thread of
+    // the whole launch as one aligned 8-byte system-scope store {solve id, value} -- host_prog: the number of k_picard_final launches
+    // of this solve that have started (block 0, from the device counter iter_count: kernel arguments stay constant over the
+    // iterations); host_done: set by the workgroup whose atomicSub takes n_active to zero (atomics on one address are totally ordered:
+    // exactly one workgroup sees the old value 1).  nullptr: the blocking poll every check_every iterations is used instead.
+    unsigned long long* host_prog = nullptr;
+    unsigned long long* host_done = nullptr;
+    int* iter_count = nullptr;
+    unsigned solve_id = 0;
     int* f_cur = nullptr;
     int* f_nxt = nullptr;
     int* f_best = nullptr;
@@ -2167,6 +2152,11 @@ struct PicardTail {
     const double* r_axis = nullptr;
     const double* z_axis = nullptr;
 };
+// one member leaves the iteration (one thread per member): count it out and, if it was the last one, tell the host
+__device__ __forceinline__ void picard_member_frozen(const PicardTail& t) {
+    if (atomicSub(t.n_active, 1) == 1 && t.host_done)
+        __hip_atomic_store(t.host_done, ((unsigned long long)t.solve_id << 32) | 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // shared scratch of picard_final_body (declared by the calling kernel)
 struct PicardShared {
     double sh[4], sh2[4], shd[4], shp[4];
@@ -2263,7 +2253,7 @@ __device__ __forceinline__ void picard_final_body(const int b, const PicardTail&
         }
         m.diverged = 1;
         m.active = 0;
-        atomicSub(t.n_active, 1);
+        picard_member_frozen(t);
         t.f_cur[b] = cur; t.f_nxt[b] = m_nxt; t.f_best[b] = m_best; t.f_prev[b] = prev; t.f_active[b] = 0;
         return;
     }
@@ -2292,7 +2282,7 @@ __device__ __forceinline__ void picard_final_body(const int b, const PicardTail&
     int active = 1;
     if (upd && gsc) { m.converged = 1; active = 0; }
     else if (it + 1 >= ctl.max_iter) active = 0;
-    if (!active) { m.active = 0; atomicSub(t.n_active, 1); }
+    if (!active) { m.active = 0; picard_member_frozen(t); }
     // publish the slot indices / activity the field kernels index (was a separate k_publish_slots launch)
     t.f_cur[b] = cur; t.f_nxt[b] = nx; t.f_best[b] = best; t.f_prev[b] = prev; t.f_active[b] = active;
     if (t.topo && active) {  // k_topology_final for the next iteration, on the new current iterate
@@ -2328,6 +2318,12 @@ __device__ __forceinline__ void picard_final_body(const int b, const PicardTail&
 __global__ void __launch_bounds__(256) k_picard_final(PicardTail t) {
     __shared__ PicardShared S;
     const int b = blockIdx.x;
+    if (b == 0 && threadIdx.x == 0 && t.host_prog) {  // progress word: this launch of the solve has started (see PicardTail)
+        const int k = *t.iter_count + 1;
+        *t.iter_count = k;
+        __hip_atomic_store(t.host_prog, ((unsigned long long)t.solve_id << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (!t.st[b].active) return;
     picard_final_body(b, t, S);
 }
@@ -2354,8 +2350,14 @@ __device__ __forceinline__ int blend_tiles_x(int nr) { return (nr + BL_WR - 1) /
 // Round 4: the per-point bookkeeping taken out of the point loop (round 3's form: profiles/r04_negative/blend_tile_round3.hip.h.txt).  What a LANE accumulates is kept per COLUMN
 // of its pair (sum |new - cur|, min, running max + the row it came from, max |r|), so the lane's column predicates (window lane,
 // inside the grid, interior column) are applied ONCE per lane after the rows instead of as selects per point; the non-finite
-// check of the elliptic solve's output is read off the partial sum of |new - cur| (a non-finite `new` makes its owner's sum
-// non-finite: `cur` is an accepted iterate); the arg-max candidate travels as (value, row tag) and becomes a grid index once per
+// check of the elliptic solve's output is read off the partial sum of |new - cur|.  CONTRACT of that verdict: a non-finite `new`
+// ALWAYS makes its owner's sum non-finite, whatever `cur` holds (inf - inf = NaN, inf - x = inf), so nothing the reference's
+// `isnan(Psi_new).any() or isinf(Psi_new).any()` flags is missed; the verdict is a superset only where `new` is finite and either
+// `cur` is non-finite or the difference overflows (|new - cur| > 1.8e308).  Neither occurs on the reference's paths: `cur` is an
+// accepted iterate, and a preserved start is sanitised in its interior before the first iteration (_prepare_initial_flux) while a
+// non-finite RING value makes `new` non-finite too (the ring is Dirichlet data of the elliptic solve) --
+// tests/test_gpu_parity.py::test_non_finite_entry_in_a_preserved_start.  The min / arg-max candidates take -inf as a minimum and
+// never as a maximum, as np.min / np.argmax order it.  The arg-max candidate travels as (value, row tag) and becomes a grid index once per
 // lane; the (value, index) wave reductions are a value reduction plus a 32-bit index reduction among the lanes that hold the
 // extreme value; the residual is sanitised on a cold path (a wave that sees |r| > CAP or a NaN -- never in a healthy run) and its
 // sum of squares is scaled by a power of two taken from the WAVE's own largest |r| (exact scaling, no division, no workgroup

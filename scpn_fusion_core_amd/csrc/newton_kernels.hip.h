@@ -96,14 +96,15 @@ __device__ __forceinline__ void dlartg(double f, double g, double& c, double& s,
 }
 
 // L*v at an interior point (fusion_kernel_solver_runtime.py:54-68 apply_gs_operator); same arithmetic as resid_at
-__device__ __forceinline__ double lop_at(const double* v, const Lvl& L, int iz, int ir) {
-    long c = (long)iz * L.ld + ir;
+// (c = iz * L.ld + ir, the point's linear index)
+__device__ __forceinline__ double lop_at_lin(const double* v, const Lvl& L, long c, int ir) {
     double p = v[c], e = v[c + 1], w = v[c - 1], n = v[c + L.ld], s = v[c - L.ld];
     double d2r = divc(e - 2.0 * p + w, L.dr2, L.inv_dr2);
     double d1r = divc(e - w, L.two_dr, L.inv_two_dr);
     double d2z = divc(n - 2.0 * p + s, L.dz2, L.inv_dz2);
     return d2r - divc(d1r, L.r_safe[ir], L.r_inv[ir]) + d2z;
 }
+__device__ __forceinline__ double lop_at(const double* v, const Lvl& L, int iz, int ir) { return lop_at_lin(v, L, (long)iz * L.ld + ir, ir); }
 
 // ------------------------------------------------------------------------------------------------ Newton level
 // r_k = L psi - Source on the interior (zero ring) + per-block sum r^2.  2-D grid (ceil(nr/64), ceil(nz/4), B), block 64x4.
@@ -725,26 +726,31 @@ __global__ void __launch_bounds__(1024) k_gm_cycle_small(double* Vb, double* xb,
     const double eps = 2.220446049250313e-16;
     auto vec = [&](int j) { return Vb + ((long)j * B + b) * stride; };
     const int tid = threadIdx.x;
-    // this thread's grid points (fixed for the whole cycle); w lives in registers, one entry per point
-    int cix[MP];
+    // this thread's grid points (fixed for the whole cycle); w lives in registers, one entry per point.  A point is kept as ONE word:
+    // linear index iz * ld + ir in the low 20 bits (the launcher admits grids of at most 20 000 points here), column ir above them --
+    // the operator needs both, and recovering (iz, ir) from the index by an integer division per point and column cost the registers
+    // that spilled the four-point instantiation (128 VGPRs + 136 B of scratch; now no scratch)
+    int cpk[MP];
     double wr[MP];
 #pragma unroll
     for (int j = 0; j < MP; ++j) {
         const long q = tid + (long)j * NT;
-        cix[j] = -1;
+        cpk[j] = -1;
         wr[j] = 0.0;
         if (q < nint) {
             const int iz = 1 + (int)(q / ni), ir = 1 + (int)(q - (long)(iz - 1) * ni);
-            cix[j] = iz * ld + ir;
+            cpk[j] = (iz * ld + ir) | (ir << 20);
         }
     }
+#define CIX(j) (cpk[j] & 0xFFFFF)
+#define CIR(j) (cpk[j] >> 20)
     // ---- v0 = M^-1 r / ||M^-1 r||
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < MP; ++j)
-        if (cix[j] >= 0) {
-            double v = r[cix[j]];
-            if (precond) v = ivd[cix[j]] * v;
+        if (cpk[j] >= 0) {
+            double v = r[CIX(j)];
+            if (precond) v = ivd[CIX(j)] * v;
             wr[j] = v;
             s += v * v;
         }
@@ -754,7 +760,7 @@ __global__ void __launch_bounds__(1024) k_gm_cycle_small(double* Vb, double* xb,
         double* v0 = vec(0);
 #pragma unroll
         for (int j = 0; j < MP; ++j)
-            if (cix[j] >= 0) v0[cix[j]] = wr[j] * f;
+            if (cpk[j] >= 0) v0[CIX(j)] = wr[j] * f;
     }
     if (tid == 0) {
         g.tmp = tmp;
@@ -771,10 +777,9 @@ __global__ void __launch_bounds__(1024) k_gm_cycle_small(double* Vb, double* xb,
         s = 0.0;
 #pragma unroll
         for (int j = 0; j < MP; ++j)
-            if (cix[j] >= 0) {
-                const int iz = cix[j] / ld, ir = cix[j] - iz * ld;
-                double av = lop_at(vc, L, iz, ir) - dterm[cix[j]] * vc[cix[j]];
-                if (precond) av = ivd[cix[j]] * av;
+            if (cpk[j] >= 0) {
+                double av = lop_at_lin(vc, L, CIX(j), CIR(j)) - dterm[CIX(j)] * vc[CIX(j)];
+                if (precond) av = ivd[CIX(j)] * av;
                 wr[j] = av;
                 s += av * av;
             }
@@ -786,7 +791,7 @@ __global__ void __launch_bounds__(1024) k_gm_cycle_small(double* Vb, double* xb,
             s = 0.0;
 #pragma unroll
             for (int j = 0; j < MP; ++j) {
-                vr[j] = cix[j] >= 0 ? vk[cix[j]] : 0.0;
+                vr[j] = cpk[j] >= 0 ? vk[CIX(j)] : 0.0;
                 s += vr[j] * wr[j];
             }
             const double t = block_sum_bcast<NT>(s, sh);
@@ -804,7 +809,7 @@ __global__ void __launch_bounds__(1024) k_gm_cycle_small(double* Vb, double* xb,
             double* vn = vec(col + 1);
 #pragma unroll
             for (int j = 0; j < MP; ++j)
-                if (cix[j] >= 0) vn[cix[j]] = breakdown ? wr[j] : wr[j] * f;
+                if (cpk[j] >= 0) vn[CIX(j)] = breakdown ? wr[j] : wr[j] * f;
         }
         if (tid == 0) {
             double* hc = g.h + col * (GM_R + 1);
@@ -856,21 +861,20 @@ __global__ void __launch_bounds__(1024) k_gm_cycle_small(double* Vb, double* xb,
             const double* vk = vec(k);
 #pragma unroll
             for (int j = 0; j < MP; ++j)
-                if (cix[j] >= 0) acc[j] += yk * vk[cix[j]];
+                if (cpk[j] >= 0) acc[j] += yk * vk[CIX(j)];
         }
 #pragma unroll
         for (int j = 0; j < MP; ++j)
-            if (cix[j] >= 0) x[cix[j]] += acc[j];
+            if (cpk[j] >= 0) x[CIX(j)] += acc[j];
     }
     __syncthreads();
     // ---- true residual r = b - A x, restart / exit logic
     s = 0.0;
 #pragma unroll
     for (int j = 0; j < MP; ++j)
-        if (cix[j] >= 0) {
-            const int iz = cix[j] / ld, ir = cix[j] - iz * ld;
-            const double v = rhs[cix[j]] - (lop_at(x, L, iz, ir) - dterm[cix[j]] * x[cix[j]]);
-            r[cix[j]] = v;
+        if (cpk[j] >= 0) {
+            const double v = rhs[CIX(j)] - (lop_at_lin(x, L, CIX(j), CIR(j)) - dterm[CIX(j)] * x[CIX(j)]);
+            r[CIX(j)] = v;
             s += v * v;
         }
     const double rnorm = sqrt(block_sum_bcast<NT>(s, sh));
@@ -894,6 +898,8 @@ __global__ void __launch_bounds__(1024) k_gm_cycle_small(double* Vb, double* xb,
         }
     }
 }
+#undef CIX
+#undef CIR
 
 // same cycle for grids up to 129^2: the work vector w lives in LDS (one 8-byte slot per interior point, 127 KB at 129^2),
 // the loops over the thread's points are rolled (no register arrays)

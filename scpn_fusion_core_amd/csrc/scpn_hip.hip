@@ -176,6 +176,7 @@ struct Solver {
     unsigned long long* h_word = nullptr;  // pinned + mapped: {sequence, value} posted by k_post_word
     unsigned long long* d_word = nullptr;  // device alias of h_word
     unsigned word_seq = 0;
+    DBuf<int> d_iter_count;  // launches of k_picard_final of the running solve (device side of the progress word h_word[1])
     std::vector<double> i_target;
     std::vector<double> vac_r, vac_z, vac_i;
     int n_vac = 0;
@@ -189,6 +190,7 @@ struct Solver {
     double mu0_tables = NAN;
 
     std::vector<int> h_seed_act;  // host image of d_scr_sa (uploaded asynchronously by the seed phase)
+    std::vector<Member> h_scr_st; // host image of d_scr_st for the final J_phi pass (uploaded asynchronously)
     // profiling
     bool prof_on = false;
     std::vector<ProfEntry> prof;
@@ -385,7 +387,7 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
                           const DefectOut* dfo, bool in_zero) {
     static std::once_flag attr_once;  // (two stream-group threads may reach a first launch at the same time)
     // (+ 3 KiB behind the planes: the residual coefficients the waves of a six-row DEFECT tile share, see SHARE_D in the kernel)
-    constexpr bool share_d = DEFECT && LZT / NWT >= 6 && NWT >= 6 && (TILE_SHARE_D != 0);
+    constexpr bool share_d = DEFECT && LZT / NWT >= 6 && NWT >= 6;
     constexpr size_t lds = (size_t)LZT * 128 * sizeof(double) + (share_d ? 6 * 64 * sizeof(double) : 0);
     auto kern_any = &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE>;
     // the instantiation that also finishes the J_raw sum (LazySrc::part) exists for the V-cycle's first level-0 launch only
@@ -425,7 +427,7 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
         dd.e = dfo->e;
         cF = dfo->rhs; nz_c = dfo->nz_c; nr_c = dfo->nr_c; ld_c = dfo->ld_c;
     }
-    static const int xcd_env = [] { const char* e = std::getenv("SCPN_HIP_XCD"); return e ? std::atoi(e) : 1; }();
+    static const int xcd_env = [] { const char* e = std::getenv("SCPN_HIP_XCD"); return (e ? std::atoi(e) : 1) != 0 ? 1 : 0; }();  // any non-zero value = on
     LazySrc lzs;
     if (h->lazy_src && src.base == h->lazy_src) {
         lzs.st = h->d_st.p; lzs.neg_mu0R = h->d_neg_mu0R.p;
@@ -494,8 +496,9 @@ static Fld smooth(Solver* h, const Lvl& L, Fld in, Fld alt, Fld src, double omeg
         Fld a = in, b = alt;
         int left = n_sweeps;
         ProlongSrc pso = prolong ? *prolong : ProlongSrc{};  // only the first launch adds the coarse correction
-        // *in_zero (in / out): `in` is known to be the zero field and nobody has written it -- the first tile launch starts from
-        // +0.0 without reading it; reset to false when a path that does read `in` was taken instead
+        // *in_zero (input only): `in` is known to be the zero field and nobody has written it -- the first tile launch starts from
+        // +0.0 without reading it.  A path that does read `in` is a hard error with the flag set (the std::logic_error above):
+        // the caller has not written the zeros
         bool iz = in_zero && *in_zero;
         while (left > 0) {
             const int S = std::min(3, left);
@@ -721,25 +724,6 @@ static void set_tables_mu0(Solver* h, double mu0) {
 }
 
 // ------------------------------------------------------------------------------------------ creation
-// Which stream group of an ensemble handle the next create_impl() call builds (set by scpn_gs_create around S_create).
-static thread_local int t_group_index = 0, t_group_count = 1;
-// Stream of one group.  Experiment switch SCPN_HIP_CURESERVE=n (two-group handles only): each group keeps n compute units the OTHER
-// group's stream may not use (hipExtStreamCreateWithCUMask), so a group's one-workgroup-per-member coarse V-cycle kernel -- which
-// needs a whole CU (150 KiB of LDS) -- finds CUs that the other group's tile kernels are not refilling.  Mask bit i addresses
-// XCD i % 8, shader engine (i / 8) % 4, CU i / 32 of that engine (the driver deals the bits round-robin), so bits [0, 16) are two
-// CUs of every XCD and bits [16, 32) two others.
-static void create_group_stream(hipStream_t* st) {
-    static const int reserve = [] { const char* e = std::getenv("SCPN_HIP_CURESERVE"); return e ? std::atoi(e) : 0; }();
-    if (reserve <= 0 || t_group_count != 2) { HIP_TRY(hipStreamCreate(st)); return; }
-    hipDeviceProp_t pr;
-    HIP_TRY(hipGetDeviceProperties(&pr, g_device));
-    const int ncu = pr.multiProcessorCount, nres = std::min(reserve, ncu / 4);
-    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-    for (int i = 0; i < ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-    const int lo = (1 - t_group_index) * nres;  // the other group's reserve: not for this stream
-    for (int i = lo; i < lo + nres; ++i) mask[(size_t)i / 32] &= ~(1u << (i % 32));
-    HIP_TRY(hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()));
-}
 static Solver* create_impl(int nr, int nz, int batch, const double* r_axis, const double* z_axis, double dr, double dz) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available");
@@ -753,7 +737,7 @@ static Solver* create_impl(int nr, int nz, int batch, const double* r_axis, cons
         h->r_axis.assign(r_axis, r_axis + nr);
         if (z_axis) h->z_axis.assign(z_axis, z_axis + nz);
         else { h->z_axis.assign(nz, 0.0); for (int i = 0; i < nz; ++i) h->z_axis[i] = i * dz; }
-        create_group_stream(&h->stream);
+        HIP_TRY(hipStreamCreate(&h->stream));
         size_t n = (size_t)h->stride * batch;
         h->psi_slots.alloc(3 * n);
         h->W.alloc(n);
@@ -785,7 +769,7 @@ static Solver* create_impl(int nr, int nz, int batch, const double* r_axis, cons
         h->d_scal.alloc(8);
         HIP_TRY(hipHostMalloc((void**)&h->h_nactive, sizeof(int) * 4, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void**)&h->h_word, 64, hipHostMallocMapped));
-        *h->h_word = 0ull;
+        std::memset(h->h_word, 0, 64);  // word 0: poll_word; 1 / 2: progress / done words of the run-ahead Picard loop
         HIP_TRY(hipHostGetDevicePointer((void**)&h->d_word, h->h_word, 0));
         h->i_target.assign(batch, 0.0);
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1021,6 +1005,15 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     if (hist_gs) { d_hist_gs.alloc((size_t)B * max_iter); HIP_TRY(hipMemsetAsync(d_hist_gs.p, 0, sizeof(double) * B * max_iter, st)); }
     if (trace) { d_trace.alloc((size_t)B * max_iter * 6); HIP_TRY(hipMemsetAsync(d_trace.p, 0, sizeof(double) * B * max_iter * 6, st)); }
     const int check_every = std::max(1, p->check_every);
+    // SCPN_HIP_RUNAHEAD=n: iterations the host may enqueue beyond the one whose final kernel the device has started (default 2;
+    // 0 = the blocking poll every check_every iterations of rounds 1-4)
+    static const int run_ahead_env = [] { const char* e = std::getenv("SCPN_HIP_RUNAHEAD"); return e ? std::max(0, std::atoi(e)) : 2; }();
+    const int run_ahead = h->d_word ? run_ahead_env : 0;
+    const unsigned solve_id = ++h->word_seq;
+    if (run_ahead > 0) {
+        h->d_iter_count.alloc(1);
+        HIP_TRY(hipMemsetAsync(h->d_iter_count.p, 0, sizeof(int), h->stream));
+    }
     const double om_alpha = 1.0 - p->alpha;
     const int* act = h->d_active.p;
     int topo_count = nblk2;
@@ -1104,6 +1097,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         pt.ctl = ctl; pt.hist_diff = d_hist_diff.p; pt.hist_gs = d_hist_gs.p; pt.trace = d_trace.p; pt.n_active = h->d_nactive.p;
         pt.f_cur = h->d_cur.p; pt.f_nxt = h->d_nxt.p; pt.f_best = h->d_best.p; pt.f_prev = h->d_prev.p; pt.f_active = h->d_active.p;
         pt.nr = nr; pt.r_axis = h->d_r.p; pt.z_axis = h->d_z.p;
+        if (run_ahead > 0) { pt.host_prog = h->d_word + 1; pt.host_done = h->d_word + 2; pt.iter_count = h->d_iter_count.p; pt.solve_id = solve_id; }
         if (h->use_fused && p->method != 3) {
             ProfScope ps(h, "blend_fused", 1);
             nb_d = nb_r = nblk2;
@@ -1159,20 +1153,58 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         }
     };
     int k = 0;
-    if (n_act > 0 && max_iter > 0) {
-        iter_k = 0;
-        iteration(true);
-        ++k;
-        if (k % check_every == 0 || k >= max_iter) {
-            n_act = poll_word(h, h->d_nactive.p);
+    if (run_ahead > 0) {
+        // Run-ahead loop: the host never blocks on the device's queue running empty.  It enqueues iteration k + 1 as soon as the
+        // device has STARTED the final kernel of iteration k + 1 - run_ahead (progress word), and stops the moment the device says
+        // that the last member has left the iteration (done word).  At most `run_ahead` iterations are enqueued beyond the one
+        // that froze the last member (their kernels see frozen members only), where the blocking poll every `check_every`
+        // iterations ran on average check_every / 2 + the drain of the queue at every poll.
+        using clk = std::chrono::steady_clock;
+        bool done = n_act <= 0;
+        while (!done && k < max_iter) {
+            iter_k = k;
+            iteration(k == 0);
+            ++k;
+            const auto t0 = clk::now();
+            auto next_query = t0 + std::chrono::milliseconds(2);
+            for (unsigned spins = 0;; ++spins) {
+                const unsigned long long wd = __atomic_load_n(h->h_word + 2, __ATOMIC_ACQUIRE);
+                if ((unsigned)(wd >> 32) == solve_id) { done = true; break; }
+                const unsigned long long wp = __atomic_load_n(h->h_word + 1, __ATOMIC_ACQUIRE);
+                const int started = (unsigned)(wp >> 32) == solve_id ? (int)(unsigned)(wp & 0xffffffffull) : 0;
+                if (k - started < run_ahead) break;
+                cpu_relax();
+                if ((spins & 0xffu) != 0xffu) continue;
+                const auto now = clk::now();
+                if (now - t0 > std::chrono::microseconds(200)) std::this_thread::yield();
+                if (now < next_query) continue;
+                next_query = now + std::chrono::milliseconds(2);
+                const hipError_t qs = hipStreamQuery(st);
+                if (qs == hipSuccess) {  // everything enqueued has run: the words are final
+                    const unsigned long long w2 = __atomic_load_n(h->h_word + 2, __ATOMIC_ACQUIRE);
+                    done = (unsigned)(w2 >> 32) == solve_id;
+                    break;
+                }
+                if (qs != hipErrorNotReady) throw std::runtime_error(std::string("stream failed inside the Picard loop: ") + hipGetErrorString(qs));
+                if (now - t0 > std::chrono::seconds(120)) HIP_TRY(hipStreamSynchronize(st));
+            }
         }
-    }
-    while (n_act > 0 && k < max_iter) {
-        iter_k = k;
-        iteration(false);
-        ++k;
-        if (k % check_every == 0 || k >= max_iter) {
-            n_act = poll_word(h, h->d_nactive.p);
+    } else {
+        if (n_act > 0 && max_iter > 0) {
+            iter_k = 0;
+            iteration(true);
+            ++k;
+            if (k % check_every == 0 || k >= max_iter) {
+                n_act = poll_word(h, h->d_nactive.p);
+            }
+        }
+        while (n_act > 0 && k < max_iter) {
+            iter_k = k;
+            iteration(false);
+            ++k;
+            if (k % check_every == 0 || k >= max_iter) {
+                n_act = poll_word(h, h->d_nactive.p);
+            }
         }
     }
     HIP_TRY(hipStreamSynchronize(st));
@@ -1181,7 +1213,8 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         std::vector<Member> fin(B);
         HIP_TRY(hipMemcpyAsync(fin.data(), h->d_st.p, sizeof(Member) * B, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        std::vector<Member> tmp(fin);
+        std::vector<Member>& tmp = h->h_scr_st;  // (lives in the handle: its asynchronous upload below outlives this block)
+        tmp = fin;
         bool any = false;
         for (int b = 0; b < B; ++b) { tmp[b].active = (fin[b].iterations > 0) ? 1 : 0; any |= tmp[b].active != 0; }
         if (any) {
@@ -1193,7 +1226,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             if (lazy)  // the source field held J_raw during the iterations: leave the last source in it, as the eager path does
                 SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, srcF, jF, 0, prevF, (const Member*)d_tmp.p, nz, nr, ld, (const double*)h->d_r.p,
                                    (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
-            // (`tmp` is a pageable host vector: its upload above was staged by the runtime before hipMemcpyAsync returned; the
+            // (the host image `tmp` is the handle's h_scr_st: nothing here depends on when the runtime stages a pageable upload; the
             //  results read-back below waits for these launches)
         }
         for (int b = 0; b < B; ++b)
@@ -2117,9 +2150,7 @@ int scpn_gs_create(scpn_gs** out, int nr, int nz, int batch, const double* r_axi
     for (int gi = 0; gi < ng; ++gi) {
         int cnt = (batch - done + (ng - gi) - 1) / (ng - gi);
         Solver* k = nullptr;
-        t_group_index = gi; t_group_count = ng;
         int rc = S_create(&k, nr, nz, cnt, r_axis, z_axis, dr, dz);
-        t_group_index = 0; t_group_count = 1;
         if (rc) { delete g; return rc; }
         k->ensemble_B = batch;
         g->kids.push_back(k);

@@ -77,3 +77,21 @@ def test_scpn_fusion_rs_stand_in_exports_the_gpu_tier_surface(monkeypatch):
         assert isinstance(mod.py_gpu_available(), bool)
     finally:
         sys.modules.pop("scpn_fusion_rs", None)
+
+
+def test_reference_bridge_loads_the_shipped_library():
+    """Seam B1 through the REFERENCE's own ``HPCBridge`` (imported from the reference checkout in a child process, so nothing of it
+    stays importable here): trust gate, six symbols, prototypes -- tools/check_reference_bridge.py.  Skipped where the reference
+    checkout does not exist (the GPU box)."""
+    import subprocess
+    import sys
+
+    import pytest
+
+    from tests.conftest import ROOT
+
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "check_reference_bridge.py")], capture_output=True, text=True, timeout=120)
+    if r.returncode == 77:
+        pytest.skip("no reference checkout")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "reference bridge check: passed" in r.stdout and "FAIL" not in r.stdout

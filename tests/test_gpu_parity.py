@@ -584,7 +584,7 @@ def test_config5_scan_256_members_on_one_gpu(hip, orc):
     n, total = 513, 256
     cfg = iter_like_cfg(n, method="multigrid", omega=1.0, tol=1e-8, max_iter=1000, alpha=0.12)
     t = shape_scan_member_table(cfg, total)
-    assert 1.5 <= t["kappa"].min() and t["kappa"].max() <= 1.9 and np.ptp(t["coil_z"][:, 0]) > 1.4  # the coil heights really move
+    assert 1.5 <= t["kappa"].min() and t["kappa"].max() <= 1.9 and np.ptp(t["coil_z"][:, 0]) > 0.9  # the coil heights really move (2.4 m x 0.4)
     check = sorted({0, total - 1, int(np.argmin(t["kappa"])), int(np.argmax(t["kappa"])),
                     *(int(m) for m in np.random.default_rng(5).choice(total, size=4, replace=False))})
     assert len(check) >= 8
@@ -649,3 +649,26 @@ def test_picard_tail_cold_path_sanitises_an_overflowing_residual(hip, orc):
     got, want = np.asarray(res["trace"])[:, 5], ref["trace"][:, 5]
     assert np.all(np.isfinite(got)) and 1e249 < want.max() <= 1e250  # residuals beyond the cap were clipped, the squares did not overflow
     np.testing.assert_allclose(got, want, rtol=1e-9)
+
+
+@pytest.mark.parametrize("value,where", [(np.inf, (10, 12)), (np.nan, (10, 12)), (-np.inf, (16, 16)), (np.inf, (0, 5)), (np.nan, (32, 7))])
+def test_non_finite_entry_in_a_preserved_start(hip, orc, value, where):
+    """``preserve_initial_state`` with a non-finite entry in the supplied flux (core/fusion_kernel_newton_solver.py:441-470: the
+    interior is sanitised by ``_prepare_initial_flux``, a non-finite RING value stays Dirichlet data and makes the first elliptic
+    solve non-finite -> the divergence path).  The fused Picard tail reads its non-finite verdict off sum |new - cur| (see its
+    header): same converged / diverged / iteration outcome and the same flux as the CPU port in every case."""
+    from scpn_fusion_core_amd.ensemble import EnsembleSolver
+
+    cfg = iter_like_cfg(33, tol=1e-6, max_iter=50)
+    start = orc.picard_solve(cfg)["psi"].copy()
+    start[where] = value
+    ref = orc.picard_solve(cfg, psi0=start, preserve=True)
+    with EnsembleSolver(cfg, batch=2) as es:
+        es.set_psi(np.stack([start, start]))
+        res = es.solve_equilibrium(preserve_initial_state=True)
+        psi = es.get_psi()
+    for k in ("converged", "diverged", "iterations"):
+        assert res[0][k] == ref[k] == res[1][k], (k, res[0][k], ref[k])
+    fin = np.isfinite(ref["psi"])
+    assert np.array_equal(np.isfinite(psi[0]), fin)
+    assert np.abs(psi[0][fin] - ref["psi"][fin]).max() <= 1e-10 * np.abs(ref["psi"][fin]).max()

@@ -36,10 +36,6 @@ SWITCHES = [
 # name -> (defines, tile geometry the run forces)
 EXPERIMENT_BUILDS = {
     "mid40": (("TILE_MID_LZ=40", "TILE_MID_NW=10"), "32"),  # another tile geometry: 40 rows x 10 waves (the MID slot)
-    "pw0": (("TILE_PWIDE=0",), "48"),                # prolongation: coarse loads per fine row, one row at a time (rounds 1-3)
-    "pw0lg2": (("TILE_PWIDE=0", "TILE_LG=2"), "48"), # ... two rows in flight
-    "glds0": (("TILE_GLDS=0",), "48"),               # six-row post-smoother: inner-row sources through registers instead of LDS-DMA
-    "shd0": (("TILE_SHARE_D=0",), "48"),             # six-row pre-smoother: residual coefficients loaded by every wave at the defect stage
     "cvb0": (("CV_BLOCKS=0",), "48"),                # coarse kernel: 17^2 .. 65^2 levels as column pairs with three LDS reads per update (rounds 2-3), separate defect / prolongation passes
 }
 

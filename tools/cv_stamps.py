@@ -1,7 +1,13 @@
+"""s_memrealtime stamps inside the in-LDS coarse V-cycle kernel (one workgroup): phase durations of one launch.
+usage: [STAMPS_VARIANT=name STAMPS_DEFINES="A=1 B"] python tools/cv_stamps.py"""
 import os, sys, ctypes as C
 sys.path.insert(0, ".")
 from scpn_fusion_core_amd import _lib
-os.environ["SCPN_HIP_LIB"] = str(_lib.build(variant="stamps_plain", defines=("CV_STAMPS",)))  # experiment build, made on first use
+# experiment build, made on first use.  STAMPS_VARIANT / STAMPS_DEFINES select another stamped build (e.g. STAMPS_VARIANT=stamps_cvb0
+# STAMPS_DEFINES="CV_BLOCKS=0": the column-pair form of the 17^2..65^2 levels) -- session scripts pass these instead of editing this file
+variant = os.environ.get("STAMPS_VARIANT", "stamps_plain")
+defines = ("CV_STAMPS", *os.environ.get("STAMPS_DEFINES", "").split())
+os.environ["SCPN_HIP_LIB"] = str(_lib.build(variant=variant, defines=defines))
 os.environ["SCPN_HIP_GROUPS"] = "1"
 import numpy as np
 from scpn_fusion_core_amd.ensemble import EnsembleSolver
