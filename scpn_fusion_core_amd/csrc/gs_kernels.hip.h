@@ -1936,68 +1936,6 @@ __global__ void __launch_bounds__(1024) k_xpoint_saddle(Fld psiF, Member* st, in
 #define JS_ROWS_N 64
 #endif
 constexpr int JS_ROWS = JS_ROWS_N;  // rows per workgroup of the column-pair kernels (k_jsum, k_source)
-// psi_axis, psi_boundary and the normalisation from the candidates of the axis / X-point search (core/fusion_kernel.py:262-288,
-// 404-417): the largest psi (pa), psi at the masked arg-min of |grad psi| if there is one (else the smallest psi), and the
-// reference's guards.  One function for k_picard_final (which stores them) and for the speculative k_jsum (which needs them
-// one launch earlier): the same bits in both.
-struct AxisBnd { double pa, pb, denom; };
-__device__ __forceinline__ AxisBnd axis_boundary(const VI wmx, const VI wmn, const double psi_at_min, const double min_psi) {
-    double pa = wmx.i >= 0 ? wmx.v : 0.0;
-    if (fabs(pa) < 1e-6) pa = 1e-6;
-    double pb;
-    if (wmn.i >= 0) {
-        pb = psi_at_min;
-        if (!finite_d(pb)) pb = nan_to_num300(pb);
-    } else {
-        pb = min_psi;
-    }
-    if (fabs(pa - pb) < 0.1) pb = pa * 0.1;
-    double denom = pb - pa;  // core/fusion_kernel.py:415-417
-    if (fabs(denom) < 1e-9) denom = 1e-9;
-    return AxisBnd{pa, pb, denom};
-}
-// The topology finish of member b by ONE 256-thread workgroup from the per-tile candidates the fused Picard tail left (what
-// k_picard_final does for the member's state): every reduction here is order-independent (largest value / smallest index,
-// smallest value / smallest index, minimum), so any workgroup obtains the bits k_picard_final will store.  Result in every thread.
-struct TopoScratch { VI shx[4], shn[4]; double shd[4], shp[4], out[3]; };
-__device__ __forceinline__ AxisBnd topo_finish_local(const TopoPart* topo, int ntopo, int b, TopoScratch& S) {
-    VI tmx{0.0, -1}, tmn{0.0, -1};
-    double tminpsi = INFINITY, tpsi = 0.0;
-    for (int i = threadIdx.x; i < ntopo; i += 256) {
-        const TopoPart* q = topo + (long)b * ntopo + i;
-        const VI cmx{ld_val(&q->maxv), ld_val(&q->maxi)}, cmn{ld_val(&q->minb), ld_val(&q->mini)};
-        const double cpsi = ld_val(&q->psi_at_min), cminpsi = ld_val(&q->minpsi);
-        tmx = vi_max(tmx, cmx);
-        const VI nmn = vi_min(tmn, cmn);
-        if (nmn.i != tmn.i) tpsi = cpsi;
-        tmn = nmn;
-        tminpsi = fmin(tminpsi, cminpsi);
-    }
-    const VI own = tmn;
-    tmx = wave_vi<true>(tmx);
-    tmn = wave_vi<false>(tmn);
-    const double wmp = wave_max(-tminpsi);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (tmn.i >= 0 && own.i == tmn.i) S.shp[w] = tpsi;  // (a grid index lives in exactly one partial: one lane per wave at most)
-    if (lane == 0) { S.shx[w] = tmx; S.shn[w] = tmn; S.shd[w] = wmp; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        VI wmx = S.shx[0], wmn = S.shn[0];
-        double rmp = S.shd[0], pmin = S.shp[0];
-#pragma unroll
-        for (int i = 1; i < 4; ++i) {
-            wmx = vi_max(wmx, S.shx[i]);
-            const VI n2 = vi_min(wmn, S.shn[i]);
-            if (n2.i != wmn.i) pmin = S.shp[i];
-            wmn = n2;
-            rmp = fmax(rmp, S.shd[i]);
-        }
-        const AxisBnd ab = axis_boundary(wmx, wmn, pmin, -rmp);
-        S.out[0] = ab.pa; S.out[1] = ab.denom; S.out[2] = 1.0 / ab.denom;
-    }
-    __syncthreads();
-    return AxisBnd{S.out[0], S.out[2], S.out[1]};  // (pa, 1 / denom in .pb, denom)
-}
 // finishes the J_raw sum of member b: I = (sum * dr) * dz, scale = I_target / I  (core/fusion_kernel.py:436-438); all 256 threads
 __device__ __forceinline__ void jsum_final_body(int b, Member* st, const double* part, int nblk, double dr, double dz, double* sh,
                                                 bool commit = true) {
@@ -2011,26 +1949,17 @@ __device__ __forceinline__ void jsum_final_body(int b, Member* st, const double*
         st[b].jscale = fabs(ic) > 1e-9 ? itg / ic : 0.0;
     }
 }
-// topo != nullptr: the SPECULATIVE form of the Picard loop -- the launch runs BEFORE k_picard_final has finished the previous
-// iteration: psiF is the iterate the fused tail just wrote (the `nxt` slot), the member's activity is the one it entered that
-// iteration with, and psi_axis / the normalisation are formed here from the tail's per-tile candidates (topo_finish_local: the
-// bits k_picard_final stores afterwards).  A member that k_picard_final then switches off has had its J_raw computed for nothing.
 template <int HM>
 __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz, int nr, int ld,
                                               const double* r_axis, const double* inv_mu0R, Prof pf,
-                                              double* part, int nblk, Fld rawF, const TopoPart* topo, int ntopo) {
+                                              double* part, int nblk, Fld rawF) {
     __shared__ double sh[4];
-    __shared__ TopoScratch ts;
     int b = blockIdx.z;
     // the member's words in one round trip (activity, slots, normalisation), as in the tile kernels
     const int act_w = st[b].active;
     const int k_psi = *psiF.slot_ptr(b), k_raw = *rawF.slot_ptr(b);
-    double pa = st[b].psi_axis, den = st[b].denom, iden = st[b].inv_denom;
+    const double pa = st[b].psi_axis, den = st[b].denom, iden = st[b].inv_denom;
     if (!act_w) return;
-    if (topo) {  // (uniform)
-        const AxisBnd ab = topo_finish_local(topo, ntopo, b, ts);
-        pa = ab.pa; iden = ab.pb; den = ab.denom;
-    }
     const double* psi = psiF.at_slot(b, k_psi);
     double* raw = rawF.base ? rawF.at_slot(b, k_raw) : nullptr;  // lazy-source mode: J_raw is kept, consumers apply scale and -mu0 R
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -2237,7 +2166,7 @@ struct PicardShared {
 // One 256-thread workgroup finishes member b: diff / GS RMS, best / ping-pong slots, convergence
 // (core/fusion_kernel_newton_solver.py:518-571) and, with t.topo, the axis / X-point of the next iterate.  The partial of index i is
 // combined by thread i % 256 in ascending i, then lanes, then waves 0..3.
-__device__ __forceinline__ void picard_final_body(const int b, const PicardTail& t, PicardShared& S, int* goes_on = nullptr) {
+__device__ __forceinline__ void picard_final_body(const int b, const PicardTail& t, PicardShared& S) {
     Member* st = t.st;
     const int nblk = t.nblk, nblk_r = t.nblk_r, ntopo = t.ntopo;
     const PicardCtl& ctl = t.ctl;
@@ -2326,7 +2255,6 @@ __device__ __forceinline__ void picard_final_body(const int b, const PicardTail&
         m.active = 0;
         picard_member_frozen(t);
         t.f_cur[b] = cur; t.f_nxt[b] = m_nxt; t.f_best[b] = m_best; t.f_prev[b] = prev; t.f_active[b] = 0;
-        if (goes_on) *goes_on = 0;
         return;
     }
     double diff = tot / (double)ctl.n_total;
@@ -2357,7 +2285,6 @@ __device__ __forceinline__ void picard_final_body(const int b, const PicardTail&
     if (!active) { m.active = 0; picard_member_frozen(t); }
     // publish the slot indices / activity the field kernels index (was a separate k_publish_slots launch)
     t.f_cur[b] = cur; t.f_nxt[b] = nx; t.f_best[b] = best; t.f_prev[b] = prev; t.f_active[b] = active;
-    if (goes_on) *goes_on = active;
     if (t.topo && active) {  // k_topology_final for the next iteration, on the new current iterate
         VI wmx = S.shx[0], wmn = S.shn[0];
         double rmp = S.shd[0], pmin = S.shp[0];
@@ -2370,14 +2297,22 @@ __device__ __forceinline__ void picard_final_body(const int b, const PicardTail&
             rmp = fmax(rmp, S.shd[i]);
         }
         rmp = -rmp;
-        double xr = 0.0, xz = 0.0;
+        double pa = wmx.i >= 0 ? wmx.v : 0.0;
+        if (fabs(pa) < 1e-6) pa = 1e-6;
+        double pb, xr = 0.0, xz = 0.0;
         if (wmn.i >= 0) {
             int iz = (int)(wmn.i / t.nr), ir = (int)(wmn.i - (long)iz * t.nr);
+            pb = pmin;  // psi of the new iterate at the arg-min, carried with the partials
             xr = t.r_axis[ir];
             xz = t.z_axis[iz];
+            if (!finite_d(pb)) pb = nan_to_num300(pb);
+        } else {
+            pb = rmp;
         }
-        const AxisBnd ab = axis_boundary(wmx, wmn, pmin, rmp);  // (pmin: psi of the new iterate at the arg-min, carried with the partials)
-        m.psi_axis = ab.pa; m.psi_bnd = ab.pb; m.denom = ab.denom; m.inv_denom = 1.0 / ab.denom; m.x_idx = wmn.i; m.x_r = xr; m.x_z = xz;
+        if (fabs(pa - pb) < 0.1) pb = pa * 0.1;
+        double denom = pb - pa;  // core/fusion_kernel.py:415-417
+        if (fabs(denom) < 1e-9) denom = 1e-9;
+        m.psi_axis = pa; m.psi_bnd = pb; m.denom = denom; m.inv_denom = 1.0 / denom; m.x_idx = wmn.i; m.x_r = xr; m.x_z = xz;
     }
 }
 __global__ void __launch_bounds__(256) k_picard_final(PicardTail t) {
@@ -2391,19 +2326,6 @@ __global__ void __launch_bounds__(256) k_picard_final(PicardTail t) {
     }
     if (!t.st[b].active) return;
     picard_final_body(b, t, S);
-}
-// The scalar tails of two iterations in one launch (speculative k_jsum order: ... tail(k) -> k_jsum(k+1) -> THIS -> V-cycle(k+1)):
-// finish iteration k as k_picard_final does, then -- if the member goes on -- the J_raw sum of iteration k + 1 as k_jsum_final does.
-__global__ void __launch_bounds__(256) k_picard_final_sum(PicardTail t, const double* jpart, int nblkj, double dr, double dz) {
-    __shared__ PicardShared S;
-    __shared__ double sh[4];
-    __shared__ int goes_on;
-    const int b = blockIdx.x;
-    if (!t.st[b].active) return;
-    picard_final_body(b, t, S, &goes_on);  // (thread 0 leaves it last; the others wait at the barrier)
-    __syncthreads();
-    if (!goes_on) return;  // (switched off: its current integral stays the one of the iteration it stopped in)
-    jsum_final_body(b, t.st, jpart, nblkj, dr, dz, sh);
 }
 // reciprocals (two words) of dz, 2 dz, dr for the exact divisions of the divertor-row gradient (host IEEE division)
 struct GradRecip { double dz, inv_dz, lo_dz, two_dz, inv_two_dz, lo_two_dz, dr, inv_dr, lo_dr; };

@@ -1049,17 +1049,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
     // SCPN_HIP_SUMFUSE=0 / 1 forces it off / on.
     static const int sumfuse_env = [] { const char* e = std::getenv("SCPN_HIP_SUMFUSE"); return e ? std::atoi(e) : -1; }();
     const bool sum_fuse = (sumfuse_env == 1 || (sumfuse_env < 0 && B <= 14)) && lazy && nblkj <= 256;
-    // Speculative source update (16-member groups of the fused multigrid path): from the second iteration on k_jsum runs directly
-    // behind the fused tail -- on the iterate the tail just wrote, with the axis / boundary values formed from the tail's per-tile
-    // candidates inside k_jsum -- and ONE scalar launch (k_picard_final_sum) then finishes the previous iteration and the J_raw sum
-    // together: ten launches per iteration instead of eleven.  Members that the scalar tail switches off have had a J_raw computed
-    // for nothing; nothing else changes (same values, same iteration counts).  SCPN_HIP_SPECJSUM=0: the separate launches.
-    static const bool specjsum_env = [] { const char* e = std::getenv("SCPN_HIP_SPECJSUM"); return !(e && e[0] == '0'); }();
-    const bool spec_jsum = specjsum_env && topo_in_final && lazy && !sum_fuse && h->use_fused && p->method != 3 && !p->external_profile_mode;
-    bool final_pending = false;
-    PicardTail pt_pending;
     auto iteration = [&](bool first) {
-        const bool spec = spec_jsum && !first;  // (then the previous iteration's scalar tail is still pending)
         if (first || !topo_in_final) {
             ProfScope ps(h, "topology", first || !h->use_fused || p->method == 3 || p->xpoint_saddle ? 2 : 1);
             int ntopo = topo_count;  // partial count produced by the previous iteration's fused tail
@@ -1074,20 +1064,10 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
                 SCPN_LAUNCH(k_xpoint_saddle, dim3(B), dim3(1024), 0, st, curF, h->d_st.p, nz, nr, ld, h->dr, h->dz, n_mask_rows,
                                    (const double*)h->d_r.p, (const double*)h->d_z.p);
         }
-        if (spec) {
-            {
-                ProfScope ps(h, "source", 1);
-                SCPN_LAUNCH((pf.hmode ? k_jsum<1> : k_jsum<0>), gjs, dim3(256), 0, st, nxtF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
-                                   (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, srcF, (const TopoPart*)h->d_topo.p, topo_count);
-            }
-            ProfScope ps(h, "picard_final", 1);
-            SCPN_LAUNCH(k_picard_final_sum, dim3(B), dim3(256), 0, st, pt_pending, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
-            final_pending = false;
-        } else if (!p->external_profile_mode) {
+        if (!p->external_profile_mode) {
             ProfScope ps(h, "source", (lazy ? 2 : 3) - (sum_fuse ? 1 : 0));
             SCPN_LAUNCH((pf.hmode ? k_jsum<1> : k_jsum<0>), gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
-                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, lazy ? srcF : Fld{nullptr, nullptr, 0, 0},
-                               (const TopoPart*)nullptr, 0);
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, lazy ? srcF : Fld{nullptr, nullptr, 0, 0});
             if (sum_fuse) { h->jsum_part = h->d_jpart.p; h->jsum_nblk = nblkj; }  // (the V-cycle's first level-0 launch finishes the sum)
             else
                 SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
@@ -1165,21 +1145,12 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             SCPN_LAUNCH(k_resid_norms, dim3(nblk_r, B), dim3(256), 0, st, nxtF, srcF, L0, h->d_part2.p, h->d_part3.p, nblk_r, act);
         }
         topo_count = nb_d;
-        pt.nblk = nb_d; pt.nblk_r = nb_r; pt.ntopo = nb_d;
-        pt.topo = topo_in_final ? (const TopoPart*)h->d_topo.p : (const TopoPart*)nullptr;
-        if (spec_jsum) {  // (finished by the next iteration's k_picard_final_sum, or by the launch behind the loop)
-            pt_pending = pt;
-            final_pending = true;
-        } else {
+        {
             ProfScope ps(h, "picard_final", 1);
+            pt.nblk = nb_d; pt.nblk_r = nb_r; pt.ntopo = nb_d;
+            pt.topo = topo_in_final ? (const TopoPart*)h->d_topo.p : (const TopoPart*)nullptr;
             SCPN_LAUNCH(k_picard_final, dim3(B), dim3(256), 0, st, pt);
         }
-    };
-    auto finish_pending = [&] {
-        if (!final_pending) return;
-        ProfScope ps(h, "picard_final", 1);
-        SCPN_LAUNCH(k_picard_final, dim3(B), dim3(256), 0, st, pt_pending);
-        final_pending = false;
     };
     int k = 0;
     if (run_ahead > 0) {
@@ -1236,7 +1207,6 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             }
         }
     }
-    finish_pending();
     HIP_TRY(hipStreamSynchronize(st));
     // ---- J_phi of the last source update (recomputed from the pre-blend psi kept in slot `prev`)
     if (!p->external_profile_mode) {
@@ -1405,7 +1375,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
         if (!p->external_profile_mode) {
             ProfScope ps(h, "source", 3);
             SCPN_LAUNCH((pf.hmode ? k_jsum<1> : k_jsum<0>), gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
-                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0}, (const TopoPart*)nullptr, 0);
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0});
             SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
             SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, dstSrc, jF, 1, curF, (const Member*)h->d_st.p, nz, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);
@@ -1465,7 +1435,7 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
             SCPN_LAUNCH(k_topology_final, dim3(B), dim3(256), 0, st, pF, scr.p, (const TopoPart*)h->d_topo.p, nblk1, nr, ld,
                                (const double*)h->d_r.p, (const double*)h->d_z.p);
             SCPN_LAUNCH((pf.hmode ? k_jsum<1> : k_jsum<0>), gjs, dim3(256), 0, st, pF, (const Member*)scr.p, nz, nr, ld, (const double*)h->d_r.p,
-                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0}, (const TopoPart*)nullptr, 0);
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, Fld{nullptr, nullptr, 0, 0});
             SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, scr.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
             SCPN_LAUNCH(k_source, gjs, dim3(256), 0, st, src2F, jF, 0, pF, (const Member*)scr.p, nz, nr, ld, (const double*)h->d_r.p,
                                (const double*)h->d_inv_mu0R.p, (const double*)h->d_neg_mu0R.p, pf);

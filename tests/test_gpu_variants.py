@@ -19,8 +19,7 @@ SWITCHES = [
     {"SCPN_HIP_DEFECT_MINLVL": "9"},
     {"SCPN_HIP_POLL": "memcpy"},
     {"SCPN_HIP_XCD_BLEND": "0"},
-    {"SCPN_HIP_SUMFUSE": "0"},                                  # no sum in the first consumer: the speculative k_jsum order of 16-member groups (k_picard_final_sum)
-    {"SCPN_HIP_SUMFUSE": "0", "SCPN_HIP_SPECJSUM": "0"},         # ... and the plain order: k_picard_final, k_jsum, k_jsum_final
+    {"SCPN_HIP_SUMFUSE": "0"},                                  # separate k_jsum_final launch instead of the sum in its first consumer
     {"SCPN_HIP_TILEGEO": "32"},                                 # tile geometries: the default of this 2-member run is 24 rows x 12 waves
     {"SCPN_HIP_TILEGEO": "48"},                                 # 48 rows x 8 waves (six rows per wave, inner sources in LDS slots): ensembles of more than 12 members
     {"SCPN_HIP_TILEGEO": "48", "SCPN_HIP_SUMFUSE": "0"},
@@ -75,14 +74,11 @@ def test_experiment_builds_are_bit_identical():
         assert (got["psi"], got["jphi"], got["iterations"], got["special"]) == (base["psi"], base["jphi"], base["iterations"], base["special"]), (name, got, base)
 
 
-@pytest.mark.parametrize("env", [{"SCPN_HIP_TILEGEO": "32"}, {"SCPN_HIP_TILEGEO": "48"}, {"SCPN_HIP_SUMFUSE": "0"}],
-                         ids=["tile_32_rows", "tile_48_rows", "speculative_source_update"])
+@pytest.mark.parametrize("env", [{"SCPN_HIP_TILEGEO": "32"}, {"SCPN_HIP_TILEGEO": "48"}], ids=["tile_32_rows", "tile_48_rows"])
 def test_operator_parity_suite_under_each_tile_geometry(env):
     """The tile geometry is chosen by the size of a stream group (a level-0 launch of at most ~220 tiles: 24 rows x 12 waves; up to
     16 members: 32 x 8; more: 48 x 8), so the default run of tests/test_gpu_parity.py pins mostly the first against the reference
-    fixtures and the oracle.  Run the same suite with each of the other two forced.  Likewise the small groups of that suite finish the
-    J_raw sum in its first consumer; with that switched off the Picard loop takes the order of the 16-member groups -- k_jsum
-    speculatively behind the fused tail, one scalar launch for two iterations -- against the same golden iteration traces."""
+    fixtures and the oracle.  Run the same suite with each of the other two forced."""
     from scpn_fusion_core_amd import _lib
 
     _lib.require_gpu()
