@@ -17,11 +17,18 @@ def test_bench_line_contract():
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
         assert isinstance(d[key], typ), key
-    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] in ("weak", "strong") and d["dtype"] == "f64"
     assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     members = d["config"]["global_members"]
     assert abs(d["value"] - members / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
-    assert d["config"]["converged_members_rank0"] == d["config"]["members_per_gpu"]
+    assert d["config"]["converged_members_rank0"] == d["config"]["members_rank0"]
+    # the workload is SURVEY 8(d) cfg 5 in full: currents, I_p AND the kappa scan through the coil heights
+    assert "kappa in [1.5, 1.9]" in d["config"]["workload"] and 1.5 <= d["config"]["kappa_range_rank0"][0] < d["config"]["kappa_range_rank0"][1] <= 1.9
+    if d["scaling"] == "weak":
+        assert members == d["config"]["members_per_gpu"] * d["n_gpus"]
+        s1 = d["strong_scaling_n1"]  # the other scaling label's N = 1 value rides on the weak line
+        assert s1["scaling"] == "strong" and s1["total_members"] == s1["converged_members"] == 256 and s1["n_gpus"] == 1
+        assert abs(s1["value"] - 256 / (s1["ms_per_step"] * 1e-3)) <= 0.01 * s1["value"]
 
 
 def test_roofline_and_cpu_baseline_objects():
@@ -55,8 +62,20 @@ def test_roofline_and_cpu_baseline_objects():
     assert cf["config2_fixed_boundary_257"]["converged_members"] == cf["config2_fixed_boundary_257"]["members"]
     assert cf["config3_single_free_boundary_513"]["diiid_like"]["picard"]["converged"] and cf["config4_transport_coupled_loop_513"]["value"] > 0
     assert cf["smoother_200_sweeps_513"]["value"] > 0 and cf["smoother_200_sweeps_513"]["published_reference"]["numpy_s"] == 18.85
+    assert r["bound_observed"] is None or isinstance(r["bound_observed"], str)  # what the committed counters say limits the kernel
+    for key in ("config2_fixed_boundary_257", "config4_transport_coupled_loop_513"):
+        assert "vacuum field per handle" in cf[key]["memoised_setup"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # every member the CPU leg solved is compared with the device's result of the timed run
+    assert c["host_cores"] >= c["cores"] == c["members_compared"] == len(c["psi_rel_linf_vs_gpu_per_member"])
+    assert c["picard_iterations_equal_on_all_compared_members"] is True and abs(c["psi_rel_linf_vs_gpu"] - max(c["psi_rel_linf_vs_gpu_per_member"])) <= 1e-3 * c["psi_rel_linf_vs_gpu"] < 1e-12
+    p = d["parity"]  # the strict-parity gate with all five thresholds, on both lanes
+    assert p["pass"] is True and set(p["thresholds"]) == {"psi_n_rmse", "axis_error_m", "boundary_max_abs_error_wb",
+                                                            "current_closure_relative_error", "xpoint_psi_n_error"}
+    assert len(p["free_boundary_lane"]["checks"]) == 5 and all(p["free_boundary_lane"]["checks"].values())
+    for case in p["native_profile_source_lane"]["cases"].values():
+        assert len(case["checks"]) == 5 and case["pass"] and case["psi_max_abs_error_wb"] <= 1e-10 and case["psi_n_rmse"] <= 1e-9
 
 
 def test_pmc_traffic_file_matches_the_families_bench_reports():
