@@ -17,7 +17,9 @@ SWITCHES = [
     {"SCPN_HIP_LAZYSRC": "0"},
     {"SCPN_HIP_GROUPS": "2"},
     {"SCPN_HIP_DEFECT_MINLVL": "9"},
-    {"SCPN_HIP_POLL": "memcpy"},
+    {"SCPN_HIP_RUNAHEAD": "0"},                                 # the blocking poll every check_every iterations (rounds 1-4) instead of the run-ahead loop
+    {"SCPN_HIP_RUNAHEAD": "0", "SCPN_HIP_POLL": "memcpy"},      # ... by hipMemcpyAsync + stream synchronise instead of the host-mapped word
+    {"SCPN_HIP_RUNAHEAD": "1"}, {"SCPN_HIP_RUNAHEAD": "4"},     # other run-ahead depths
     {"SCPN_HIP_XCD_BLEND": "0"},
     {"SCPN_HIP_SUMFUSE": "0"},                                  # separate k_jsum_final launch instead of the sum in its first consumer
     {"SCPN_HIP_TILEGEO": "32"},                                 # tile geometries: the default of this 2-member run is 24 rows x 12 waves
