@@ -294,3 +294,28 @@ def test_native_lane_validation_precedes_the_device():
             lane(*args)
     with pytest.raises(ValueError, match="plasma_current_a"):
         strict_parity_metrics(ok.T, ok.T, r, z, jtor=ok.T)
+
+
+def test_shape_scan_table_contract():
+    """cases.shape_scan_member_table (BASELINE config 5 / SURVEY 8(d) cfg 5): the current half equals scan_member_table, kappa has a
+    stream of its own (member m does not depend on the ensemble size), the coil heights are the reference's build_config expression
+    (validation/benchmark_vs_freegs.py:424-432), and the scan is refused on any other coil set."""
+    from scpn_fusion_core_amd.cases import (diiid_like_cfg, iter_like_coil_positions, member_cfg, scan_member_table,
+                                            shape_scan_member_table)
+
+    cfg = iter_like_cfg(33)
+    t = shape_scan_member_table(cfg, 40)
+    cur, tgt = scan_member_table(cfg, 40)
+    assert np.array_equal(t["currents"], cur) and np.array_equal(t["targets"], tgt)
+    assert np.array_equal(shape_scan_member_table(cfg, 7)["kappa"], t["kappa"][:7])
+    assert t["kappa"].min() >= 1.5 and t["kappa"].max() <= 1.9 and np.unique(t["kappa"]).size == 40
+    r17, z17 = iter_like_coil_positions(1.7)
+    assert [c["r"] for c in cfg["coils"]] == r17 and [c["z"] for c in cfg["coils"]] == z17  # the config's own coil set is kappa = 1.7
+    for m in (0, 39):
+        k = float(t["kappa"][m])
+        assert list(t["coil_z"][m]) == [1.2 * k * 2.0, -(1.2 * k * 2.0), 1.2 * k * 2.0 * 1.1, -(1.2 * k * 2.0) * 1.1, 0.0]
+        one = member_cfg(cfg, t["currents"][m], t["targets"][m], t["coil_r"][m], t["coil_z"][m])
+        assert [c["z"] for c in one["coils"]] == list(t["coil_z"][m]) and one["physics"]["plasma_current_target"] == t["targets"][m]
+        assert cfg["coils"][0]["z"] == z17[0]  # (member_cfg copies: the ensemble's config is untouched)
+    with pytest.raises(ValueError, match="ITER-like five-coil"):
+        shape_scan_member_table(diiid_like_cfg(33), 4)
