@@ -324,6 +324,17 @@ int scpn_gs_sync(scpn_gs *h);
  * SCPN_HIP_GROUPS overrides the default of 2 for batch >= 16) so latency-bound coarse-level kernels of one
  * group overlap bandwidth-bound fine-level kernels of another */
 int scpn_gs_num_groups(scpn_gs *h);
+/* Arithmetic of the handle's hot kernels (tile smoother, in-LDS coarse V-cycle, fused Picard tail):
+ *   0 = exact (default): every expression keeps the operation order of the reference NumPy code
+ *       (core/multigrid_solve.py:184-206,211-249) -- the linear operators are bit-identical to it;
+ *   1 = contracted: the same red-black Gauss-Seidel / V-cycle / Picard iteration with fused multiply-adds and
+ *       reciprocal multiplies (the update is one chain of four FMAs) -- results agree with mode 0 to rounding
+ *       (<= 1e-10 max|psi| on converged equilibria, asserted by tests/test_gpu_fast_arith.py against the CPU oracle).
+ * The default of new handles comes from the environment variable SCPN_HIP_ARITH (exact | contracted).  The stateless
+ * operator API (section 2), the dispatcher providers and the legacy ABI (section 1) are always exact.
+ * Returns SCPN_E_ARG for another mode. */
+int scpn_gs_set_arith(scpn_gs *h, int mode);
+int scpn_gs_get_arith(scpn_gs *h);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Ensemble gather over RCCL / xGMI (one process per GPU).  The path shards across members, so the only

@@ -140,6 +140,8 @@ SIGNATURES = {
     "scpn_gs_profile_names": (_i, [_vp, C.c_char_p, _i]),
     "scpn_gs_sync": (_i, [_vp]),
     "scpn_gs_num_groups": (_i, [_vp]),
+    "scpn_gs_set_arith": (_i, [_vp, _i]),
+    "scpn_gs_get_arith": (_i, [_vp]),
     # ensemble gather over RCCL
     "scpn_comm_unique_id": (_i, [C.c_char_p]),
     "scpn_comm_prepare": (_i, [_i, C.POINTER(_i)]),

@@ -695,6 +695,7 @@ struct DefectDst {
     const double* r_safe = nullptr;
     const double* r_inv = nullptr;
     const double* r_inv_lo = nullptr;
+    double kd = 1;  // contracted arithmetic: a_c / omega (the defect is kd * (omega * psi - [omega-scaled Gauss-Seidel value]))
 };
 // Where the tile lives: a wave owns NROWS = LZ / NW CONSECUTIVE rows (NROWS even, so the parity of a row is a compile-time
 // property of its index i), and a lane the column pair (2l, 2l+1) of those rows: psi and source of the pair stay in registers
@@ -718,7 +719,15 @@ __device__ __forceinline__ double wave_shift(double x) {  // 0x138: wave_shr:1 =
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT, int WPEU, bool SUMF = false, bool GS1T = false>
+// FAST (contracted arithmetic, Solver::arith == 1; every other instantiation keeps the reference's operation order bit for bit):
+// the update (a_E E + a_W W + a_NS (S + N) - src) / a_C relaxed by omega becomes ONE chain of four (omega == 1) or five fused
+// multiply-adds -- the column coefficients and the source are scaled by omega / a_C once per tile (the lazy-source factors
+// (-mu0 R) * scale fold into the same product), no division sequence, no separate products -- and the defect
+// src - L*psi = a_C (psi - gs) is read off the same chain (six operations instead of 27).  With omega == 1 the column predicate
+// folds into the operands too: a column that is never updated carries zero coefficients and -psi as its scaled source, so
+// the chain returns psi itself (exactly: 0 * x + psi) and the sweeps carry no select at all; the row test is a wave-uniform branch.
+// Results differ from the exact instantiations by rounding only (tests/test_gpu_fast_arith.py: <= 1e-10 max|psi| on converged equilibria).
+template <int S, bool PROLONG, bool DEFECT, int LZT, int NWT, int WPEU, bool SUMF = false, bool GS1T = false, bool FAST = false>
 __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld inF, Fld srcF, Lvl L, double omega, double om1,
                                                     const int* active, Fld coarseF, int nz_c, int nr_c, int ld_c, LazySrc lzs,
                                                     DefectDst dd, int xcd_remap) {
@@ -777,11 +786,12 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     // DEFECT: r_safe / its reciprocal (two words) of the lane's even / odd column, requested with the rest (the defect stage
     // then starts without a memory round trip)
     double rs0 = 1.0, rs1 = 1.0, ri0 = 1.0, ri1 = 1.0, rl0 = 0.0, rl1 = 0.0;
-    constexpr bool EARLY_D = DEFECT && NROWS < 6;  // (six rows per wave: no registers to spare through the sweeps)
+    constexpr bool FOLD = FAST && GS1T;  // (see the template header: column predicate folded into the operands)
+    constexpr bool EARLY_D = DEFECT && !FAST && NROWS < 6;  // (six rows per wave: no registers to spare through the sweeps)
     // Six rows per wave: the six values are the same for all waves of the tile (same columns), so wave k requests the k-th of them
     // here -- one double in flight per lane -- parks it in LDS behind the tile's planes, and the defect stage reads all six from
     // there (an LDS access instead of a memory round trip in the middle of the tile's life).
-    constexpr bool SHARE_D = DEFECT && !EARLY_D && NW >= 6;
+    constexpr bool SHARE_D = DEFECT && !FAST && !EARLY_D && NW >= 6;
     double* const CO = lds + LZ * 128;  // [6][64] doubles (allocated by the launcher for SHARE_D instantiations)
     double co_x = 0.0;
     if (SHARE_D) {
@@ -821,6 +831,9 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     double v0[NROWS], v1[NROWS], s0[NROWS], s1[NROWS];
     double* const b0 = A0 + lzb * 64 + lane;  // the lane's slot of the wave's first row in the colour-0 / colour-1 plane
     double* const b1 = A1 + lzb * 64 + lane;
+    // FAST: the factor every source value is multiplied by on load (omega / a_C, times the lazy-source factors once the scale is known)
+    const double fsc = FAST ? omega * inv_a_c : 1.0;
+    double sf0 = fsc, sf1 = fsc;
     // ---- load phase (out-of-domain cells hold clamped copies, see above)
     const unsigned lane_off = (unsigned)min(max(c0, 0), ld - 2) * 8u;
 #ifdef TILE_FAKE_LOADS
@@ -900,6 +913,10 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         }
         if (COEF_LATE && g0 + LG >= NROWS) { ae0 = *pe0; aw0 = *pw0; ae1 = *pe1; aw1 = *pw1; }
         if constexpr (lz_sum) if (g0 == 0) lz_sc = lazy_scale_from_parts(lzs, b, lane, lz_x0, lz_itg, bx_ == 0 && by_ == 0 && threadIdx.x == 0);
+        if (FAST && lazy && g0 == 0) {  // Source * omega / a_C = J_raw * [(-mu0 R) * scale * omega / a_C]: one product per value
+            sf0 = lz_sc != 0.0 ? (lz_n0 * lz_sc) * fsc : 0.0;
+            sf1 = lz_sc != 0.0 ? (lz_n1 * lz_sc) * fsc : 0.0;
+        }
 #pragma unroll
         for (int j = 0; j < LG; ++j) {
             const int i = g0 + j;
@@ -925,12 +942,15 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             double2* const pr = dma_row ? reinterpret_cast<double2*>(pair_base(i)) + lane : nullptr;
             if (dma_row) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's DMA has landed; everything else is needed by now anyway)
             double sx = dma_row ? pr->x : sv2[j].x, sy = dma_row ? pr->y : sv2[j].y;  // source of the even / odd column
-            if (lazy) {  // Source = (-mu0 R) * (scale != 0 ? J_raw * scale : 0), the expression of k_source (uniform branches)
+            if (FAST) {
+                sx = sx * sf0; sy = sy * sf1;
+                if (FOLD) { sx = colok0 ? sx : -vx; sy = colok1 ? sy : -vy; }  // a column that is never updated: the chain returns psi
+            } else if (lazy) {  // Source = (-mu0 R) * (scale != 0 ? J_raw * scale : 0), the expression of k_source (uniform branches)
                 if (lz_sc != 0.0) { sx = lz_n0 * (sx * lz_sc); sy = lz_n1 * (sy * lz_sc); }
                 else { sx = lz_n0 * 0.0; sy = lz_n1 * 0.0; }
             }
             if (dma_row) {
-                if (lazy) *pr = double2{sx, sy};  // (in place; a plain right-hand side is already what the sweeps read)
+                if (lazy || FAST) *pr = double2{sx, sy};  // (in place; a plain right-hand side is already what the exact sweeps read)
             } else if (SRCL && i > 0 && i < NROWS - 1) {
                 b0[i * 64] = (i & 1) ? sy : sx;
                 b1[i * 64] = (i & 1) ? sx : sy;
@@ -940,6 +960,16 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         if (PROLONG) __builtin_amdgcn_sched_barrier(0);
     }
     if (SHARE_D) { if (w < 6) CO[w * 64 + lane] = co_x; }
+    // FAST: the stencil coefficients scaled by omega / a_C (FOLD: zero in a column that is never updated)
+    const double ans_f = a_ns * fsc;
+    double cn0 = ans_f, cn1 = ans_f;
+    if (FAST) {
+        ae0 = ae0 * fsc; aw0 = aw0 * fsc; ae1 = ae1 * fsc; aw1 = aw1 * fsc;
+        if (FOLD) {
+            ae0 = colok0 ? ae0 : 0.0; aw0 = colok0 ? aw0 : 0.0; cn0 = colok0 ? ans_f : 0.0;
+            ae1 = colok1 ? ae1 : 0.0; aw1 = colok1 ? aw1 : 0.0; cn1 = colok1 ? ans_f : 0.0;
+        }
+    }
     // the wave's first and last row, both colours, for the waves above and below
     b0[0] = v0[0];
     b1[0] = v1[0];
@@ -977,11 +1007,24 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         const double ae = p ? ae1 : ae0, aw = p ? aw1 : aw0;
         const double sv = (GLDS && i > 0 && i < NROWS - 1) ? pair_base(i)[2 * lane + p]
                           : ((SRCL && i > 0 && i < NROWS - 1) ? (c ? b1 : b0)[i * 64] : (c ? s1[i] : s0[i]));
+        if constexpr (FAST) {
+            const double cn = FOLD ? (p ? cn1 : cn0) : ans_f;
+            const double base = GS1 ? -sv : __builtin_fma(om1, mine[i], -sv);
+            double nw = __builtin_fma(ae, E, __builtin_fma(aw, W, __builtin_fma(cn, Sv, __builtin_fma(cn, N, base))));
+            if constexpr (FOLD) {
+                mine[i] = nw;  // (the caller tests the row, wave-uniformly; the column predicate is in the operands)
+            } else {
+                asm volatile("" : "+v"(nw));
+                const bool keep = (hs <= hmax[i]) & (p ? colok1 : colok0);
+                mine[i] = keep ? nw : mine[i];
+            }
+        } else {
         const double gsv = divc4(ae * E + aw * W + a_ns * Sv + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
         double nw = GS1 ? __builtin_fma(om1, mine[i], gsv) : om1 * mine[i] + omega * gsv;
         asm volatile("" : "+v"(nw));  // (an opaque use: keeps the compiler from sinking the chain into an exec-masked branch)
         const bool keep = (hs <= hmax[i]) & (p ? colok1 : colok0);
         mine[i] = keep ? nw : mine[i];
+        }
     };
     auto half_sweep = [&](auto gauss_seidel, auto colour, const int hs) {
         constexpr int c = decltype(colour)::value;
@@ -989,7 +1032,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
         const double(&oth)[NROWS] = c ? v0 : v1;
         const double* const ob = c ? b0 : b1;  // boundary rows of the other colour
         const double Sb = ob[o_s], Nb = ob[o_n];
-        if (NROWS >= TILE_SKIP_MIN_ROWS && hmax_low < 2 * S - 1) {
+        if ((FOLD || NROWS >= TILE_SKIP_MIN_ROWS) && hmax_low < 2 * S - 1) {
             // a wave some of whose rows drop out before the last pass -- the tile's first / last wave (one row per pass, all of them
             // by the last pass) and waves that overhang the grid: a row is SKIPPED under its wave-uniform test -- 15-20 % of a
             // six-row tile's pass arithmetic; the rows left are short of the other waves' six interleaved chains anyway
@@ -1054,14 +1097,23 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             const double C = mine[i];
             constexpr bool inner = SRCL && i > 0 && i < NROWS - 1;
             const double sv = inner ? (c ? b1 : b0)[i * 64] : (c ? s1[i] : s0[i]);
+            double dv;
+            if constexpr (FAST) {
+                // src - L*psi = a_C (psi - gs): u is the omega-scaled Gauss-Seidel value of the point (the chain of the sweeps)
+                const double ae = p ? ae1 : ae0, aw = p ? aw1 : aw0, cn = FOLD ? (p ? cn1 : cn0) : ans_f;
+                const double u = __builtin_fma(ae, E, __builtin_fma(aw, W, __builtin_fma(cn, Sv, __builtin_fma(cn, N, -sv))));
+                dv = dd.kd * (GS1T ? C - u : __builtin_fma(omega, C, -u));
+            } else {
             const double rs = p ? rs1 : rs0, ri = p ? ri1 : ri0, rl = p ? rl1 : rl0;
             const double d2r = divc4(E - 2.0 * C + W, dd.dr2, dd.inv_dr2, dd.lo_dr2);
             const double d1r = divc4(E - W, dd.two_dr, dd.inv_two_dr, dd.lo_two_dr);
             const double d2z = divc4(N - 2.0 * C + Sv, dd.dz2, dd.inv_dz2, dd.lo_dz2);
             const double lpsi = d2r - divc4(d1r, rs, ri, rl) + d2z;
-            double dv = -(lpsi - sv);
+            dv = -(lpsi - sv);
+            }
             asm volatile("" : "+v"(dv));
-            const bool keep = (hmax[i] >= H - 2) & (p ? colok1 : colok0);
+            // (FOLD: a column that is never updated has u == psi, i.e. dv == 0 by itself)
+            const bool keep = FOLD ? (hmax[i] >= H - 2) : ((hmax[i] >= H - 2) & (p ? colok1 : colok0));
             const double d = keep ? dv : -0.0;
             if (inner) (c ? b1 : b0)[i * 64] = d;  // (the slot its source came from: the planes become the defect planes)
             else if (c) s1[i] = d;

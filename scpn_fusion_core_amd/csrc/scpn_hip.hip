@@ -151,6 +151,11 @@ struct Solver {
     const double* jsum_part = nullptr;  // != nullptr: k_jsum's partial sums wait for the first lazy tile launch to finish them (LazySrc::part)
     int jsum_nblk = 0;
     bool use_fused = true;  // SCPN_HIP_FUSED=0 selects the one-pass-per-launch kernels (A/B testing)
+    // Arithmetic of the resident solver's hot kernels (scpn_gs_set_arith; default from SCPN_HIP_ARITH): 0 = exact, every expression
+    // in the reference's operation order (bit-exact operators); 1 = contracted: fused multiply-adds and reciprocal multiplies in the
+    // tile smoother / coarse V-cycle / Picard tail -- the same iteration to rounding (<= 1e-10 max|psi| on converged equilibria).
+    // The stateless operator API (scpn_mg_*, the dispatcher providers, the legacy ABI) is always exact.
+    int arith = 0;
     // fields (B members each)
     DBuf<double> psi_slots;  // 3 ping-pong slots
     DBuf<double> W, W2, src, src2, bc, jphi, ext, old, dense, and_psi, and_res, and_part, and_alpha;
@@ -407,13 +412,32 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
         if constexpr (!(HAS_GS1 && HAS_SUMF)) return (decltype(kern_any))nullptr;
         else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE, true, true>;
     }();
+    // contracted arithmetic (Solver::arith == 1): the three-sweep launches only -- one- and two-sweep launches stay exact
+    constexpr bool HAS_FAST = S == 3;
+    auto kern_fast = [] {
+        if constexpr (!HAS_FAST) return (decltype(kern_any))nullptr;
+        else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE, false, false, true>;
+    }();
+    auto kern_fast_gs1 = [] {
+        if constexpr (!HAS_FAST) return (decltype(kern_any))nullptr;
+        else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE, false, true, true>;
+    }();
+    auto kern_fast_sum = [] {
+        if constexpr (!(HAS_FAST && HAS_SUMF)) return (decltype(kern_any))nullptr;
+        else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE, true, false, true>;
+    }();
+    auto kern_fast_sum_gs1 = [] {
+        if constexpr (!(HAS_FAST && HAS_SUMF)) return (decltype(kern_any))nullptr;
+        else return &k_smooth_tile<S, PROLONG, DEFECT, LZT, NWT, TILE_WPE, true, true, true>;
+    }();
     std::call_once(attr_once, [&] {
-        for (auto k : {kern_any, kern_sum_any, kern_gs1, kern_sum_gs1})
+        for (auto k : {kern_any, kern_sum_any, kern_gs1, kern_sum_gs1, kern_fast, kern_fast_gs1, kern_fast_sum, kern_fast_sum_gs1})
             if (k) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     });
     const bool gs1 = HAS_GS1 && omega == 1.0 && gauss_seidel_forms();
-    auto kern = gs1 ? kern_gs1 : kern_any;
-    auto kern_sum = gs1 ? kern_sum_gs1 : kern_sum_any;
+    const bool fast = HAS_FAST && h->arith == 1;
+    auto kern = fast ? (gs1 ? kern_fast_gs1 : kern_fast) : (gs1 ? kern_gs1 : kern_any);
+    auto kern_sum = fast ? (gs1 ? kern_fast_sum_gs1 : kern_fast_sum) : (gs1 ? kern_sum_gs1 : kern_sum_any);
     constexpr int H = 2 * S + (DEFECT ? 2 : 0);
     static_assert(LZT - 2 * H >= 2, "tile too short for its halo");
     dim3 g(cdiv(L.nr, 128 - 2 * H), cdiv(L.nz, LZT - 2 * H), h->B);
@@ -424,6 +448,7 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
         dd.dr2 = L.dr2; dd.dz2 = L.dz2; dd.two_dr = L.two_dr; dd.inv_dr2 = L.inv_dr2; dd.inv_dz2 = L.inv_dz2;
         dd.inv_two_dr = L.inv_two_dr; dd.r_safe = L.r_safe; dd.r_inv = L.r_inv;
         dd.lo_dr2 = L.lo_dr2; dd.lo_dz2 = L.lo_dz2; dd.lo_two_dr = L.lo_two_dr; dd.r_inv_lo = L.r_inv_lo;
+        dd.kd = L.a_c / omega;
         dd.e = dfo->e;
         cF = dfo->rhs; nz_c = dfo->nz_c; nr_c = dfo->nr_c; ld_c = dfo->ld_c;
     }
@@ -746,6 +771,8 @@ static Solver* create_impl(int nr, int nz, int batch, const double* r_axis, cons
         {
             const char* e = std::getenv("SCPN_HIP_FUSED");
             h->use_fused = !(e && e[0] == '0');
+            const char* a = std::getenv("SCPN_HIP_ARITH");
+            h->arith = (a && (!std::strcmp(a, "1") || !std::strcmp(a, "contracted") || !std::strcmp(a, "fast"))) ? 1 : 0;
         }
         HIP_TRY(hipMemsetAsync(h->psi_slots.p, 0, sizeof(double) * 3 * n, h->stream));
         HIP_TRY(hipMemsetAsync(h->W.p, 0, sizeof(double) * n, h->stream));
@@ -2289,6 +2316,13 @@ int scpn_debug_cv_stamps(unsigned long long* out) {
 }
 #endif
 int scpn_gs_num_groups(scpn_gs* g) { return g ? (int)g->kids.size() : 0; }
+int scpn_gs_set_arith(scpn_gs* g, int mode) {
+    if (!g) return fail(SCPN_E_ARG, "null handle");
+    if (mode != 0 && mode != 1) return fail(SCPN_E_ARG, "scpn_gs_set_arith: mode must be 0 (exact) or 1 (contracted)");
+    for (auto* k : g->kids) k->arith = mode;
+    return SCPN_OK;
+}
+int scpn_gs_get_arith(scpn_gs* g) { return (g && !g->kids.empty()) ? g->kids[0]->arith : 0; }
 int scpn_gs_snapshot_psi(scpn_gs* g) {
     if (!g) return fail(SCPN_E_ARG, "null handle");
     return each_group(g, [&](int, Solver* k) { return S_snapshot_psi(k); });

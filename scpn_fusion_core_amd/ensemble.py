@@ -22,6 +22,7 @@ from . import _lib
 from ._lib import NewtonOpts, NewtonResult, PicardParams, PicardResult, as_f64, check, ptr
 
 _METHODS = {"multigrid": 0, "sor": 1, "jacobi": 2, "anderson": 3, "newton": 1}  # newton: its warm-up is the SOR branch
+_ARITHMETIC_NAMES = ("exact", "contracted")  # scpn_gs_set_arith modes 0 / 1
 _PED_DEFAULT = {"ped_top": 0.92, "ped_width": 0.05, "ped_height": 1.0, "core_alpha": 0.3}  # core/fusion_kernel.py:181-192
 
 
@@ -173,10 +174,15 @@ class EnsembleSolver:
     coil_r, coil_z : array (batch, n_coils), optional
         Per-member positions of ``cfg["coils"]`` (a shape scan: every member its own coil geometry on the shared grid); they
         feed the vacuum field of the seed and are the default coil set of ``solve_free_boundary``.
+    arithmetic : ``"exact"`` | ``"contracted"``, optional
+        Arithmetic of the handle's hot kernels (``scpn_gs_set_arith``, include/scpn_hip.h): ``"exact"`` keeps the reference's
+        operation order (bit-exact linear operators), ``"contracted"`` runs the same iteration with fused multiply-adds
+        (agreement to rounding, <= 1e-10 max|psi| on converged equilibria).  Default: ``cfg["solver"]["arithmetic"]`` if present,
+        else the library's default (environment variable ``SCPN_HIP_ARITH``, else exact).
     """
 
     def __init__(self, cfg: dict, batch: int = 1, coil_currents=None, current_targets=None, device: int | None = None,
-                 r_axis=None, z_axis=None, coil_r=None, coil_z=None):
+                 r_axis=None, z_axis=None, coil_r=None, coil_z=None, arithmetic: str | None = None):
         self._L = _lib.require_gpu()
         if device is not None:
             check(self._L.scpn_set_device(int(device)))
@@ -196,6 +202,9 @@ class EnsembleSolver:
         check(self._L.scpn_gs_create(C.byref(h), self.NR, self.NZ, self.batch, self.R, self.Z, self.dR, self.dZ))
         self._h = h
         _note_live_handle(+1, self._L.scpn_gs_num_groups(h))
+        mode = arithmetic if arithmetic is not None else cfg.get("solver", {}).get("arithmetic")
+        if mode is not None:
+            self.arithmetic = mode
         coils = cfg.get("coils", [])
         self.n_coils = len(coils)
         self.coil_r = np.tile(np.array([c["r"] for c in coils], dtype=np.float64), (self.batch, 1)) if coil_r is None else as_f64(coil_r).reshape(self.batch, -1)
@@ -565,6 +574,16 @@ class EnsembleSolver:
             if n:
                 out[name] = {"ms": round(ms, 3), "launches": int(n)}
         return out
+
+    @property
+    def arithmetic(self) -> str:
+        return _ARITHMETIC_NAMES[int(self._L.scpn_gs_get_arith(self._h))]
+
+    @arithmetic.setter
+    def arithmetic(self, mode: str):
+        if mode not in _ARITHMETIC_NAMES:
+            raise ValueError(f"arithmetic must be one of {_ARITHMETIC_NAMES}, not {mode!r}")
+        check(self._L.scpn_gs_set_arith(self._h, _ARITHMETIC_NAMES.index(mode)))
 
     @property
     def num_groups(self) -> int:
