@@ -1199,7 +1199,27 @@ template <bool GS1>
 __device__ __forceinline__ double relaxed(double om1, double old, double omega, double gs) {
     return GS1 ? __builtin_fma(om1, old, gs) : om1 * old + omega * gs;
 }
-struct CvC { double dr2, dz2, two_dr, inv_dr2, inv_dz2, inv_two_dr; };
+struct CvC { double dr2, dz2, two_dr, inv_dr2, inv_dz2, inv_two_dr; double kd = 1.0, omega = 1.0; };
+// One relaxed update of the coarse kernel.  Exact: (1 - omega) old + omega (a_E E + a_W W + a_NS S + a_NS N - src) / a_C in the
+// reference's operation order (DIV5: the five-instruction quotient of the general forms).  FAST (contracted arithmetic, see
+// k_smooth_tile): the caller's coefficients and source are already scaled by omega / a_C -- one chain of four / five FMAs.
+template <bool GS1, bool FAST, bool DIV5 = false>
+__device__ __forceinline__ double cv_upd(double ae, double E, double aw, double W, double a_ns, double S, double N, double sv, double old,
+                                         double a_c, double inv_a_c, double lo_a_c, double omega, double om1) {
+    if constexpr (FAST) {
+        return __builtin_fma(ae, E, __builtin_fma(aw, W, __builtin_fma(a_ns, S, __builtin_fma(a_ns, N, GS1 ? -sv : __builtin_fma(om1, old, -sv)))));
+    } else {
+        const double x = ae * E + aw * W + a_ns * S + a_ns * N - sv;
+        return relaxed<GS1>(om1, old, omega, DIV5 ? divc(x, a_c, inv_a_c) : divc4(x, a_c, inv_a_c, lo_a_c));
+    }
+}
+// FAST: the defect src - L*psi = a_C (psi - gs) = kd (omega psi - u), u the omega-scaled Gauss-Seidel value from scaled operands
+template <bool GS1>
+__device__ __forceinline__ double cv_defect_fast(double p, double ae, double E, double aw, double W, double a_ns, double S, double N, double sv,
+                                                 const CvC& k) {
+    const double u = __builtin_fma(ae, E, __builtin_fma(aw, W, __builtin_fma(a_ns, S, __builtin_fma(a_ns, N, -sv))));
+    return k.kd * (GS1 ? p - u : __builtin_fma(k.omega, p, -u));
+}
 // L*psi - rhs at one point from its five values (core/multigrid_solve.py:211-249, the expression of cv_resid / mg_residual)
 __device__ __forceinline__ double cv_resid_pt(double p, double e, double w, double n, double s, double rhs_c, double r_safe, double r_inv,
                                               const CvC& k) {
@@ -1216,7 +1236,7 @@ __device__ __forceinline__ bool cv_block_level(int nz, int nr) {
 }
 // add_c / nrc: (block levels only) the coarse-grid correction whose bilinear prolongation is added to psi while the blocks are loaded
 // (psi += P e, the loop of k_vcycle_coarse); dscr / kk: (block levels only) where the defect -(L*psi - rhs) of the smoothed level goes
-template <bool GS1>
+template <bool GS1, bool FAST = false>
 __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const double* tab, int nz, int nr, double a_ns,
                                           double a_c, double inv_a_c, double lo_a_c, double omega, double om1, int n_sweeps,
                                           const double* add_c = nullptr, int nrc = 0, double* dscr = nullptr, const CvC* kk = nullptr) {
@@ -1248,18 +1268,16 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     {  // top-left and bottom-right
                         const double W_tl = dpp_f64<0x111>(v01), S_tl = dpp_f64<0x114>(v10);  // lane-1's right column, lane-4's bottom row
                         const double E_br = dpp_f64<0x101>(v10), N_br = dpp_f64<0x104>(v01);  // lane+1's left column, lane+4's top row
-                        const double g0 = divc4(ae0 * v01 + aw0 * W_tl + a_ns * S_tl + a_ns * v10 - s00, a_c, inv_a_c, lo_a_c);
-                        const double g1 = divc4(ae1 * E_br + aw1 * v10 + a_ns * v01 + a_ns * N_br - s11, a_c, inv_a_c, lo_a_c);
-                        const double n0 = relaxed<GS1>(om1, v00, omega, g0), n1 = relaxed<GS1>(om1, v11, omega, g1);
+                        const double n0 = cv_upd<GS1, FAST>(ae0, v01, aw0, W_tl, a_ns, S_tl, v10, s00, v00, a_c, inv_a_c, lo_a_c, omega, om1);
+                        const double n1 = cv_upd<GS1, FAST>(ae1, E_br, aw1, v10, a_ns, v01, N_br, s11, v11, a_c, inv_a_c, lo_a_c, omega, om1);
                         v00 = k_tl ? n0 : v00;
                         v11 = k_br ? n1 : v11;
                     }
                     {  // top-right and bottom-left
                         const double E_tr = dpp_f64<0x101>(v00), S_tr = dpp_f64<0x114>(v11);
                         const double W_bl = dpp_f64<0x111>(v11), N_bl = dpp_f64<0x104>(v00);
-                        const double g0 = divc4(ae1 * E_tr + aw1 * v00 + a_ns * S_tr + a_ns * v11 - s01, a_c, inv_a_c, lo_a_c);
-                        const double g1 = divc4(ae0 * v11 + aw0 * W_bl + a_ns * v00 + a_ns * N_bl - s10, a_c, inv_a_c, lo_a_c);
-                        const double n0 = relaxed<GS1>(om1, v01, omega, g0), n1 = relaxed<GS1>(om1, v10, omega, g1);
+                        const double n0 = cv_upd<GS1, FAST>(ae1, E_tr, aw1, v00, a_ns, S_tr, v11, s01, v01, a_c, inv_a_c, lo_a_c, omega, om1);
+                        const double n1 = cv_upd<GS1, FAST>(ae0, v11, aw0, W_bl, a_ns, v00, N_bl, s10, v10, a_c, inv_a_c, lo_a_c, omega, om1);
                         v01 = k_tr ? n0 : v01;
                         v10 = k_bl ? n1 : v10;
                     }
@@ -1289,8 +1307,7 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     //  of a 4-lane row, a lane without a point, or the fill outside the 16-lane row -- no select per neighbour)
                     const double E = dpp_f64<0x101>(v), W = dpp_f64<0x111>(v);  // row_shl:1 / row_shr:1
                     const double N = dpp_f64<0x104>(v), S = dpp_f64<0x114>(v);  // row_shl:4 / row_shr:4
-                    const double gs = divc4(ae * E + aw * W + a_ns * S + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
-                    const double nw = relaxed<GS1>(om1, v, omega, gs);
+                    const double nw = cv_upd<GS1, FAST>(ae, E, aw, W, a_ns, S, N, sv, v, a_c, inv_a_c, lo_a_c, omega, om1);
                     if (in && par == (s & 1)) v = nw;
                 }
             } else {
@@ -1298,8 +1315,7 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     const double Es = __shfl(v, lane + 1, 64), Ws = __shfl(v, lane - 1, 64);
                     const double Ns = __shfl(v, lane + lw, 64), Ss = __shfl(v, lane - lw, 64);
                     const double E = hasE ? Es : rE, W = hasW ? Ws : rW, N = hasN ? Ns : rN, S = hasS ? Ss : rS;
-                    const double gs = divc4(ae * E + aw * W + a_ns * S + a_ns * N - sv, a_c, inv_a_c, lo_a_c);
-                    const double nw = relaxed<GS1>(om1, v, omega, gs);
+                    const double nw = cv_upd<GS1, FAST>(ae, E, aw, W, a_ns, S, N, sv, v, a_c, inv_a_c, lo_a_c, omega, om1);
                     if (in && par == (s & 1)) v = nw;
                 }
             }
@@ -1352,9 +1368,8 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     {  // colour 0, (row + column) even: top-left (2by, 2bx) and bottom-right (2by+1, 2bx+1)
                         const double S_tl = pS[0], N_br = p[2 * nr + 1];
                         const double W_tl = wave_shift<0x138>(v01), E_br = wave_shift<0x130>(v10);
-                        const double g0 = divc4(ae0 * v01 + aw0 * W_tl + a_ns * S_tl + a_ns * v10 - s00, a_c, inv_a_c, lo_a_c);
-                        const double g1 = divc4(ae1 * E_br + aw1 * v10 + a_ns * v01 + a_ns * N_br - s11, a_c, inv_a_c, lo_a_c);
-                        const double n0 = relaxed<GS1>(om1, v00, omega, g0), n1 = relaxed<GS1>(om1, v11, omega, g1);
+                        const double n0 = cv_upd<GS1, FAST>(ae0, v01, aw0, W_tl, a_ns, S_tl, v10, s00, v00, a_c, inv_a_c, lo_a_c, omega, om1);
+                        const double n1 = cv_upd<GS1, FAST>(ae1, E_br, aw1, v10, a_ns, v01, N_br, s11, v11, a_c, inv_a_c, lo_a_c, omega, om1);
                         v00 = k_tl ? n0 : v00;
                         v11 = n1;
                         p[0] = v00;
@@ -1365,9 +1380,8 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     {  // colour 1: top-right (2by, 2bx+1) and bottom-left (2by+1, 2bx)
                         const double S_tr = pS[1], N_bl = p[2 * nr];
                         const double E_tr = wave_shift<0x130>(v00), W_bl = wave_shift<0x138>(v11);
-                        const double g0 = divc4(ae1 * E_tr + aw1 * v00 + a_ns * S_tr + a_ns * v11 - s01, a_c, inv_a_c, lo_a_c);
-                        const double g1 = divc4(ae0 * v11 + aw0 * W_bl + a_ns * v00 + a_ns * N_bl - s10, a_c, inv_a_c, lo_a_c);
-                        const double n0 = relaxed<GS1>(om1, v01, omega, g0), n1 = relaxed<GS1>(om1, v10, omega, g1);
+                        const double n0 = cv_upd<GS1, FAST>(ae1, E_tr, aw1, v00, a_ns, S_tr, v11, s01, v01, a_c, inv_a_c, lo_a_c, omega, om1);
+                        const double n1 = cv_upd<GS1, FAST>(ae0, v11, aw0, W_bl, a_ns, v00, N_bl, s10, v10, a_c, inv_a_c, lo_a_c, omega, om1);
                         v01 = k_tr ? n0 : v01;
                         v10 = k_bl ? n1 : v10;
                         p[1] = v01;
@@ -1384,10 +1398,18 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     const double S0 = pS[0], S1 = pS[1], N0 = p[2 * nr], N1 = p[2 * nr + 1];
                     const double W0 = wave_shift<0x138>(v01), W1 = wave_shift<0x138>(v11), E0 = wave_shift<0x130>(v00), E1 = wave_shift<0x130>(v10);
                     double* const d = dscr + (2 * by) * nr + 2 * bx;
-                    const double d00 = -cv_resid_pt(v00, v01, W0, v10, S0, s00, rs0, ri0, *kk);
-                    const double d01 = -cv_resid_pt(v01, E0, v00, v11, S1, s01, rs1, ri1, *kk);
-                    const double d10 = -cv_resid_pt(v10, v11, W1, N0, v00, s10, rs0, ri0, *kk);
-                    const double d11 = -cv_resid_pt(v11, E1, v10, N1, v01, s11, rs1, ri1, *kk);
+                    double d00, d01, d10, d11;
+                    if constexpr (FAST) {
+                        d00 = cv_defect_fast<GS1>(v00, ae0, v01, aw0, W0, a_ns, S0, v10, s00, *kk);
+                        d01 = cv_defect_fast<GS1>(v01, ae1, E0, aw1, v00, a_ns, S1, v11, s01, *kk);
+                        d10 = cv_defect_fast<GS1>(v10, ae0, v11, aw0, W1, a_ns, v00, N0, s10, *kk);
+                        d11 = cv_defect_fast<GS1>(v11, ae1, E1, aw1, v10, a_ns, v01, N1, s11, *kk);
+                    } else {
+                        d00 = -cv_resid_pt(v00, v01, W0, v10, S0, s00, rs0, ri0, *kk);
+                        d01 = -cv_resid_pt(v01, E0, v00, v11, S1, s01, rs1, ri1, *kk);
+                        d10 = -cv_resid_pt(v10, v11, W1, N0, v00, s10, rs0, ri0, *kk);
+                        d11 = -cv_resid_pt(v11, E1, v10, N1, v01, s11, rs1, ri1, *kk);
+                    }
                     if (k_tl) d[0] = d00;
                     if (k_tr) d[1] = d01;
                     if (k_bl) d[nr] = d10;
@@ -1439,15 +1461,13 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                 double* const p = pc[j];
                 if (m1 == 0) {  // the wave updates the first column of its pairs: E is the lane's own second column
                     if (ok0[j]) {
-                        const double gs = divc4(ae0[j] * v1[j] + aw0[j] * p[-1] + a_ns * p[-nr] + a_ns * p[nr] - s0[j], a_c, inv_a_c, lo_a_c);
-                        const double nw = relaxed<GS1>(om1, v0[j], omega, gs);
+                        const double nw = cv_upd<GS1, FAST>(ae0[j], v1[j], aw0[j], p[-1], a_ns, p[-nr], p[nr], s0[j], v0[j], a_c, inv_a_c, lo_a_c, omega, om1);
                         v0[j] = nw;
                         p[0] = nw;
                     }
                 } else if (m1 == mv) {  // the second column: W is the lane's own first column
                     if (ok1[j]) {
-                        const double gs = divc4(ae1[j] * p[2] + aw1[j] * v0[j] + a_ns * p[1 - nr] + a_ns * p[1 + nr] - s1[j], a_c, inv_a_c, lo_a_c);
-                        const double nw = relaxed<GS1>(om1, v1[j], omega, gs);
+                        const double nw = cv_upd<GS1, FAST>(ae1[j], p[2], aw1[j], v0[j], a_ns, p[1 - nr], p[1 + nr], s1[j], v1[j], a_c, inv_a_c, lo_a_c, omega, om1);
                         v1[j] = nw;
                         p[1] = nw;
                     }
@@ -1455,9 +1475,8 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     const double oth = p[e ? 2 : -1];
                     const double Sv = p[e - nr], Nv = p[e + nr];
                     const double E = e ? oth : v1[j], W = e ? v0[j] : oth, C = e ? v1[j] : v0[j];
-                    const double gs = divc4((e ? ae1[j] : ae0[j]) * E + (e ? aw1[j] : aw0[j]) * W + a_ns * Sv + a_ns * Nv - (e ? s1[j] : s0[j]),
-                                            a_c, inv_a_c, lo_a_c);
-                    const double nw = relaxed<GS1>(om1, C, omega, gs);
+                    const double nw = cv_upd<GS1, FAST>(e ? ae1[j] : ae0[j], E, e ? aw1[j] : aw0[j], W, a_ns, Sv, Nv, e ? s1[j] : s0[j], C, a_c, inv_a_c,
+                                                        lo_a_c, omega, om1);
                     if (e) v1[j] = nw; else v0[j] = nw;
                     p[e] = nw;
                 }
@@ -1491,8 +1510,8 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
                     const int off = flag[j] ^ parity, ir = kcol[j] + off;
                     if (ir <= nr - 2) {
                         const int c = cbase[j] + off;
-                        double gs = divc(a_e[ir] * psi[c + 1] + a_w[ir] * psi[c - 1] + a_ns * psi[c - nr] + a_ns * psi[c + nr] - rhs[c], a_c, inv_a_c);
-                        psi[c] = relaxed<GS1>(om1, psi[c], omega, gs);
+                        psi[c] = cv_upd<GS1, FAST, true>(a_e[ir], psi[c + 1], a_w[ir], psi[c - 1], a_ns, psi[c - nr], psi[c + nr], rhs[c], psi[c], a_c, inv_a_c,
+                                                         lo_a_c, omega, om1);
                     }
                 }
             }
@@ -1507,8 +1526,8 @@ __device__ __forceinline__ void cv_smooth(double* psi, const double* rhs, const 
             int ir = 1 + ((iz + 1 + parity) & 1) + 2 * k;
             if (ir <= nr - 2) {
                 int c = iz * nr + ir;
-                double gs = divc(a_e[ir] * psi[c + 1] + a_w[ir] * psi[c - 1] + a_ns * psi[c - nr] + a_ns * psi[c + nr] - rhs[c], a_c, inv_a_c);
-                psi[c] = relaxed<GS1>(om1, psi[c], omega, gs);
+                psi[c] = cv_upd<GS1, FAST, true>(a_e[ir], psi[c + 1], a_w[ir], psi[c - 1], a_ns, psi[c - nr], psi[c + nr], rhs[c], psi[c], a_c, inv_a_c, lo_a_c,
+                                                 omega, om1);
             }
         }
         __syncthreads();
@@ -1524,7 +1543,10 @@ __device__ __forceinline__ double cv_resid(const double* psi, const double* rhs,
     double lpsi = d2r - divc(d1r, rs[ir], rs[nr + ir]) + d2z;
     return lpsi - rhs[c];
 }
-template <bool GS1>
+// FAST (contracted arithmetic, see k_smooth_tile): every level's coefficient tables and right-hand side live in LDS scaled by
+// omega / a_C of the level (the tables as they are staged, the top-level rhs as it is loaded, a restricted defect as it is
+// stored), the updates are FMA chains (cv_upd) and the defect is read off the same chain (cv_defect_fast).
+template <bool GS1, bool FAST = false>
 __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, CoarseV V, double omega, double om1, int pre,
                                                         int post, const int* active) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1548,29 +1570,43 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
             const int iz = i / nr, ir = i - iz * nr;
             tmp[k] = g[(long)iz * V.ld0 + ir];
         }
-        for (int i = threadIdx.x; i < V.tab_total; i += blockDim.x) lds[V.off_tab[0] + i] = V.tabs[i];  // (one round trip for all levels)
+        if constexpr (FAST) {
+            // (a_e, a_w of level l scaled by omega / a_C; r_safe and its reciprocals are not used by the contracted forms)
+            for (int i = threadIdx.x; i < V.tab_total; i += blockDim.x) {
+                int l = 0;
+                while (l + 1 < V.n && i >= V.off_tab[l + 1] - V.off_tab[0]) ++l;
+                const double f = (i - (V.off_tab[l] - V.off_tab[0]) < 2 * V.nr[l]) ? omega * V.inv_a_c[l] : 1.0;
+                lds[V.off_tab[0] + i] = V.tabs[i] * f;
+            }
+        } else {
+            for (int i = threadIdx.x; i < V.tab_total; i += blockDim.x) lds[V.off_tab[0] + i] = V.tabs[i];  // (one round trip for all levels)
+        }
+        const double f0 = FAST ? omega * V.inv_a_c[0] : 1.0;
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
             const int i = threadIdx.x + k * (int)blockDim.x;
-            if (i < n) { rhs[i] = tmp[k]; psi[i] = 0.0; }
+            if (i < n) { rhs[i] = FAST ? tmp[k] * f0 : tmp[k]; psi[i] = 0.0; }
         }
         for (int i = threadIdx.x + RB * blockDim.x; i < n; i += blockDim.x) {  // levels beyond 5120 points
             const int iz = i / nr, ir = i - iz * nr;
-            rhs[i] = g[(long)iz * V.ld0 + ir];
+            const double x = g[(long)iz * V.ld0 + ir];
+            rhs[i] = FAST ? x * f0 : x;
             psi[i] = 0.0;
         }
     }
     __syncthreads();
     CV_STAMP(1);
+    const double inv_om = FAST ? 1.0 / omega : 1.0;
     for (int l = 0; l < V.n - 1; ++l) {
         double* psi = lds + V.off_psi[l];
         const double* rhs = lds + V.off_rhs[l];
         const double* tab = lds + V.off_tab[l];
-        const CvC kk{V.dr2[l], V.dz2[l], V.two_dr[l], V.inv_dr2[l], V.inv_dz2[l], V.inv_two_dr[l]};
+        const CvC kk{V.dr2[l], V.dz2[l], V.two_dr[l], V.inv_dr2[l], V.inv_dz2[l], V.inv_two_dr[l], FAST ? V.a_c[l] * inv_om : 1.0, omega};
         double* scr = lds + V.off_scr;
         const bool blk = cv_block_level(V.nz[l], V.nr[l]);  // (block levels: the smoother leaves the defect in the scratch field itself)
-        cv_smooth<GS1>(psi, rhs, tab, V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, pre, nullptr, 0,
-                       blk ? scr : nullptr, &kk);
+        const double ans_l = FAST ? V.a_ns[l] * (omega * V.inv_a_c[l]) : V.a_ns[l];  // (FAST: scaled like the tables)
+        cv_smooth<GS1, FAST>(psi, rhs, tab, V.nz[l], V.nr[l], ans_l, V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, pre, nullptr, 0,
+                             blk ? scr : nullptr, &kk);
         CV_STAMP(2 + 2 * l);
         // coarse rhs = restrict_full_weight(-(L*psi - rhs)); coarse e = 0
         double* rc = lds + V.off_rhs[l + 1];
@@ -1583,7 +1619,12 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
             const int wi = nrf - 2, ni = (V.nz[l] - 2) * wi;
             for (int i = threadIdx.x; i < ni; i += blockDim.x) {
                 const int iz = 1 + i / wi, ir = 1 + (i - (iz - 1) * wi);
-                scr[iz * nrf + ir] = -cv_resid(psi, rhs, rs, nrf, kk, iz, ir);
+                if constexpr (FAST) {
+                    const int c = iz * nrf + ir;
+                    scr[c] = cv_defect_fast<GS1>(psi[c], tab[ir], psi[c + 1], tab[nrf + ir], psi[c - 1], ans_l, psi[c - nrf], psi[c + nrf], rhs[c], kk);
+                } else {
+                    scr[iz * nrf + ir] = -cv_resid(psi, rhs, rs, nrf, kk, iz, ir);
+                }
             }
         }
         __syncthreads();
@@ -1593,7 +1634,8 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
             for (int i = threadIdx.x; i < ni; i += blockDim.x) {
                 const int ic = 1 + i / wi, jc = 1 + (i - (ic - 1) * wi);
                 const double* d = scr + (2 * ic) * nrf + 2 * jc;
-                rc[ic * nrc + jc] = fw9(d[0], d[-nrf], d[nrf], d[-1], d[1], d[-nrf - 1], d[-nrf + 1], d[nrf - 1], d[nrf + 1]);
+                const double rv = fw9(d[0], d[-nrf], d[nrf], d[-1], d[1], d[-nrf - 1], d[-nrf + 1], d[nrf - 1], d[nrf + 1]);
+                rc[ic * nrc + jc] = FAST ? rv * (omega * V.inv_a_c[l + 1]) : rv;
             }
             for (int i = threadIdx.x; i < nc; i += blockDim.x) {
                 const int ic = i / nrc, jc = i - ic * nrc;
@@ -1606,7 +1648,8 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
     }
     {
         const int l = V.n - 1;  // base case: 50 sweeps (multigrid_solve.py:293)
-        cv_smooth<GS1>(lds + V.off_psi[l], lds + V.off_rhs[l], lds + V.off_tab[l], V.nz[l], V.nr[l], V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, 50);
+        cv_smooth<GS1, FAST>(lds + V.off_psi[l], lds + V.off_rhs[l], lds + V.off_tab[l], V.nz[l], V.nr[l],
+                             FAST ? V.a_ns[l] * (omega * V.inv_a_c[l]) : V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, 50);
         CV_STAMP(20);
     }
     for (int l = V.n - 2; l >= 0; --l) {
@@ -1636,8 +1679,8 @@ __global__ void __launch_bounds__(1024) k_vcycle_coarse(Fld eF, Fld rhsF, Coarse
             __syncthreads();
         }
         CV_STAMP(21 + 2 * l);
-        cv_smooth<GS1>(psi, lds + V.off_rhs[l], lds + V.off_tab[l], nzf, nrf, V.a_ns[l], V.a_c[l], V.inv_a_c[l], V.lo_a_c[l], omega, om1, post,
-                       blk ? pc : nullptr, nrc);
+        cv_smooth<GS1, FAST>(psi, lds + V.off_rhs[l], lds + V.off_tab[l], nzf, nrf, FAST ? V.a_ns[l] * (omega * V.inv_a_c[l]) : V.a_ns[l], V.a_c[l],
+                             V.inv_a_c[l], V.lo_a_c[l], omega, om1, post, blk ? pc : nullptr, nrc);
         CV_STAMP(22 + 2 * l);
     }
     {
@@ -2426,6 +2469,11 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {  // result in eve
 #undef SCPN_U32_STEP
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+// FAST (contracted arithmetic, see k_smooth_tile): the blend is one product + one FMA, and the residual is the stencil form
+// a_E E + a_W W + a_NS (N + S) - a_C psi - Source as one FMA chain (six operations per point instead of 31; the waves fetch
+// a_e / a_w of the lane's columns where the exact form fetches r_safe and its reciprocal).  The divertor-row gradient keeps the
+// exact quotients: it decides a discrete quantity (the arg-min of |grad psi|).
+template <bool FAST = false>
 __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
                                                              double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
                                                              double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm,
@@ -2490,7 +2538,8 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
     // two columns now, behind the row loads, and hands them to the other waves through LDS at the barrier below
     const bool int_x = own_x && c0 >= 1 && c0 <= nr - 2, int_y = own_y && c0 + 1 <= nr - 2;  // (c0 + 1 >= 1 always)
     {
-        const double* const arr = w == 0 ? L.r_safe : (w == 1 ? L.r_inv : (w == 2 ? L.r_inv_lo : lazy_nm));
+        const double* const arr = FAST ? (w == 0 ? L.a_e : (w == 1 ? L.a_w : (w == 2 ? nullptr : lazy_nm)))
+                                       : (w == 0 ? L.r_safe : (w == 1 ? L.r_inv : (w == 2 ? L.r_inv_lo : lazy_nm)));
         // r_safe, 1/r_safe: 1.0; low word: 0.0; -mu0 R: 0.0 outside the interior, 1.0 when the source field already holds the source
         const double* const dflt = &g_const_f64[(w <= 1 || (w == 3 && !lazy_nm)) ? 1 : 0];
         const bool have = arr != nullptr;
@@ -2504,8 +2553,13 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
     for (int i = 0; i < BL_NROWS; ++i) {
         const int lz = w + BL_NW * i, gz = z0 + lz;
         double2 vi;
-        vi.x = om_alpha * pc[i].x + alpha * pn[i].x;
-        vi.y = om_alpha * pc[i].y + alpha * pn[i].y;
+        if constexpr (FAST) {
+            vi.x = __builtin_fma(alpha, pn[i].x, om_alpha * pc[i].x);
+            vi.y = __builtin_fma(alpha, pn[i].y, om_alpha * pc[i].y);
+        } else {
+            vi.x = om_alpha * pc[i].x + alpha * pn[i].x;
+            vi.y = om_alpha * pc[i].y + alpha * pn[i].y;
+        }
         if (lz >= 1 && lz <= BL_WZ && gz < nz) {  // owned row (wave-uniform)
             dsx += fabs(pn[i].x - pc[i].x);
             dsy += fabs(pn[i].y - pc[i].y);
@@ -2527,6 +2581,7 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
     // from the tile; lanes whose column is not an interior grid column compute on clamped copies and are dropped after the rows
     const double rs0 = sh_coef[0][lane], rs1 = sh_coef[1][lane], ri0 = sh_coef[2][lane], ri1 = sh_coef[3][lane];
     const double rl0 = sh_coef[4][lane], rl1 = sh_coef[5][lane], nm0 = sh_coef[6][lane], nm1 = sh_coef[7][lane];
+    const double fnm0 = nm0 * lz_sc, fnm1 = nm1 * lz_sc;
     double2 rv[BL_NROWS];
 #pragma unroll
     for (int i = 0; i < BL_NROWS; ++i) {
@@ -2541,6 +2596,13 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
         // Source = (-mu0 R) * (J_raw * scale) when the source field holds J_raw (lazy source, see k_smooth_tile); otherwise the
         // factors are 1.0 (exact identity).  Branch- and select-free: for scale == 0 the product is +-0 where k_source writes
         // (-mu0 R) * 0.0 -- the same |r| (only the sign of a zero source can differ, for finite J_raw).
+        if constexpr (FAST) {
+            // (rs0 / ri0 hold a_e / a_w of the even column, rs1 / ri1 of the odd one; fnm = (-mu0 R) * scale)
+            const double nsx = N.x + S.x, nsy = N.y + S.y;
+            rv[i].x = __builtin_fma(rs0, py, __builtin_fma(ri0, Wn, __builtin_fma(L.a_ns, nsx, __builtin_fma(-fnm0, sv[i].x, -L.a_c * px))));
+            rv[i].y = __builtin_fma(rs1, En, __builtin_fma(ri1, px, __builtin_fma(L.a_ns, nsy, __builtin_fma(-fnm1, sv[i].y, -L.a_c * py))));
+            continue;
+        }
         const double sx = nm0 * (sv[i].x * lz_sc), sy = nm1 * (sv[i].y * lz_sc);
         const double d2rx = divc4(py - 2.0 * px + Wn, L.dr2, L.inv_dr2, L.lo_dr2);
         const double d2ry = divc4(En - 2.0 * py + px, L.dr2, L.inv_dr2, L.lo_dr2);

@@ -645,10 +645,14 @@ static Fld vcycle(Solver* h, Fld in0, Fld bufA, Fld bufB, Fld src0, double omega
         std::call_once(attr_once, [] {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vcycle_coarse<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vcycle_coarse<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vcycle_coarse<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vcycle_coarse<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         });
         ProfScope ps(h, "vcycle_coarse", 1);
         // (omega == 1.0: the instantiation whose relaxation steps are single fmas, as in the tile smoother)
-        auto kern = (omega == 1.0 && gauss_seidel_forms()) ? &k_vcycle_coarse<true> : &k_vcycle_coarse<false>;
+        const bool gs1 = omega == 1.0 && gauss_seidel_forms();
+        auto kern = h->arith == 1 ? (gs1 ? &k_vcycle_coarse<true, true> : &k_vcycle_coarse<false, true>)
+                                  : (gs1 ? &k_vcycle_coarse<true> : &k_vcycle_coarse<false>);
         SCPN_LAUNCH(kern, dim3(B), dim3(1024), H.cv_lds, h->stream, cur[lc], rhs_of(lc), H.cv, omega, 1.0 - omega, pre, post, active);
         top = lc;
     } else {
@@ -1134,7 +1138,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             gq.two_dz = 2.0 * L0.dz; gq.inv_two_dz = 1.0 / gq.two_dz; gq.lo_two_dz = recip_lo(gq.two_dz);
             gq.dr = L0.dr; gq.inv_dr = 1.0 / L0.dr; gq.lo_dr = recip_lo(L0.dr);
             static const int xcd_blend = [] { const char* e = std::getenv("SCPN_HIP_XCD_BLEND"); return e ? std::atoi(e) : 1; }();
-            SCPN_LAUNCH(k_blend_tile, dim3(cdiv(nr, BL_WR), cdiv(nz, BL_WZ), B), dim3(64 * BL_NW), 0, st, nxtF, curF, newF, bcF, srcF,
+            SCPN_LAUNCH((h->arith == 1 ? k_blend_tile<true> : k_blend_tile<false>), dim3(cdiv(nr, BL_WR), cdiv(nz, BL_WZ), B), dim3(64 * BL_NW), 0, st, nxtF, curF, newF, bcF, srcF,
                                (const Member*)h->d_st.p, L0, p->alpha, om_alpha, n_mask_rows, h->d_part1.p, h->d_pbad.p, h->d_part2.p,
                                h->d_part3.p, h->d_topo.p, nblk2, lazy ? (const double*)h->d_neg_mu0R.p : (const double*)nullptr, gq, xcd_blend);
         } else {
