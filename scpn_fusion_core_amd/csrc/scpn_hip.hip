@@ -775,8 +775,6 @@ static Solver* create_impl(int nr, int nz, int batch, const double* r_axis, cons
         {
             const char* e = std::getenv("SCPN_HIP_FUSED");
             h->use_fused = !(e && e[0] == '0');
-            const char* a = std::getenv("SCPN_HIP_ARITH");
-            h->arith = (a && (!std::strcmp(a, "1") || !std::strcmp(a, "contracted") || !std::strcmp(a, "fast"))) ? 1 : 0;
         }
         HIP_TRY(hipMemsetAsync(h->psi_slots.p, 0, sizeof(double) * 3 * n, h->stream));
         HIP_TRY(hipMemsetAsync(h->W.p, 0, sizeof(double) * n, h->stream));
@@ -2184,6 +2182,10 @@ int scpn_gs_create(scpn_gs** out, int nr, int nz, int batch, const double* r_axi
         int rc = S_create(&k, nr, nz, cnt, r_axis, z_axis, dr, dz);
         if (rc) { delete g; return rc; }
         k->ensemble_B = batch;
+        // (the environment default applies to resident handles only: the stateless operator API builds its solvers through
+        //  create_impl and is always exact)
+        const char* a = std::getenv("SCPN_HIP_ARITH");
+        k->arith = (a && (!std::strcmp(a, "1") || !std::strcmp(a, "contracted") || !std::strcmp(a, "fast"))) ? 1 : 0;
         g->kids.push_back(k);
         g->off.push_back(done);
         done += cnt;
