@@ -176,6 +176,10 @@ def main() -> int:
                          "ceil(total/gpus) per rank; overrides --batch and reports \"scaling\": \"strong\"")
     ap.add_argument("--grid", type=int, default=513)
     ap.add_argument("--check-every", type=int, default=8)
+    ap.add_argument("--arith", choices=("exact", "contracted"), default="contracted",
+                    help="arithmetic of the timed run (scpn_gs_set_arith): contracted = FMA chains, psi within 1e-10 max|psi| of the CPU "
+                         "reference (tests/test_gpu_fast_arith.py); exact = the reference's operation order, bit-exact operators.  The "
+                         "other mode is timed after the clock and reported under \"arithmetic_modes\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-newton", action="store_true", help="skip the Newton-lane figure reported beside the metric")
@@ -257,7 +261,8 @@ def main() -> int:
     table = shape_scan_member_table(cfg, total)  # config-5 scan: coil currents, I_p and kappa (coil heights) per member
     currents, targets = table["currents"][lo:hi], table["targets"][lo:hi]
     coil_r, coil_z = table["coil_r"][lo:hi], table["coil_z"][lo:hi]
-    es = EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, coil_r=coil_r, coil_z=coil_z, device=local_rank)
+    es = EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, coil_r=coil_r, coil_z=coil_z, device=local_rank,
+                        arithmetic=args.arith)
     n_pts = args.grid * args.grid
 
     if comm is None and world > 1:
@@ -273,29 +278,57 @@ def main() -> int:
         elif host_sync is not None:
             host_sync.barrier()
 
+    rank_t = {"solve_s": 0.0, "gather_wait_s": 0.0}  # this rank's share of the timed region (per_rank table of the line)
+
     def step():
+        t_a = time.perf_counter()
         es.fill_psi(0.0)
         res = es.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
+        t_b = time.perf_counter()
         if comm is not None:  # ensemble gather of the psi blocks over RCCL/xGMI (the path's only exchange step): launched
             comm.wait()       # asynchronously, it runs while the next step solves; every gather ends inside the timed region
             comm.allgather_psi(es, total=total)
+        rank_t["solve_s"] += t_b - t_a
+        rank_t["gather_wait_s"] += time.perf_counter() - t_b
         return res
 
     for _ in range(args.warmup):
         res = step()
     barrier()
+    rank_t["solve_s"] = rank_t["gather_wait_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+    t_last = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_t["final_barrier_s"] = time.perf_counter() - t_last  # the last gather + the wait for the slowest rank
     if comm is not None:
         elapsed = comm.allreduce_max(elapsed)
     elif host_sync is not None:
         elapsed = host_sync.allreduce_max(elapsed)
 
+    # ---- per-rank figures of the timed region (every rank sends one record over the rendezvous socket; after the clock) and, for
+    #      N > 1, the duration of ONE un-overlapped ensemble gather: a sub-linear curve can then be attributed
+    from scpn_fusion_core_amd.distributed import gather_rank_stats, rendezvous_port
+
+    gather_ms = None
+    if comm is not None:
+        comm.wait()
+        comm.barrier()
+        tg = time.perf_counter()
+        comm.allgather_psi(es, total=total)
+        comm.wait()
+        gather_ms = comm.allreduce_max(time.perf_counter() - tg) * 1e3
+    its_rank = [sum(r["picard_iterations"]) for r in res]
+    per_rank = gather_rank_stats(rank, world, {
+        "members": B, "solve_ms": round(rank_t["solve_s"] / args.steps * 1e3, 3), "gather_wait_ms": round(rank_t["gather_wait_s"] / args.steps * 1e3, 3),
+        "final_barrier_ms": round(rank_t["final_barrier_s"] * 1e3, 3), "picard_iterations_max": max(its_rank), "picard_iterations_min": min(its_rank),
+        "converged_members": sum(int(r["converged"]) for r in res)},
+        addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), port=rendezvous_port())
+
     # member 0 of the last timed solve, kept for the full-size parity figure reported with the CPU baseline
-    n_cpu = max(1, min(16, os.cpu_count() or 1, B))  # members the CPU leg solves (one per host core): ALL of them are compared
+    n_cpu = max(1, min(os.cpu_count() or 1, B))  # members the CPU leg solves (one per host core, all host cores if B allows): ALL of them are compared
     psi_gpu_cmp = [es.get_psi(m) for m in range(n_cpu)] if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     picard_gpu = [list(r["picard_iterations"]) for r in res]
     n_conv = sum(int(r["converged"]) for r in res)
@@ -309,6 +342,34 @@ def main() -> int:
     #      psi + coarse rhs + coarse e out -- what the PMC counters confirm, `traffic`) / its mean launch time.  The SURVEY
     #      8(d) per-point figures of the UNFUSED operator sequence (3 sweeps x 24 B + residual 24 + restriction 10 = 106 B/pt)
     #      are kept as `survey_8d_equivalent`: a statement about fusion, not about memory traffic.
+    # ---- the OTHER arithmetic mode on the same handle, timed the same way but outside the headline's clock (rank 0, N = 1)
+    arith_modes = None
+    if rank == 0 and world == 1:
+        other = "exact" if args.arith == "contracted" else "contracted"
+        psi_head = es.get_psi()
+        es.arithmetic = other
+        step()
+        es.sync()
+        to = time.perf_counter()
+        for _ in range(args.steps):
+            ores = step()
+        es.sync()
+        dto = (time.perf_counter() - to) / args.steps
+        psi_other = es.get_psi()
+        es.arithmetic = args.arith
+        o_its = [sum(r["picard_iterations"]) for r in ores]
+        arith_modes = {
+            args.arith: {"value": round(value, 3), "ms_per_step": round(elapsed / args.steps * 1e3, 2), "headline": True,
+                         "picard_iterations_per_member": [min(picard_total), max(picard_total)]},
+            other: {"value": round(B / dto, 3), "ms_per_step": round(dto * 1e3, 2), "headline": False,
+                    "picard_iterations_per_member": [min(o_its), max(o_its)], "converged_members": sum(int(r["converged"]) for r in ores)},
+            "psi_rel_linf_between_modes": float(np.abs(psi_other - psi_head).max() / np.abs(psi_head).max()),
+            "members_with_equal_iteration_counts": int(sum(a == b for a, b in zip(o_its, picard_total))),
+            "what": "exact = every expression in the reference's operation order (bit-exact linear operators); contracted = the same "
+                    "iteration with FMA chains and reciprocal multiplies (scpn_gs_set_arith, include/scpn_hip.h); both checked against the CPU "
+                    "reference: tests/test_gpu_parity.py / tests/test_gpu_fast_arith.py"}
+        del psi_head, psi_other
+
     roofline = None
     if not args.no_roofline and rank == 0:
         es.fill_psi(0.0)
@@ -421,7 +482,10 @@ def main() -> int:
             cpu["psi_rel_linf_vs_gpu"] = max(errs)  # the worst of the compared members
             cpu["members_compared"] = cores
             cpu["psi_rel_linf_vs_gpu_per_member"] = [float(f"{e:.3e}") for e in errs]
+            cpu["arithmetic_of_the_compared_gpu_run"] = args.arith
             cpu["picard_iterations_equal_on_all_compared_members"] = bool(all(same))
+            cpu["picard_iterations_max_abs_difference"] = int(max(max(abs(int(a) - int(b)) for a, b in zip(outs[m][0]["picard_iterations"], picard_gpu[m]))
+                                                                  if len(outs[m][0]["picard_iterations"]) == len(picard_gpu[m]) else 10**6 for m in range(cores)))
             cpu["picard_iterations_gpu_member0"] = picard_gpu[0]
             if not all(same):
                 cpu["picard_iterations_mismatch"] = {str(m): {"cpu": list(outs[m][0]["picard_iterations"]), "gpu": picard_gpu[m]}
@@ -462,10 +526,10 @@ def main() -> int:
     # ---- strict-parity gate (outside the timed region), all FIVE thresholds of
     #      validation/benchmark_freegs_public_example_reconstruction.py:491-497:
     #      (1) the harness's own native lane (:275-315: a supplied current density inside a supplied Dirichlet ring) solved on the device
-    #          on both public-example grids, compared with the flux map the imported reference function produced (data file
-    #          scpn_fusion_core_amd/data/freegs_native_lane.npz = tests/golden/freegs_native.npz, written by tests/golden/make_golden.py);
+    #          on both public-example grids, compared with the flux map the imported reference function produced (fixture
+    #          tests/golden/freegs_native.npz, written by tests/golden/make_golden.py);
     #      (2) the HIP free-boundary solve of the DIII-D-like case at 129^2 against the reference's own NumPy-lane flux map
-    #          (scpn_fusion_core_amd/data/d3d129_reference_lane.npz), current closure from the device's J_phi.
+    #          (tests/golden/d3d129_reference_lane.npz), current closure from the device's J_phi.
     parity = None
     if rank == 0:
         try:
@@ -474,7 +538,7 @@ def main() -> int:
                                                           same_case_profile_source_comparison, strict_parity_metrics)
 
             gated = ("psi_n_rmse", "axis_error_m", "boundary_max_abs_error_wb", "current_closure_relative_error", "xpoint_psi_n_error_max")
-            fn = np.load(ROOT / "scpn_fusion_core_amd" / "data" / "freegs_native_lane.npz")
+            fn = np.load(ROOT / "tests" / "golden" / "freegs_native.npz")
             native = {}
             for cid in ("freegs_01_test_tokamak_freeboundary", "freegs_16_diiid_public_example"):
                 spec = json.loads(str(fn[f"{cid}_spec"]))
@@ -485,7 +549,7 @@ def main() -> int:
                                                           spec["plasma_current_a"], spec["xpoints"], native_plasma_psi=dev)
                 native[cid] = {**{k: rec[k] for k in gated}, "psi_max_abs_error_wb": float(np.abs(dev - fn[f"{cid}_native_plasma_psi"]).max()),
                                "checks": rec["checks"], "pass": bool(rec["pass"] and len(rec["checks"]) == 5)}
-            g = np.load(ROOT / "scpn_fusion_core_amd" / "data" / "d3d129_reference_lane.npz")  # data only: the reference lane's flux map
+            g = np.load(ROOT / "tests" / "golden" / "d3d129_reference_lane.npz")  # data only: the reference lane's flux map
             gcfg = diiid_like_cfg(129)
             with EnsembleSolver(gcfg, batch=2, device=local_rank) as ges:
                 ges.solve_free_boundary(max_outer_iter=20, tol=1e-4)
@@ -552,10 +616,16 @@ def main() -> int:
                                      "PF-coil Green's-function boundary, Picard+V-cycle tol 1e-8 (BASELINE configs[4] = configs[2]'s solve x 256)",
                        "grid": args.grid, "members_per_gpu": per_rank, "members_rank0": B, "global_members": total,
                        "kappa_range_rank0": [round(float(table["kappa"][lo:hi].min()), 4), round(float(table["kappa"][lo:hi].max()), 4)],
+                       "arithmetic": args.arith,
                        "parallelism": f"ensemble-sharded x{world}", "rccl": comm.info() if comm is not None else ({"error": comm_error, "gather": "not run"} if comm_error else None),
                        "converged_members_rank0": n_conv, "outer_iterations": [min(outer), max(outer)],
                        "picard_iterations_per_member": [min(picard_total), max(picard_total)]},
         }
+        line["per_rank"] = per_rank
+        if gather_ms is not None:
+            line["gather_ms"] = round(gather_ms, 3)  # one ensemble all-gather on its own (in the timed steps it overlaps the next solve)
+        if arith_modes is not None:
+            line["arithmetic_modes"] = arith_modes
         if roofline is not None:
             line["roofline"] = roofline
         if cpu is not None:

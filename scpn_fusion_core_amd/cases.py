@@ -73,12 +73,15 @@ def diiid_like_cfg(n, tol=1e-8, max_iter=1000, alpha=0.12):
 
 
 def scan_member_table(cfg: dict, total: int, seed: int = 2026) -> tuple[np.ndarray, np.ndarray]:
-    """The coil-current half of the config-5 scan: coil currents I_k*(1+0.1u) and plasma current Ip*(1+0.1u),
-    u ~ U(-1, 1) from ``np.random.default_rng(seed)``; returns (currents [total, n_coils], I_p targets [total])."""
+    """The coil-current half of the config-5 scan: coil currents I_k*(1+0.1u) from ``np.random.default_rng(seed)`` and plasma current
+    Ip*(1+0.1u) from ``np.random.default_rng([seed, 7])``, u ~ U(-1, 1); returns (currents [total, n_coils], I_p targets [total]).
+    Row m of both is the same for every ``total``."""
     base = np.array([c["current"] for c in cfg["coils"]], dtype=np.float64)
     rng = np.random.default_rng(seed)
     currents = base[None, :] * (1.0 + 0.1 * rng.uniform(-1.0, 1.0, size=(total, base.size)))
-    targets = cfg["physics"]["plasma_current_target"] * (1.0 + 0.1 * rng.uniform(-1.0, 1.0, size=total))
+    # (own stream, as kappa below: member m's I_p must not depend on `total` -- member 7 of a 32-member weak-scaling block IS member 7
+    #  of the 256-member strong-scaling ensemble.  Rounds 1-5 drew the targets behind the (total, n) current block of ONE generator.)
+    targets = cfg["physics"]["plasma_current_target"] * (1.0 + 0.1 * np.random.default_rng([seed, 7]).uniform(-1.0, 1.0, size=total))
     return currents, targets
 
 

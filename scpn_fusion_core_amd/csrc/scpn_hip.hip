@@ -1502,8 +1502,11 @@ static void newton_solve_impl(Solver* h, const scpn_picard_params* p, const scpn
                     SCPN_LAUNCH(kern, dim3(B), dim3(1024), 0, st, V, buf(XV), buf(RES), (const double*)buf(RHS), (const double*)buf(DG),
                                        (const double*)buf(IVD), stride, B, L0, h->nt_gm.p, h->nt_st.p, precond, maxit, d_nsolve);
                 };
-                if (nint <= 1024L * 2) launch(k_gm_cycle_small<2>);
-                else if (nint <= 1024L * GM_SMALL_PTS) launch(k_gm_cycle_small<GM_SMALL_PTS>);
+                // (the register variants keep (point index, column) of a point in ONE signed word -- index in bits 0..19, column from
+                //  bit 20 up: a thin grid whose columns reach 2048 or whose pitched size reaches 2^20 takes the LDS variant instead)
+                const bool packs = nr < 2048 && (long)nz * ld < (1L << 20);
+                if (packs && nint <= 1024L * 2) launch(k_gm_cycle_small<2>);
+                else if (packs && nint <= 1024L * GM_SMALL_PTS) launch(k_gm_cycle_small<GM_SMALL_PTS>);
                 else {
                     static std::once_flag once;
                     std::call_once(once, [] {

@@ -152,6 +152,19 @@ def gather_rows(rank: int, world: int, rows: np.ndarray, total: int, *, addr: st
     return np.concatenate(blocks, axis=0)
 
 
+def gather_rank_stats(rank: int, world: int, stats: dict, *, addr: str, port: int) -> list[dict]:
+    """One small JSON record per rank, assembled on every rank in rank order (the ``per_rank`` table of the bench line: what makes
+    a sub-linear scaling curve attributable to imbalance, to the gather or to the launch path).  ``world == 1``: no socket is opened."""
+    import json
+
+    rec = json.dumps({"rank": int(rank), **stats}).encode()
+    parts = [rec] if world == 1 else exchange(rank, world, rec, addr=addr, port=port)
+    out = [json.loads(p.decode()) for p in parts]
+    if [r.get("rank") for r in out] != list(range(world)):
+        raise ValueError(f"per-rank records out of order: {[r.get('rank') for r in out]}")
+    return out
+
+
 def free_port(addr: str = "127.0.0.1") -> int:
     """A TCP port that is free now AND whose successor is free (the rendezvous may use ``port + 1``)."""
     for _ in range(64):

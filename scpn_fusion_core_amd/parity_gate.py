@@ -56,16 +56,25 @@ def native_profile_source_reconstruction(r_axis, z_axis, boundary_psi, jtor, *, 
     """
     r_axis, z_axis = np.asarray(r_axis, dtype=np.float64), np.asarray(z_axis, dtype=np.float64)
     boundary_psi, jtor = np.asarray(boundary_psi, dtype=np.float64), np.asarray(jtor, dtype=np.float64)
-    if boundary_psi.shape != jtor.shape:
-        raise ValueError("boundary_psi and jtor must have matching shapes")
-    if boundary_psi.shape[-2:] != (r_axis.size, z_axis.size) or boundary_psi.ndim not in (2, 3):
-        raise ValueError("boundary_psi must have shape len(R) x len(Z)")
-    if r_axis.size < 3 or z_axis.size < 3:
-        raise ValueError("native reconstruction requires at least 3x3 grid")
-    if not np.all(np.isfinite(boundary_psi)) or not np.all(np.isfinite(jtor)):
-        raise ValueError("native reconstruction inputs must be finite")
-    if not np.all(np.diff(r_axis) > 0.0) or not np.all(np.diff(z_axis) > 0.0):
-        raise ValueError("native reconstruction axes must be strictly increasing")
+    steps = {"R": np.diff(r_axis), "Z": np.diff(z_axis)}
+
+    def uniform(d):  # the device operator takes ONE spacing per direction (axis[1] - axis[0]); the reference's matrix uses mean(diff)
+        return d.size > 0 and bool(np.all(np.abs(d - d[0]) <= 1.0e-9 * np.abs(d[0])))
+
+    # (condition that must hold, the reference's message when it does not) -- evaluated in the reference's order (:280-289)
+    requirements = (
+        (boundary_psi.shape == jtor.shape, "boundary_psi and jtor must have matching shapes"),
+        (boundary_psi.ndim in (2, 3) and boundary_psi.shape[-2:] == (r_axis.size, z_axis.size), "boundary_psi must have shape len(R) x len(Z)"),
+        (min(r_axis.size, z_axis.size) >= 3, "native reconstruction requires at least 3x3 grid"),
+        (bool(np.isfinite(boundary_psi).all() and np.isfinite(jtor).all()), "native reconstruction inputs must be finite"),
+        (all(bool((d > 0.0).all()) for d in steps.values()), "native reconstruction axes must be strictly increasing"),
+        # this lane only (the reference accepts any increasing axes and builds its matrix from the mean spacing): the device stencil is
+        # that of a uniform grid, so non-uniform axes would silently solve a different system
+        (all(uniform(d) for d in steps.values()), "native reconstruction on the device requires uniformly spaced axes"),
+    )
+    for holds, message in requirements:
+        if not holds:
+            raise ValueError(message)
     # device layout is (nz, nr): transpose the R-slow maps; right-hand side -mu0 R J (:305), ring from boundary_psi (:306-309)
     source = np.ascontiguousarray(np.swapaxes(-MU0 * r_axis[:, np.newaxis] * jtor, -1, -2))
     ring = np.swapaxes(boundary_psi, -1, -2)

@@ -854,9 +854,6 @@ def gen_freegs_native():
         print(cid, {k: rec[k] for k in ("psi_n_rmse", "axis_error_m", "boundary_max_abs_error_wb", "current_closure_relative_error",
                                         "xpoint_psi_n_error_max", "native_plasma_psi_rmse")})
     save("freegs_native.npz", **out)
-    # the same data file beside the package: bench.py's parity block reads it from there (it does not read tests/)
-    import shutil
-    shutil.copyfile(OUT / "freegs_native.npz", OUT.parents[1] / "scpn_fusion_core_amd" / "data" / "freegs_native_lane.npz")
 
 
 if __name__ == "__main__":

@@ -302,6 +302,7 @@ def test_strong_scaling_plan_and_two_rank_shape_scan(tmp_path):
     cfg = iter_like_cfg(17)
     t5, t256 = shape_scan_member_table(cfg, STRONG_TOTAL), shape_scan_member_table(cfg, 256)
     assert np.array_equal(t5["coil_z"], t256["coil_z"][:STRONG_TOTAL]) and np.array_equal(t5["currents"], t256["currents"][:STRONG_TOTAL])
+    assert np.array_equal(t5["targets"], t256["targets"][:STRONG_TOTAL]) and np.ptp(t256["targets"]) > 2.0  # I_p too (own generator stream), +-10 % of 15
     assert 1.5 <= t256["kappa"].min() < 1.52 and 1.88 < t256["kappa"].max() <= 1.9
     assert np.allclose(t256["coil_z"][:, 0], 1.2 * t256["kappa"] * 2.0) and np.allclose(t256["coil_z"][:, 3], -1.1 * 1.2 * t256["kappa"] * 2.0)
     assert np.array_equal(t256["coil_z"][:, 4], np.zeros(256)) and np.array_equal(t256["coil_r"], np.tile(t256["coil_r"][0], (256, 1)))
@@ -323,3 +324,46 @@ def test_strong_scaling_plan_and_two_rank_shape_scan(tmp_path):
         got = np.load(tmp_path / f"strong{rank}.npz")
         assert list(got["plan"]) == [STRONG_TOTAL, a, b, b - a, 3] and str(got["scaling"]) == "strong"
         assert np.array_equal(got["psi"], serial)
+
+
+def _stats_worker(rank, world, port, out_dir):
+    import json
+
+    from scpn_fusion_core_amd.distributed import gather_rank_stats
+
+    rows = gather_rank_stats(rank, world, {"members": 32, "solve_ms": 100.0 + rank, "gather_wait_ms": 0.5 * rank, "final_barrier_ms": 1.0,
+                                           "picard_iterations_max": 419 - rank, "picard_iterations_min": 413, "converged_members": 32},
+                             addr="127.0.0.1", port=port)
+    with open(os.path.join(out_dir, f"stats{rank}.json"), "w") as fh:
+        json.dump(rows, fh)
+
+
+def test_per_rank_table_of_the_bench_line(tmp_path):
+    """``bench.py``'s ``per_rank`` table: one record per rank, in rank order, the same on every rank -- the keys a first 8-GPU run
+    needs to tell imbalance (solve_ms, picard_iterations_max) from gather cost (gather_wait_ms, final_barrier_ms)."""
+    import json
+
+    from scpn_fusion_core_amd.distributed import gather_rank_stats
+
+    one = gather_rank_stats(0, 1, {"members": 32}, addr="127.0.0.1", port=1)  # world 1: no socket
+    assert one == [{"rank": 0, "members": 32}]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_stats_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    tables = [json.load(open(tmp_path / f"stats{r}.json")) for r in range(2)]
+    assert tables[0] == tables[1] and [row["rank"] for row in tables[0]] == [0, 1]
+    for row in tables[0]:
+        assert {"rank", "members", "solve_ms", "gather_wait_ms", "final_barrier_ms", "picard_iterations_max", "picard_iterations_min",
+                "converged_members"} <= set(row)
+    assert tables[0][1]["solve_ms"] == 101.0 and tables[0][1]["picard_iterations_max"] == 418
+    # the bench line wires exactly this table (static check of the source: bench.py needs a GPU to run)
+    src = open(os.path.join(os.path.dirname(__file__), "..", "bench.py")).read()
+    assert 'line["per_rank"] = per_rank' in src and "gather_rank_stats(rank, world" in src and '"gather_ms"' in src

@@ -289,7 +289,8 @@ def test_native_lane_validation_precedes_the_device():
     ok = np.zeros((9, 7))
     for args, msg in (((r, z, ok, np.zeros((9, 6))), "matching shapes"), ((r, z, ok.T, ok.T), "len\\(R\\) x len\\(Z\\)"),
                       ((r[:2], z, ok[:2], ok[:2]), "at least 3x3"), ((r, z, np.full((9, 7), np.nan), ok), "must be finite"),
-                      ((r[::-1], z, ok, ok), "strictly increasing")):
+                      ((r[::-1], z, ok, ok), "strictly increasing"),
+                      ((np.concatenate([r[:-1], [r[-1] + 0.3]]), z, ok, ok), "uniformly spaced")):  # (this lane only: one spacing per direction)
         with pytest.raises(ValueError, match=msg):
             lane(*args)
     with pytest.raises(ValueError, match="plasma_current_a"):
