@@ -476,6 +476,34 @@ def main() -> int:
                                            "by oracle/numpy_lane.py, extrapolated to member 0's iteration count"}
         except Exception as exc:  # the baseline line must not be lost to the optional lane
             cpu["numpy_lane"] = {"error": str(exc)}
+        # third CPU lane -- north_star's literal comparator: the polyglot Picard + damped-Jacobi lane (core/jax_gs_solver.py:58-167,
+        # harness benchmarks/polyglot_gs_solver_comparison.py) at 513 x 513 with the parameters of validation/polyglot/gs_picard_reference.toml:
+        # the NumPy restatement on one core (what the harness's Python row runs), the C port on one core and on `cores` cores (one solve
+        # each, concurrently).  The device figure is configs.polyglot_picard_jacobi_513; the ratio is formed below once both exist.
+        try:
+            from benchmarks.configs import POLYGLOT_CASE_513 as pc
+            from oracle import numpy_lane as npl
+
+            kw = dict(mu0=pc["mu0"], n_picard=pc["n_picard"], n_jacobi=pc["n_jacobi"], alpha=pc["alpha"], omega_j=pc["omega_j"], beta_mix=pc["beta_mix"])
+            pos = (pc["R_min"], pc["R_max"], pc["Z_min"], pc["Z_max"], pc["NR"], pc["NZ"], pc["Ip_target"])
+            tp = time.perf_counter()
+            psi_np = npl.polyglot_picard_jacobi(*pos, **kw)
+            t_np = time.perf_counter() - tp
+            tp = time.perf_counter()
+            psi_c = orc.gs_solve_np(*pos, pc["mu0"], pc["n_picard"], pc["n_jacobi"], pc["alpha"], pc["omega_j"], pc["beta_mix"])
+            t_c1 = time.perf_counter() - tp
+            tp = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=cores) as pool:
+                list(pool.map(lambda _: orc.gs_solve_np(*pos, pc["mu0"], pc["n_picard"], pc["n_jacobi"], pc["alpha"], pc["omega_j"], pc["beta_mix"]), range(cores)))
+            t_cn = time.perf_counter() - tp
+            cpu["polyglot_513"] = {"n_picard": pc["n_picard"], "n_jacobi": pc["n_jacobi"], "numpy_one_core_ms": round(t_np * 1e3, 2),
+                                   "c_port_one_core_ms": round(t_c1 * 1e3, 2), "c_port_all_cores_solves_per_s": round(cores / t_cn, 2), "cores": cores,
+                                   "numpy_vs_c_port_psi_rel_linf": float(np.abs(psi_np - psi_c).max() / np.abs(psi_np).max()),
+                                   "psi_axis": float(psi_np.max()),
+                                   "sample": "one 513x513 solve with the TOML's n_picard x n_jacobi (8 x 16 damped-Jacobi steps); the lane's defaults "
+                                             "(80 x 200) cost 125 x as many steps on every lane"}
+        except Exception as exc:
+            cpu["polyglot_513"] = {"error": f"{type(exc).__name__}: {exc}"}
         if psi_gpu_cmp is not None:  # EVERY member the CPU leg solved against the device's result of the timed run (same inputs, full size)
             errs = [float(np.abs(psi_gpu_cmp[m] - outs[m][0]["psi"]).max() / np.abs(outs[m][0]["psi"]).max()) for m in range(cores)]
             same = [list(outs[m][0]["picard_iterations"]) == picard_gpu[m] for m in range(cores)]
@@ -636,6 +664,15 @@ def main() -> int:
             line["newton_fd_mg"] = newton
         if configs is not None:
             line["configs"] = configs
+            try:  # north_star's literal comparison: device lane vs the CPU lanes of the same 513x513 polyglot case
+                pg, pcb = configs["polyglot_picard_jacobi_513"]["toml_parameters"], cpu["polyglot_513"]
+                configs["polyglot_picard_jacobi_513"]["vs_cpu"] = {
+                    "hip_solves_per_s": round(1e3 / pg["hip_ms"], 2), "x_numpy_one_core": round(pcb["numpy_one_core_ms"] / pg["hip_ms"], 1),
+                    "x_c_port_one_core": round(pcb["c_port_one_core_ms"] / pg["hip_ms"], 1),
+                    "x_c_port_all_cores": round((1e3 / pg["hip_ms"]) / pcb["c_port_all_cores_solves_per_s"], 2), "cores": pcb["cores"],
+                    "psi_axis_equal": bool(pg["psi_axis"] == pcb["psi_axis"])}
+            except (KeyError, TypeError, ZeroDivisionError):
+                pass
         if strong_n1 is not None:
             line["strong_scaling_n1"] = strong_n1
         if world > 1 and comm is None:  # the N>1 metric includes the ensemble gather: without it the line is not a scaling point

@@ -16,6 +16,11 @@ import numpy as np
 PUBLISHED_SMOOTHER_513 = {"numpy_s": 18.85, "wgpu_f32_s": 0.66, "source": "validation/reports/gpu_gs_solver_benchmark.json:35"}
 
 
+# validation/polyglot/gs_picard_reference.toml (values restated) on a 513 x 513 grid
+POLYGLOT_CASE_513 = {"R_min": 1.0, "R_max": 3.0, "Z_min": -1.2, "Z_max": 1.2, "NR": 513, "NZ": 513, "Ip_target": 1.0e6,
+                     "mu0": 1.2566370614359173e-6, "n_picard": 8, "n_jacobi": 16, "alpha": 0.1, "omega_j": 0.6666666666666666, "beta_mix": 0.5}
+
+
 def _best_of(fn, reps=3):
     ts, out = [], None
     for _ in range(reps):
@@ -121,6 +126,54 @@ def measure_configs(device: int = 0, members: int = 32, check_every: int = 8) ->
             "memoised_setup": "vacuum field per handle: calculate_vacuum_field of an unchanged coil set (1.8 ms for 32 members at 513^2) is evaluated once per resident handle, the reference pays it in every solve_equilibrium call"}
     except Exception as exc:  # an optional figure must not cost the bench line
         out["config4_transport_coupled_loop_513"] = {"error": str(exc)}
+
+    # ---- the polyglot Picard + damped-Jacobi lane at 513^2 (north_star's literal comparator; harness
+    #      benchmarks/polyglot_gs_solver_comparison.py times gs_solve_np(**case) of validation/polyglot/gs_picard_reference.toml)
+    try:
+        from scpn_fusion_core_amd.polyglot import gs_solve_hip
+
+        out["polyglot_picard_jacobi_513"] = {"unit": "ms per solve (ONE 513x513 equilibrium, host arrays in and out)", "case": dict(POLYGLOT_CASE_513)}
+        for label, kw in (("toml_parameters", {}), ("lane_defaults", {"n_picard": 80, "n_jacobi": 200})):
+            case = {**POLYGLOT_CASE_513, **kw}
+            gs_solve_hip(**case)
+            t, psi = _best_of(lambda: gs_solve_hip(**case), 3)
+            out["polyglot_picard_jacobi_513"][label] = {"n_picard": case["n_picard"], "n_jacobi": case["n_jacobi"], "hip_ms": round(t * 1e3, 3),
+                                                        "psi_axis": float(psi.max())}
+    except Exception as exc:
+        out["polyglot_picard_jacobi_513"] = {"error": f"{type(exc).__name__}: {exc}"}
+
+    # ---- the dispatcher seam (counterpart of benchmarks/bench_dispatcher_kernel_tiers.py:35,138: multigrid_solve through dispatch()):
+    #      host buffers in and out per call (seam B3) vs the same V-cycles on a resident handle
+    try:
+        from scpn_fusion_core_amd import multi_compat
+
+        n = 257
+        psi0, source, _rr, r, z = bench_problem(n, n)
+        fn = multi_compat.dispatch("multigrid_solve")
+        args = (source, np.zeros_like(source), float(r[0]), float(r[-1]), float(z[0]), float(z[-1]), n, n)
+        fn(*args, tol=1e-8, max_cycles=50)
+        t_seam, res = _best_of(lambda: fn(*args, tol=1e-8, max_cycles=50), 3)
+        cyc = int(res[2])
+        cfgd = iter_like_cfg(n)
+        cfgd["dimensions"] = {"R_min": float(r[0]), "R_max": float(r[-1]), "Z_min": float(z[0]), "Z_max": float(z[-1])}
+        with EnsembleSolver(cfgd, batch=1, device=device, arithmetic="exact") as es:
+            es.set_source(source, 0)
+
+            def resident():
+                es.fill_psi(0.0)
+                for _ in range(cyc):
+                    es.vcycle(omega=1.0, pre_smooth=3, post_smooth=3, min_grid=5)
+                es.sync()
+            resident()
+            t_res, _ = _best_of(resident, 3)
+        out["dispatcher_multigrid_solve_257"] = {
+            "unit": "ms per call", "tier": "GPU", "cycles": cyc, "residual": float(res[1]), "converged": bool(res[3]),
+            "dispatch_host_buffers_ms": round(t_seam * 1e3, 3), "resident_handle_same_cycles_ms": round(t_res * 1e3, 3),
+            "seam_overhead_ms": round((t_seam - t_res) * 1e3, 3),
+            "workload": "dispatch('multigrid_solve')(source, psi_bc, ...) at 257x257, tol 1e-8 (host arrays copied in and out, hierarchy built per call, "
+                        "residual checked per cycle) vs the same number of V-cycles on a resident handle"}
+    except Exception as exc:
+        out["dispatcher_multigrid_solve_257"] = {"error": f"{type(exc).__name__}: {exc}"}
 
     # ---- smoother benchmark (resident fp64, 200 sweeps, omega 1.3)
     n = 513

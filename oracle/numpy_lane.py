@@ -132,3 +132,39 @@ def picard_iteration(psi: np.ndarray, psi_bc: np.ndarray, rr: np.ndarray, zz: np
     new[0, :], new[-1, :], new[:, 0], new[:, -1] = psi_bc[0, :], psi_bc[-1, :], psi_bc[:, 0], psi_bc[:, -1]
     diff = float(np.mean(np.abs(new - psi)))
     return (1.0 - alpha) * psi + alpha * new, diff
+
+
+def polyglot_picard_jacobi(r_min: float, r_max: float, z_min: float, z_max: float, nr: int, nz: int, ip_target: float, *, mu0: float = 4e-7 * np.pi,
+                           n_picard: int = 80, n_jacobi: int = 200, alpha: float = 0.1, omega_j: float = 0.667, beta_mix: float = 0.5) -> np.ndarray:
+    """The "polyglot" fixed-boundary lane in NumPy (core/jax_gs_solver.py:58-167 ``gs_solve_np``: zero ring, Gaussian seed,
+    ``n_picard`` x [L-mode source normalised to ``ip_target`` from the interior maximum, ``n_jacobi`` damped-Jacobi steps, blend]).
+    The lane the reference's benchmarks/polyglot_gs_solver_comparison.py times as its Python row -- here as the NumPy comparator of
+    ``polyglot.gs_solve_hip`` at 513 x 513 (bench.py ``configs.polyglot_picard_jacobi_513``).  The stencil coefficients are rebuilt
+    in every Jacobi step, as the reference does (its per-step cost is what is being compared)."""
+    r_axis, z_axis = np.linspace(r_min, r_max, nr), np.linspace(z_min, z_max, nz)
+    rr = np.meshgrid(r_axis, z_axis)[0]
+    dr, dz = r_axis[1] - r_axis[0], z_axis[1] - z_axis[0]
+    inner = (slice(1, -1), slice(1, -1))
+    psi = 0.01 * np.exp(-((rr - 0.5 * (r_min + r_max)) ** 2) / 0.5)
+    psi[[0, -1], :] = 0.0
+    psi[:, [0, -1]] = 0.0
+    for _ in range(n_picard):
+        # source: psi_N against the interior maximum and a zero boundary flux, clipped to [0, 1]
+        span = 0.0 - float(psi[inner].max())
+        if abs(span) < 1e-9:
+            span = float(np.sign(span)) * 1e-9 if span != 0 else 1e-9
+        psi_n = np.clip((psi - float(psi[inner].max())) / span, 0.0, 1.0)
+        shape = np.where((psi_n >= 0.0) & (psi_n < 1.0), 1.0 - psi_n, 0.0)
+        j_raw = beta_mix * (rr * shape) + (1.0 - beta_mix) * (shape / (mu0 * np.maximum(rr, 1e-10)))
+        rhs = -mu0 * rr * (j_raw * (ip_target / max(abs(np.sum(j_raw) * dr * dz), 1e-9)))
+        work = psi.copy()
+        for _ in range(n_jacobi):
+            r_safe = np.maximum(rr[inner], 1e-10)
+            dr2, dz2 = dr * dr, dz * dz
+            east, west = 1.0 / dr2 - 1.0 / (2.0 * r_safe * dr), 1.0 / dr2 + 1.0 / (2.0 * r_safe * dr)
+            gs = (east * work[1:-1, 2:] + west * work[1:-1, :-2] + (1.0 / dz2) * (work[:-2, 1:-1] + work[2:, 1:-1]) - rhs[inner]) / (2.0 / dr2 + 2.0 / dz2)
+            nxt = work.copy()
+            nxt[inner] = (1.0 - omega_j) * work[inner] + omega_j * gs
+            work = nxt
+        psi = (1.0 - alpha) * psi + alpha * work
+    return psi

@@ -1737,8 +1737,12 @@ __global__ void k_jacobi(Fld outF, Fld psiF, Fld srcF, Lvl L, const int* active)
 // LDS (double-buffered by step parity: ONE barrier per step).  Halo 6 (even: pairs stay aligned) >= S, window 36 x 116.
 // Out-of-domain cells hold clamped copies that no kept update or store reads, as in the smoother.  Same arithmetic as k_jacobi
 // (sanitised inputs, x / a_c through divc4, clip), bit-identical for finite x.
-template <int S>
-__global__ void __launch_bounds__(512, 6) k_jacobi_reg(Fld outF, Fld psiF, Fld srcF, Lvl L, const int* active) {
+// DAMPED: the damped-Jacobi step of the polyglot lane (core/jax_gs_solver.py:58-86, the arithmetic of k_jacobi_damped below:
+// a_NS * (S + N) association, no sanitising, no clip, psi <- (1 - omega_j) psi + omega_j * update) in the same blocked form --
+// Jacobi reads only OLD values, so S steps per launch are bit-identical to S launches of one step.
+template <int S, bool DAMPED = false>
+__global__ void __launch_bounds__(512, 6) k_jacobi_reg(Fld outF, Fld psiF, Fld srcF, Lvl L, const int* active, double omega_j = 1.0,
+                                                       double om1_j = 0.0) {
     constexpr int LZ = 48, NW = 8, NROWS = LZ / NW, H = 6;
     static_assert(S <= H, "the halo must cover the steps of one launch");
     __shared__ __attribute__((aligned(16))) double2 xch[2][NW][2][64];  // [step parity][wave][first / last row][lane]
@@ -1774,10 +1778,12 @@ __global__ void __launch_bounds__(512, 6) k_jacobi_reg(Fld outF, Fld psiF, Fld s
         v[i] = *reinterpret_cast<const double2*>(in_b + vo);
         sv[i] = *reinterpret_cast<const double2*>(src_b + vo);
     }
+    if (!DAMPED) {
 #pragma unroll
-    for (int i = 0; i < NROWS; ++i) {
-        v[i].x = sanitize1(v[i].x); v[i].y = sanitize1(v[i].y);
-        sv[i].x = sanitize1(sv[i].x); sv[i].y = sanitize1(sv[i].y);
+        for (int i = 0; i < NROWS; ++i) {
+            v[i].x = sanitize1(v[i].x); v[i].y = sanitize1(v[i].y);
+            sv[i].x = sanitize1(sv[i].x); sv[i].y = sanitize1(sv[i].y);
+        }
     }
     // a cell is updated iff it is an interior grid point and not on the tile's rim (rows: wave-uniform tests)
     const bool colok0 = lane >= 1 && in0, colok1 = lane <= 62 && in1;
@@ -1802,9 +1808,18 @@ __global__ void __launch_bounds__(512, 6) k_jacobi_reg(Fld outF, Fld psiF, Fld s
             const double2 o = v[i];
             const double2 up = i < NROWS - 1 ? v[i < NROWS - 1 ? i + 1 : 0] : nb;
             const double Wx = wave_shift<0x138>(o.y), Ey = wave_shift<0x130>(o.x);
-            const double nx = divc4(ae0 * o.y + aw0 * Wx + a_ns * old_m1.x + a_ns * up.x - sv[i].x, a_c, inv_a_c, lo_a_c);
-            const double ny = divc4(ae1 * Ey + aw1 * o.x + a_ns * old_m1.y + a_ns * up.y - sv[i].y, a_c, inv_a_c, lo_a_c);
-            const double cx = fmin(fmax(nx, -CAP), CAP), cy = fmin(fmax(ny, -CAP), CAP);
+            double cx, cy;
+            if constexpr (DAMPED) {
+                const double ux = divc4(ae0 * o.y + aw0 * Wx + a_ns * (old_m1.x + up.x) - sv[i].x, a_c, inv_a_c, lo_a_c);
+                const double uy = divc4(ae1 * Ey + aw1 * o.x + a_ns * (old_m1.y + up.y) - sv[i].y, a_c, inv_a_c, lo_a_c);
+                cx = om1_j * o.x + omega_j * ux;
+                cy = om1_j * o.y + omega_j * uy;
+            } else {
+                const double nx = divc4(ae0 * o.y + aw0 * Wx + a_ns * old_m1.x + a_ns * up.x - sv[i].x, a_c, inv_a_c, lo_a_c);
+                const double ny = divc4(ae1 * Ey + aw1 * o.x + a_ns * old_m1.y + a_ns * up.y - sv[i].y, a_c, inv_a_c, lo_a_c);
+                cx = fmin(fmax(nx, -CAP), CAP);
+                cy = fmin(fmax(ny, -CAP), CAP);
+            }
             v[i].x = (rowok[i] & colok0) ? cx : o.x;
             v[i].y = (rowok[i] & colok1) ? cy : o.y;
             old_m1 = o;
@@ -3421,93 +3436,213 @@ __global__ void __launch_bounds__(256) k_map_scale(Fld jF, Member* st, int nz, i
 }
 
 // LAPACK dgtsv for one right-hand side (what scipy.linalg.solve_banded((1,1), ...) calls): Gaussian elimination with partial
-// pivoting; dl, d, du, b are overwritten (b <- x); returns info
-__device__ __forceinline__ int gtsv1(int n, double* dl, double* d, double* du, double* b) {
+// pivoting; dl, d, du, b are overwritten (b <- x); returns info.  Element i of an array lies at [i * st]: st = 1 for a system
+// stored contiguously, st = batch for the [n][batch] device layout of the batched kernels below, in which the lanes of a wave
+// (consecutive systems) read consecutive addresses.
+//
+// Same operations in the same order as the reference routine, but the recurrence runs in REGISTERS: step i needs the current
+// d[i], du[i], b[i] (carried from step i - 1) and the ORIGINAL dl[i], d[i+1], du[i+1], b[i+1], which no earlier step has touched --
+// so the originals of GT_K steps are requested together in front of the steps that use them (one memory round trip per GT_K
+// steps instead of a store -> load round trip through memory inside every step, which is what bounded rounds 1-5's form at
+// ~1.1 us per row whatever the layout), and the finished rows are stored behind them.  The back substitution carries x[i+1], x[i+2]
+// the same way.
+constexpr int GT_K = 8;
+__device__ __forceinline__ int gtsv1(int n, double* __restrict__ dl, double* __restrict__ d, double* __restrict__ du, double* __restrict__ b, long st = 1) {
+#define GT(a, i) (a)[(long)(i) * st]
     if (n == 0) return 0;
-    for (int i = 0; i < n - 1; ++i) {
-        const bool last = i == n - 2;
-        if (fabs(d[i]) >= fabs(dl[i])) {
-            if (d[i] != 0.0) {
-                const double fact = dl[i] / d[i];
-                d[i + 1] = d[i + 1] - fact * du[i];
-                b[i + 1] = b[i + 1] - fact * b[i];
-            } else return i + 1;
-            if (!last) dl[i] = 0.0;
-        } else {
-            const double fact = d[i] / dl[i];
-            d[i] = dl[i];
-            double temp = d[i + 1];
-            d[i + 1] = du[i] - fact * temp;
-            if (!last) {
-                dl[i] = du[i + 1];
-                du[i + 1] = -fact * dl[i];
+    double di = GT(d, 0), dui = n > 1 ? GT(du, 0) : 0.0, bi = GT(b, 0);  // current values of row i
+    // originals of rows i0 + k (dl) and i0 + k + 1 (d, du, b); clamped reads beyond the end are never used.  The chunk behind the
+    // one being eliminated is already in flight (double buffer): a wave of systems is alone on its SIMD, nothing else hides the latency
+    auto fetch = [&](int i0, double (&o_dl)[GT_K], double (&o_d1)[GT_K], double (&o_du1)[GT_K], double (&o_b1)[GT_K]) {
+#pragma unroll
+        for (int k = 0; k < GT_K; ++k) {
+            const int i = min(i0 + k, n - 2);
+            o_dl[k] = GT(dl, i);
+            o_d1[k] = GT(d, i + 1);
+            o_du1[k] = GT(du, min(i + 1, n - 2));
+            o_b1[k] = GT(b, i + 1);
+        }
+    };
+    auto eliminate = [&](int i0, const double (&o_dl)[GT_K], const double (&o_d1)[GT_K], const double (&o_du1)[GT_K], const double (&o_b1)[GT_K]) -> int {
+#pragma unroll
+        for (int k = 0; k < GT_K; ++k) {
+            const int i = i0 + k;
+            if (i >= n - 1) break;
+            const bool last = i == n - 2;
+            const double dli = o_dl[k];
+            double d1 = o_d1[k], du1 = o_du1[k], b1 = o_b1[k];
+            if (fabs(di) >= fabs(dli)) {
+                if (di != 0.0) {
+                    const double fact = dli / di;
+                    d1 = d1 - fact * dui;
+                    b1 = b1 - fact * bi;
+                } else {
+                    GT(d, i) = di; GT(du, i) = dui; GT(b, i) = bi;  // (the state the reference leaves behind a zero pivot)
+                    return i + 1;
+                }
+                GT(d, i) = di; GT(du, i) = dui; GT(b, i) = bi;
+                if (!last) GT(dl, i) = 0.0;
+            } else {
+                const double fact = di / dli;
+                GT(d, i) = dli;
+                const double temp = d1;
+                d1 = dui - fact * temp;
+                if (!last) {
+                    GT(dl, i) = du1;
+                    du1 = -fact * du1;
+                }
+                GT(du, i) = temp;
+                GT(b, i) = b1;
+                b1 = bi - fact * b1;
             }
-            du[i] = temp;
-            temp = b[i];
-            b[i] = b[i + 1];
-            b[i + 1] = temp - fact * b[i + 1];
+            di = d1; dui = du1; bi = b1;
+        }
+        return 0;
+    };
+    if (n > 1) {
+        double a_dl[GT_K], a_d1[GT_K], a_du1[GT_K], a_b1[GT_K], c_dl[GT_K], c_d1[GT_K], c_du1[GT_K], c_b1[GT_K];
+        fetch(0, a_dl, a_d1, a_du1, a_b1);
+        for (int i0 = 0; i0 < n - 1; i0 += 2 * GT_K) {
+            // (a chunk's rows are only ever modified by the elimination of the chunk in front of it: rows up to i0 + GT_K by the
+            //  first call below, whose stores touch rows < i0 + GT_K of d / du / b and dl -- the second fetch reads rows > i0 + GT_K)
+            if (i0 + GT_K < n - 1) fetch(i0 + GT_K, c_dl, c_d1, c_du1, c_b1);
+            int info = eliminate(i0, a_dl, a_d1, a_du1, a_b1);
+            if (info) return info;
+            if (i0 + GT_K >= n - 1) break;
+            if (i0 + 2 * GT_K < n - 1) fetch(i0 + 2 * GT_K, a_dl, a_d1, a_du1, a_b1);
+            info = eliminate(i0 + GT_K, c_dl, c_d1, c_du1, c_b1);
+            if (info) return info;
         }
     }
-    if (d[n - 1] == 0.0) return n;
-    b[n - 1] = b[n - 1] / d[n - 1];
-    if (n > 1) b[n - 2] = (b[n - 2] - du[n - 2] * b[n - 1]) / d[n - 2];
-    for (int i = n - 3; i >= 0; --i) b[i] = (b[i] - du[i] * b[i + 1] - dl[i] * b[i + 2]) / d[i];
+    GT(d, n - 1) = di; GT(b, n - 1) = bi;
+    if (di == 0.0) return n;
+    double x1 = bi / di, x2 = 0.0;  // x[i + 1], x[i + 2]
+    GT(b, n - 1) = x1;
+    if (n > 1) {
+        const double x0 = (GT(b, n - 2) - GT(du, n - 2) * x1) / GT(d, n - 2);
+        GT(b, n - 2) = x0;
+        x2 = x1; x1 = x0;
+    }
+    auto fetch_back = [&](int i0, double (&r_b)[GT_K], double (&r_du)[GT_K], double (&r_dl)[GT_K], double (&r_d)[GT_K]) {
+#pragma unroll
+        for (int k = 0; k < GT_K; ++k) {
+            const int i = max(i0 - k, 0);
+            r_b[k] = GT(b, i); r_du[k] = GT(du, i); r_dl[k] = GT(dl, i); r_d[k] = GT(d, i);
+        }
+    };
+    auto substitute = [&](int i0, const double (&r_b)[GT_K], const double (&r_du)[GT_K], const double (&r_dl)[GT_K], const double (&r_d)[GT_K]) {
+#pragma unroll
+        for (int k = 0; k < GT_K; ++k) {
+            const int i = i0 - k;
+            if (i < 0) break;
+            const double x0 = (r_b[k] - r_du[k] * x1 - r_dl[k] * x2) / r_d[k];
+            GT(b, i) = x0;
+            x2 = x1; x1 = x0;
+        }
+    };
+    if (n > 2) {
+        double a_b[GT_K], a_du[GT_K], a_dl[GT_K], a_d[GT_K], c_b[GT_K], c_du[GT_K], c_dl[GT_K], c_d[GT_K];
+        fetch_back(n - 3, a_b, a_du, a_dl, a_d);
+        for (int i0 = n - 3; i0 >= 0; i0 -= 2 * GT_K) {  // (a chunk stores x into rows it has already read; the chunk below is in flight meanwhile)
+            if (i0 - GT_K >= 0) fetch_back(i0 - GT_K, c_b, c_du, c_dl, c_d);
+            substitute(i0, a_b, a_du, a_dl, a_d);
+            if (i0 - GT_K < 0) break;
+            if (i0 - 2 * GT_K >= 0) fetch_back(i0 - 2 * GT_K, a_b, a_du, a_dl, a_d);
+            substitute(i0 - GT_K, c_b, c_du, c_dl, c_d);
+        }
+    }
     return 0;
+#undef GT
 }
-// batched tridiagonal solve: one thread per system; work arrays [batch][n] (dl, du use n-1 entries)
-__global__ void k_gtsv(int batch, int n, double* dl, double* d, double* du, double* b, int* info) {
+// dst[c][r] = src[r][c] for a (rows x cols) array: the [batch][n] host layout of the C ABI <-> the [n][batch] device layout of the
+// batched one-thread-per-system kernels.  32 x 32 tiles through LDS (+1 column: no bank conflicts); grid (ceil(cols/32), ceil(rows/32))
+__global__ void __launch_bounds__(256) k_transpose(double* __restrict__ dst, const double* __restrict__ src, int rows, int cols) {
+    __shared__ double t[32][33];
+    dst += (long)blockIdx.z * rows * cols;  // (gridDim.z arrays of rows x cols lying behind each other, transposed in one launch)
+    src += (long)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < rows && c < cols) t[ty + 8 * k][tx] = src[(long)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < rows && c < cols) dst[(long)c * rows + r] = t[tx][ty + 8 * k];
+    }
+}
+// batched tridiagonal solve: one thread per system.  Work arrays: element i of system s at [s * sys + i * el] -- (sys, el) =
+// (1, batch) for the [n][batch] layout (coalesced: the default), (n, 1) for [batch][n] (dl, du use n-1 entries)
+__global__ void __launch_bounds__(64) k_gtsv(int batch, int n, double* dl, double* d, double* du, double* b, int* info, long sys, long el) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= batch) return;
-    info[s] = gtsv1(n, dl + (long)s * n, d + (long)s * n, du + (long)s * n, b + (long)s * n);
+    info[s] = gtsv1(n, dl + s * sys, d + s * sys, du + s * sys, b + s * sys, el);
 }
 // CurrentDiffusionSolver.step (core/current_diffusion.py:277-353) for `batch` independent profiles: Sauter resistivity
 // (:175-207), Crank-Nicolson assembly, dgtsv.  one thread per member; scratch [batch][4n]
 struct CdConst { double r0, a, dt, z_eff, mu0_a2; };
-__global__ void __launch_bounds__(64) k_current_diffusion(int batch, int n, const double* rho, double* psi, CdConst c, const double* te, const double* ne,
-                                    const double* j_bs, const double* j_cd, const double* j_ext, double* scratch, int* info) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= batch) return;
-    double* p = psi + (long)s * n;
-    double* sub = scratch + (long)s * 4 * n;
-    double* diag = sub + n;
-    double* sup = diag + n;
-    double* rhs = sup + n;
+// Two launches: the Crank-Nicolson rows are independent of each other -- k_cd_assemble builds them with one thread per (member,
+// rho point) (the pow / sqrt of the Sauter resistivity were 60 % of rounds 1-5's one-thread-per-member kernel) -- and
+// k_cd_solve runs the dgtsv recurrence, one thread per member, and leaves the new psi in the rhs rows.
+// Element i of member s of every profile / scratch row at [s * sys + i * el] (see k_gtsv); scratch = sub, diag, sup, rhs of
+// batch * n doubles each.
+__global__ void __launch_bounds__(256) k_cd_assemble(int batch, int n, const double* rho, const double* psi, CdConst c, const double* te,
+                                                    const double* j_bs, const double* j_cd, const double* j_ext, double* scratch, long sys, long el) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, tot = (long)batch * n;
+    if (t >= tot) return;
+    // consecutive threads walk the contiguous axis of the SCRATCH layout; the profiles are read where the ABI left them ([batch][n]:
+    // with the [n][batch] scratch these reads are strided -- 5 values per thread of a 10-us kernel -- which saves five transposes)
+    const int i = el == 1 ? (int)(t % n) : (int)(t / batch), s = el == 1 ? (int)(t / n) : (int)(t % batch);
+    const long base = s * sys, ibase = (long)s * n;
+#define AT(a, i) (a)[base + (long)(i) * el]
+#define IN(a, i) (a)[ibase + (i)]
+    double* sub = scratch;
+    double* diag = scratch + tot;
+    double* sup = scratch + 2 * tot;
+    double* rhs = scratch + 3 * tot;
     const double drho = rho[1] - rho[0];
     const double drho2 = drho * drho;
     const double alpha = c.dt / 2.0;
     // q_from_psi (:210-233) only feeds the collisionality nu_star_e, which the reference computes and discards (:199, noqa F841)
-    for (int i = 0; i < n; ++i) {
-        const long o = (long)s * n + i;
-        double tk = fmax(te[o], 1e-3), eps = fmax(rho[i] * c.a / c.r0, 1e-6);
-        const double eta_sp = 1.65e-9 * c.z_eff * 17.0 / pow(tk, 1.5);
-        double ft = 1.0 - ((1.0 - eps) * (1.0 - eps)) / (sqrt(1.0 - eps * eps) * (1.0 + 1.46 * sqrt(eps)));
-        ft = fmax(0.0, fmin(ft, 1.0));
-        const double cr = 1.0 - (1.0 + 0.36 / c.z_eff) * ft + (0.59 / c.z_eff) * (ft * ft);
-        const double eta = fmax(eta_sp / (1.0 - ft) * cr, eta_sp);
-        const double D = eta / c.mu0_a2;
-        const double jt = (j_bs[o] + j_cd[o]) + (j_ext ? j_ext[o] : 0.0);
-        if (i == 0) {
-            diag[0] = 1.0 + alpha * 4.0 * D / drho2;
-            rhs[0] = p[0] + alpha * 4.0 * D * (p[1] - p[0]) / drho2 + c.dt * c.r0 * eta * jt;
-            sup[0] = -alpha * 4.0 * D / drho2;
-        } else if (i < n - 1) {
-            const double r = rho[i];
-            const double cp = D * (1.0 / drho2 - 1.0 / (2.0 * r * drho));
-            const double cc = D * (-2.0 / drho2);
-            const double cn = D * (1.0 / drho2 + 1.0 / (2.0 * r * drho));
-            sub[i] = -alpha * cp;
-            diag[i] = 1.0 - alpha * cc;
-            const double l = cp * p[i - 1] + cc * p[i] + cn * p[i + 1];
-            rhs[i] = p[i] + alpha * l + c.dt * c.r0 * eta * jt;
-            sup[i] = -alpha * cn;
-        } else {
-            diag[n - 1] = 1.0;
-            sub[n - 1] = 0.0;
-            rhs[n - 1] = p[n - 1];
-        }
+    double tk = fmax(IN(te, i), 1e-3), eps = fmax(rho[i] * c.a / c.r0, 1e-6);
+    const double eta_sp = 1.65e-9 * c.z_eff * 17.0 / pow(tk, 1.5);
+    double ft = 1.0 - ((1.0 - eps) * (1.0 - eps)) / (sqrt(1.0 - eps * eps) * (1.0 + 1.46 * sqrt(eps)));
+    ft = fmax(0.0, fmin(ft, 1.0));
+    const double cr = 1.0 - (1.0 + 0.36 / c.z_eff) * ft + (0.59 / c.z_eff) * (ft * ft);
+    const double eta = fmax(eta_sp / (1.0 - ft) * cr, eta_sp);
+    const double D = eta / c.mu0_a2;
+    const double jt = (IN(j_bs, i) + IN(j_cd, i)) + (j_ext ? IN(j_ext, i) : 0.0);
+    if (i == 0) {
+        AT(sub, 0) = 0.0;
+        AT(diag, 0) = 1.0 + alpha * 4.0 * D / drho2;
+        AT(rhs, 0) = IN(psi, 0) + alpha * 4.0 * D * (IN(psi, 1) - IN(psi, 0)) / drho2 + c.dt * c.r0 * eta * jt;
+        AT(sup, 0) = -alpha * 4.0 * D / drho2;
+    } else if (i < n - 1) {
+        const double r = rho[i];
+        const double cp = D * (1.0 / drho2 - 1.0 / (2.0 * r * drho));
+        const double cc = D * (-2.0 / drho2);
+        const double cn = D * (1.0 / drho2 + 1.0 / (2.0 * r * drho));
+        AT(sub, i) = -alpha * cp;
+        AT(diag, i) = 1.0 - alpha * cc;
+        const double l = cp * IN(psi, i - 1) + cc * IN(psi, i) + cn * IN(psi, i + 1);
+        AT(rhs, i) = IN(psi, i) + alpha * l + c.dt * c.r0 * eta * jt;
+        AT(sup, i) = -alpha * cn;
+    } else {
+        AT(diag, n - 1) = 1.0;
+        AT(sub, n - 1) = 0.0;
+        AT(sup, n - 1) = 0.0;
+        AT(rhs, n - 1) = IN(psi, n - 1);
     }
-    info[s] = gtsv1(n, sub + 1, diag, sup, rhs);
-    for (int i = 0; i < n; ++i) p[i] = rhs[i];
+#undef AT
+#undef IN
+}
+__global__ void __launch_bounds__(64) k_cd_solve(int batch, int n, double* scratch, int* info, long sys, long el) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= batch) return;
+    const long tot = (long)batch * n, base = s * sys;
+    info[s] = gtsv1(n, scratch + base + el, scratch + tot + base, scratch + 2 * tot + base, scratch + 3 * tot + base, el);
 }
 
 

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <atomic>
 #include <chrono>
 #include <map>
@@ -137,6 +138,7 @@ struct ProfEntry {
 
 struct Solver {
     int nr = 0, nz = 0, B = 0, ld = 0;
+    int device = 0;  // the HIP device it was created on
     int ensemble_B = 0;  // members of the whole ensemble this stream group belongs to (0: it is the whole ensemble)
     long stride = 0;
     double dr = 0, dz = 0;
@@ -759,7 +761,7 @@ static Solver* create_impl(int nr, int nz, int batch, const double* r_axis, cons
     HIP_TRY(hipSetDevice(g_device));
     auto* h = new Solver();
     try {
-        h->nr = nr; h->nz = nz; h->B = batch;
+        h->nr = nr; h->nz = nz; h->B = batch; h->device = g_device;
         h->ld = pitch_of(nr);
         h->stride = stride_of(nz, h->ld);
         h->dr = dr; h->dz = dz;
@@ -1005,8 +1007,8 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             ProfScope ps(h, "seed_jacobi", 10);
             const dim3 gj(cdiv(nr, 116), cdiv(nz, 36), B);  // (window 36 x 116 of a 48 x 128 register tile)
             for (int s = 0; s < 5; ++s) {
-                SCPN_LAUNCH(k_jacobi_reg<5>, gj, dim3(512), 0, st, WF, curF, srcF, L0, (const int*)d_sa.p);
-                SCPN_LAUNCH(k_jacobi_reg<5>, gj, dim3(512), 0, st, curF, WF, srcF, L0, (const int*)d_sa.p);
+                SCPN_LAUNCH(k_jacobi_reg<5>, gj, dim3(512), 0, st, WF, curF, srcF, L0, (const int*)d_sa.p, 1.0, 0.0);
+                SCPN_LAUNCH(k_jacobi_reg<5>, gj, dim3(512), 0, st, curF, WF, srcF, L0, (const int*)d_sa.p, 1.0, 0.0);
             }
         } else {
             ProfScope ps(h, "seed_jacobi", 50);
@@ -2544,12 +2546,59 @@ int scpn_gs_profile_read(scpn_gs* g, const char* name, double* total_ms, long* l
 }
 
 // ---- operator library on host buffers -------------------------------------------------------
+// The stateless operators run on a solver object that lives for one call.  Building one costs ~5 ms (a dozen device allocations,
+// the coefficient tables of every multigrid level) against 0.1-1 ms of work for a 257^2 V-cycle, so the last few are kept and
+// handed to the next call on the SAME grid -- the reference's GPU-tier provider keeps its PyGpuSolver instances the same way, keyed
+// by (nr, nz, r_left, r_right, z_bottom, z_top) (core/_multi_compat_providers.py:720,755-792).  A pooled solver is only ever used by
+// one call at a time (it leaves the pool while in use); every call uploads all of its inputs, so nothing of a previous call is
+// read.  SCPN_HIP_OPCACHE=0 turns the pool off; objects above 4 GB are never kept.
 struct TempSolver {
     Solver* h = nullptr;
-    TempSolver(int nr, int nz, int batch, const double* r_axis, const double* z_axis, double dr, double dz) {
-        h = create_impl(nr, nz, batch, r_axis, z_axis, dr, dz);
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::vector<Solver*>& idle() { static std::vector<Solver*> v; return v; }
+    static bool enabled() {
+        static const bool on = [] { const char* e = std::getenv("SCPN_HIP_OPCACHE"); return !(e && e[0] == '0'); }();
+        return on;
     }
-    ~TempSolver() { if (h) { (void)hipStreamSynchronize(h->stream); delete h; } }
+    static bool same_grid(const Solver* k, int nr, int nz, int batch, const double* r_axis, const double* z_axis, double dr, double dz) {
+        if (k->nr != nr || k->nz != nz || k->B != batch || k->dr != dr || k->dz != dz || k->device != g_device) return false;
+        if (std::memcmp(k->r_axis.data(), r_axis, sizeof(double) * nr) != 0) return false;
+        for (int i = 0; i < nz; ++i)
+            if (k->z_axis[i] != (z_axis ? z_axis[i] : i * dz)) return false;
+        return true;
+    }
+    TempSolver(int nr, int nz, int batch, const double* r_axis, const double* z_axis, double dr, double dz) {
+        if (enabled()) {
+            std::lock_guard<std::mutex> lk(mu());
+            auto& v = idle();
+            for (size_t i = 0; i < v.size(); ++i)
+                if (same_grid(v[i], nr, nz, batch, r_axis, z_axis, dr, dz)) { h = v[i]; v.erase(v.begin() + (long)i); break; }
+        }
+        if (h) {  // back to the state create_impl leaves (the fields are overwritten by the call's uploads)
+            h->arith = 0; h->prof_on = false; h->lazy_src = nullptr; h->jsum_part = nullptr; h->snap_valid = false;
+            h->vac_valid = false; h->n_vac = 0;
+            std::fill(h->i_target.begin(), h->i_target.end(), 0.0);
+        } else {
+            h = create_impl(nr, nz, batch, r_axis, z_axis, dr, dz);
+        }
+    }
+    ~TempSolver() {
+        if (!h) return;
+        const bool healthy = hipStreamSynchronize(h->stream) == hipSuccess;
+        const bool small = (double)h->stride * h->B * sizeof(double) * 12.0 < 4.0e9;
+        if (enabled() && healthy && small && std::uncaught_exceptions() == 0) {
+            Solver* evict = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(mu());
+                auto& v = idle();
+                v.push_back(h);
+                if (v.size() > 4) { evict = v.front(); v.erase(v.begin()); }
+            }
+            delete evict;
+        } else {
+            delete h;
+        }
+    }
 };
 static int check_grid(const void* a, const void* b, const double* r_axis, int nz, int nr, int batch, double dr, double dz) {
     if (!a || !b || !r_axis) return fail(SCPN_E_ARG, "null buffer");
@@ -2798,6 +2847,16 @@ int scpn_coil_flux(const double* r_axis, const double* z_axis, int nz, int nr, i
     HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * n * batch, hipMemcpyDeviceToHost));
     API_END
 }
+// Device layout of the batched one-thread-per-system kernels (k_gtsv, k_current_diffusion): [n][batch] (default; the ABI's
+// [batch][n] arrays are transposed on the device on the way in and out) or, with SCPN_HIP_F4_LAYOUT=rows, the [batch][n] layout
+// of rounds 1-5 (every access of a wave strided by n doubles) -- kept for the before / after timing of tools/config4_split.py.
+static bool f4_transposed() {
+    static const bool t = [] { const char* e = std::getenv("SCPN_HIP_F4_LAYOUT"); return !(e && std::string(e) == "rows"); }();
+    return t;
+}
+static void f4_transpose(double* dst, const double* src, int rows, int cols, int arrays = 1) {  // dst[c][r] = src[r][c], `arrays` of them back to back
+    SCPN_LAUNCH(k_transpose, dim3(cdiv(cols, 32), cdiv(rows, 32), arrays), dim3(256), 0, 0, dst, src, rows, cols);
+}
 int scpn_tridiag_solve(int batch, int n, const double* dl, const double* d, const double* du, const double* b, double* x, int* info) {
     if (batch < 1 || n < 1 || !d || !b || !x || (n > 1 && (!dl || !du))) return fail(SCPN_E_ARG, "bad arguments");
     API_BEGIN
@@ -2816,7 +2875,16 @@ int scpn_tridiag_solve(int batch, int n, const double* dl, const double* d, cons
     }
     HIP_TRY(hipMemcpy(w.p + tot, d, sizeof(double) * tot, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(w.p + 3 * tot, b, sizeof(double) * tot, hipMemcpyHostToDevice));
-    SCPN_LAUNCH(k_gtsv, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, w.p, w.p + tot, w.p + 2 * tot, w.p + 3 * tot, di.p);
+    if (f4_transposed()) {  // [batch][n] -> [n][batch]: lane s of a wave reads consecutive addresses at every step of the recurrence
+        DBuf<double> wt;
+        wt.alloc(4 * tot);
+        f4_transpose(wt.p, w.p, batch, n, 4);  // dl, d, du, b in one launch
+        SCPN_LAUNCH(k_gtsv, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, wt.p, wt.p + tot, wt.p + 2 * tot, wt.p + 3 * tot, di.p, 1L, (long)batch);
+        f4_transpose(w.p + 3 * tot, wt.p + 3 * tot, n, batch);
+        HIP_TRY(hipDeviceSynchronize());
+    } else {
+        SCPN_LAUNCH(k_gtsv, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, w.p, w.p + tot, w.p + 2 * tot, w.p + 3 * tot, di.p, (long)n, 1L);
+    }
     HIP_TRY(hipMemcpy(x, w.p + 3 * tot, sizeof(double) * tot, hipMemcpyDeviceToHost));
     if (info) HIP_TRY(hipMemcpy(info, di.p, sizeof(int) * batch, hipMemcpyDeviceToHost));
     API_END
@@ -2843,9 +2911,18 @@ int scpn_current_diffusion_step(int batch, int n, const double* rho, double* psi
     CdConst c;
     const double mu0 = (4.0 * 3.141592653589793) * 1e-7;  // core/current_diffusion.py:20
     c.r0 = r0; c.a = a; c.dt = dt; c.z_eff = z_eff; c.mu0_a2 = mu0 * (a * a);
-    SCPN_LAUNCH(k_current_diffusion, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, (const double*)drho_.p, dpsi.p, c, (const double*)dte.p,
-                       (const double*)nullptr, (const double*)djb.p, (const double*)djc.p, j_ext ? (const double*)dje.p : (const double*)nullptr,
-                       scratch.p, di.p);
+    const dim3 ga(cdiv((long)tot, 256));
+    if (f4_transposed()) {  // rows assembled straight into the [n][batch] scratch; the solved rhs rows come back through one transpose
+        SCPN_LAUNCH(k_cd_assemble, ga, dim3(256), 0, 0, batch, n, (const double*)drho_.p, (const double*)dpsi.p, c, (const double*)dte.p,
+                           (const double*)djb.p, (const double*)djc.p, j_ext ? (const double*)dje.p : (const double*)nullptr, scratch.p, 1L, (long)batch);
+        SCPN_LAUNCH(k_cd_solve, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, scratch.p, di.p, 1L, (long)batch);
+        f4_transpose(dpsi.p, scratch.p + 3 * tot, n, batch);
+    } else {
+        SCPN_LAUNCH(k_cd_assemble, ga, dim3(256), 0, 0, batch, n, (const double*)drho_.p, (const double*)dpsi.p, c, (const double*)dte.p,
+                           (const double*)djb.p, (const double*)djc.p, j_ext ? (const double*)dje.p : (const double*)nullptr, scratch.p, (long)n, 1L);
+        SCPN_LAUNCH(k_cd_solve, dim3(cdiv(batch, 64)), dim3(64), 0, 0, batch, n, scratch.p, di.p, (long)n, 1L);
+        HIP_TRY(hipMemcpy(dpsi.p, scratch.p + 3 * tot, sizeof(double) * tot, hipMemcpyDeviceToDevice));
+    }
     HIP_TRY(hipMemcpy(psi, dpsi.p, sizeof(double) * tot, hipMemcpyDeviceToHost));
     if (info) HIP_TRY(hipMemcpy(info, di.p, sizeof(int) * batch, hipMemcpyDeviceToHost));
     API_END
@@ -2954,7 +3031,15 @@ int scpn_gs_solve_np(double r_min, double r_max, double z_min, double z_max, int
                            beta_mix);
         SCPN_LAUNCH(k_copy, g2, BLK2D, 0, st, aF, psiF, nz, nr, h->ld, (const int*)nullptr);
         Fld in = aF, out = bF;
-        for (int j = 0; j < n_jacobi; ++j) {
+        int j = 0;
+        if (nz >= 16 && nr >= 16) {  // five temporally blocked steps per launch (register tile, as the seed relaxation): 40 launches for 200 steps
+            const dim3 gj(cdiv(nr, 116), cdiv(nz, 36), 1);
+            for (; j + 5 <= n_jacobi; j += 5) {
+                SCPN_LAUNCH((k_jacobi_reg<5, true>), gj, dim3(512), 0, st, out, in, srcF, L, (const int*)nullptr, omega_j, 1.0 - omega_j);
+                std::swap(in, out);
+            }
+        }
+        for (; j < n_jacobi; ++j) {
             SCPN_LAUNCH(k_jacobi_damped, g2, BLK2D, 0, st, out, in, srcF, L, omega_j, 1.0 - omega_j);
             std::swap(in, out);
         }

@@ -113,6 +113,20 @@ def test_polyglot_lane(golden):
     assert abs(psi17.max() - 0.042651828900105285) < 1e-15
 
 
+def test_numpy_lane_polyglot(golden):
+    """oracle/numpy_lane.py::polyglot_picard_jacobi (the NumPy comparator bench.py times at 513 x 513) against the reference's own
+    ``gs_solve_np`` output: bit-exact (the lane IS NumPy, same expressions), incl. the published psi_axis."""
+    from oracle import numpy_lane as npl
+
+    g = golden("polyglot.npz")
+    p = g["params"]
+    for n in (17, 65):
+        psi = npl.polyglot_picard_jacobi(p[0], p[1], p[2], p[3], n, n, p[4], mu0=p[5], n_picard=int(p[6]), n_jacobi=int(p[7]), alpha=p[8],
+                                         omega_j=p[9], beta_mix=p[10])
+        assert np.array_equal(psi, g[f"psi{n}"]), n
+    assert float(g["psi17"].max()) == 0.042651828900105285
+
+
 def test_polyglot_lane_diagnostics(golden):
     """gs_delta_star_np / gs_equation_residual_np (core/jax_gs_solver.py:196-316) restated in the oracle."""
     g = golden("polyglot.npz")
