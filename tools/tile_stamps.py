@@ -18,19 +18,26 @@ for n, B in ((513, int(os.environ.get("STAMPS_B", "32"))),):
     es.set_psi(np.broadcast_to(psi0, (B, n, n)).copy()); es.set_source(np.broadcast_to(src, (B, n, n)).copy())
     mode = os.environ.get("STAMPS_MODE", "plain")
     import time
-    for _ in range(5):
+    if mode == "picard":  # the Picard iteration itself (the fused tail of the level-0 post-smoother only exists inside it): fixed iteration count
+        es.close()
+        es = EnsembleSolver(iter_like_cfg(n, tol=1e-300, max_iter=20), batch=B)
+        es.solve_equilibrium()
+        es.sync(); t0 = time.perf_counter(); es.solve_equilibrium(); es.sync()
+        print(f"{(time.perf_counter() - t0) / 20 * 1e6:.1f} us per Picard iteration (stamped build)")
+    for _ in range(0 if mode == "picard" else 5):
         if mode == "plain": es.rb_sor(1.3, 3)
         else: es.vcycle(1.0, 3, 3, 5)
     es.sync(); t0 = time.perf_counter()
-    for _ in range(20):
+    for _ in range(0 if mode == "picard" else 20):
         if mode == "plain": es.rb_sor(1.3, 3)
         else: es.vcycle(1.0, 3, 3, 5)
-    es.sync(); print(f"{(time.perf_counter() - t0) / 20 * 1e6:.1f} us per call (stamped build)")
+    es.sync()
+    if mode != "picard": print(f"{(time.perf_counter() - t0) / 20 * 1e6:.1f} us per call (stamped build)")
     L = C.CDLL(os.environ["SCPN_HIP_LIB"])
     buf = (C.c_ulonglong * 128)()
     L.scpn_debug_tile_stamps(buf)
     names = ["start", "loaded"] + [f"pass {i}" for i in range(6)] + ["stored", "defect", "end", "drain"]
-    idx = (0, 1, 11, 2, 3, 4, 5, 6, 7, 10) if os.environ.get("STAMPS_DRAIN") else ((0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10) if mode == "defect" else (0, 1, 2, 3, 4, 5, 6, 7, 8, 10))
+    idx = (0, 1, 11, 2, 3, 4, 5, 6, 7, 10) if os.environ.get("STAMPS_DRAIN") else ((0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10) if mode in ("defect", "picard") else (0, 1, 2, 3, 4, 5, 6, 7, 8, 10))
     print(f"--- n={n} B={B}: per-phase us (rows kernel: successive tiles of workgroup 1; tile kernel: 8 sampled workgroups); last column = start offset")
     rows = []
     for g in range(8):
