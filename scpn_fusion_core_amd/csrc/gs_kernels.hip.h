@@ -597,7 +597,20 @@ struct LazySrc {
     int nblk = 0;
     double dr = 0, dz = 0;
     Member* st_rw = nullptr;
+    // Source ON THE FLY (contracted arithmetic, L-mode): the "source" field IS the current iterate psi -- J_raw is not stored at
+    // all.  Every consumer forms J_raw = (0.5 R + 0.5 / (mu0 R)) * shape(psi_N) from psi on load (jraw_shape below: the
+    // expression of j_raw_at with the division by the normalisation span as a reciprocal multiply), so k_jsum becomes a
+    // read-only pass, the pre-smoother (whose input is that same psi) loads one field instead of two and the Picard tail,
+    // which reads the current iterate anyway, none for the source: 76 instead of 100 bytes per point and iteration on level 0.
+    int jfly = 0;
+    const double* r_axis = nullptr;
+    const double* inv_mu0R = nullptr;
 };
+// shape(psi_N) of the L-mode profile (core/fusion_kernel.py:419-429: p = ff = 1 - psi_N inside 0 <= psi_N < 1, else 0)
+__device__ __forceinline__ double jraw_shape(double psi, double psi_axis, double inv_denom) {
+    const double pn = (psi - psi_axis) * inv_denom;
+    return (pn >= 0.0 && pn < 1.0) ? 1.0 - pn : 0.0;
+}
 // the scale of member b from the partial sums (core/fusion_kernel.py:436-438, the arithmetic of jsum_final_body: wave totals of
 // 64-value chunks added in order to +0.0); x0 = this lane's value of the first chunk, already loaded
 __device__ __forceinline__ double lazy_scale_from_parts(const LazySrc& z, int b, int lane, double x0, double itg, bool store) {
@@ -774,6 +787,14 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
     const double lz_x0 = *((lz_sum && lane < lzs.nblk) ? lzs.part + ((long)b * lzs.nblk + lane) : &g_const_f64[0]);
     double lz_n0 = *(lazy ? lzs.neg_mu0R + min(max(c0, 0), nr - 1) : &g_const_f64[1]);
     double lz_n1 = *(lazy ? lzs.neg_mu0R + min(max(c0 + 1, 0), nr - 1) : &g_const_f64[1]);
+    // source on the fly (FAST instantiations only; uniform): the member's normalisation and the column factor 0.5 R + 0.5 / (mu0 R)
+    const bool jfly = FAST && lazy && lzs.jfly != 0;
+    const double jf_pa = *(jfly ? &lzs.st[b].psi_axis : &g_const_f64[0]), jf_id = *(jfly ? &lzs.st[b].inv_denom : &g_const_f64[1]);
+    if (jfly) {
+        const int ca = min(max(c0, 0), nr - 1), cb = min(max(c0 + 1, 0), nr - 1);
+        lz_n0 = lz_n0 * (0.5 * lzs.r_axis[ca] + 0.5 * lzs.inv_mu0R[ca]);
+        lz_n1 = lz_n1 * (0.5 * lzs.r_axis[cb] + 0.5 * lzs.inv_mu0R[cb]);
+    }
     // (PROLONG, wide load: the stencil coefficients are first used by the sweeps -- they are requested behind the LAST group of row
     //  loads, so that they hold no registers while the earlier groups are in flight)
     constexpr bool COEF_LATE = PROLONG;
@@ -901,6 +922,8 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             if (GLDS && i > 0 && i < NROWS - 1)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_b + vo),
                                                  (__attribute__((address_space(3))) void*)pair_base(i), 16, 0, 0);
+            else if (jfly && src_b == in_b && !in_zero)
+                sv2[j] = pv[j];  // (source on the fly in the pre-smoother: its input IS the field the source is formed from)
             else
                 sv2[j] = *reinterpret_cast<const double2*>(src_b + vo);
             if (PWIDE) {
@@ -943,6 +966,7 @@ __global__ void __launch_bounds__(64 * NWT, WPEU) k_smooth_tile(Fld outF, Fld in
             if (dma_row) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's DMA has landed; everything else is needed by now anyway)
             double sx = dma_row ? pr->x : sv2[j].x, sy = dma_row ? pr->y : sv2[j].y;  // source of the even / odd column
             if (FAST) {
+                if (jfly) { sx = jraw_shape(sx, jf_pa, jf_id); sy = jraw_shape(sy, jf_pa, jf_id); }
                 sx = sx * sf0; sy = sy * sf1;
                 if (FOLD) { sx = colok0 ? sx : -vx; sy = colok1 ? sy : -vy; }  // a column that is never updated: the chain returns psi
             } else if (lazy) {  // Source = (-mu0 R) * (scale != 0 ? J_raw * scale : 0), the expression of k_source (uniform branches)
@@ -2059,7 +2083,9 @@ __device__ __forceinline__ void jsum_final_body(int b, Member* st, const double*
         st[b].jscale = fabs(ic) > 1e-9 ? itg / ic : 0.0;
     }
 }
-template <int HM>
+// FLY (source on the fly, see LazySrc): J_raw in the form its consumers rebuild it in -- (0.5 R + 0.5 / (mu0 R)) * shape(psi_N) -- so that
+// the sum normalises exactly the current density the smoothers and the tail will see; nothing is stored (rawF.base == nullptr).
+template <int HM, bool FLY = false>
 __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz, int nr, int ld,
                                               const double* r_axis, const double* inv_mu0R, Prof pf,
                                               double* part, int nblk, Fld rawF) {
@@ -2094,10 +2120,10 @@ __global__ void __launch_bounds__(256) k_jsum(Fld psiF, const Member* st, int nz
             for (int j = 0; j < JS_BATCH; ++j) {
                 const int iz = blockIdx.y * JS_ROWS + ty + 4 * (k0 + j);
                 if (k0 + j < JS_ROWS / 4 && iz < nz) {
-                    const double j0 = j_raw_at<HM>(v[j].x, R0, m0, pa, den, iden, pf);
+                    const double j0 = FLY ? (0.5 * R0 + 0.5 * m0) * jraw_shape(v[j].x, pa, iden) : j_raw_at<HM>(v[j].x, R0, m0, pa, den, iden, pf);
                     s += j0;
                     double j1 = 0.0;
-                    if (two) { j1 = j_raw_at<HM>(v[j].y, R1, m1, pa, den, iden, pf); s += j1; }
+                    if (two) { j1 = FLY ? (0.5 * R1 + 0.5 * m1) * jraw_shape(v[j].y, pa, iden) : j_raw_at<HM>(v[j].y, R1, m1, pa, den, iden, pf); s += j1; }
                     if (raw) {
                         if (two) *reinterpret_cast<double2*>(raw + (long)iz * ld + c0) = double2{j0, j1};
                         else raw[(long)iz * ld + c0] = j0;
@@ -2492,7 +2518,7 @@ template <bool FAST = false>
 __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld curF, Fld newF, Fld bcF, Fld srcF, const Member* st, Lvl L,
                                                              double alpha, double om_alpha, int n_mask_rows, double* psum, int* pbad,
                                                              double* rmax, double* rsum, TopoPart* topo, int nblk, const double* lazy_nm,
-                                                             GradRecip gq, int xcd_remap) {
+                                                             GradRecip gq, int xcd_remap, const double* jfly_r, const double* jfly_m) {
     __shared__ __attribute__((aligned(16))) double t[BL_LB][128];
     __shared__ VI sh_mx[BL_NW], sh_mn[BL_NW];
     __shared__ double sh_dsum[BL_NW], sh_p2[BL_NW], sh_minp[BL_NW], sh_s2[BL_NW];
@@ -2511,6 +2537,9 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
     const int act_w = st[b].active;
     const int k_cur = *curF.slot_ptr(b), k_new = *newF.slot_ptr(b), k_bc = *bcF.slot_ptr(b), k_src = *srcF.slot_ptr(b), k_nxt = *nxtF.slot_ptr(b);
     const double lz_sc = *(lazy_nm ? &st[b].jscale : &g_const_f64[1]);
+    // source on the fly (FAST; jfly_r = r_axis, jfly_m = 1 / (mu0 R); uniform): the source is rebuilt from `cur`, which this kernel loads anyway
+    const bool jfly = FAST && lazy_nm != nullptr && jfly_r != nullptr;
+    const double jf_pa = *(jfly ? &st[b].psi_axis : &g_const_f64[0]), jf_id = *(jfly ? &st[b].inv_denom : &g_const_f64[1]);
     if (!act_w) return;
     BLEND_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2538,7 +2567,7 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
         const bool rowring = gzc == 0 || gzc == nz - 1;
         pc[i] = *reinterpret_cast<const double2*>(cur_b + vo);
         pn[i] = *reinterpret_cast<const double2*>((rowring ? bc_b : new_b) + vo);
-        sv[i] = *reinterpret_cast<const double2*>(src_b + vo);
+        if (!jfly) sv[i] = *reinterpret_cast<const double2*>(src_b + vo);
     }
     if (edge_cols) {
 #pragma unroll
@@ -2553,13 +2582,18 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
     // two columns now, behind the row loads, and hands them to the other waves through LDS at the barrier below
     const bool int_x = own_x && c0 >= 1 && c0 <= nr - 2, int_y = own_y && c0 + 1 <= nr - 2;  // (c0 + 1 >= 1 always)
     {
-        const double* const arr = FAST ? (w == 0 ? L.a_e : (w == 1 ? L.a_w : (w == 2 ? nullptr : lazy_nm)))
+        const double* const arr = FAST ? (w == 0 ? L.a_e : (w == 1 ? L.a_w : (w == 2 ? (jfly ? jfly_r : nullptr) : lazy_nm)))
                                        : (w == 0 ? L.r_safe : (w == 1 ? L.r_inv : (w == 2 ? L.r_inv_lo : lazy_nm)));
         // r_safe, 1/r_safe: 1.0; low word: 0.0; -mu0 R: 0.0 outside the interior, 1.0 when the source field already holds the source
         const double* const dflt = &g_const_f64[(w <= 1 || (w == 3 && !lazy_nm)) ? 1 : 0];
         const bool have = arr != nullptr;
-        sh_coef[2 * w][lane] = *((have && int_x) ? arr + c0 : dflt);
-        sh_coef[2 * w + 1][lane] = *((have && int_y) ? arr + c0 + 1 : dflt);
+        double cx = *((have && int_x) ? arr + c0 : dflt), cy = *((have && int_y) ? arr + c0 + 1 : dflt);
+        if (jfly && w == 2) {  // the column factor of J_raw: 0.5 R + 0.5 / (mu0 R)
+            cx = int_x ? 0.5 * cx + 0.5 * jfly_m[c0] : 0.0;
+            cy = int_y ? 0.5 * cy + 0.5 * jfly_m[c0 + 1] : 0.0;
+        }
+        sh_coef[2 * w][lane] = cx;
+        sh_coef[2 * w + 1][lane] = cy;
     }
     // ---- stage 1: blend, store, stage the tile; per-COLUMN accumulators, no per-point predicates (rows: wave-uniform tests)
     double dsx = 0.0, dsy = 0.0, mnx = INFINITY, mny = INFINITY, bvx = -INFINITY, bvy = -INFINITY;
@@ -2596,7 +2630,7 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
     // from the tile; lanes whose column is not an interior grid column compute on clamped copies and are dropped after the rows
     const double rs0 = sh_coef[0][lane], rs1 = sh_coef[1][lane], ri0 = sh_coef[2][lane], ri1 = sh_coef[3][lane];
     const double rl0 = sh_coef[4][lane], rl1 = sh_coef[5][lane], nm0 = sh_coef[6][lane], nm1 = sh_coef[7][lane];
-    const double fnm0 = nm0 * lz_sc, fnm1 = nm1 * lz_sc;
+    const double fnm0 = jfly ? (nm0 * lz_sc) * rl0 : nm0 * lz_sc, fnm1 = jfly ? (nm1 * lz_sc) * rl1 : nm1 * lz_sc;  // (jfly: rl = the column factor)
     double2 rv[BL_NROWS];
 #pragma unroll
     for (int i = 0; i < BL_NROWS; ++i) {
@@ -2614,8 +2648,9 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
         if constexpr (FAST) {
             // (rs0 / ri0 hold a_e / a_w of the even column, rs1 / ri1 of the odd one; fnm = (-mu0 R) * scale)
             const double nsx = N.x + S.x, nsy = N.y + S.y;
-            rv[i].x = __builtin_fma(rs0, py, __builtin_fma(ri0, Wn, __builtin_fma(L.a_ns, nsx, __builtin_fma(-fnm0, sv[i].x, -L.a_c * px))));
-            rv[i].y = __builtin_fma(rs1, En, __builtin_fma(ri1, px, __builtin_fma(L.a_ns, nsy, __builtin_fma(-fnm1, sv[i].y, -L.a_c * py))));
+            const double jx = jfly ? jraw_shape(pc[i].x, jf_pa, jf_id) : sv[i].x, jy = jfly ? jraw_shape(pc[i].y, jf_pa, jf_id) : sv[i].y;
+            rv[i].x = __builtin_fma(rs0, py, __builtin_fma(ri0, Wn, __builtin_fma(L.a_ns, nsx, __builtin_fma(-fnm0, jx, -L.a_c * px))));
+            rv[i].y = __builtin_fma(rs1, En, __builtin_fma(ri1, px, __builtin_fma(L.a_ns, nsy, __builtin_fma(-fnm1, jy, -L.a_c * py))));
             continue;
         }
         const double sx = nm0 * (sv[i].x * lz_sc), sy = nm1 * (sv[i].y * lz_sc);

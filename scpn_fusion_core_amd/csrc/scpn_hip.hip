@@ -148,6 +148,7 @@ struct Solver {
     // multigrid hierarchies keyed by min_grid
     std::map<int, Hier> hier;
     const double* lazy_src = nullptr;  // base of the level-0 source field while it holds J_raw (lazy-source Picard iterations)
+    bool lazy_jfly = false;            // ... or, source on the fly (LazySrc::jfly): lazy_src is the CURRENT ITERATE the consumers rebuild J_raw from
     DBuf<double> d_snap, d_fluxpart;    // scpn_gs_snapshot_psi's copy of the iterate / scpn_gs_flux_change's partial sums
     bool snap_valid = false;
     const double* jsum_part = nullptr;  // != nullptr: k_jsum's partial sums wait for the first lazy tile launch to finish them (LazySrc::part)
@@ -458,6 +459,7 @@ static void launch_tile_g(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, dou
     LazySrc lzs;
     if (h->lazy_src && src.base == h->lazy_src) {
         lzs.st = h->d_st.p; lzs.neg_mu0R = h->d_neg_mu0R.p;
+        if (h->lazy_jfly) { lzs.jfly = 1; lzs.r_axis = h->d_r.p; lzs.inv_mu0R = h->d_inv_mu0R.p; }
         if (h->jsum_part) {  // the first consumer of J_raw after k_jsum finishes the sum
             if (kern_sum) {
                 lzs.part = h->jsum_part; lzs.nblk = h->jsum_nblk; lzs.dr = h->dr; lzs.dz = h->dz; lzs.st_rw = h->d_st.p;
@@ -1065,9 +1067,14 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
                       vcycle_lazy_ok(h, 3, 3, 5);
     struct LazyGuard {
         Solver* h;
-        ~LazyGuard() { h->lazy_src = nullptr; h->jsum_part = nullptr; }
+        ~LazyGuard() { h->lazy_src = nullptr; h->jsum_part = nullptr; h->lazy_jfly = false; }
     } lazy_guard{h};
-    if (lazy) h->lazy_src = srcF.base;
+    // Source on the fly (contracted arithmetic, L-mode; LazySrc::jfly): J_raw is never stored -- the level-0 consumers rebuild it from
+    // the current iterate, which the pre-smoother and the tail load anyway.  SCPN_HIP_JFLY=0 keeps the stored J_raw field.
+    static const bool jfly_env = [] { const char* e = std::getenv("SCPN_HIP_JFLY"); return !(e && e[0] == '0'); }();
+    const bool jfly = jfly_env && lazy && h->arith == 1 && !p->hmode;
+    const Fld src0F = jfly ? curF : srcF;  // what the V-cycle's level-0 kernels are handed as their source field
+    if (lazy) { h->lazy_src = src0F.base; h->lazy_jfly = jfly; }
     // the fused tail (k_blend_tile) leaves the topology partials of the next iterate, and k_picard_final finishes them for the
     // members that stay active: from the second iteration on there is no topology launch at all
     const bool topo_in_final = h->use_fused && p->method != 3 && !p->xpoint_saddle;
@@ -1097,8 +1104,8 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         }
         if (!p->external_profile_mode) {
             ProfScope ps(h, "source", (lazy ? 2 : 3) - (sum_fuse ? 1 : 0));
-            SCPN_LAUNCH((pf.hmode ? k_jsum<1> : k_jsum<0>), gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
-                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, lazy ? srcF : Fld{nullptr, nullptr, 0, 0});
+            SCPN_LAUNCH((jfly ? k_jsum<0, true> : pf.hmode ? k_jsum<1> : k_jsum<0>), gjs, dim3(256), 0, st, curF, (const Member*)h->d_st.p, nz, nr, ld, (const double*)h->d_r.p,
+                               (const double*)h->d_inv_mu0R.p, pf, h->d_jpart.p, nblkj, (lazy && !jfly) ? srcF : Fld{nullptr, nullptr, 0, 0});
             if (sum_fuse) { h->jsum_part = h->d_jpart.p; h->jsum_nblk = nblkj; }  // (the V-cycle's first level-0 launch finishes the sum)
             else
                 SCPN_LAUNCH(k_jsum_final, dim3(B), dim3(256), 0, st, h->d_st.p, (const double*)h->d_jpart.p, nblkj, h->dr, h->dz);
@@ -1112,7 +1119,7 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
         //  bit-exact and measured slower or unsafe in rounds 1-2: profiles/r02_negative/tile_kernel_r02_variants.hip.h.txt)
         int nb_d = nblk1, nb_r = nblk_r;
         if (p->method == 0) {
-            newF = vcycle(h, curF, WF, W2F, srcF, p->sor_omega, 3, 3, 5, act);
+            newF = vcycle(h, curF, WF, W2F, src0F, p->sor_omega, 3, 3, 5, act);
         } else if (p->method == 1 || p->method == 3 || p->method == 4) {  // "sor", "anderson" and any other method string (iterative_solver.py:376-378)
             SCPN_LAUNCH(k_sanitize, g2, BLK2D, 0, st, WF, curF, nz, nr, ld);
             SCPN_LAUNCH(k_sanitize, g2, BLK2D, 0, st, src2F, srcF, nz, nr, ld);
@@ -1140,7 +1147,8 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             static const int xcd_blend = [] { const char* e = std::getenv("SCPN_HIP_XCD_BLEND"); return e ? std::atoi(e) : 1; }();
             SCPN_LAUNCH((h->arith == 1 ? k_blend_tile<true> : k_blend_tile<false>), dim3(cdiv(nr, BL_WR), cdiv(nz, BL_WZ), B), dim3(64 * BL_NW), 0, st, nxtF, curF, newF, bcF, srcF,
                                (const Member*)h->d_st.p, L0, p->alpha, om_alpha, n_mask_rows, h->d_part1.p, h->d_pbad.p, h->d_part2.p,
-                               h->d_part3.p, h->d_topo.p, nblk2, lazy ? (const double*)h->d_neg_mu0R.p : (const double*)nullptr, gq, xcd_blend);
+                               h->d_part3.p, h->d_topo.p, nblk2, lazy ? (const double*)h->d_neg_mu0R.p : (const double*)nullptr, gq, xcd_blend,
+                               jfly ? (const double*)h->d_r.p : (const double*)nullptr, jfly ? (const double*)h->d_inv_mu0R.p : (const double*)nullptr);
         } else {
             ProfScope ps(h, "blend_norms", 2);
             SCPN_LAUNCH(k_blend, dim3(nblk1, B), dim3(256), 0, st, nxtF, curF, newF, bcF, (const Member*)h->d_st.p, nz, nr, ld, p->alpha,
