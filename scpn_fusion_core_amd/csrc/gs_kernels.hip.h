@@ -2721,6 +2721,21 @@ __global__ void __launch_bounds__(64 * BL_NW, BL_WPE) k_blend_tile(Fld nxtF, Fld
             const double2 P = *reinterpret_cast<const double2*>(&t[lz][2 * lane]);
             const double px = P.x, py = P.y;
             auto grad = [&](double p, double n_, double s_, double e_, double w_, int gc) {
+                if constexpr (FAST) {
+                    // contracted: reciprocal multiplies and the SQUARED magnitude (the arg-min of |grad psi|^2 is the arg-min of |grad psi|;
+                    // a non-finite operand makes the value non-finite, which never wins -- the reference's nan_to_num only matters in a
+                    // state the non-finite check has already flagged)
+                    double gzv, grv;
+                    if (gz == 0) gzv = (n_ - p) * gq.inv_dz;  // (row tests are wave-uniform)
+                    else if (gz == nz - 1) gzv = (p - s_) * gq.inv_dz;
+                    else gzv = (n_ - s_) * gq.inv_two_dz;
+                    grv = (e_ - w_) * L.inv_two_dr;
+                    if (edge_cols) {
+                        const double g0 = (e_ - p) * gq.inv_dr, g1 = (p - w_) * gq.inv_dr;
+                        grv = gc == 0 ? g0 : (gc == nr - 1 ? g1 : grv);
+                    }
+                    return __builtin_fma(grv, grv, gzv * gzv);
+                }
                 const double ps = nan_to_num300(p), nn = nan_to_num300(n_), ss = nan_to_num300(s_), ee = nan_to_num300(e_), ww = nan_to_num300(w_);
                 double gzv, grv;
                 if (gz == 0) gzv = divc4(nn - ps, gq.dz, gq.inv_dz, gq.lo_dz);  // (row tests are wave-uniform)
