@@ -602,7 +602,7 @@ def main() -> int:
         try:
             from benchmarks.configs import measure_configs
 
-            configs = measure_configs(device=local_rank, members=B, check_every=args.check_every)
+            configs = measure_configs(device=local_rank, members=B, check_every=args.check_every, arithmetic=args.arith)
         except Exception as exc:
             configs = {"error": f"{type(exc).__name__}: {exc}"}
 

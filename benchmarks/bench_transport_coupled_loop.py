@@ -24,7 +24,7 @@ from scpn_fusion_core_amd.ensemble import EnsembleSolver  # noqa: E402
 from scpn_fusion_core_amd.cases import iter_like_cfg  # noqa: E402
 
 
-def coupled_steps(n: int = 513, B: int = 32, steps: int = 4, device: int | None = None, verbose: bool = False) -> dict:
+def coupled_steps(n: int = 513, B: int = 32, steps: int = 4, device: int | None = None, verbose: bool = False, arithmetic: str | None = None) -> dict:
     """`steps` coupled steps (after one warm-up step) of a B-member ensemble on the n x n ITER-like grid; returns the timing rows and
     the mean seconds per coupled step.  Device work only (no oracle)."""
     cfg = iter_like_cfg(n, tol=1e-6, max_iter=400)
@@ -35,6 +35,8 @@ def coupled_steps(n: int = 513, B: int = 32, steps: int = 4, device: int | None 
     cd = tc.CurrentDiffusionSolver(rho, R0=6.2, a=2.0, B0=5.3, batch=B)
     rows = []
     kw = {} if device is None else {"device": device}
+    if arithmetic is not None:
+        kw["arithmetic"] = arithmetic
     with EnsembleSolver(cfg, batch=B, current_targets=15.0 * scale[:, 0], **kw) as es:
         es.solve_equilibrium()
         for k in range(steps + 1):

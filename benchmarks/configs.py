@@ -30,7 +30,9 @@ def _best_of(fn, reps=3):
     return min(ts), out
 
 
-def measure_configs(device: int = 0, members: int = 32, check_every: int = 8) -> dict:
+def measure_configs(device: int = 0, members: int = 32, check_every: int = 8, arithmetic: str = "contracted") -> dict:
+    """``arithmetic`` (``scpn_gs_set_arith``) applies to the resident-handle rows (configs 2, 3, 4); the smoother benchmark and the
+    dispatcher seam run the bit-exact operators whatever it says."""
     from scpn_fusion_core_amd.cases import bench_problem, diiid_like_cfg, iter_like_cfg
     from scpn_fusion_core_amd.ensemble import EnsembleSolver
 
@@ -39,7 +41,8 @@ def measure_configs(device: int = 0, members: int = 32, check_every: int = 8) ->
     cfg2 = iter_like_cfg(257, tol=1e-8, max_iter=1000)
     ip = cfg2["physics"]["plasma_current_target"]
     rng = np.random.default_rng(2026)
-    with EnsembleSolver(cfg2, batch=members, current_targets=ip * (1.0 + 0.1 * (2.0 * rng.random(members) - 1.0)), device=device) as es:
+    out["arithmetic"] = arithmetic
+    with EnsembleSolver(cfg2, batch=members, current_targets=ip * (1.0 + 0.1 * (2.0 * rng.random(members) - 1.0)), device=device, arithmetic=arithmetic) as es:
         def run2():
             es.fill_psi(0.0)
             r = es.solve_equilibrium(check_every=check_every)
@@ -55,11 +58,11 @@ def measure_configs(device: int = 0, members: int = 32, check_every: int = 8) ->
         "memoised_setup": "vacuum field per handle: calculate_vacuum_field of an unchanged coil set (1.8 ms for 32 members at 513^2) is evaluated once per resident handle, the reference pays it in every solve_equilibrium call"}
 
     # ---- config 3: one equilibrium at a time
-    def single(cfg, newton=False):
+    def single(cfg, newton=False, arith=None, **lane):
         c = cfg if not newton else {**cfg, "solver": {**cfg["solver"], "solver_method": "newton", "gmres_preconditioner": "multigrid",
                                                        "newton_jacobian": "finite_difference", "newton_damping": 1.0,
-                                                       "max_iterations": 60, "newton_warmup_steps": 2}}
-        with EnsembleSolver(c, batch=1, device=device) as one:
+                                                       "max_iterations": 60, "newton_warmup_steps": 2, **lane}}
+        with EnsembleSolver(c, batch=1, device=device, arithmetic=arith or arithmetic) as one:
             def run():
                 one.fill_psi(0.0)
                 r = one.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=check_every)
@@ -73,8 +76,11 @@ def measure_configs(device: int = 0, members: int = 32, check_every: int = 8) ->
     d3d, it1 = diiid_like_cfg(513), iter_like_cfg(513, tol=1e-8, max_iter=1000)
     out["config3_single_free_boundary_513"] = {
         "unit": "ms per equilibrium (ONE member, unbatched)",
-        "diiid_like": {"picard": single(d3d), "newton_fd_mg": single(d3d, True)},
-        "iter_like_bench_member": {"picard": single(it1), "newton_fd_mg": single(it1, True)},
+        "diiid_like": {"picard": single(d3d), "picard_exact_arithmetic": single(d3d, arith="exact"), "newton_fd_mg": single(d3d, True),
+                       # the lane's Krylov cap (gmres_restart, default 8: the best setting of the 32-member ensemble) is what costs this case
+                       # its extra Newton steps: 13 of its 20 linear solves end at the cap (tools/d3d_newton_fb_hist.py, tools/newton_krylov_cap.py)
+                       "newton_fd_mg_krylov24": single(d3d, True, gmres_restart=24)},
+        "iter_like_bench_member": {"picard": single(it1), "picard_exact_arithmetic": single(it1, arith="exact"), "newton_fd_mg": single(it1, True)},
         "workload": "solve_free_boundary(max_outer_iter=20, tol=1e-4, optimize_shape=False), 513x513, Picard tol 1e-8 "
                     "(DIII-D-like: validation/diiid_config.json; the real shot g145419 is not in the reference checkout)"}
 
@@ -117,7 +123,7 @@ def measure_configs(device: int = 0, members: int = 32, check_every: int = 8) ->
     try:
         from benchmarks.bench_transport_coupled_loop import coupled_steps
 
-        run = coupled_steps(513, members, 3, device=device)
+        run = coupled_steps(513, members, 3, device=device, arithmetic=arithmetic)
         out["config4_transport_coupled_loop_513"] = {
             "value": round(run["member_steps_per_s"], 2), "unit": "member-steps/s", "members": members,
             "s_per_coupled_step_ensemble": round(run["s_per_coupled_step_ensemble"], 4),
