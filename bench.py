@@ -41,11 +41,22 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec; the copy bandwidth me
 # >= 1 the zero input is not read: SMOOTH_PRE_COARSE_LEVEL_BYTES); smooth_*_post = prolong-add + 3 sweeps (coarse e in = 8/4).
 FAMILY_BYTES = {"smooth_pre": (26.0, 106.0), "smooth_post": (26.0, 90.0), "smooth": (24.0, 72.0),
                 "blend_fused": (32.0, 40.0), "source": (16.0, 24.0)}
+# contracted arithmetic, L-mode: source on the fly (LazySrc::jfly) -- J_raw is never stored: the level-0 pre-smoother
+# reads psi ONCE (it is both its input and the field the source is rebuilt from), the tail rebuilds the source from `cur`, k_jsum only reads
+FAMILY_BYTES_JFLY = {"smooth_pre": (18.0, 106.0), "smooth_post": (26.0, 90.0), "smooth": (24.0, 72.0),
+                     "blend_fused": (24.0, 40.0), "source": (8.0, 24.0)}
 SMOOTH_PRE_COARSE_LEVEL_BYTES = 18.0  # src in, psi out, coarse rhs out
+# cells a tile loads / cells it keeps (48 x 128 register tile, halo 8 / 6; the tail's 16 x 128 tile keeps 14 x 124)
+HALO_REDUNDANCY = {"smooth_pre": (48 * 128) / (32 * 112), "smooth_post": (48 * 128) / (36 * 116), "blend_fused": (16 * 128) / (14 * 124)}
+ARITH = {"mode": "exact"}  # set by main(): which byte table prices the launches
+
+
+def family_table() -> dict:
+    return FAMILY_BYTES_JFLY if ARITH["mode"] == "contracted" else FAMILY_BYTES
 
 
 def family_bytes_per_point(family: str, lvl: int) -> float:
-    return SMOOTH_PRE_COARSE_LEVEL_BYTES if (family == "smooth_pre" and lvl >= 1) else FAMILY_BYTES.get(family, (16.0, 16.0))[0]
+    return SMOOTH_PRE_COARSE_LEVEL_BYTES if (family == "smooth_pre" and lvl >= 1) else family_table().get(family, (16.0, 16.0))[0]
 
 
 def counters_of(kernel_symbol: str) -> dict | None:
@@ -62,7 +73,11 @@ def counters_of(kernel_symbol: str) -> dict | None:
         if not rows:
             return None
         r = max(rows, key=lambda x: float(x["grid_size"]))  # the level-0 launch shape
-        pick = {k: float(r[k]) for k in ("valu_busy", "lds_busy", "waves_per_simd", "wait_frac", "stall_frac", "issue_frac", "clock_GHz") if r.get(k)}
+        pick = {k: float(r[k]) for k in ("valu_busy", "lds_busy", "waves_per_simd", "wait_frac", "stall_frac", "issue_frac", "clock_GHz", "insts_valu",
+                                         "median_us") if r.get(k)}
+        if "insts_valu" in pick and pick.get("clock_GHz"):
+            # wave-instructions x 4 cycles each / (1 024 SIMDs x clock): the time the launch needs for pure VALU issue on the whole chip
+            pick["valu_issue_us"] = round(pick["insts_valu"] * 4.0 / (1024.0 * pick["clock_GHz"] * 1e3), 2)
         pick.update({"source": f"profiles/{tag}_sq_by_kernel.csv", "kernel": r["kernel"], "grid_size": int(float(r["grid_size"]))})
         return pick
     except (OSError, ValueError, KeyError):
@@ -89,7 +104,7 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
     if not groups:
         return None
     dom = max(groups, key=lambda k: sum(v["ms"] for _, v in groups[k]))
-    fused_pt, survey_pt = FAMILY_BYTES.get(dom, (16.0, 16.0))
+    fused_pt, survey_pt = family_table().get(dom, (16.0, 16.0))
     try:
         pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
         if pmc.get("grid") != grid:
@@ -135,12 +150,11 @@ def roofline_of(fam: dict, grid: int, members_per_launch: float, num_groups: int
                                      "gbs_equivalent": round(bytes_survey / (tot_ms * 1e-3) / 1e9, 1)},
             "avg_launch_us": round(1e3 * tot_ms / tot_launch, 2), "launches": int(tot_launch),
             "groups": num_groups, "members_per_launch": int(members_per_launch), "isolated_kernel_timing": True,
-            "limiter": {"class": "tiles in flight x tile lifetime on a chip where neither VALU (see counters) nor HBM (counter traffic = compulsory bytes) is "
-                                 "saturated; what shortens a tile's life is memory round trips in its load phase (post-smoother six -> one by LDS-DMA: -5 % per "
-                                 "iteration) and vector work outside the stencil (Picard tail -31 % VALU: -2 %); bytes alone do not (a tail with 25 % less traffic and "
-                                 "8 % more arithmetic is slower), larger tiles pack worse than the arithmetic they save; the iteration time is the length of one stream "
-                                 "group's serial chain of eleven kernels (a 10 us sleep in the coarse V-cycle arrives as +11.5 us), stretched x1.3 by the other group",
-                        "counters": ctr, "evidence": "profiles/r04_experiments.md, profiles/r03_experiments.md, DESIGN.md section 6"},
+            # what the committed SQ counters of this very kernel say (profiles/<tag>_sq_by_kernel.csv): VALU issue time against the launch,
+            # wave occupancy, wait / stall split; and the geometric redundancy of its tile
+            "limiter": {"counters": ctr, "halo_redundancy": round(HALO_REDUNDANCY[dom], 3) if dom in HALO_REDUNDANCY else None,
+                        "valu_issue_frac_of_launch": (round(ctr["valu_issue_us"] / ctr["median_us"], 3) if ctr and ctr.get("valu_issue_us") and ctr.get("median_us") else None),
+                        "arithmetic": ARITH["mode"], "evidence": "profiles/r06_experiments.md, DESIGN.md section 6"},
             "per_level": per_level, "families_ms": fam}
 
 
@@ -248,6 +262,7 @@ def main() -> int:
                 print(f"bench.py: no communicator ({comm_error}) and not every rank has a GPU -- {'; '.join(missing)}", file=sys.stderr)
             return 3
     _lib.require_gpu()
+    ARITH["mode"] = args.arith
     cfg = make_cfg(args.grid)
     from scpn_fusion_core_amd.distributed import plan_ensemble
 
@@ -397,7 +412,7 @@ def main() -> int:
             old_groups = os.environ.get("SCPN_HIP_GROUPS")
             os.environ["SCPN_HIP_GROUPS"] = "1"
             try:
-                with EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, coil_r=coil_r, coil_z=coil_z, device=local_rank) as one:
+                with EnsembleSolver(cfg, batch=B, coil_currents=currents, current_targets=targets, coil_r=coil_r, coil_z=coil_z, device=local_rank, arithmetic=args.arith) as one:
                     one.fill_psi(0.0)
                     one.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
                     one.fill_psi(0.0)
@@ -411,9 +426,10 @@ def main() -> int:
                 else:
                     os.environ["SCPN_HIP_GROUPS"] = old_groups
             full = {}
-            for name, (key, bpp) in {"smooth_tile_L0_pre": ("smooth_pre", FAMILY_BYTES["smooth_pre"][0]),
-                                     "smooth_tile_L0_post": ("smooth_post", FAMILY_BYTES["smooth_post"][0]),
-                                     "blend_fused": ("blend_fused", FAMILY_BYTES["blend_fused"][0])}.items():
+            for name, (key, bpp) in {"smooth_tile_L0_pre": ("smooth_pre", family_table()["smooth_pre"][0]),
+                                     "smooth_tile_L0_post": ("smooth_post", family_table()["smooth_post"][0]),
+                                     "blend_fused": ("blend_fused", family_table()["blend_fused"][0]),
+                                     "source": ("source", family_table()["source"][0])}.items():
                 if name in fam1 and fam1[name]["launches"]:
                     us = 1e3 * fam1[name]["ms"] / fam1[name]["launches"]
                     gbs = bpp * n_pts * B / us / 1e3
@@ -530,7 +546,7 @@ def main() -> int:
                                       "newton_warmup_steps": 2}}
             psi_picard = es.get_psi()
             es.close()  # (done with the Picard handle; keeps this lane's two group streams on hardware queues of their own)
-            with EnsembleSolver(ncfg, batch=B, coil_currents=currents, current_targets=targets, coil_r=coil_r, coil_z=coil_z, device=local_rank) as nes:
+            with EnsembleSolver(ncfg, batch=B, coil_currents=currents, current_targets=targets, coil_r=coil_r, coil_z=coil_z, device=local_rank, arithmetic=args.arith) as nes:
                 def nstep():
                     nes.fill_psi(0.0)
                     return nes.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)
@@ -579,7 +595,7 @@ def main() -> int:
                                "checks": rec["checks"], "pass": bool(rec["pass"] and len(rec["checks"]) == 5)}
             g = np.load(ROOT / "tests" / "golden" / "d3d129_reference_lane.npz")  # data only: the reference lane's flux map
             gcfg = diiid_like_cfg(129)
-            with EnsembleSolver(gcfg, batch=2, device=local_rank) as ges:
+            with EnsembleSolver(gcfg, batch=2, device=local_rank, arithmetic=args.arith) as ges:
                 ges.solve_free_boundary(max_outer_iter=20, tol=1e-4)
                 gpsi, gj = ges.get_psi(0), ges.get_jphi(0)
             gd, gax = gcfg["dimensions"], g["axis_x"]
@@ -614,7 +630,7 @@ def main() -> int:
             es.close()
             t256 = shape_scan_member_table(cfg, 256)
             with EnsembleSolver(cfg, batch=256, coil_currents=t256["currents"], current_targets=t256["targets"], coil_r=t256["coil_r"],
-                                coil_z=t256["coil_z"], device=local_rank) as big:
+                                coil_z=t256["coil_z"], device=local_rank, arithmetic=args.arith) as big:
                 def bstep():
                     big.fill_psi(0.0)
                     return big.solve_free_boundary(max_outer_iter=20, tol=1e-4, check_every=args.check_every)

@@ -488,7 +488,10 @@ static void launch_tile(Solver* h, const Lvl& L, Fld out, Fld in, Fld src, doubl
     if constexpr (S == 3) {
         const int members = h->ensemble_B > 0 ? h->ensemble_B : h->B;
         const long tiles0 = (long)cdiv(h->nr, 128 - 16) * cdiv(h->nz, 40 - 16) * members;  // (counted in 24-row windows of 112 columns)
-        const int geo = geo_env ? geo_env : (members > mid_maxb ? 48 : (tiles0 <= tiny_max ? 24 : 32));
+        // (SCPN_HIP_TILEGEO_SUB=24 / 32 / 48: another geometry for the levels below the finest one -- experiments)
+        static const int geo_sub = [] { const char* e = std::getenv("SCPN_HIP_TILEGEO_SUB"); return e ? std::atoi(e) : 0; }();
+        const bool sub_level = L.nz != h->nz || L.nr != h->nr;
+        const int geo = (sub_level && geo_sub) ? geo_sub : geo_env ? geo_env : (members > mid_maxb ? 48 : (tiles0 <= tiny_max ? 24 : 32));
         if (geo == 48) return launch_tile_g<S, PROLONG, DEFECT, TILE_BIG_LZ, TILE_BIG_NW>(h, L, out, in, src, omega, active, ps, dfo, in_zero);
         if (geo == 24) return launch_tile_g<S, PROLONG, DEFECT, TILE_TINY_LZ, TILE_TINY_NW>(h, L, out, in, src, omega, active, ps, dfo, in_zero);
     }
