@@ -175,7 +175,11 @@ typedef struct scpn_picard_params {
     int preserve_initial_state;
     int has_boundary_flux; /* use the field set by scpn_gs_set_boundary_flux as Dirichlet map */
     int external_profile_mode;
-    int check_every;     /* host polls the device convergence word every this many iterations (>=1) */
+    int check_every;     /* host polls the device convergence word every this many iterations (>=1).  ONLY used by the blocking-poll
+                          * loop (environment SCPN_HIP_RUNAHEAD=0, or no host-mapped memory): the default run-ahead loop follows the device
+                          * through two host-mapped words {solve id, launches started} / {solve id, done} every iteration and ignores it.
+                          * Measured gain of the run-ahead loop on the 32-member bench: +0.1 ... +0.3 %, i.e. inside box noise
+                          * (profiles/r05_ab_runahead_bench.txt); it matters for short solves of few members */
     int fail_on_diverge;
     int skip_seed;       /* 1: do not run _seed_plasma (not a reference behaviour; benchmarking aid) */
     int anderson_m;      /* solver.anderson_depth (default 5, at most 5) */

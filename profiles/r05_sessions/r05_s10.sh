@@ -1,4 +1,9 @@
 #!/bin/bash
+# NOTE (round 6): this script drives switches / tools that are NOT in the tree at HEAD (SCPN_HIP_PAIR ): they exist only with the archived diffs of
+# profiles/r05_negative/ applied (cu_reservation_for_the_coarse_kernel.md, issue_priority_s_setprio.md, paired_tile_launches.diff.txt) or, for the
+# timing emulation, profiles/r05_emu_fuse_timing_experiment.diff.txt.  Without them the environment variables are ignored (a no-op A/B) and
+# tools/pair_stamps.py / libscpn_hip.base.so are absent.  Kept as the record of how the round-5 tables were produced.
+if [ -z "$SCPN_R05_DIFFS_APPLIED" ]; then echo "$0: archived experiment -- apply the round-5 diffs first (see the header), then export SCPN_R05_DIFFS_APPLIED=1" >&2; exit 2; fi
 # r05 session 10: paired tile launches (k_smooth_tile_pair; SCPN_HIP_PAIR bit 0: pre-smoothers of levels 1 + 2, bit 1: post-smoothers 2 + 1)
 set -o pipefail
 export GPU_MAX_HW_QUEUES=8
