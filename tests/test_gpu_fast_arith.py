@@ -186,3 +186,72 @@ def test_contracted_mode_leaves_the_stateless_operators_exact(ES, orc, monkeypat
     dr, dz = float(r[1] - r[0]), float(z[1] - z[0])
     assert np.array_equal(mgs.multigrid_vcycle(psi0.copy(), source, rr, dr, dz), orc.multigrid_vcycle(psi0, source, rr, dr, dz))
     assert np.array_equal(mgs.mg_smooth(psi0.copy(), source, rr, dr, dz, 1.3, 6), orc.mg_smooth(psi0, source, rr, dr, dz, 1.3, 6))
+
+
+@pytest.mark.parametrize("nr,nz,batch", [(97, 161, 3), (200, 141, 5), (130, 67, 2), (65, 257, 7), (513, 300, 13)])
+def test_contracted_non_square_grids_odd_batches_vs_oracle(ES, orc, nr, nz, batch):
+    """Edge tiles (grids that are no multiple of the tile window, even sizes), ensembles that split unevenly over the stream groups, the
+    source-on-the-fly path in every tile geometry: every member against its own CPU solve, fixed boundary then three free-boundary outer iterations."""
+    cfg = iter_like_cfg(33, tol=1e-6, max_iter=300)
+    cfg["grid_resolution"] = [nr, nz]
+    targets = 15.0 * (1.0 + 0.05 * np.linspace(-1, 1, batch))
+    with ES(cfg, batch=batch, current_targets=targets, arithmetic="contracted") as es:
+        res = es.solve_equilibrium(check_every=7)
+        psi = es.get_psi()
+        fres = es.solve_free_boundary(max_outer_iter=3, tol=1e-4)
+        fpsi = es.get_psi()
+    co = cfg["coils"]
+    for b in sorted({0, batch // 2, batch - 1}):
+        c = {**cfg, "physics": dict(cfg["physics"], plasma_current_target=float(targets[b]))}
+        ref = orc.picard_solve(c)
+        assert _counts_close(res[b]["iterations"], ref["iterations"]) and res[b]["converged"] == ref["converged"], (b, res[b]["iterations"], ref["iterations"])
+        assert np.abs(psi[b] - ref["psi"]).max() <= PSI_TOL * np.abs(ref["psi"]).max(), b
+        fref = orc.free_boundary_solve(c, [k["r"] for k in co], [k["z"] for k in co], [k["current"] for k in co], [1.0] * len(co),
+                                       psi0=ref["psi"], max_outer=3, tol=1e-4)
+        assert _counts_close(fres[b]["picard_iterations"], fref["picard_iterations"]), (b, fres[b]["picard_iterations"], fref["picard_iterations"])
+        assert np.abs(fpsi[b] - fref["psi"]).max() <= 1e-9 * np.abs(fref["psi"]).max(), b  # (three unconverged outer iterations: the Picard tolerance 1e-6 is what both reach)
+
+
+def test_contracted_external_profile_mode_and_frozen_members(ES, orc):
+    """Paths of the contracted build that do NOT rebuild the source on the fly: external_profile_mode (the source field holds the mapped
+    current: BASELINE config 4's re-solve) and an ensemble in which members converge at different iterations (frozen members are skipped)."""
+    from scpn_fusion_core_amd import transport_coupling as tc
+
+    n = 129
+    cfg = iter_like_cfg(n, tol=1e-8, max_iter=1000)
+    rho = np.linspace(0, 1, 64)
+    p1 = np.stack([5.0 * (1 - rho**2) ** 1.5, 5.05 * (1 - rho**2) ** 1.5])
+    jb = np.stack([1e-3 * rho * (1 - rho), 1.01e-3 * rho * (1 - rho)])
+    with ES(cfg, batch=2, arithmetic="contracted") as es:
+        es.solve_equilibrium()
+        _resid, res = tc.gs_transport_outer_step(es, rho, p1, jb)
+        psi1 = es.get_psi()
+    ref = orc.picard_solve(cfg, external_profile_mode=True)
+    for b in range(2):
+        assert _counts_close(res[b]["iterations"], ref["iterations"]) and res[b]["converged"], (res[b]["iterations"], ref["iterations"])
+        assert np.abs(psi1[b] - ref["psi"]).max() <= PSI_TOL * np.abs(ref["psi"]).max(), b
+    # members with very different targets: the loose one converges (and freezes) dozens of iterations before the tight one
+    cfg2 = iter_like_cfg(65, tol=1e-7, max_iter=600)
+    targets = np.array([15.0, 3.0, 15.0, 0.0])  # (member 3: the zero-current short-circuit)
+    with ES(cfg2, batch=4, current_targets=targets, arithmetic="contracted") as es:
+        res = es.solve_equilibrium(check_every=5)
+        psi = es.get_psi()
+    for b in range(3):
+        ref = orc.picard_solve({**cfg2, "physics": dict(cfg2["physics"], plasma_current_target=float(targets[b]))})
+        assert _counts_close(res[b]["iterations"], ref["iterations"]), (b, res[b]["iterations"], ref["iterations"])
+        assert np.abs(psi[b] - ref["psi"]).max() <= PSI_TOL * np.abs(ref["psi"]).max(), b
+    assert res[3]["iterations"] == 0 and res[3]["converged"] and res[0]["iterations"] != res[1]["iterations"]
+    assert np.array_equal(psi[0], psi[2])
+
+
+def test_contracted_hmode_ensemble_keeps_the_stored_source(ES, orc):
+    """H-mode (mtanh pedestal: two tanh per point) is not rebuilt on the fly -- the contracted kernels read the stored J_raw field."""
+    cfg = iter_like_cfg(129, tol=1e-8, max_iter=600)
+    cfg["physics"]["profiles"] = {"mode": "h-mode", "p_prime": {"ped_top": 0.9}}
+    ref = orc.picard_solve(cfg)
+    with ES(cfg, batch=16, arithmetic="contracted") as es:  # (16 members: two stream groups, the 48 x 8 geometry)
+        res = es.solve_equilibrium()
+        psi = es.get_psi()
+    assert _counts_close(res[0]["iterations"], ref["iterations"]), (res[0]["iterations"], ref["iterations"])
+    assert np.abs(psi[0] - ref["psi"]).max() <= PSI_TOL * np.abs(ref["psi"]).max()
+    assert all(np.array_equal(psi[0], psi[b]) for b in range(16))
