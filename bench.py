@@ -70,6 +70,9 @@ def counters_of(kernel_symbol: str) -> dict | None:
         want = {"smooth_pre": "k_smooth_tile<3, false, true", "smooth_post": "k_smooth_tile<3, true, false",
                 "smooth": "k_smooth_tile<3, false, false", "blend_fused": "k_blend_tile", "source": "k_jsum<"}.get(kernel_symbol, kernel_symbol)
         rows = [r for r in csv.DictReader(open(path)) if want in r["kernel"]]
+        # the trace may hold the kernels of both arithmetic modes: the contracted instantiations carry a trailing `true` template argument
+        fast = [r for r in rows if r["kernel"].rstrip().endswith("true>")]
+        rows = (fast or rows) if ARITH["mode"] == "contracted" else ([r for r in rows if r not in fast] or rows)
         if not rows:
             return None
         r = max(rows, key=lambda x: float(x["grid_size"]))  # the level-0 launch shape
@@ -194,6 +197,7 @@ def main() -> int:
                     help="arithmetic of the timed run (scpn_gs_set_arith): contracted = FMA chains, psi within 1e-10 max|psi| of the CPU "
                          "reference (tests/test_gpu_fast_arith.py); exact = the reference's operation order, bit-exact operators.  The "
                          "other mode is timed after the clock and reported under \"arithmetic_modes\"")
+    ap.add_argument("--no-arith-modes", action="store_true", help="skip the timing of the other arithmetic mode (profile runs: one kernel set per trace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-newton", action="store_true", help="skip the Newton-lane figure reported beside the metric")
@@ -359,7 +363,7 @@ def main() -> int:
     #      are kept as `survey_8d_equivalent`: a statement about fusion, not about memory traffic.
     # ---- the OTHER arithmetic mode on the same handle, timed the same way but outside the headline's clock (rank 0, N = 1)
     arith_modes = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_arith_modes:
         other = "exact" if args.arith == "contracted" else "contracted"
         psi_head = es.get_psi()
         es.arithmetic = other

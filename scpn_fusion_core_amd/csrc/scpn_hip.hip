@@ -2586,6 +2586,11 @@ struct TempSolver {
                 if (same_grid(v[i], nr, nz, batch, r_axis, z_axis, dr, dz)) { h = v[i]; v.erase(v.begin() + (long)i); break; }
         }
         if (h) {  // back to the state create_impl leaves (the fields are overwritten by the call's uploads)
+            if (!h->stream) {  // (an idle pooled solver holds no stream: see the destructor)
+                if (hipStreamCreate(&h->stream) != hipSuccess) { h->stream = nullptr; delete h; h = nullptr; }
+            }
+        }
+        if (h) {
             h->arith = 0; h->prof_on = false; h->lazy_src = nullptr; h->jsum_part = nullptr; h->snap_valid = false;
             h->vac_valid = false; h->n_vac = 0;
             std::fill(h->i_target.begin(), h->i_target.end(), 0.0);
@@ -2598,6 +2603,11 @@ struct TempSolver {
         const bool healthy = hipStreamSynchronize(h->stream) == hipSuccess;
         const bool small = (double)h->stride * h->B * sizeof(double) * 12.0 < 4.0e9;
         if (enabled() && healthy && small && std::uncaught_exceptions() == 0) {
+            // an idle solver gives its stream back: every live stream is mapped onto one of the few hardware queues, and a parked
+            // stream would make the stream groups of a resident handle share theirs (measured: BASELINE config 4 inside bench.py
+            // 1 083 -> 693 member-steps/s with four pooled streams alive)
+            (void)hipStreamDestroy(h->stream);
+            h->stream = nullptr;
             Solver* evict = nullptr;
             {
                 std::lock_guard<std::mutex> lk(mu());

@@ -6,13 +6,14 @@
 # turns them into the committed files under profiles/.
 set -e
 tag=${1:-r02a}
+EXTRA="${@:2}"  # extra bench.py arguments for every pass, e.g. `--arith exact`
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/k -o k -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-newton --no-configs > $out/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/k -o k -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-newton --no-configs --no-arith-modes $EXTRA > $out/bench_under_rocprof.log 2>&1
 echo "kernel stats done"
 export SCPN_HIP_GROUPS=1
-PMC_CMD="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-newton --no-configs"
+PMC_CMD="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-newton --no-configs --no-arith-modes $EXTRA"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/f -o f -- $PMC_CMD > $out/pmc_fetch.log 2>&1
 echo "fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/w -o w -- $PMC_CMD > $out/pmc_write.log 2>&1
