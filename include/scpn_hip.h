@@ -337,6 +337,9 @@ int scpn_gs_num_groups(scpn_gs *h);
  * The default of new handles comes from the environment variable SCPN_HIP_ARITH (exact | contracted).  The stateless
  * operator API (section 2), the dispatcher providers and the legacy ABI (section 1) are always exact.
  * Returns SCPN_E_ARG for another mode. */
+/* The stateless operators (section 2) keep the solver objects of the last few grids in a pool (as the reference's GPU provider caches
+ * its PyGpuSolver per grid, core/_multi_compat_providers.py:720,755-792); SCPN_HIP_OPCACHE=0 turns it off.  Counters for tests / tools. */
+int scpn_operator_pool_stats(long *hits, long *misses, int *idle);
 int scpn_gs_set_arith(scpn_gs *h, int mode);
 int scpn_gs_get_arith(scpn_gs *h);
 

@@ -140,6 +140,7 @@ SIGNATURES = {
     "scpn_gs_profile_names": (_i, [_vp, C.c_char_p, _i]),
     "scpn_gs_sync": (_i, [_vp]),
     "scpn_gs_num_groups": (_i, [_vp]),
+    "scpn_operator_pool_stats": (_i, [C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(_i)]),
     "scpn_gs_set_arith": (_i, [_vp, _i]),
     "scpn_gs_get_arith": (_i, [_vp]),
     # ensemble gather over RCCL

@@ -144,6 +144,7 @@ struct Solver {
     double dr = 0, dz = 0;
     std::vector<double> r_axis, z_axis;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;  // false: the shared stream of the stateless operators (TempSolver)
 
     // multigrid hierarchies keyed by min_grid
     std::map<int, Hier> hier;
@@ -223,7 +224,7 @@ struct Solver {
         for (auto& e : prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         if (h_nactive) (void)hipHostFree(h_nactive);
         if (h_word) (void)hipHostFree(h_word);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream && owns_stream) (void)hipStreamDestroy(stream);
     }
 };
 
@@ -705,6 +706,26 @@ static void upload(Solver* h, double* dst_base, int member, const double* host) 
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
 }
+static inline void cpu_relax() {  // a spin-wait hint where the host ISA has one
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
+// Wait for a stream by polling it for a few milliseconds before blocking: a blocking wait sleeps on an interrupt, and on some hosts
+// that sleep only ends at the next scheduler tick (a 1-ms call of a stateless operator then takes 20-30 ms: observed on one box of the pool, round 6)
+static hipError_t stream_wait(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q != hipErrorNotReady) return q;
+        cpu_relax();
+        if ((spins & 0x3ffu) == 0x3ffu && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) return hipStreamSynchronize(st);
+    }
+}
 static void download(Solver* h, const double* src_base, int member, double* host) {
     if (member >= 0) {
         HIP_TRY(hipMemcpy2DAsync(host, sizeof(double) * h->nr, src_base + (long)member * h->stride, sizeof(double) * h->ld,
@@ -714,7 +735,7 @@ static void download(Solver* h, const double* src_base, int member, double* host
             HIP_TRY(hipMemcpy2DAsync(host + (long)b * h->nz * h->nr, sizeof(double) * h->nr, src_base + (long)b * h->stride,
                                      sizeof(double) * h->ld, sizeof(double) * h->nr, h->nz, hipMemcpyDeviceToHost, h->stream));
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(stream_wait(h->stream));
 }
 // psi lives in ping-pong slots: member b is at slot cur[b]
 static std::vector<int> host_cur(Solver* h) {
@@ -828,15 +849,6 @@ static bool omega_ok(double w) { return std::isfinite(w) && w >= 1.0 && w < 2.0;
 
 // Value of the device int at `dptr` once everything enqueued on the handle's stream so far has run (the stream is NOT
 // synchronised through the runtime: see k_post_word).  SCPN_HIP_POLL=memcpy restores hipMemcpyAsync + hipStreamSynchronize.
-static inline void cpu_relax() {  // a spin-wait hint where the host ISA has one
-#if defined(__x86_64__) || defined(__i386__)
-    __builtin_ia32_pause();
-#elif defined(__aarch64__)
-    asm volatile("yield" ::: "memory");
-#else
-    std::atomic_signal_fence(std::memory_order_seq_cst);
-#endif
-}
 static int poll_word(Solver* h, const int* dptr) {
     static const bool use_memcpy = [] { const char* e = std::getenv("SCPN_HIP_POLL"); return e && std::string(e) == "memcpy"; }();
     hipStream_t st = h->stream;
@@ -2563,6 +2575,7 @@ int scpn_gs_profile_read(scpn_gs* g, const char* name, double* total_ms, long* l
 // by (nr, nz, r_left, r_right, z_bottom, z_top) (core/_multi_compat_providers.py:720,755-792).  A pooled solver is only ever used by
 // one call at a time (it leaves the pool while in use); every call uploads all of its inputs, so nothing of a previous call is
 // read.  SCPN_HIP_OPCACHE=0 turns the pool off; objects above 4 GB are never kept.
+static std::atomic<long> g_pool_hits{0}, g_pool_misses{0};
 struct TempSolver {
     Solver* h = nullptr;
     static std::mutex& mu() { static std::mutex m; return m; }
@@ -2585,29 +2598,37 @@ struct TempSolver {
             for (size_t i = 0; i < v.size(); ++i)
                 if (same_grid(v[i], nr, nz, batch, r_axis, z_axis, dr, dz)) { h = v[i]; v.erase(v.begin() + (long)i); break; }
         }
+        (h ? g_pool_hits : g_pool_misses)++;
         if (h) {  // back to the state create_impl leaves (the fields are overwritten by the call's uploads)
-            if (!h->stream) {  // (an idle pooled solver holds no stream: see the destructor)
-                if (hipStreamCreate(&h->stream) != hipSuccess) { h->stream = nullptr; delete h; h = nullptr; }
-            }
-        }
-        if (h) {
             h->arith = 0; h->prof_on = false; h->lazy_src = nullptr; h->jsum_part = nullptr; h->snap_valid = false;
             h->vac_valid = false; h->n_vac = 0;
             std::fill(h->i_target.begin(), h->i_target.end(), 0.0);
         } else {
             h = create_impl(nr, nz, batch, r_axis, z_axis, dr, dz);
         }
+        // The stateless operators share ONE stream (created once per process and device): every live stream is mapped onto one of the
+        // few hardware queues, and a stream per pooled solver made the stream groups of a resident handle share theirs (BASELINE config 4
+        // inside bench.py: 1 083 -> 693 member-steps/s with four parked streams) while creating / destroying a stream per call costs
+        // milliseconds.  Concurrent stateless calls from several host threads are serialised on it.
+        static const bool share_env = [] { const char* e = std::getenv("SCPN_HIP_OPSTREAM"); return !(e && e[0] == '0'); }();
+        if (enabled() && share_env) {
+            static std::mutex sm;
+            static hipStream_t shared = nullptr;
+            static int shared_dev = -1;
+            std::lock_guard<std::mutex> lk(sm);
+            if (!shared && hipStreamCreate(&shared) == hipSuccess) shared_dev = g_device;
+            if (shared && shared_dev == g_device && h->stream != shared) {
+                if (h->stream && h->owns_stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+                h->stream = shared;
+                h->owns_stream = false;
+            }
+        }
     }
     ~TempSolver() {
         if (!h) return;
-        const bool healthy = hipStreamSynchronize(h->stream) == hipSuccess;
+        const bool healthy = stream_wait(h->stream) == hipSuccess;
         const bool small = (double)h->stride * h->B * sizeof(double) * 12.0 < 4.0e9;
         if (enabled() && healthy && small && std::uncaught_exceptions() == 0) {
-            // an idle solver gives its stream back: every live stream is mapped onto one of the few hardware queues, and a parked
-            // stream would make the stream groups of a resident handle share theirs (measured: BASELINE config 4 inside bench.py
-            // 1 083 -> 693 member-steps/s with four pooled streams alive)
-            (void)hipStreamDestroy(h->stream);
-            h->stream = nullptr;
             Solver* evict = nullptr;
             {
                 std::lock_guard<std::mutex> lk(mu());
@@ -2628,6 +2649,13 @@ static int check_grid(const void* a, const void* b, const double* r_axis, int nz
     return SCPN_OK;
 }
 
+// pool statistics of the stateless operators (tests / tools): hits, misses, idle solvers
+int scpn_operator_pool_stats(long* hits, long* misses, int* idle) {
+    if (hits) *hits = g_pool_hits.load();
+    if (misses) *misses = g_pool_misses.load();
+    if (idle) { std::lock_guard<std::mutex> lk(TempSolver::mu()); *idle = (int)TempSolver::idle().size(); }
+    return SCPN_OK;
+}
 int scpn_mg_smooth(double* psi, const double* source, const double* r_axis, int nz, int nr, int batch, double dr, double dz, double omega,
                    int n_sweeps) {
     if (!omega_ok(omega)) return fail(SCPN_E_ARG, "omega must be finite and satisfy 1.0 <= omega < 2.0");

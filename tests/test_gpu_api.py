@@ -273,3 +273,34 @@ def test_rccl_ensemble_gather_through_the_c_abi_on_one_rank():
         comm.barrier()
     finally:
         comm.close()
+
+
+def test_stateless_operator_pool_reuses_solvers_without_changing_results():
+    """The solver object of a stateless operator call is pooled per grid (scpn_operator_pool_stats): a second call on the same grid is a
+    pool hit, another grid / batch a miss; results are bit-identical whether the object is fresh or reused, and a call with other inputs
+    on a reused object sees nothing of the previous one."""
+    import ctypes as C
+
+    from scpn_fusion_core_amd import _lib, multigrid_solve as mgs
+    from tests._problems import bench_problem
+
+    def stats():
+        h, m, i = C.c_long(), C.c_long(), C.c_int()
+        assert _lib.lib().scpn_operator_pool_stats(C.byref(h), C.byref(m), C.byref(i)) == 0
+        return h.value, m.value, i.value
+
+    psi0, source, rr, r, z = bench_problem(97, 141)
+    dr, dz = float(r[1] - r[0]), float(z[1] - z[0])
+    first = mgs.multigrid_vcycle(psi0.copy(), source, rr, dr, dz)
+    h0, m0, _ = stats()
+    again = mgs.multigrid_vcycle(psi0.copy(), source, rr, dr, dz)
+    h1, m1, idle = stats()
+    assert h1 == h0 + 1 and m1 == m0 and idle >= 1 and np.array_equal(first, again)
+    other = mgs.multigrid_vcycle(2.0 * psi0, 3.0 * source, rr, dr, dz)  # same grid, other data: reused object, fresh result
+    assert not np.array_equal(other, first) and np.array_equal(other, mgs.multigrid_vcycle(2.0 * psi0, 3.0 * source, rr, dr, dz))
+    assert np.array_equal(mgs.multigrid_vcycle(psi0.copy(), source, rr, dr, dz), first)
+    batched = mgs.multigrid_vcycle(np.stack([psi0, psi0]), np.stack([source, source]), rr, dr, dz)  # another batch size: its own object
+    h2, m2, _ = stats()
+    assert m2 == m1 + 1 and np.array_equal(batched[0], first) and np.array_equal(batched[1], first)
+    smooth = mgs.mg_smooth(psi0.copy(), source, rr, dr, dz, 1.3, 4)  # another operator on the pooled object of this grid
+    assert stats()[0] > h2 and np.array_equal(smooth, mgs.mg_smooth(psi0.copy(), source, rr, dr, dz, 1.3, 4))
