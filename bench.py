@@ -340,7 +340,7 @@ def main() -> int:
         comm.wait()
         gather_ms = comm.allreduce_max(time.perf_counter() - tg) * 1e3
     its_rank = [sum(r["picard_iterations"]) for r in res]
-    per_rank = gather_rank_stats(rank, world, {
+    rank_table = gather_rank_stats(rank, world, {
         "members": B, "solve_ms": round(rank_t["solve_s"] / args.steps * 1e3, 3), "gather_wait_ms": round(rank_t["gather_wait_s"] / args.steps * 1e3, 3),
         "final_barrier_ms": round(rank_t["final_barrier_s"] * 1e3, 3), "picard_iterations_max": max(its_rank), "picard_iterations_min": min(its_rank),
         "converged_members": sum(int(r["converged"]) for r in res)},
@@ -669,7 +669,7 @@ def main() -> int:
                        "converged_members_rank0": n_conv, "outer_iterations": [min(outer), max(outer)],
                        "picard_iterations_per_member": [min(picard_total), max(picard_total)]},
         }
-        line["per_rank"] = per_rank
+        line["per_rank"] = rank_table
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 3)  # one ensemble all-gather on its own (in the timed steps it overlaps the next solve)
         if arith_modes is not None:

@@ -24,6 +24,20 @@ def test_bench_line_contract():
     assert d["config"]["converged_members_rank0"] == d["config"]["members_rank0"]
     # the workload is SURVEY 8(d) cfg 5 in full: currents, I_p AND the kappa scan through the coil heights
     assert "kappa in [1.5, 1.9]" in d["config"]["workload"] and 1.5 <= d["config"]["kappa_range_rank0"][0] < d["config"]["kappa_range_rank0"][1] <= 1.9
+    # which arithmetic the headline was timed in, and the other mode beside it (same handle, after the clock)
+    assert d["config"]["arithmetic"] in ("exact", "contracted")
+    am = d["arithmetic_modes"]
+    assert am[d["config"]["arithmetic"]]["headline"] is True and am[d["config"]["arithmetic"]]["value"] == d["value"]
+    other = "exact" if d["config"]["arithmetic"] == "contracted" else "contracted"
+    assert am[other]["headline"] is False and am[other]["converged_members"] == d["config"]["members_rank0"] and am[other]["value"] > 0
+    assert am["psi_rel_linf_between_modes"] < 1e-10 and am["members_with_equal_iteration_counts"] >= d["config"]["members_rank0"] - 2
+    # one record per rank: what makes an N > 1 curve attributable (imbalance / gather / launch path)
+    pr = d["per_rank"]
+    assert isinstance(pr, list) and len(pr) == d["n_gpus"] and [row["rank"] for row in pr] == list(range(d["n_gpus"]))
+    for row in pr:
+        assert {"members", "solve_ms", "gather_wait_ms", "final_barrier_ms", "picard_iterations_max", "picard_iterations_min", "converged_members"} <= set(row)
+        assert row["solve_ms"] <= d["ms_per_step"] * 1.02 and row["converged_members"] == row["members"]
+    assert ("gather_ms" in d) == (d["n_gpus"] > 1)
     if d["scaling"] == "weak":
         assert members == d["config"]["members_per_gpu"] * d["n_gpus"]
         s1 = d["strong_scaling_n1"]  # the other scaling label's N = 1 value rides on the weak line
@@ -48,10 +62,14 @@ def test_roofline_and_cpu_baseline_objects():
     assert full["members_per_launch"] == d["config"]["members_per_gpu"]
     for k in full["kernels"].values():
         assert 0.0 < k["frac"] <= 1.0 and abs(k["frac"] - k["achieved"] / r["peak"]) < 1e-3
-    lim = r["limiter"]  # what limits the kernel, with the counters it is read from (never a hard-coded figure)
-    assert isinstance(lim, dict) and lim["class"] and "counters" in lim and lim["evidence"]
+    lim = r["limiter"]  # what limits the kernel: keys COMPUTED from the committed SQ counters of that kernel (no prose, no hard-coded figure)
+    assert isinstance(lim, dict) and "counters" in lim and lim["evidence"] and "class" not in lim and lim["arithmetic"] == d["config"]["arithmetic"]
+    assert lim["halo_redundancy"] is None or 1.0 < lim["halo_redundancy"] < 2.5
     if lim["counters"] is not None:
         assert lim["counters"]["source"].startswith("profiles/") and 0.0 < lim["counters"]["valu_busy"] <= 1.0
+        assert 0.0 < lim["valu_issue_frac_of_launch"] <= 1.0 and lim["counters"]["valu_issue_us"] > 0
+        # the counters are those of the kernel instantiation of the timed arithmetic (contracted instantiations end in `true>`)
+        assert lim["counters"]["kernel"].rstrip().endswith("true>") == (d["config"]["arithmetic"] == "contracted")
     it = r["iteration"]  # HBM bytes of one Picard iteration (all its kernels, PMC) / iteration time
     assert it is None or (0.0 < it["frac"] <= 1.0 and abs(it["frac"] - it["achieved"] / it["peak"]) < 1e-3 and it["kernels_counted"])
     mb = r["measured_bandwidth"]
@@ -65,7 +83,13 @@ def test_roofline_and_cpu_baseline_objects():
     assert r["bound_observed"] is None or isinstance(r["bound_observed"], str)  # what the committed counters say limits the kernel
     for key in ("config2_fixed_boundary_257", "config4_transport_coupled_loop_513"):
         assert "vacuum field per handle" in cf[key]["memoised_setup"]
+    pg = cf["polyglot_picard_jacobi_513"]  # north_star's literal comparator: the polyglot lane at 513^2, device vs its CPU twins
+    assert pg["toml_parameters"]["hip_ms"] > 0 and pg["vs_cpu"]["psi_axis_equal"] is True and pg["vs_cpu"]["x_numpy_one_core"] > 1.0
+    assert cf["dispatcher_multigrid_solve_257"]["converged"] and cf["dispatcher_multigrid_solve_257"]["dispatch_host_buffers_ms"] > 0
+    assert cf["arithmetic"] == d["config"]["arithmetic"]
     c = d["cpu_baseline"]
+    assert c["arithmetic_of_the_compared_gpu_run"] == d["config"]["arithmetic"] and c["picard_iterations_max_abs_difference"] <= 1
+    assert c["polyglot_513"]["numpy_vs_c_port_psi_rel_linf"] < 1e-12 and c["polyglot_513"]["numpy_one_core_ms"] > 0
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     # every member the CPU leg solved is compared with the device's result of the timed run
     assert c["host_cores"] >= c["cores"] == c["members_compared"] == len(c["psi_rel_linf_vs_gpu_per_member"])

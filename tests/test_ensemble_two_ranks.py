@@ -366,4 +366,4 @@ def test_per_rank_table_of_the_bench_line(tmp_path):
     assert tables[0][1]["solve_ms"] == 101.0 and tables[0][1]["picard_iterations_max"] == 418
     # the bench line wires exactly this table (static check of the source: bench.py needs a GPU to run)
     src = open(os.path.join(os.path.dirname(__file__), "..", "bench.py")).read()
-    assert 'line["per_rank"] = per_rank' in src and "gather_rank_stats(rank, world" in src and '"gather_ms"' in src
+    assert 'line["per_rank"] = rank_table' in src and "gather_rank_stats(rank, world" in src and '"gather_ms"' in src
