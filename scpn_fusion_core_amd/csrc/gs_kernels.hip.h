@@ -1764,9 +1764,12 @@ __global__ void k_jacobi(Fld outF, Fld psiF, Fld srcF, Lvl L, const int* active)
 // DAMPED: the damped-Jacobi step of the polyglot lane (core/jax_gs_solver.py:58-86, the arithmetic of k_jacobi_damped below:
 // a_NS * (S + N) association, no sanitising, no clip, psi <- (1 - omega_j) psi + omega_j * update) in the same blocked form --
 // Jacobi reads only OLD values, so S steps per launch are bit-identical to S launches of one step.
-template <int S, bool DAMPED = false>
+// FAST (contracted arithmetic, the seed relaxation of a resident handle in that mode; never with DAMPED: the polyglot lane is a stateless
+// operator and stays exact): the step as a chain of four FMAs on coefficients / sources scaled by 1 / a_C once per tile, then the clip.
+template <int S, bool DAMPED = false, bool FAST = false>
 __global__ void __launch_bounds__(512, 6) k_jacobi_reg(Fld outF, Fld psiF, Fld srcF, Lvl L, const int* active, double omega_j = 1.0,
                                                        double om1_j = 0.0) {
+    static_assert(!(FAST && DAMPED), "the damped form is the polyglot lane's: exact only");
     constexpr int LZ = 48, NW = 8, NROWS = LZ / NW, H = 6;
     static_assert(S <= H, "the halo must cover the steps of one launch");
     __shared__ __attribute__((aligned(16))) double2 xch[2][NW][2][64];  // [step parity][wave][first / last row][lane]
@@ -1818,6 +1821,11 @@ __global__ void __launch_bounds__(512, 6) k_jacobi_reg(Fld outF, Fld psiF, Fld s
         rowok[i] = gz >= 1 && gz <= nz - 2 && lz >= 1 && lz <= LZ - 2;
     }
     const double a_ns = L.a_ns, a_c = L.a_c, inv_a_c = L.inv_a_c, lo_a_c = L.lo_a_c;
+    const double fe0 = ae0 * inv_a_c, fw0 = aw0 * inv_a_c, fe1 = ae1 * inv_a_c, fw1 = aw1 * inv_a_c, fns = a_ns * inv_a_c;  // (FAST)
+    if (FAST) {
+#pragma unroll
+        for (int i = 0; i < NROWS; ++i) { sv[i].x = sv[i].x * inv_a_c; sv[i].y = sv[i].y * inv_a_c; }
+    }
     const int w_s = w > 0 ? w - 1 : 0, w_n = w < NW - 1 ? w + 1 : NW - 1;  // (the tile's first / last row is never updated)
 #pragma unroll 1
     for (int s = 0; s < S; ++s) {
@@ -1838,6 +1846,11 @@ __global__ void __launch_bounds__(512, 6) k_jacobi_reg(Fld outF, Fld psiF, Fld s
                 const double uy = divc4(ae1 * Ey + aw1 * o.x + a_ns * (old_m1.y + up.y) - sv[i].y, a_c, inv_a_c, lo_a_c);
                 cx = om1_j * o.x + omega_j * ux;
                 cy = om1_j * o.y + omega_j * uy;
+            } else if constexpr (FAST) {
+                const double nx = __builtin_fma(fe0, o.y, __builtin_fma(fw0, Wx, __builtin_fma(fns, old_m1.x, __builtin_fma(fns, up.x, -sv[i].x))));
+                const double ny = __builtin_fma(fe1, Ey, __builtin_fma(fw1, o.x, __builtin_fma(fns, old_m1.y, __builtin_fma(fns, up.y, -sv[i].y))));
+                cx = fmin(fmax(nx, -CAP), CAP);
+                cy = fmin(fmax(ny, -CAP), CAP);
             } else {
                 const double nx = divc4(ae0 * o.y + aw0 * Wx + a_ns * old_m1.x + a_ns * up.x - sv[i].x, a_c, inv_a_c, lo_a_c);
                 const double ny = divc4(ae1 * Ey + aw1 * o.x + a_ns * old_m1.y + a_ns * up.y - sv[i].y, a_c, inv_a_c, lo_a_c);

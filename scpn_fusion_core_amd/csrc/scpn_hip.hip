@@ -1024,8 +1024,9 @@ static void picard_solve_impl(Solver* h, const scpn_picard_params* p, scpn_picar
             ProfScope ps(h, "seed_jacobi", 10);
             const dim3 gj(cdiv(nr, 116), cdiv(nz, 36), B);  // (window 36 x 116 of a 48 x 128 register tile)
             for (int s = 0; s < 5; ++s) {
-                SCPN_LAUNCH(k_jacobi_reg<5>, gj, dim3(512), 0, st, WF, curF, srcF, L0, (const int*)d_sa.p, 1.0, 0.0);
-                SCPN_LAUNCH(k_jacobi_reg<5>, gj, dim3(512), 0, st, curF, WF, srcF, L0, (const int*)d_sa.p, 1.0, 0.0);
+                auto kj = h->arith == 1 ? &k_jacobi_reg<5, false, true> : &k_jacobi_reg<5, false, false>;
+                SCPN_LAUNCH(kj, gj, dim3(512), 0, st, WF, curF, srcF, L0, (const int*)d_sa.p, 1.0, 0.0);
+                SCPN_LAUNCH(kj, gj, dim3(512), 0, st, curF, WF, srcF, L0, (const int*)d_sa.p, 1.0, 0.0);
             }
         } else {
             ProfScope ps(h, "seed_jacobi", 50);
