@@ -255,3 +255,52 @@ def test_contracted_hmode_ensemble_keeps_the_stored_source(ES, orc):
     assert _counts_close(res[0]["iterations"], ref["iterations"]), (res[0]["iterations"], ref["iterations"])
     assert np.abs(psi[0] - ref["psi"]).max() <= PSI_TOL * np.abs(ref["psi"]).max()
     assert all(np.array_equal(psi[0], psi[b]) for b in range(16))
+
+
+@pytest.mark.parametrize("name", ["iter65_saddle", "d3d33_saddle"])
+def test_contracted_saddle_detection_vs_reference_fixture(ES, golden, name):
+    """xpoint_use_saddle_detection (core/fusion_kernel.py:284-329): the iteration then takes the separate topology kernels every iteration
+    (no topology partials from the tail) -- contracted arithmetic against the REFERENCE's own fixture (tests/golden/saddle.npz)."""
+    g = golden("saddle.npz")
+    cfg = configs_from(g)[name]
+    with ES(cfg, batch=2, arithmetic="contracted") as es:
+        res = es.solve_equilibrium(check_every=4)
+        psi = es.get_psi()
+    st = g[f"{name}_stats"]
+    for b in range(2):
+        assert _counts_close(res[b]["iterations"], int(st[1])) and res[b]["converged"] == bool(st[0]), (res[b]["iterations"], int(st[1]))
+        assert np.abs(psi[b] - g[f"{name}_psi"]).max() <= PSI_TOL * np.abs(g[f"{name}_psi"]).max()
+
+
+def test_contracted_newton_lane_reaches_the_oracle_picard_solution(ES, orc):
+    """The multigrid / finite-difference Newton lane with contracted V-cycles and source evaluations: the fixed point of the reference's
+    Picard iteration (CPU oracle) to 1e-8 (the lane's own bar in exact arithmetic, tests/test_gpu_newton.py)."""
+    n = 129
+    ref = orc.picard_solve(iter_like_cfg(n, tol=1e-8, max_iter=1000))
+    c = iter_like_cfg(n, method="newton", tol=1e-8, max_iter=60)
+    c["solver"].update(gmres_preconditioner="multigrid", newton_jacobian="finite_difference", newton_damping=1.0)
+    with ES(c, batch=2, arithmetic="contracted") as es:
+        rn = es.solve_equilibrium()
+        psi = es.get_psi()
+    assert all(r["converged"] for r in rn) and 1 <= rn[0]["iterations"] - 15 <= 9, rn[0]["iterations"]
+    assert np.abs(psi[0] - ref["psi"]).max() <= 1e-8 * np.abs(ref["psi"]).max() and np.array_equal(psi[0], psi[1])
+
+
+def test_contracted_shape_optimisation_through_the_config_key(golden):
+    """`solver.arithmetic = "contracted"` travels with the case: the shape-optimisation variant of config 3 (device Picard solves + host
+    bounded least squares, FusionKernel mirror) against the REFERENCE's fixture at its own tolerances."""
+    from scpn_fusion_core_amd.free_boundary import CoilSet
+    from scpn_fusion_core_amd.fusion_kernel import FusionKernel
+
+    g = golden("shape_d3d.npz")
+    cfg = copy.deepcopy(configs_from(g)["shape_d3d129"])
+    cfg["solver"]["arithmetic"] = "contracted"
+    k = FusionKernel(cfg)
+    coils = CoilSet(positions=[(c["r"], c["z"]) for c in cfg["coils"]], currents=np.array([c["current"] for c in cfg["coils"]], dtype=float),
+                    turns=[1] * len(cfg["coils"]), current_limits=np.full(len(cfg["coils"]), 5.0e7), target_flux_points=np.array(g["points"]))
+    out = k.solve_free_boundary(coils, max_outer_iter=4, tol=1e-6, optimize_shape=True)
+    assert k._es.arithmetic == "contracted"
+    assert out["outer_iterations"] == int(g["stats"][0])
+    np.testing.assert_allclose(out["coil_currents"], g["currents"], rtol=1e-6, atol=1e-12)
+    assert np.abs(k.Psi - g["psi"]).max() <= 1e-8 * np.abs(g["psi"]).max()
+    k.close()
