@@ -304,3 +304,25 @@ def test_contracted_shape_optimisation_through_the_config_key(golden):
     np.testing.assert_allclose(out["coil_currents"], g["currents"], rtol=1e-6, atol=1e-12)
     assert np.abs(k.Psi - g["psi"]).max() <= 1e-8 * np.abs(g["psi"]).max()
     k.close()
+
+
+@pytest.mark.parametrize("value,where", [(np.inf, (20, 24)), (np.nan, (20, 24)), (np.inf, (0, 9)), (np.nan, (64, 13)), (-np.inf, (31, 0))])
+def test_contracted_non_finite_entry_in_a_preserved_start(ES, orc, value, where):
+    """The divergence path on the TILE kernels under contracted arithmetic (65 x 65; core/fusion_kernel_newton_solver.py:441-470,518-532): an
+    interior non-finite entry is sanitised before the first iteration, a non-finite RING value is Dirichlet data and makes the first elliptic
+    solve non-finite -- same converged / diverged / iteration outcome and the same finite pattern as the CPU port (in a column that is never
+    updated the folded operands return psi itself: 0 * x + psi, also for a non-finite psi)."""
+    cfg = iter_like_cfg(65, tol=1e-6, max_iter=60)
+    start = orc.picard_solve(cfg)["psi"].copy()
+    start[where] = value
+    ref = orc.picard_solve(cfg, psi0=start, preserve=True)
+    with ES(cfg, batch=2, arithmetic="contracted") as es:
+        es.set_psi(np.stack([start, start]))
+        res = es.solve_equilibrium(preserve_initial_state=True)
+        psi = es.get_psi()
+    for k in ("converged", "diverged"):
+        assert res[0][k] == ref[k] == res[1][k], (k, res[0][k], ref[k])
+    assert _counts_close(res[0]["iterations"], ref["iterations"]), (res[0]["iterations"], ref["iterations"])
+    fin = np.isfinite(ref["psi"])
+    assert np.array_equal(np.isfinite(psi[0]), fin)
+    assert np.abs(psi[0][fin] - ref["psi"][fin]).max() <= PSI_TOL * np.abs(ref["psi"][fin]).max()
